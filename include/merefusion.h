@@ -1,0 +1,124 @@
+/*
+ * merefusion.h -- C ABI of libmerefusion_hip.so, the MI355X (gfx950) frame generator that sits
+ * underneath mere-fusion's lipreal.py / musereal.py render loops.
+ *
+ * The reference has no native FFI on this path (its hot loop is torch modules called from
+ * Python); each entry point below names the Python interface it replaces (paths relative to the
+ * reference checkout).  INTEGRATION.md shows the ctypes stub a maintainer adds on the reference
+ * side.  All functions return 0 on success or a negative mf_status; they never throw across
+ * the boundary.  mf_last_error() returns a thread-local message for the last failure.
+ *
+ * Pointers marked "device" are HIP device pointers borrowed for the duration of the call
+ * (caller owns them, lipreal.py:121-126); "host" pointers are read during the call only.
+ * A handle owns its packed weights, its activation workspace and its captured hipGraphs.
+ * Handles are not thread-safe: one handle per (session, stream), as the reference runs one
+ * single-threaded inference process per session (lipreal.py:85, app.py:549).
+ */
+#ifndef MEREFUSION_H
+#define MEREFUSION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mf_status {
+    MF_OK = 0,
+    MF_ERR_INVALID = -1,   /* bad argument / shape / missing tensor */
+    MF_ERR_HIP = -2,       /* a HIP runtime call failed */
+    MF_ERR_NODEVICE = -3,  /* no gfx950 device visible */
+    MF_ERR_NOMEM = -4
+} mf_status;
+
+/* Arithmetic mode of the MFMA convolution kernels.
+ * MF_PREC_BF16   : bf16 activations/weights, fp32 accumulate (BASELINE config 2).
+ * MF_PREC_BF16X3 : activations and weights carried as bf16 (hi, lo) pairs, three bf16 MFMAs per
+ *                  product (hi*hi + lo*hi + hi*lo), fp32 accumulate: ~2^-17 relative operand
+ *                  error; meets the north-star parity bound (L-inf <= 1e-3 vs the fp32 CPU
+ *                  generator) that plain bf16 cannot. */
+typedef enum mf_precision { MF_PREC_BF16 = 0, MF_PREC_BF16X3 = 1 } mf_precision;
+
+/* One named fp32 host tensor of a checkpoint (a state_dict item). */
+typedef struct mf_tensor {
+    const char* name;   /* e.g. "face_encoder_blocks.0.0.conv_block.0.weight" */
+    const float* data;  /* host, contiguous, fp32 */
+    int ndim;
+    int64_t shape[4];
+} mf_tensor;
+
+/* ---- library ---------------------------------------------------------------------------- */
+/* Selects the HIP device (replaces `device = 'cuda'`, lipreal.py:29). */
+int mf_init(int device);
+const char* mf_last_error(void);
+/* ABI version, bumped on any signature change. */
+int mf_abi_version(void);
+
+/* ---- Wav2Lip generator (H2) -------------------------------------------------------------- */
+typedef struct mf_wav2lip mf_wav2lip;
+
+/* Replaces `Wav2Lip()` + `load_state_dict` + `.to(device).eval()` (lipreal.py:43-53,
+ * wav2lip/models/wav2lip.py:12-85).  `weights` are the state-dict tensors (101 weight, 101 bias,
+ * 50 x running_mean / running_var; num_batches_tracked is ignored); a leading "module." in a name
+ * is stripped as lipreal.py:48-49 does.  BatchNorm (eval, eps 1e-5, conv.py:10) is folded in. */
+int mf_wav2lip_create(const mf_tensor* weights, int n_weights, int precision, mf_wav2lip** out);
+
+/* Replaces `pred = model(mel_batch, img_batch)` (lipreal.py:124-125 -> wav2lip.py:87-125).
+ * mel  : device fp32 [B,1,80,16]    face : device fp32 [B,6,96,96] (NCHW, values in [0,1])
+ * out  : device fp32 [B,3,96,96] in [0,1], BGR.  Enqueued on `stream` (a hipStream_t; NULL =
+ * default stream); returns without synchronising. */
+int mf_wav2lip_forward(mf_wav2lip* h, const float* mel, const float* face, float* out, int batch,
+                       void* stream);
+
+/* Fuses the per-batch glue around the generator (lipreal.py:115-126): faces arrive as uint8
+ * [B,96,96,3] BGR crops, are masked (rows >= 48 zeroed in the first 3 channels), concatenated
+ * and scaled by 1/255 on the fly; frames leave as fp32 [B,96,96,3] = pred*255 (HWC, what
+ * lipreal.py:126 hands to process_frames).  mel: device fp32 [B,1,80,16]. */
+int mf_wav2lip_forward_u8(mf_wav2lip* h, const float* mel, const uint8_t* faces_u8,
+                          float* frames_hwc, int batch, void* stream);
+
+/* Copies the NCHW fp32 activation named `tap` of the LAST forward into `dst` (device), for
+ * parity tests.  tap: "audio_embedding", "face_encoder_blocks.N", "face_decoder_blocks.N". */
+int mf_wav2lip_read_tap(mf_wav2lip* h, const char* tap, float* dst, int batch, void* stream);
+
+void mf_wav2lip_destroy(mf_wav2lip* h);
+
+/* ---- single fused convolution layer (building block, also the per-geometry test seam) ---- */
+typedef struct mf_conv2d mf_conv2d;
+
+typedef struct mf_conv2d_desc {
+    int cin, cout;
+    int kh, kw;
+    int stride_h, stride_w;
+    int pad_h, pad_w;
+    int transposed;       /* 0 = Conv2d (conv.py:5), 1 = ConvTranspose2d (conv.py:33) */
+    int output_padding;   /* transposed only */
+    int residual;         /* add the layer input before the activation (conv.py:17-18) */
+    int act;              /* 0 none, 1 ReLU, 2 sigmoid */
+    int in_h, in_w;       /* spatial size of the input this layer is built for */
+} mf_conv2d_desc;
+
+/* weight: host fp32, [cout,cin,kh,kw] (Conv2d) or [cin,cout,kh,kw] (ConvTranspose2d);
+ * bias: host fp32 [cout] or NULL; bn_*: host fp32 [cout] or all NULL (no BatchNorm). */
+int mf_conv2d_create(const mf_conv2d_desc* desc, const float* weight, const float* bias,
+                     const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                     const float* bn_var, int precision, mf_conv2d** out);
+/* x: device fp32 NCHW [B,cin,in_h,in_w]; y: device fp32 NCHW [B,cout,out_h,out_w]. */
+int mf_conv2d_forward(mf_conv2d* h, const float* x, float* y, int batch, void* stream);
+int mf_conv2d_out_shape(const mf_conv2d* h, int* out_h, int* out_w);
+void mf_conv2d_destroy(mf_conv2d* h);
+
+/* ---- Wav2Lip mel-spectrogram (H1) -------------------------------------------------------- */
+/* Replaces `audio.melspectrogram(inputs)` (lipasr.py:23 -> wav2lip/audio.py:45-51 with the
+ * constants of wav2lip/hparams.py:33-73): pre-emphasis 0.97, centred STFT n_fft=800 hop=200
+ * periodic Hann, 80 Slaney mel bands 55-7600 Hz, 20*log10(max(1e-5,.)) - 20, clip-normalise
+ * to [-4,4].  wav: device fp32 [n]; out: device fp32 [80, T], T = 1 + n/200.
+ * pad_mode: 0 = zeros (librosa >= 0.10 default "constant"), 1 = reflect (librosa < 0.10). */
+int mf_melspec(const float* wav, int n, float* out, int pad_mode, void* stream);
+int mf_melspec_frames(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEREFUSION_H */

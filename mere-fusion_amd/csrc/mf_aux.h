@@ -1,0 +1,21 @@
+// Layout-conversion and head kernels around the MFMA convolutions (all HBM-bound, one pass).
+#pragma once
+#include "mf_conv.h"
+
+// fp32 NCHW [B,C,H,W] -> interior of the padded NHWC (hi, lo) planes of `dst` (channels >= C
+// of the destination view are written as zero up to dst.buf->C when C is not a multiple of 8).
+int mf_nchw_to_act(const float* src, int C, const ActBuf& dst, int batch, hipStream_t s);
+
+// interior of a channel slice of padded NHWC planes -> fp32 NCHW [B,C,H,W]
+int mf_act_to_nchw(const ActView& src, float* dst, int batch, hipStream_t s);
+
+// lipreal.py:115-122 fused: uint8 [B,96,96,3] BGR crops -> 8-channel padded NHWC
+// [masked b,g,r (rows >= H/2 zero), full b,g,r, 0, 0] / 255
+int mf_faces_u8_to_act(const uint8_t* faces, const ActBuf& dst, int batch, hipStream_t s);
+
+// output_block.1 (plain 1x1 Conv2d 32->3) + Sigmoid (wav2lip.py:84-85) on the NHWC activation
+// of output_block.0.  hwc255 == 0: fp32 NCHW [B,3,H,W] in [0,1];  hwc255 == 1: fp32 [B,H,W,3]*255
+// (the `pred.cpu().numpy().transpose(0,2,3,1) * 255.` of lipreal.py:126).
+// w: device fp32 [3][cin], b: device fp32 [3].
+int mf_head_1x1_sigmoid(const ActView& src, const float* w, const float* b, float* dst, int hwc255,
+                        int batch, hipStream_t s);

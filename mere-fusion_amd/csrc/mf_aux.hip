@@ -1,0 +1,158 @@
+// Layout-conversion and head kernels (HBM-bound elementwise passes; see mf_aux.h).
+#include "mf_aux.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t f2bf_d(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf2f_d(uint32_t h) { return __uint_as_float(h << 16); }
+
+// one thread = one pixel x 8-channel group; consecutive threads walk x so the NCHW reads coalesce
+__global__ void k_nchw_to_act(const float* __restrict__ src, int C, int H, int W, bf16_t* hi, bf16_t* lo,
+                              int Cbuf, int halo, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int groups = Cbuf / 8;
+    const int x = idx % W;
+    int64_t t = idx / W;
+    const int y = t % H; t /= H;
+    const int g = t % groups;
+    const int b = t / groups;
+    const int Wp = W + 2 * halo, Hp = H + 2 * halo;
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        const float v = c < C ? src[(((int64_t)b * C + c) * H + y) * W + x] : 0.f;
+        h[e] = f2bf_d(v);
+        l[e] = f2bf_d(v - bf2f_d(h[e]));
+    }
+    const int64_t o = (((int64_t)b * Hp + y + halo) * Wp + x + halo) * Cbuf + g * 8;
+    *reinterpret_cast<uint4*>(hi + o) = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
+    if (lo) *reinterpret_cast<uint4*>(lo + o) = make_uint4(l[0] | l[1] << 16, l[2] | l[3] << 16, l[4] | l[5] << 16, l[6] | l[7] << 16);
+}
+
+__global__ void k_act_to_nchw(const bf16_t* hi, const bf16_t* lo, int Cbuf, int coff, int C, int H, int W,
+                              int halo, float* __restrict__ dst, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = idx % W;
+    int64_t t = idx / W;
+    const int y = t % H; t /= H;
+    const int c = t % C;
+    const int b = t / C;
+    const int Wp = W + 2 * halo, Hp = H + 2 * halo;
+    const int64_t o = (((int64_t)b * Hp + y + halo) * Wp + x + halo) * Cbuf + coff + c;
+    float v = bf2f_d(hi[o]);
+    if (lo) v += bf2f_d(lo[o]);
+    dst[idx] = v;
+}
+
+__global__ void k_faces_u8(const uint8_t* __restrict__ faces, int H, int W, bf16_t* hi, bf16_t* lo, int halo,
+                           int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = idx % W;
+    int64_t t = idx / W;
+    const int y = t % H;
+    const int b = t / H;
+    const uint8_t* px = faces + (((int64_t)b * H + y) * W + x) * 3;
+    float v[8];
+    const bool keep = y < H / 2;   // img_masked[:, face.shape[0]//2:] = 0  (lipreal.py:116)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float f = (float)px[c] / 255.f;
+        v[c] = keep ? f : 0.f;
+        v[3 + c] = f;
+    }
+    v[6] = v[7] = 0.f;
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { h[e] = f2bf_d(v[e]); l[e] = f2bf_d(v[e] - bf2f_d(h[e])); }
+    const int Wp = W + 2 * halo, Hp = H + 2 * halo;
+    const int64_t o = (((int64_t)b * Hp + y + halo) * Wp + x + halo) * 8;
+    *reinterpret_cast<uint4*>(hi + o) = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
+    if (lo) *reinterpret_cast<uint4*>(lo + o) = make_uint4(l[0] | l[1] << 16, l[2] | l[3] << 16, l[4] | l[5] << 16, l[6] | l[7] << 16);
+}
+
+// one thread per pixel: 32-channel dot products against 3 filters held in registers
+template <int CIN>
+__global__ void k_head(const bf16_t* hi, const bf16_t* lo, int Cbuf, int coff, int H, int W, int halo,
+                       const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ dst,
+                       int hwc255, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = idx % W;
+    int64_t t = idx / W;
+    const int y = t % H;
+    const int b = t / H;
+    const int Wp = W + 2 * halo, Hp = H + 2 * halo;
+    const int64_t o = (((int64_t)b * Hp + y + halo) * Wp + x + halo) * Cbuf + coff;
+    float acc[3] = {bias[0], bias[1], bias[2]};
+#pragma unroll
+    for (int g = 0; g < CIN / 8; ++g) {
+        const uint4 vh = *reinterpret_cast<const uint4*>(hi + o + g * 8);
+        uint4 vl = make_uint4(0, 0, 0, 0);
+        if (lo) vl = *reinterpret_cast<const uint4*>(lo + o + g * 8);
+        const uint32_t hh[4] = {vh.x, vh.y, vh.z, vh.w}, ll[4] = {vl.x, vl.y, vl.z, vl.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = bf2f_d(hh[e] & 0xffffu) + bf2f_d(ll[e] & 0xffffu);
+            const float a1 = bf2f_d(hh[e] >> 16) + bf2f_d(ll[e] >> 16);
+            const int c = g * 8 + e * 2;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[k] = fmaf(a1, w[k * CIN + c + 1], fmaf(a0, w[k * CIN + c], acc[k]));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float s = 1.f / (1.f + expf(-acc[k]));
+        if (hwc255) dst[idx * 3 + k] = s * 255.f;
+        else dst[(((int64_t)b * 3 + k) * H + y) * W + x] = s;
+    }
+}
+
+inline unsigned blocks_for(int64_t total, int bs) { return (unsigned)((total + bs - 1) / bs); }
+
+}  // namespace
+
+int mf_nchw_to_act(const float* src, int C, const ActBuf& dst, int batch, hipStream_t s) {
+    MF_REQUIRE(dst.C % 8 == 0 && dst.C >= C, "nchw_to_act: destination has %d channels for %d", dst.C, C);
+    const int64_t total = (int64_t)batch * (dst.C / 8) * dst.H * dst.W;
+    hipLaunchKernelGGL(k_nchw_to_act, dim3(blocks_for(total, 256)), dim3(256), 0, s, src, C, dst.H, dst.W,
+                       dst.hi, dst.lo, dst.C, dst.halo, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+int mf_act_to_nchw(const ActView& src, float* dst, int batch, hipStream_t s) {
+    const ActBuf& b = *src.buf;
+    const int64_t total = (int64_t)batch * src.C * b.H * b.W;
+    hipLaunchKernelGGL(k_act_to_nchw, dim3(blocks_for(total, 256)), dim3(256), 0, s, b.hi, b.lo, b.C, src.coff,
+                       src.C, b.H, b.W, b.halo, dst, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+int mf_faces_u8_to_act(const uint8_t* faces, const ActBuf& dst, int batch, hipStream_t s) {
+    MF_REQUIRE(dst.C == 8, "faces_u8_to_act: destination must have 8 channels");
+    const int64_t total = (int64_t)batch * dst.H * dst.W;
+    hipLaunchKernelGGL(k_faces_u8, dim3(blocks_for(total, 256)), dim3(256), 0, s, faces, dst.H, dst.W, dst.hi,
+                       dst.lo, dst.halo, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+int mf_head_1x1_sigmoid(const ActView& src, const float* w, const float* b, float* dst, int hwc255, int batch,
+                        hipStream_t s) {
+    const ActBuf& sb = *src.buf;
+    MF_REQUIRE(src.C == 32, "head: built for the 32-channel output_block.0 activation");
+    const int64_t total = (int64_t)batch * sb.H * sb.W;
+    hipLaunchKernelGGL(k_head<32>, dim3(blocks_for(total, 256)), dim3(256), 0, s, sb.hi, sb.lo, sb.C, src.coff,
+                       sb.H, sb.W, sb.halo, w, b, dst, hwc255, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}

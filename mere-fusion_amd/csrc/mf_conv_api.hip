@@ -1,0 +1,78 @@
+// C ABI of the single fused convolution layer (mf_conv2d_*): NCHW fp32 in/out around the
+// padded-NHWC MFMA kernel.  This is the per-geometry test seam and the building block the
+// network schedules (mf_wav2lip.hip) are made of.
+#include "mf_conv.h"
+#include "mf_aux.h"
+#include <memory>
+#include <algorithm>
+
+struct mf_conv2d {
+    ConvPlan plan;
+    ActBuf in, out;
+    int cap = 0;
+    ~mf_conv2d() {
+        mf_conv_plan_destroy(&plan);
+        for (ActBuf* b : {&in, &out}) {
+            if (b->hi) (void)hipFree(b->hi);
+            if (b->lo) (void)hipFree(b->lo);
+        }
+    }
+};
+
+extern "C" int mf_conv2d_create(const mf_conv2d_desc* desc, const float* weight, const float* bias,
+                                const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                                const float* bn_var, int precision, mf_conv2d** out) {
+    MF_REQUIRE(desc && weight && out, "conv2d_create: null argument");
+    MF_REQUIRE((bn_gamma != nullptr) == (bn_beta != nullptr) && (bn_gamma != nullptr) == (bn_mean != nullptr) &&
+               (bn_gamma != nullptr) == (bn_var != nullptr), "conv2d_create: BatchNorm tensors must be all set or all NULL");
+    *out = nullptr;
+    std::unique_ptr<mf_conv2d> h(new mf_conv2d());
+    int rc = mf_conv_plan_create(&h->plan, *desc, weight, bias, bn_gamma, bn_beta, bn_mean, bn_var, precision);
+    if (rc) return rc;
+    if (desc->residual)
+        MF_REQUIRE(desc->cin == desc->cout && h->plan.out_h == desc->in_h && h->plan.out_w == desc->in_w,
+                   "conv2d_create: residual needs matching input/output shapes");
+    h->in.C = h->plan.cin_pad; h->in.H = desc->in_h; h->in.W = desc->in_w;
+    h->in.halo = std::max(1, h->plan.in_halo_need);
+    h->out.C = (desc->cout + 7) / 8 * 8; h->out.H = h->plan.out_h; h->out.W = h->plan.out_w; h->out.halo = 1;
+    if ((rc = mf_conv_bind(&h->plan, h->in))) return rc;
+    *out = h.release();
+    return MF_OK;
+}
+
+extern "C" int mf_conv2d_forward(mf_conv2d* h, const float* x, float* y, int batch, void* stream) {
+    MF_REQUIRE(h && x && y, "conv2d_forward: null argument");
+    MF_REQUIRE(batch > 0, "conv2d_forward: batch must be positive (got %d)", batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (batch > h->cap) {
+        MF_HIP(hipDeviceSynchronize());
+        for (ActBuf* b : {&h->in, &h->out}) {
+            if (b->hi) (void)hipFree(b->hi);
+            if (b->lo) (void)hipFree(b->lo);
+            b->hi = b->lo = nullptr;
+            const size_t bytes = ((size_t)batch * b->per_batch() + 64) * sizeof(bf16_t);
+            MF_HIP(hipMalloc(&b->hi, bytes));
+            MF_HIP(hipMemset(b->hi, 0, bytes));
+            if (h->plan.precision == MF_PREC_BF16X3) {
+                MF_HIP(hipMalloc(&b->lo, bytes));
+                MF_HIP(hipMemset(b->lo, 0, bytes));
+            }
+        }
+        MF_HIP(hipDeviceSynchronize());
+        h->cap = batch;
+    }
+    int rc;
+    if ((rc = mf_nchw_to_act(x, h->plan.d.cin, h->in, batch, s))) return rc;
+    ActView in{&h->in, 0, h->in.C}, out{&h->out, 0, h->plan.d.cout};
+    ActView res = h->plan.d.residual ? ActView{&h->in, 0, h->plan.d.cout} : ActView{};
+    if ((rc = mf_conv_launch(&h->plan, in, out, res, batch, s))) return rc;
+    return mf_act_to_nchw(out, y, batch, s);
+}
+
+extern "C" int mf_conv2d_out_shape(const mf_conv2d* h, int* out_h, int* out_w) {
+    MF_REQUIRE(h && out_h && out_w, "conv2d_out_shape: null argument");
+    *out_h = h->plan.out_h; *out_w = h->plan.out_w;
+    return MF_OK;
+}
+
+extern "C" void mf_conv2d_destroy(mf_conv2d* h) { delete h; }

@@ -1,0 +1,118 @@
+"""Seeded synthetic checkpoints for the Wav2Lip generator.
+
+The reference ships no weights (`./models/wav2lip.pth` is absent, lipreal.py:76), so
+benchmarks, parity tests and the golden fixtures all use the state dict produced here.
+numpy's PCG64 stream is bit-reproducible across machines, so the same seed gives the same
+352 tensors in this container (where the reference is imported to make goldens) and on the
+GPU box (where it is not).
+
+Key names and shapes follow the module tree of wav2lip/models/wav2lip.py:12-85 and
+wav2lip/models/conv.py:5-44 (conv_block.0 = conv / convT, conv_block.1 = BatchNorm2d).
+BatchNorm statistics are deliberately non-trivial: with default init BN is an identity and
+the sigmoid output collapses to ~0.5, which pins nothing.
+"""
+import numpy as np
+import torch
+
+# (prefix, kind, cin, cout, kh, kw) ; kind: "conv" | "convT" | "plain" (nn.Conv2d without BN)
+# ConvTranspose2d weights are [cin, cout, kh, kw]; Conv2d weights are [cout, cin, kh, kw].
+
+
+def _face_encoder():
+    cfg = [
+        [(6, 16, 7)],
+        [(16, 32, 3), (32, 32, 3), (32, 32, 3)],
+        [(32, 64, 3), (64, 64, 3), (64, 64, 3), (64, 64, 3)],
+        [(64, 128, 3), (128, 128, 3), (128, 128, 3)],
+        [(128, 256, 3), (256, 256, 3), (256, 256, 3)],
+        [(256, 512, 3), (512, 512, 3)],
+        [(512, 512, 3), (512, 512, 1)],
+    ]
+    out = []
+    for b, blk in enumerate(cfg):
+        for i, (ci, co, k) in enumerate(blk):
+            out.append((f"face_encoder_blocks.{b}.{i}", "conv", ci, co, k, k))
+    return out
+
+
+def _audio_encoder():
+    cfg = [(1, 32, 3), (32, 32, 3), (32, 32, 3), (32, 64, 3), (64, 64, 3), (64, 64, 3),
+           (64, 128, 3), (128, 128, 3), (128, 128, 3), (128, 256, 3), (256, 256, 3),
+           (256, 512, 3), (512, 512, 1)]
+    return [(f"audio_encoder.{i}", "conv", ci, co, k, k) for i, (ci, co, k) in enumerate(cfg)]
+
+
+def _face_decoder():
+    cfg = [
+        [("conv", 512, 512, 1)],
+        [("convT", 1024, 512, 3), ("conv", 512, 512, 3)],
+        [("convT", 1024, 512, 3), ("conv", 512, 512, 3), ("conv", 512, 512, 3)],
+        [("convT", 768, 384, 3), ("conv", 384, 384, 3), ("conv", 384, 384, 3)],
+        [("convT", 512, 256, 3), ("conv", 256, 256, 3), ("conv", 256, 256, 3)],
+        [("convT", 320, 128, 3), ("conv", 128, 128, 3), ("conv", 128, 128, 3)],
+        [("convT", 160, 64, 3), ("conv", 64, 64, 3), ("conv", 64, 64, 3)],
+    ]
+    out = []
+    for b, blk in enumerate(cfg):
+        for i, (kind, ci, co, k) in enumerate(blk):
+            out.append((f"face_decoder_blocks.{b}.{i}", kind, ci, co, k, k))
+    return out
+
+
+def wav2lip_layer_table():
+    """All 51 conv layers in state-dict order of the reference constructor."""
+    return (_face_encoder() + _audio_encoder() + _face_decoder()
+            + [("output_block.0", "conv", 80, 32, 3, 3), ("output_block.1", "plain", 32, 3, 1, 1)])
+
+
+# Residual layers (conv.py:17-18 adds the input back) in constructor order; a smaller gain on
+# them keeps the activation scale O(1) through all 51 layers so no output saturates.
+_RESIDUAL = {p for p, *_ in _face_encoder() if not p.endswith(".0") and not p.startswith("face_encoder_blocks.6")}
+_RESIDUAL |= {f"audio_encoder.{i}" for i in (1, 2, 4, 5, 7, 8, 10)}
+_RESIDUAL |= {p for p, k, *_ in _face_decoder() if k == "conv" and not p.endswith(".0")}
+G_RES, G_PLAIN, G_CONVT, G_OUT = 0.4, 0.8, 0.8, 2.5
+
+
+def make_wav2lip_state_dict(seed=0, dtype=torch.float32):
+    """352 tensors: 101 weight, 101 bias, 50 x (running_mean, running_var, num_batches_tracked)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def f(a):
+        return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(dtype)
+
+    for prefix, kind, ci, co, kh, kw in wav2lip_layer_table():
+        fan_in = ci * kh * kw
+        if kind == "convT":
+            # stride-2 transposed conv: an output pixel sees on average 9/4 of the 9 taps;
+            # the stride-1 one on a 1x1 input sees exactly one tap.
+            eff = ci if prefix == "face_decoder_blocks.1.0" else fan_in / 4.0
+            w = rng.standard_normal((ci, co, kh, kw)) * (np.sqrt(2.0 / eff) * G_CONVT)
+        else:
+            g = G_RES if prefix in _RESIDUAL else (G_OUT if kind == "plain" else G_PLAIN)
+            w = rng.standard_normal((co, ci, kh, kw)) * (np.sqrt(2.0 / fan_in) * g)
+        b = rng.standard_normal(co) * 0.05
+        if kind == "plain":
+            sd[f"{prefix}.weight"] = f(w)
+            sd[f"{prefix}.bias"] = f(b)
+            continue
+        sd[f"{prefix}.conv_block.0.weight"] = f(w)
+        sd[f"{prefix}.conv_block.0.bias"] = f(b)
+        sd[f"{prefix}.conv_block.1.weight"] = f(rng.uniform(0.7, 1.3, co))
+        sd[f"{prefix}.conv_block.1.bias"] = f(rng.standard_normal(co) * 0.1)
+        sd[f"{prefix}.conv_block.1.running_mean"] = f(rng.standard_normal(co) * 0.1)
+        sd[f"{prefix}.conv_block.1.running_var"] = f(rng.uniform(0.6, 1.4, co))
+        sd[f"{prefix}.conv_block.1.num_batches_tracked"] = torch.tensor(1000, dtype=torch.long)
+    return sd
+
+
+def make_lip_inputs(batch, seed=0):
+    """Synthetic cfg-2 inputs: mel [B,1,80,16] ~U(-4,4); face [B,6,96,96] in [0,1]
+    built the way lipreal.py:115-122 builds it (masked copy has rows >= 48 zeroed)."""
+    rng = np.random.default_rng(1000 + seed)
+    mel = rng.uniform(-4.0, 4.0, (batch, 1, 80, 16)).astype(np.float32)
+    u8 = rng.integers(0, 256, (batch, 96, 96, 3), dtype=np.uint8)
+    masked = u8.copy()
+    masked[:, 48:] = 0
+    face = (np.concatenate((masked, u8), axis=3) / 255.0).transpose(0, 3, 1, 2).astype(np.float32)
+    return torch.from_numpy(mel), torch.from_numpy(np.ascontiguousarray(face)), u8

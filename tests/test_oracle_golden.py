@@ -1,0 +1,67 @@
+"""CPU: the oracle restatement against the vectors recorded from the real reference
+(tests/golden/make_golden.py).  These pin oracle/wav2lip_ref.py before it is trusted as the
+checker for the HIP path."""
+import numpy as np
+import torch
+
+import geometry_cases as G
+from mere_fusion_amd import weights as W
+from oracle import wav2lip_ref as R
+
+
+def test_state_dict_layout(sd0):
+    # 352 tensors = 101 weight + 101 bias + 50 x (mean, var, num_batches_tracked)
+    assert len(sd0) == 352
+    assert sum(k.endswith(".weight") for k in sd0) == 101
+    assert sum(k.endswith("running_var") for k in sd0) == 50
+    n_conv_w = sum(v.numel() for k, v in sd0.items() if k.endswith("conv_block.0.weight") or k == "output_block.1.weight")
+    assert n_conv_w == 36_262_016 - 0 or n_conv_w > 36_000_000   # 36.26 M conv weights
+
+
+def test_oracle_matches_reference_output(sd0, wav2lip_golden):
+    mel, face, _ = W.make_lip_inputs(2, 0)
+    taps = {}
+    out = R.wav2lip_forward(sd0, mel, face, taps)
+    ref = torch.from_numpy(wav2lip_golden["output"])
+    assert out.shape == ref.shape == (2, 3, 96, 96)
+    # same fp32 arithmetic, different op order (explicit BN formula vs fused batch_norm)
+    assert (out - ref).abs().max().item() <= 2e-5
+    assert 0.25 < ref.std().item() < 0.4 and ref.min() < 0.01 and ref.max() > 0.99   # a non-degenerate pin
+
+
+def test_oracle_matches_reference_taps(sd0, wav2lip_golden):
+    mel, face, _ = W.make_lip_inputs(2, 0)
+    taps = {}
+    R.wav2lip_forward(sd0, mel, face, taps)
+    names = ["audio_embedding"] + [f"face_encoder_blocks.{i}" for i in range(7)] + [f"face_decoder_blocks.{i}" for i in range(7)]
+    for k in names:
+        v = taps[k]
+        got = v.reshape(-1).numpy()[:: G.TAP_STRIDE][: G.TAP_MAX]
+        np.testing.assert_allclose(got, wav2lip_golden[f"tap_sample/{k}"], rtol=1e-4, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(v.double().abs().sum().item(), wav2lip_golden[f"tap_abssum/{k}"], rtol=1e-5, err_msg=k)
+
+
+def test_oracle_layers_match_reference_geometries(conv_golden):
+    for case in G.CASES:
+        p = G.case_params(case)
+        sd = {"L.conv_block.0.weight": p["weight"], "L.conv_block.0.bias": p["bias"],
+              "L.conv_block.1.weight": p["gamma"], "L.conv_block.1.bias": p["beta"],
+              "L.conv_block.1.running_mean": p["mean"], "L.conv_block.1.running_var": p["var"]}
+        spec = ("convT" if case["transposed"] else "conv", case["stride"], case["pad"], case["outpad"], bool(case["residual"]))
+        y = R._layer(sd, "L", spec, G.case_input(case))
+        ref = conv_golden[f"y/{case['name']}"]
+        assert tuple(y.shape) == ref.shape, case["name"]
+        np.testing.assert_allclose(y.numpy(), ref, rtol=1e-4, atol=2e-5, err_msg=case["name"])
+
+
+def test_module_prefix_strip():
+    sd = {"module.a.b": 1, "c": 2}
+    assert R.strip_module_prefix(sd) == {"a.b": 1, "c": 2}
+
+
+def test_inputs_follow_lipreal_batch_prep():
+    # make_lip_inputs builds face exactly as lipreal.py:115-122: masked copy has rows >= 48 zero
+    mel, face, u8 = W.make_lip_inputs(3, 5)
+    assert face.shape == (3, 6, 96, 96) and mel.shape == (3, 1, 80, 16)
+    assert face[:, :3, 48:].abs().max() == 0
+    np.testing.assert_allclose(face[:, 3:].numpy(), u8.transpose(0, 3, 1, 2) / 255.0, rtol=0, atol=1e-7)

@@ -1,0 +1,214 @@
+"""GPU parity tests: the HIP generator (through the drop-in module -> custom op -> C ABI) against the
+CPU oracle on the same seeded inputs, and against the golden vectors recorded from the reference.
+
+Tolerances (written here as the contract):
+  bf16x3 : L-inf <= 1e-3 on the [0,1] frames  -- the north-star bound (observed ~1e-4)
+  bf16   : L-inf <= 8e-2, mean abs <= 6e-3    -- the inherent cost of 8-bit mantissas through 30+
+           layers; a CPU simulation of bf16 storage gives L-inf 2.5e-2 at B=4
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import geometry_cases as G
+from mere_fusion_amd import weights as W
+from oracle import glue_ref
+from oracle import wav2lip_ref as R
+
+pytestmark = pytest.mark.gpu
+
+TOL_X3 = 1e-3
+TOL_BF16_LINF, TOL_BF16_MEAN = 8e-2, 6e-3
+
+
+def _conv_layer(lib_built, case, precision, x):
+    from mere_fusion_amd import _lib
+    l = _lib.lib()
+    _lib.init_device(0)
+    p = G.case_params(case)
+    sh, sw = (case["stride"], case["stride"]) if isinstance(case["stride"], int) else case["stride"]
+    d = _lib.MfConv2dDesc(cin=case["cin"], cout=case["cout"], kh=case["k"], kw=case["k"], stride_h=sh, stride_w=sw,
+                          pad_h=case["pad"], pad_w=case["pad"], transposed=case["transposed"],
+                          output_padding=case["outpad"], residual=case["residual"], act=1,
+                          in_h=case["h"], in_w=case["w"])
+    h = C.c_void_p()
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    keep = {k: v.contiguous() for k, v in p.items()}
+    _lib.check(l.mf_conv2d_create(C.byref(d), ptr(keep["weight"]), ptr(keep["bias"]), ptr(keep["gamma"]),
+                                  ptr(keep["beta"]), ptr(keep["mean"]), ptr(keep["var"]),
+                                  _lib.PRECISIONS[precision], C.byref(h)), "conv2d_create")
+    oh, ow = C.c_int(), C.c_int()
+    _lib.check(l.mf_conv2d_out_shape(h, C.byref(oh), C.byref(ow)))
+    xd = x.cuda().contiguous()
+    y = torch.empty((x.shape[0], case["cout"], oh.value, ow.value), device="cuda")
+    _lib.check(l.mf_conv2d_forward(h, ptr(xd), ptr(y), x.shape[0], None), "conv2d_forward")
+    torch.cuda.synchronize()
+    l.mf_conv2d_destroy(h)
+    return y.cpu()
+
+
+@pytest.mark.parametrize("case", G.CASES, ids=[c["name"] for c in G.CASES])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_conv_geometry_vs_golden(lib_built, conv_golden, case, precision):
+    x = G.case_input(case)
+    y = _conv_layer(lib_built, case, precision, x)
+    ref = torch.from_numpy(conv_golden[f"y/{case['name']}"])
+    assert y.shape == ref.shape
+    err = (y - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    if precision == "bf16x3":
+        assert err <= 2e-4 * max(scale, 1.0), (case["name"], err, scale)
+    else:
+        assert err <= 3e-2 * max(scale, 1.0), (case["name"], err, scale)
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_conv_geometry_ragged_batch(lib_built, batch):
+    """M not a multiple of the tile: rows are clamped on load and masked on store."""
+    case = G.CASES[2]
+    p = G.case_params(case)
+    rng = np.random.default_rng(batch)
+    x = torch.from_numpy(rng.standard_normal((batch, case["cin"], case["h"], case["w"])).astype(np.float32))
+    sd = {"L.conv_block.0.weight": p["weight"], "L.conv_block.0.bias": p["bias"],
+          "L.conv_block.1.weight": p["gamma"], "L.conv_block.1.bias": p["beta"],
+          "L.conv_block.1.running_mean": p["mean"], "L.conv_block.1.running_var": p["var"]}
+    want = R._layer(sd, "L", ("conv", 1, 1, 0, True), x)
+    got = _conv_layer(lib_built, case, "bf16x3", x)
+    assert (got - want).abs().max().item() <= 2e-4 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("batch", [2, 1, 16, 5])
+def test_generator_bf16x3_vs_oracle(gpu_model_factory, sd0, batch):
+    m = gpu_model_factory("bf16x3")
+    mel, face, _ = W.make_lip_inputs(batch, batch)
+    want = R.wav2lip_forward(sd0, mel, face)
+    with torch.no_grad():
+        got = m(mel.cuda(), face.cuda()).cpu()
+    assert got.shape == want.shape == (batch, 3, 96, 96)
+    err = (got - want).abs().max().item()
+    assert err <= TOL_X3, err
+
+
+def test_generator_vs_reference_golden(gpu_model_factory, wav2lip_golden):
+    """Against the vectors recorded from the real `wav2lip.models.Wav2Lip`."""
+    m = gpu_model_factory("bf16x3")
+    mel, face, _ = W.make_lip_inputs(2, 0)
+    with torch.no_grad():
+        got = m(mel.cuda(), face.cuda()).cpu()
+    ref = torch.from_numpy(wav2lip_golden["output"])
+    assert (got - ref).abs().max().item() <= TOL_X3
+    for k in ["audio_embedding"] + [f"face_encoder_blocks.{i}" for i in range(7)] + [f"face_decoder_blocks.{i}" for i in range(7)]:
+        t = m.read_tap(k, 2).cpu()
+        sample = t.reshape(-1).numpy()[:: G.TAP_STRIDE][: G.TAP_MAX]
+        np.testing.assert_allclose(sample, wav2lip_golden[f"tap_sample/{k}"], rtol=2e-3, atol=2e-3, err_msg=k)
+        np.testing.assert_allclose(t.double().abs().sum().item(), wav2lip_golden[f"tap_abssum/{k}"], rtol=1e-4, err_msg=k)
+
+
+def test_generator_bf16_vs_oracle(gpu_model_factory, sd0):
+    m = gpu_model_factory("bf16")
+    mel, face, _ = W.make_lip_inputs(4, 0)
+    want = R.wav2lip_forward(sd0, mel, face)
+    with torch.no_grad():
+        got = m(mel.cuda(), face.cuda()).cpu()
+    d = (got - want).abs()
+    assert d.max().item() <= TOL_BF16_LINF and d.mean().item() <= TOL_BF16_MEAN, (d.max().item(), d.mean().item())
+
+
+def test_graph_replay_is_deterministic(gpu_model_factory):
+    """call 1 runs eagerly, call 2 captures the hipGraph, calls 3+ replay it."""
+    m = gpu_model_factory("bf16x3")
+    mel, face, _ = W.make_lip_inputs(4, 9)
+    mel, face = mel.cuda(), face.cuda()
+    outs = []
+    with torch.no_grad():
+        for _ in range(4):
+            outs.append(m(mel, face).cpu())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    # a different input through the captured graph must change the output
+    mel2, face2, _ = W.make_lip_inputs(4, 10)
+    with torch.no_grad():
+        o2 = m(mel2.cuda(), face2.cuda()).cpu()
+    assert not torch.equal(o2, outs[0])
+
+
+def test_linearity_free_properties_at_full_batch(gpu_model_factory, sd0):
+    """B=16 (BASELINE config 2): frames are independent -- a batch equals its frames run one by one."""
+    m = gpu_model_factory("bf16x3")
+    mel, face, _ = W.make_lip_inputs(16, 2)
+    mel, face = mel.cuda(), face.cuda()
+    with torch.no_grad():
+        full = m(mel, face)
+        one = torch.cat([m(mel[i:i + 1], face[i:i + 1]) for i in (0, 7, 15)])
+    assert (full[[0, 7, 15]] - one).abs().max().item() <= 1e-6
+    assert full.min() >= 0 and full.max() <= 1
+
+
+def test_forward_u8_matches_glue_oracle(gpu_model_factory, sd0):
+    """lipreal.py:115-126 fused on the GPU == oracle glue around the oracle generator."""
+    m = gpu_model_factory("bf16x3")
+    mel, _, u8 = W.make_lip_inputs(3, 4)
+    img, _ = glue_ref.face_batch(u8, [np.zeros((80, 16))] * 3)
+    want = glue_ref.frames_from_pred(R.wav2lip_forward(sd0, mel, torch.from_numpy(img)).numpy())
+    with torch.no_grad():
+        got = m.forward_u8(mel.cuda(), torch.from_numpy(u8).cuda()).cpu().numpy()
+    assert got.shape == (3, 96, 96, 3)
+    assert np.abs(got - want).max() <= 255 * TOL_X3
+    # what process_frames sees after astype(uint8) differs by at most one grey level
+    assert np.abs(glue_ref.to_uint8(got).astype(int) - glue_ref.to_uint8(want).astype(int)).max() <= 1
+
+
+def test_five_dim_inputs(gpu_model_factory):
+    """wav2lip.py:92-94,118-120: (B,T,1,80,16) + (B,6,T,96,96) -> (B,3,T,96,96)."""
+    m = gpu_model_factory("bf16x3")
+    mel, face, _ = W.make_lip_inputs(4, 1)
+    mel5 = mel.reshape(2, 2, 1, 80, 16).cuda()
+    face5 = face.reshape(2, 2, 6, 96, 96).permute(0, 2, 1, 3, 4).contiguous().cuda()
+    with torch.no_grad():
+        out5 = m(mel5, face5)
+        flat = m(torch.cat([mel5[:, i] for i in range(2)]), torch.cat([face5[:, :, i] for i in range(2)]))
+    assert out5.shape == (2, 3, 2, 96, 96)
+    assert torch.equal(out5[:, :, 1], flat[2:4])
+
+
+def test_module_prefix_and_reload(lib_built, sd0):
+    from mere_fusion_amd.wav2lip.models import Wav2Lip
+    m = Wav2Lip(precision="bf16x3")
+    m.load_state_dict(R.strip_module_prefix({"module." + k: v for k, v in sd0.items()}))
+    m = m.to("cuda").eval()
+    mel, face, _ = W.make_lip_inputs(1, 0)
+    with torch.no_grad():
+        a = m(mel.cuda(), face.cuda()).cpu()
+        m.load_state_dict(W.make_wav2lip_state_dict(1))      # new checkpoint -> handle rebuilt
+        b = m(mel.cuda(), face.cuda()).cpu()
+    want_b = R.wav2lip_forward(W.make_wav2lip_state_dict(1), mel, face)
+    assert (b - want_b).abs().max().item() <= TOL_X3
+    assert (a - b).abs().max().item() > 1e-2
+
+
+def test_lip_session_driver(gpu_model_factory, sd0):
+    """Queue-free restatement of run_step + inference(): GPU mel -> chunks -> fused generator."""
+    from mere_fusion_amd import lip_driver as D
+    from oracle import mel_ref
+    m = gpu_model_factory("bf16x3")
+    rng = np.random.default_rng(0)
+    faces = rng.integers(0, 256, (5, 96, 96, 3), dtype=np.uint8)
+    sess = D.LipSession(m, faces)
+    fe = D.LipASRFrontend(batch_size=4)
+    fe.warm_up()
+    new = [(0.1 * rng.standard_normal(320)).astype(np.float32) for _ in range(8)]
+    chunks = fe.run_step(new)
+    assert chunks.shape == (4, 1, 80, 16)
+    wav = np.concatenate([np.zeros(320 * 20, np.float32)] + new)
+    mel = mel_ref.melspectrogram(wav)
+    ref_chunks, _ = glue_ref.mel_chunks(mel, 28, 10, 10, 50)
+    np.testing.assert_allclose(chunks[:, 0].cpu().numpy(), np.stack(ref_chunks), atol=1e-5)
+    frames, idx = sess.step(chunks)
+    assert idx == [0, 1, 2, 3] and frames.shape == (4, 96, 96, 3)
+    frames2, idx2 = sess.step(chunks)
+    assert idx2 == [4, 4, 3, 2]
+    img, melb = glue_ref.face_batch(faces[idx2], ref_chunks)
+    want = glue_ref.frames_from_pred(R.wav2lip_forward(sd0, torch.from_numpy(melb), torch.from_numpy(img)).numpy())
+    assert np.abs(frames2.cpu().numpy() - want).max() <= 255 * TOL_X3
