@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void k_melspec(const float* __restrict__ wav, 
 extern "C" int mf_melspec_frames(int n) { return n < 0 ? 0 : 1 + n / HOP; }
 
 extern "C" int mf_melspec(const float* wav, int n, float* out, int pad_mode, void* stream) {
-    MF_REQUIRE(wav && out, "melspec: null argument");
     MF_REQUIRE(n > 0, "melspec: empty signal (n=%d)", n);
+    MF_REQUIRE(wav && out, "melspec: null argument");
     MF_REQUIRE(pad_mode == 0 || pad_mode == 1, "melspec: pad_mode must be 0 (zeros) or 1 (reflect)");
     MF_REQUIRE(pad_mode == 0 || n > N_FFT / 2, "melspec: reflect padding needs more than %d samples", N_FFT / 2);
     int dev = 0;

@@ -37,7 +37,7 @@ def test_errors_without_device(lib_built):
     # null handle -> MF_ERR_INVALID, never a crash
     assert l.mf_wav2lip_forward(None, None, None, None, 1, None) == -1
     assert b"null" in l.mf_last_error()
-    assert l.mf_melspec(None, 10, None, 0, None) == -1
+    assert l.mf_melspec(None, 10, None, 0, None) == -1 and l.mf_melspec(None, 0, None, 0, None) == -1
 
 
 def test_product_refuses_cpu_tensors(lib_built, sd0):
