@@ -82,6 +82,18 @@ int mf_wav2lip_forward_u8(mf_wav2lip* h, const float* mel, const uint8_t* faces_
  * parity tests.  tap: "audio_embedding", "face_encoder_blocks.N", "face_decoder_blocks.N". */
 int mf_wav2lip_read_tap(mf_wav2lip* h, const char* tap, float* dst, int batch, void* stream);
 
+/* Measurement seam for bench.py (roofline): the generator's kernel launches in execution order.
+ * layer_info: name = the reference module path ("face_decoder_blocks.4.1"), kernel = the HIP kernel
+ * the launch uses at this batch size (as rocprofv3 names it, template arguments without spaces),
+ * flops = algorithmic FLOPs of that launch (2 x conv MACs; 0 for the layout/head kernels).
+ * profile: runs `iters` forwards WITHOUT the hipGraph, bracketing every launch with hipEvents on
+ * the stream it is launched on, and returns the mean milliseconds per launch. */
+int mf_wav2lip_num_layers(const mf_wav2lip* h);
+int mf_wav2lip_layer_info(const mf_wav2lip* h, int index, int batch, char* name, int name_cap,
+                          char* kernel, int kernel_cap, double* flops);
+int mf_wav2lip_profile(mf_wav2lip* h, const float* mel, const float* face, float* out, int batch,
+                       int iters, float* ms_per_layer, void* stream);
+
 void mf_wav2lip_destroy(mf_wav2lip* h);
 
 /* ---- single fused convolution layer (building block, also the per-geometry test seam) ---- */
@@ -107,6 +119,9 @@ int mf_conv2d_create(const mf_conv2d_desc* desc, const float* weight, const floa
 /* x: device fp32 NCHW [B,cin,in_h,in_w]; y: device fp32 NCHW [B,cout,out_h,out_w]. */
 int mf_conv2d_forward(mf_conv2d* h, const float* x, float* y, int batch, void* stream);
 int mf_conv2d_out_shape(const mf_conv2d* h, int* out_h, int* out_w);
+/* Measurement seam: mean milliseconds of the convolution launch alone (layout passes excluded) over
+ * `iters` repeats on the buffers of the last mf_conv2d_forward, bracketed by hipEvents on `stream`. */
+int mf_conv2d_time(mf_conv2d* h, int batch, int iters, float* ms, void* stream);
 void mf_conv2d_destroy(mf_conv2d* h);
 
 /* ---- Wav2Lip mel-spectrogram (H1) -------------------------------------------------------- */

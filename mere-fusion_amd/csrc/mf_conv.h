@@ -4,7 +4,7 @@
 //   activations : padded NHWC  [B][H+2*halo][W+2*halo][C], bf16; the halo ring is zero and is
 //                 never written, so the kernel's gather needs no bounds predicates.  In
 //                 MF_PREC_BF16X3 every tensor is a (hi, lo) pair of such planes.
-//   weights     : BatchNorm-folded, packed per phase as [K/32][Npad][32] bf16 (hi, lo), where the
+//   weights     : BatchNorm-folded, packed per phase as [K/BK][Npad][BK] bf16 (hi, lo), where the
 //                 K axis enumerates 8-channel groups tap-major: g = tap*(Cin/8) + c/8.
 //   goff        : int32 per K group = element offset of that (tap, channel-group) relative to the
 //                 output pixel's input anchor; staged in LDS by every workgroup.
@@ -32,10 +32,11 @@ struct ActView {
 
 struct ConvPhase {
     int goff_begin;   // first entry of this phase in the goff table
-    int ngroups;      // K groups incl. padding = KT*4
-    int KT;           // number of 32-deep K tiles
+    int ngroups;      // K groups incl. padding = KT*(BK/8)
+    int KT;           // number of BK-deep K tiles
     int64_t w_off;    // element offset of this phase's packed weights
     int64_t y_off;    // element offset of this phase's first output pixel (relative to y base)
+    int64_t ws_off;   // same, in the unpadded fp32 split-K workspace
 };
 
 struct ConvArgs {
@@ -53,8 +54,30 @@ struct ConvArgs {
     int act;                  // 0 none, 1 relu, 2 sigmoid
     int tiles_m, tiles_n;
     int goff_total;
+    float* ws;                // split-K fp32 partials [split][B][Ho][Wo][N], or null
+    int64_t ws_split, wsb; int wsi, wsj;
     ConvPhase ph[MF_MAX_PHASE];
 };
+
+// ---- 3x3 stride-1 halo-tile kernel (mf_conv_halo.hip) ---------------------------------------------
+struct HaloArgs {
+    const bf16_t* x_hi; const bf16_t* x_lo;     // input view base (channel offset applied)
+    const bf16_t* w_hi; const bf16_t* w_lo;     // packed [slice][tap][Npad][CK]
+    const float* bias;
+    const bf16_t* r_hi; const bf16_t* r_lo;
+    bf16_t* y_hi; bf16_t* y_lo;                 // interior origin of the output view
+    int batch, H, W, N, Npad, n_slices;
+    int in_halo, in_hp, in_wp, x_ld;            // input buffer geometry (padded rows/cols, pixel stride)
+    int64_t xb;
+    int64_t yb; int yi, yj;
+    int64_t rb; int ri, rj;
+    int act;
+    int res_from_halo;                          // residual == the layer input: taken from the LDS halo image
+    int patches_x, patches_per_img, n_patches, tiles_n;   // filled by mf_halo_launch
+};
+struct HaloTile { int ph, bn, wgm, wgn; };
+HaloTile mf_halo_pick_tile(int H, int W, int N, int batch);
+int mf_halo_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s);
 
 struct ConvPlan {
     mf_conv2d_desc d{};
@@ -64,11 +87,16 @@ struct ConvPlan {
     int Hq = 0, Wq = 0;   // quotient grid (== output grid for Conv2d, input grid for stride-2 ConvT)
     int nphase = 1;
     int Npad = 0;
+    int BK = 64;          // contraction depth of one LDS tile: 64 (bf16) or 32 (bf16x3)
     // device
     bf16_t* w_hi = nullptr;
     bf16_t* w_lo = nullptr;
     float* bias = nullptr;
     int* goff = nullptr;
+    bool halo = false;    // 3x3 s1 p1 on a >= 16x16 map: LDS halo-tile kernel, weights packed [slice][tap][Npad][CK]
+    int n_slices = 0;
+    float* ws = nullptr;  // split-K workspace, grown on the first (eager) launch that needs it
+    int64_t ws_cap = 0;
     // host-side phase description, independent of the buffers the layer is later bound to
     struct Tap { int dy, dx; };               // input displacement in pixels relative to anchor
     std::vector<std::vector<Tap>> phase_taps; // per phase
@@ -92,6 +120,14 @@ void mf_conv_plan_destroy(ConvPlan* p);
 // row stride = Wp*C).  Must be called once before launch; rebinding to another geometry is allowed.
 int mf_conv_bind(ConvPlan* p, const ActBuf& in);
 
+struct ConvTile { int bm, bn, wgm, wgn, nsplit; };
+// rocprofv3-style name of the kernel mf_conv_launch will use at this batch size
+void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap);
+// Workgroup tile the launch will use for this batch size (kernel = k_conv_igemm<bm,bn,wgm,wgn,x3>).
+ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch);
+// Algorithmic FLOPs of the layer (2 x MACs of the convolution itself; BN/ReLU/residual excluded).
+double mf_conv_flops(const ConvPlan* p, int batch);
+
 // Enqueues the layer.  res may have buf == nullptr.
-int mf_conv_launch(const ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
+int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
                    int batch, hipStream_t stream);

@@ -12,9 +12,14 @@
 // 4-lane group.  A stride-2 ConvTranspose2d runs as 4 sub-pixel phases (blockIdx.z), each an
 // ordinary gather with 1/2/2/4 taps, so no zero-stuffed input is ever multiplied.
 //
-// One workgroup = 256 threads = 4 wave64; tile BM pixels x BN channels x 32 deep, LDS
-// double-buffered, global->register->LDS staging issued one K tile ahead of the MFMAs.
-// The padded-halo activation layout means no load in the main loop is predicated.
+// One workgroup = 256 threads = 4 wave64; tile BM pixels x BN channels x BK deep (BK = 64 in bf16,
+// 32 in bf16x3 so both modes keep the same LDS footprint).  Both operand tiles travel
+// global -> LDS by DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no staging VGPRs and
+// no ds_write pass) into a 2-stage ring: the DMA of tile k+1 is in flight while the MFMAs of tile k
+// run.  The DMA image is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE
+// address and again on the ds_read side.  The padded-halo activation layout means no load in the
+// main loop is predicated.  Layers with few output pixels and a long contraction are split along K
+// over blockIdx.y; their fp32 partial tiles are combined by k_splitk_epilogue.
 #include "mf_conv.h"
 #include <cmath>
 #include <cstring>
@@ -22,12 +27,17 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-// [rows][32] bf16 tile, 64-byte rows, 16-byte slots XOR-swizzled so that every 16-lane service
-// group of ds_read_b128 (rows l&15, slot l>>4) touches 16 distinct slots of the 256-byte bank row.
+// Swizzled LDS byte offset of the 16-byte slot (row, kg) of a [rows][BK] bf16 tile.  The XOR terms
+// make every 16-lane service group of ds_read_b128 (rows l&15 at one or two kg values) hit 16
+// distinct 16-byte slots of the 256-byte bank row (derivation in DESIGN.md).
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+    return BK == 32 ? (((row >> 2) & 1) << 1) : (((row >> 1) & 3) << 1);
+}
+template <int BK>
 __device__ __forceinline__ int tile_off(int row, int kg) {
-    return row * 64 + ((kg ^ ((0 - (row >> 2)) & 3)) << 4);
+    return row * (BK * 2) + ((kg ^ swz<BK>(row)) << 4);
 }
 
 __device__ __forceinline__ float bf2f(uint32_t h16) { return __uint_as_float(h16 << 16); }
@@ -37,23 +47,66 @@ __device__ __forceinline__ uint32_t f2bf(float f) {
     return u >> 16;
 }
 
+// 64 lanes x 16 bytes, global (per-lane address) -> LDS (wave-uniform base + lane*16)
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void epilogue_store(const ConvArgs& a, const float (&v0)[4], int64_t yo, int64_t ro,
+                                               int c, bool x3) {
+    float v[4] = {v0[0], v0[1], v0[2], v0[3]};
+    if (a.r_hi) {
+        const uint2 rh = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
+        v[0] += bf2f(rh.x & 0xffffu); v[1] += bf2f(rh.x >> 16);
+        v[2] += bf2f(rh.y & 0xffffu); v[3] += bf2f(rh.y >> 16);
+        if (x3) {
+            const uint2 rl = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
+            v[0] += bf2f(rl.x & 0xffffu); v[1] += bf2f(rl.x >> 16);
+            v[2] += bf2f(rl.y & 0xffffu); v[3] += bf2f(rl.y >> 16);
+        }
+    }
+    if (a.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (a.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+    }
+    uint32_t h[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
+    *reinterpret_cast<uint2*>(a.y_hi + yo + c) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    if (x3) {
+        uint32_t l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
+        *reinterpret_cast<uint2*>(a.y_lo + yo + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    }
+}
+
 template <int BM, int BN, int WGM, int WGN, bool X3>
 __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    constexpr int BK = X3 ? 32 : 64;
+    constexpr int KG = BK / 8;            // 16-byte groups per tile row
+    constexpr int ROWB = BK * 2;          // bytes per tile row
+    constexpr int RPC = 1024 / ROWB;      // tile rows per 1-KiB DMA chunk
     constexpr int NP = X3 ? 2 : 1;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int FM = WTM / 16, FN = WTN / 16;
     static_assert(FM >= 1 && FN >= 1, "wave tile must hold a 16x16 fragment");
-    constexpr int P_BYTES = BM * 64, W_BYTES = BN * 64;
+    constexpr int P_BYTES = BM * ROWB, W_BYTES = BN * ROWB;
     constexpr int PLANE = P_BYTES + W_BYTES;
     constexpr int STAGE = PLANE * NP;
-    constexpr int NPP = (BM * 4 + 255) / 256;   // 16-byte pieces of the pixel tile per thread
-    constexpr int NWP = (BN * 4 + 255) / 256;   // ... of the weight tile
+    constexpr int PCH = (BM + RPC - 1) / RPC, WCH = (BN + RPC - 1) / RPC;   // DMA chunks per tile
+    constexpr int NPC = (PCH + 3) / 4, NWC = (WCH + 3) / 4;                  // ... per wave
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* s_goff = reinterpret_cast<int*>(smem + 2 * STAGE);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ConvPhase ph = a.ph[blockIdx.z];
 
     // XCD-aware tile order: the dispatcher round-robins blockIdx over the 8 XCDs; give each XCD a
@@ -65,76 +118,58 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     const int tm = t / a.tiles_n, tn = t - tm * a.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
+    // split-K slice of this workgroup
+    const int kt_begin = (int)((int64_t)ph.KT * blockIdx.y / gridDim.y);
+    const int kt_end = (int)((int64_t)ph.KT * (blockIdx.y + 1) / gridDim.y);
+
     for (int i = tid; i < ph.ngroups; i += 256) s_goff[i] = a.goff[ph.goff_begin + i];
 
-    // ---- staging assignment --------------------------------------------------------------
-    const bf16_t* xp_hi[NPP];
-    const bf16_t* xp_lo[NPP];
-    int p_lds[NPP];
-    bool p_on[NPP];
+    // ---- DMA assignment: wave w moves chunks w, w+4, ... of each tile -------------------------
+    const bf16_t* xp[NPC];
+    int p_kg[NPC];
+    const int64_t x_delta = X3 ? (a.x_lo - a.x_hi) : 0;
 #pragma unroll
-    for (int i = 0; i < NPP; ++i) {
-        const int p = tid + 256 * i;
-        const int row = p >> 2, kg = p & 3;
-        p_on[i] = (BM * 4 % 256 == 0) || (p < BM * 4);
+    for (int i = 0; i < NPC; ++i) {
+        const int row = (wave + 4 * i) * RPC + lane / KG;
+        p_kg[i] = (lane % KG) ^ swz<BK>(row);
         int m = m0 + row;
         m = m < a.M ? m : a.M - 1;
         const int b = m / a.HqWq;
         const int rem = m - b * a.HqWq;
         const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
-        const int64_t base = (int64_t)b * a.xb + (int64_t)qi * a.xi + (int64_t)qj * a.xj;
-        xp_hi[i] = a.x_hi + base;
-        xp_lo[i] = X3 ? a.x_lo + base : nullptr;
-        p_lds[i] = tile_off(row, kg);
+        xp[i] = a.x_hi + ((int64_t)b * a.xb + (int64_t)qi * a.xi + (int64_t)qj * a.xj);
     }
-    const bf16_t* wp_hi[NWP];
-    const bf16_t* wp_lo[NWP];
-    int w_lds[NWP];
-    bool w_on[NWP];
+    const bf16_t* wp[NWC];
+    const int64_t w_delta = X3 ? (a.w_lo - a.w_hi) : 0;
 #pragma unroll
-    for (int i = 0; i < NWP; ++i) {
-        const int p = tid + 256 * i;
-        const int row = p >> 2, kg = p & 3;
-        w_on[i] = (BN * 4 % 256 == 0) || (p < BN * 4);
+    for (int i = 0; i < NWC; ++i) {
+        const int row = (wave + 4 * i) * RPC + lane / KG;
+        const int kg = (lane % KG) ^ swz<BK>(row);
         int n = n0 + row;
         n = n < a.Npad ? n : a.Npad - 1;
-        const int64_t off = ph.w_off + (int64_t)n * 32 + kg * 8;
-        wp_hi[i] = a.w_hi + off;
-        wp_lo[i] = X3 ? a.w_lo + off : nullptr;
-        w_lds[i] = P_BYTES + tile_off(row, kg);
+        wp[i] = a.w_hi + ph.w_off + (int64_t)n * BK + kg * 8;
     }
-    const int kg_me = tid & 3;
-    const int64_t w_kstep = (int64_t)a.Npad * 32;
+    const int64_t w_kstep = (int64_t)a.Npad * BK;
 
-    u32x4 rp[NP][NPP], rw[NP][NWP];
-
-    auto gload = [&](int kt) __attribute__((always_inline)) {
-        const int go = s_goff[kt * 4 + kg_me];
-#pragma unroll
-        for (int i = 0; i < NPP; ++i) {
-            if (p_on[i]) {
-                rp[0][i] = *reinterpret_cast<const u32x4*>(xp_hi[i] + go);
-                if (X3) rp[NP - 1][i] = *reinterpret_cast<const u32x4*>(xp_lo[i] + go);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NWP; ++i) {
-            if (w_on[i]) {
-                rw[0][i] = *reinterpret_cast<const u32x4*>(wp_hi[i] + kt * w_kstep);
-                if (X3) rw[NP - 1][i] = *reinterpret_cast<const u32x4*>(wp_lo[i] + kt * w_kstep);
-            }
-        }
-    };
-    auto swrite = [&](int s) __attribute__((always_inline)) {
+    auto stage = [&](int kt, int s) __attribute__((always_inline)) {
         char* base = smem + s * STAGE;
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
+        for (int i = 0; i < NPC; ++i) {
+            const int c = wave + 4 * i;
+            if (PCH % 4 == 0 || c < PCH) {
+                const bf16_t* src = xp[i] + s_goff[kt * KG + p_kg[i]];
+                glds16(src, base + c * 1024);
+                if (X3) glds16(src + x_delta, base + PLANE + c * 1024);
+            }
+        }
 #pragma unroll
-            for (int i = 0; i < NPP; ++i)
-                if (p_on[i]) *reinterpret_cast<u32x4*>(base + pl * PLANE + p_lds[i]) = rp[pl][i];
-#pragma unroll
-            for (int i = 0; i < NWP; ++i)
-                if (w_on[i]) *reinterpret_cast<u32x4*>(base + pl * PLANE + w_lds[i]) = rw[pl][i];
+        for (int i = 0; i < NWC; ++i) {
+            const int c = wave + 4 * i;
+            if (WCH % 4 == 0 || c < WCH) {
+                const bf16_t* src = wp[i] + kt * w_kstep;
+                glds16(src, base + P_BYTES + c * 1024);
+                if (X3) glds16(src + w_delta, base + PLANE + P_BYTES + c * 1024);
+            }
         }
     };
 
@@ -142,11 +177,6 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     const int wave_m = wave % WGM, wave_n = wave / WGM;
     const int pm0 = wave_m * WTM, cn0 = wave_n * WTN;
     const int fr = lane & 15, fk = lane >> 4;
-    int p_rd[FM], w_rd[FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) p_rd[i] = tile_off(pm0 + i * 16 + fr, fk);
-#pragma unroll
-    for (int i = 0; i < FN; ++i) w_rd[i] = P_BYTES + tile_off(cn0 + i * 16 + fr, fk);
 
     f32x4 acc[FN][FM];
 #pragma unroll
@@ -156,42 +186,45 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
 
     auto compute = [&](int s) __attribute__((always_inline)) {
         const char* base = smem + s * STAGE;
-        bf16x8 pf[NP][FM], wf[NP][FN];
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 pf[NP][FM], wf[NP][FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
-                pf[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + p_rd[i]);
+            for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    pf[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + tile_off<BK>(pm0 + i * 16 + fr, kk * 4 + fk));
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+                    wf[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + P_BYTES + tile_off<BK>(cn0 + i * 16 + fr, kk * 4 + fk));
+            }
 #pragma unroll
             for (int i = 0; i < FN; ++i)
-                wf[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + w_rd[i]);
-        }
 #pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j) {
-                if (X3) {
-                    // small cross terms first, the dominant hi*hi product last
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[NP - 1][i], pf[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], pf[NP - 1][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FM; ++j) {
+                    if (X3) {
+                        // small cross terms first, the dominant hi*hi product last
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[NP - 1][i], pf[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], pf[NP - 1][j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], pf[0][j], acc[i][j], 0, 0, 0);
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], pf[0][j], acc[i][j], 0, 0, 0);
-            }
+        }
     };
 
     __syncthreads();   // s_goff visible
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    for (int kt = 0; kt < ph.KT; ++kt) {
-        const bool more = kt + 1 < ph.KT;
-        if (more) gload(kt + 1);
-        compute(kt & 1);
-        if (more) swrite((kt + 1) & 1);
-        __syncthreads();
+    if (kt_begin < kt_end) {
+        stage(kt_begin, 0);
+        __syncthreads();   // drains the DMA (vmcnt) and publishes stage 0
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int s = (kt - kt_begin) & 1;
+            if (kt + 1 < kt_end) stage(kt + 1, s ^ 1);   // DMA of the next tile flies under the MFMAs
+            compute(s);
+            __syncthreads();
+        }
     }
 
-    // ---- epilogue: + bias, + residual, activation, bf16 (hi, lo) store ---------------------
+    // ---- epilogue ---------------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
         const int m = m0 + pm0 + j * 16 + fr;
@@ -199,6 +232,18 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
         const int b = m / a.HqWq;
         const int rem = m - b * a.HqWq;
         const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+        if (a.ws) {
+            // split-K: fp32 partial tile, combined by k_splitk_epilogue
+            float* wo = a.ws + (int64_t)blockIdx.y * a.ws_split + (int64_t)b * a.wsb + (int64_t)qi * a.wsi +
+                        (int64_t)qj * a.wsj + ph.ws_off;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int c = n0 + cn0 + i * 16 + fk * 4;
+                if (c >= a.N) continue;
+                *reinterpret_cast<float4*>(wo + c) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+            continue;
+        }
         const int64_t yo = (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
         const int64_t ro = (int64_t)b * a.rb + (int64_t)qi * a.ri + (int64_t)qj * a.rj;
 #pragma unroll
@@ -206,36 +251,34 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
             const int c = n0 + cn0 + i * 16 + fk * 4;
             if (c >= a.N) continue;
             const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
-            float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-            if (a.r_hi) {
-                const uint2 rh = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
-                v[0] += bf2f(rh.x & 0xffffu); v[1] += bf2f(rh.x >> 16);
-                v[2] += bf2f(rh.y & 0xffffu); v[3] += bf2f(rh.y >> 16);
-                if (X3) {
-                    const uint2 rl = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
-                    v[0] += bf2f(rl.x & 0xffffu); v[1] += bf2f(rl.x >> 16);
-                    v[2] += bf2f(rl.y & 0xffffu); v[3] += bf2f(rl.y >> 16);
-                }
-            }
-            if (a.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (a.act == 2) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
-            }
-            uint32_t h[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
-            *reinterpret_cast<uint2*>(a.y_hi + yo + c) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-            if (X3) {
-                uint32_t l[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
-                *reinterpret_cast<uint2*>(a.y_lo + yo + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
-            }
+            const float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+            epilogue_store(a, v, yo, ro, c, X3);
         }
     }
+}
+
+// Combines the split-K partial tiles: one thread per (output pixel, 4 channels).
+// ws layout: [split][B][Ho][Wo][N] fp32 (unpadded); output / residual are padded NHWC planes.
+__global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int nsplit, int Ho, int Wo, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int nq = a.N >> 2;
+    const int c = (int)(idx % nq) * 4;
+    int64_t p = idx / nq;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const float* w = a.ws + (((int64_t)b * Ho + oy) * Wo + ox) * a.N + c;
+    float4 s = *reinterpret_cast<const float4*>(a.bias + c);
+    for (int k = 0; k < nsplit; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)k * a.ws_split);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float v[4] = {s.x, s.y, s.z, s.w};
+    // y/r strides of the UNIT output grid are passed in (yi, yj) / (ri, rj) by the launcher
+    const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
+    const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)ox * a.rj;
+    epilogue_store(a, v, yo, ro, c, a.y_lo != nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -243,10 +286,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
 // ------------------------------------------------------------------------------------------
 namespace {
 
-struct TileCfg { int bm, bn; };
-
 template <int BM, int BN, int WGM, int WGN, bool X3>
-int launch_cfg(const ConvArgs& a, int nphase, size_t lds, hipStream_t s) {
+int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStream_t s) {
     static bool attr_done = false;
     auto kern = k_conv_igemm<BM, BN, WGM, WGN, X3>;
     if (!attr_done) {
@@ -254,18 +295,18 @@ int launch_cfg(const ConvArgs& a, int nphase, size_t lds, hipStream_t s) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    dim3 grid(a.tiles_m * a.tiles_n, 1, nphase);
+    constexpr int BK = X3 ? 32 : 64;
+    const size_t lds = 2 * (size_t)(BM + BN) * BK * 2 * (X3 ? 2 : 1) + (size_t)goff_max * 4;
+    dim3 grid(a.tiles_m * a.tiles_n, nsplit, nphase);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
 
 template <int BM, int BN, int WGM, int WGN>
-int launch_prec(const ConvArgs& a, int nphase, int goff_max, bool x3, hipStream_t s) {
-    const size_t stage = (size_t)(BM + BN) * 64 * (x3 ? 2 : 1);
-    const size_t lds = 2 * stage + (size_t)goff_max * 4;
-    return x3 ? launch_cfg<BM, BN, WGM, WGN, true>(a, nphase, lds, s)
-              : launch_cfg<BM, BN, WGM, WGN, false>(a, nphase, lds, s);
+int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3, hipStream_t s) {
+    return x3 ? launch_cfg<BM, BN, WGM, WGN, true>(a, nphase, nsplit, goff_max, s)
+              : launch_cfg<BM, BN, WGM, WGN, false>(a, nphase, nsplit, goff_max, s);
 }
 
 int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -361,19 +402,50 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
         }
     }
 
-    // ---- pack: per phase [KT][Npad][32], K groups tap-major ----------------------------------
+    const int BK = precision == MF_PREC_BF16X3 ? 32 : 64, KG = BK / 8;
+    p->BK = BK;
+    p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
+              d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16;
+    if (p->halo) {
+        // ---- pack for the halo-tile kernel: [slice][tap][Npad][CK], channels past cin are zero --------
+        p->n_slices = cdiv(d.cin, BK);
+        p->goff_total = 0;
+        const int64_t total = (int64_t)p->n_slices * 9 * p->Npad * BK;
+        std::vector<bf16_t> hi(total, 0), lo(total, 0);
+        for (int c = 0; c < d.cin; ++c)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int n = 0; n < d.cout; ++n) {
+                    const float wf = weight[(((int64_t)n * d.cin + c) * 3 + tap / 3) * 3 + tap % 3] * scale[n];
+                    const int64_t idx = (((int64_t)(c / BK) * 9 + tap) * p->Npad + n) * BK + c % BK;
+                    const bf16_t h = mf_f2bf(wf);
+                    hi[idx] = h;
+                    lo[idx] = mf_f2bf(wf - mf_bf2f(h));
+                }
+        MF_HIP(hipMalloc(&p->w_hi, total * sizeof(bf16_t)));
+        MF_HIP(hipMemcpy(p->w_hi, hi.data(), total * sizeof(bf16_t), hipMemcpyHostToDevice));
+        if (precision == MF_PREC_BF16X3) {
+            MF_HIP(hipMalloc(&p->w_lo, total * sizeof(bf16_t)));
+            MF_HIP(hipMemcpy(p->w_lo, lo.data(), total * sizeof(bf16_t), hipMemcpyHostToDevice));
+        }
+        MF_HIP(hipMalloc(&p->bias, p->Npad * sizeof(float)));
+        MF_HIP(hipMemcpy(p->bias, fbias.data(), p->Npad * sizeof(float), hipMemcpyHostToDevice));
+        p->bound_in_ld = p->bound_in_wp = -1;
+        return MF_OK;
+    }
+    // ---- pack: per phase [KT][Npad][BK], K groups tap-major (BK = 64 bf16, 32 bf16x3) ----------
     int64_t total = 0;
     int goff_total = 0;
     for (int ph = 0; ph < p->nphase; ++ph) {
         const int ngroups = (int)p->phase_taps[ph].size() * cpg;
-        const int KT = cdiv(ngroups, 4);
+        const int KT = cdiv(ngroups, KG);
         p->ph[ph].goff_begin = goff_total;
-        p->ph[ph].ngroups = KT * 4;
+        p->ph[ph].ngroups = KT * KG;
         p->ph[ph].KT = KT;
         p->ph[ph].w_off = total;
         p->ph[ph].y_off = 0;
-        total += (int64_t)KT * p->Npad * 32;
-        goff_total += KT * 4;
+        p->ph[ph].ws_off = 0;
+        total += (int64_t)KT * p->Npad * BK;
+        goff_total += KT * KG;
     }
     p->goff_total = goff_total;
     std::vector<bf16_t> hi(total, 0), lo(total, 0);
@@ -392,13 +464,13 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
             }
             for (int c = 0; c < d.cin; ++c) {
                 const int g = (int)ti * cpg + c / 8;
-                const int kt = g / 4, e = (g % 4) * 8 + c % 8;
+                const int kt = g / KG, e = (g % KG) * 8 + c % 8;
                 for (int n = 0; n < d.cout; ++n) {
                     const float w = d.transposed
                         ? weight[(((int64_t)c * d.cout + n) * k + ky) * k + kx]
                         : weight[(((int64_t)n * d.cin + c) * d.kh + ky) * d.kw + kx];
                     const float wf = w * scale[n];
-                    const int64_t idx = p->ph[ph].w_off + ((int64_t)kt * p->Npad + n) * 32 + e;
+                    const int64_t idx = p->ph[ph].w_off + ((int64_t)kt * p->Npad + n) * BK + e;
                     const bf16_t h = mf_f2bf(wf);
                     hi[idx] = h;
                     lo[idx] = mf_f2bf(wf - mf_bf2f(h));
@@ -425,7 +497,8 @@ void mf_conv_plan_destroy(ConvPlan* p) {
     if (p->w_lo) (void)hipFree(p->w_lo);
     if (p->bias) (void)hipFree(p->bias);
     if (p->goff) (void)hipFree(p->goff);
-    p->w_hi = p->w_lo = nullptr; p->bias = nullptr; p->goff = nullptr;
+    if (p->ws) (void)hipFree(p->ws);
+    p->w_hi = p->w_lo = nullptr; p->bias = nullptr; p->goff = nullptr; p->ws = nullptr; p->ws_cap = 0;
 }
 
 int mf_conv_bind(ConvPlan* p, const ActBuf& in) {
@@ -434,6 +507,7 @@ int mf_conv_bind(ConvPlan* p, const ActBuf& in) {
                p->d.in_h, p->d.in_w, in.H, in.W);
     MF_REQUIRE(in.C % 8 == 0 && in.C >= p->cin_pad, "conv: input buffer has %d channels, need >= %d (multiple of 8)", in.C, p->cin_pad);
     if (p->bound_in_ld == in.C && p->bound_in_wp == in.Wp()) return MF_OK;
+    if (p->halo) { p->bound_in_ld = in.C; p->bound_in_wp = in.Wp(); return MF_OK; }
     const int cpg = p->cin_pad / 8;
     std::vector<int> goff(p->goff_total, 0);
     for (int ph = 0; ph < p->nphase; ++ph) {
@@ -451,7 +525,7 @@ int mf_conv_bind(ConvPlan* p, const ActBuf& in) {
     return MF_OK;
 }
 
-int mf_conv_launch(const ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
+int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
                    int batch, hipStream_t stream) {
     const ActBuf& ib = *in.buf;
     const ActBuf& ob = *out.buf;
@@ -461,6 +535,30 @@ int mf_conv_launch(const ConvPlan* p, const ActView& in, const ActView& out, con
     MF_REQUIRE(ob.H == p->out_h && ob.W == p->out_w, "conv: output buffer %dx%d != %dx%d", ob.H, ob.W, p->out_h, p->out_w);
     const bool x3 = p->precision == MF_PREC_BF16X3;
     MF_REQUIRE(!x3 || (ib.lo && ob.lo), "conv: BF16X3 needs lo planes");
+
+    if (p->halo) {
+        HaloArgs ha{};
+        ha.x_hi = ib.hi + in.coff; ha.x_lo = x3 ? ib.lo + in.coff : nullptr;
+        ha.w_hi = p->w_hi; ha.w_lo = p->w_lo; ha.bias = p->bias;
+        ha.batch = batch; ha.H = p->out_h; ha.W = p->out_w; ha.N = p->d.cout; ha.Npad = p->Npad; ha.n_slices = p->n_slices;
+        ha.in_halo = ib.halo; ha.in_hp = ib.Hp(); ha.in_wp = ib.Wp(); ha.x_ld = ib.C; ha.xb = ib.per_batch();
+        const int64_t yb0 = ((int64_t)ob.halo * ob.Wp() + ob.halo) * ob.C + out.coff;
+        ha.y_hi = ob.hi + yb0; ha.y_lo = x3 ? ob.lo + yb0 : nullptr;
+        ha.yb = ob.per_batch(); ha.yi = ob.Wp() * ob.C; ha.yj = ob.C;
+        if (res.buf) {
+            const ActBuf& rb = *res.buf;
+            MF_REQUIRE(rb.H == p->out_h && rb.W == p->out_w && res.C == p->d.cout, "conv: residual view does not match the output");
+            if (res.buf == in.buf && res.coff == in.coff && p->d.cin == p->d.cout) {
+                ha.res_from_halo = 1;   // the residual is the input itself (conv.py:17-18): read it from LDS
+            } else {
+                const int64_t rb0 = ((int64_t)rb.halo * rb.Wp() + rb.halo) * rb.C + res.coff;
+                ha.r_hi = rb.hi + rb0; ha.r_lo = x3 ? rb.lo + rb0 : nullptr;
+                ha.rb = rb.per_batch(); ha.ri = rb.Wp() * rb.C; ha.rj = rb.C;
+            }
+        }
+        ha.act = p->d.act;
+        return mf_halo_launch(ha, mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch), x3, stream);
+    }
 
     ConvArgs a{};
     a.x_hi = ib.hi + in.coff; a.x_lo = x3 ? ib.lo + in.coff : nullptr;
@@ -485,24 +583,84 @@ int mf_conv_launch(const ConvPlan* p, const ActView& in, const ActView& out, con
     for (int ph = 0; ph < p->nphase; ++ph) {
         a.ph[ph] = p->ph[ph];
         a.ph[ph].y_off = ((int64_t)p->phase_oy[ph] * ob.Wp() + p->phase_ox[ph]) * ob.C;
+        a.ph[ph].ws_off = ((int64_t)p->phase_oy[ph] * p->out_w + p->phase_ox[ph]) * a.N;
         goff_max = std::max(goff_max, p->ph[ph].ngroups);
     }
 
-    // ---- tile selection: largest tile that still yields >= ~2 workgroups per CU ---------------
-    const int M = a.M, N = a.N;
+    const ConvTile tc = mf_conv_pick_tile(p, batch);
+    a.tiles_m = cdiv(a.M, tc.bm); a.tiles_n = cdiv(a.N, tc.bn);
+    if (tc.nsplit > 1) {
+        // fp32 partial tiles [split][B][Ho][Wo][N]; combined by k_splitk_epilogue below
+        const int64_t per_split = (int64_t)batch * p->out_h * p->out_w * a.N;
+        const int64_t need = per_split * tc.nsplit;
+        if (need > p->ws_cap) {
+            // only reached on an eager (un-captured) launch: the first forward at a batch size runs eagerly
+            if (p->ws) { MF_HIP(hipStreamSynchronize(stream)); MF_HIP(hipFree(p->ws)); p->ws = nullptr; p->ws_cap = 0; }
+            MF_HIP(hipMalloc(&p->ws, need * sizeof(float)));
+            p->ws_cap = need;
+        }
+        a.ws = p->ws; a.ws_split = per_split;
+        a.wsb = (int64_t)p->out_h * p->out_w * a.N;
+        a.wsi = p->out_step * p->out_w * a.N; a.wsj = p->out_step * a.N;
+    }
+    int rc = MF_ERR_INVALID;
+#define MF_CASE(BM, BN, WGM, WGN)                                                          \
+    if (tc.bm == BM && tc.bn == BN) rc = launch_prec<BM, BN, WGM, WGN>(a, p->nphase, tc.nsplit, goff_max, x3, stream);
+    MF_CASE(128, 16, 4, 1)
+    MF_CASE(128, 32, 4, 1)
+    MF_CASE(16, 64, 1, 4)
+    MF_CASE(128, 128, 2, 2)
+    MF_CASE(128, 64, 2, 2)
+    MF_CASE(64, 64, 2, 2)
+#undef MF_CASE
+    if (rc != MF_OK) {
+        if (rc == MF_ERR_INVALID) mf_set_error("conv: no kernel for tile %dx%d", tc.bm, tc.bn);
+        return rc;
+    }
+    if (tc.nsplit > 1) {
+        ConvArgs e = a;   // unit-grid strides for the combine pass
+        e.yi = ob.Wp() * ob.C; e.yj = ob.C;
+        const int64_t total = (int64_t)batch * p->out_h * p->out_w * (a.N / 4);
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e,
+                           tc.nsplit, p->out_h, p->out_w, total);
+        MF_HIP(hipGetLastError());
+    }
+    return MF_OK;
+}
+
+// Tile selection: the largest tile that still yields >= ~2 workgroups per CU (256 CUs); layers that
+// cannot fill the chip with output tiles and have a long contraction are additionally split along K.
+ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
+    const int M = batch * p->Hq * p->Wq, N = p->d.cout;
     auto tiles = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(N, bn) * p->nphase; };
-    int rc;
-#define MF_GO(BM, BN, WGM, WGN)                                                            \
-    do {                                                                                   \
-        a.tiles_m = cdiv(M, BM); a.tiles_n = cdiv(N, BN);                                  \
-        rc = launch_prec<BM, BN, WGM, WGN>(a, p->nphase, goff_max, x3, stream);            \
-    } while (0)
-    if (N <= 16) MF_GO(128, 16, 4, 1);
-    else if (N <= 32) MF_GO(128, 32, 4, 1);
-    else if (M <= 16) MF_GO(16, 64, 1, 4);
-    else if (tiles(128, 128) >= 512 && N % 128 == 0) MF_GO(128, 128, 2, 2);
-    else if (tiles(128, 64) >= 512) MF_GO(128, 64, 2, 2);
-    else MF_GO(64, 64, 2, 2);
-#undef MF_GO
-    return rc;
+    ConvTile t;
+    if (N <= 16) t = {128, 16, 4, 1, 1};
+    else if (N <= 32) t = {128, 32, 4, 1, 1};
+    else if (M <= 16) t = {16, 64, 1, 4, 1};
+    else if (tiles(128, 128) >= 512 && N % 128 == 0) t = {128, 128, 2, 2, 1};
+    else if (tiles(128, 64) >= 512) t = {128, 64, 2, 2, 1};
+    else t = {64, 64, 2, 2, 1};
+    const int nt = tiles(t.bm, t.bn);
+    int kt_min = p->ph[0].KT;
+    for (int ph = 1; ph < p->nphase; ++ph) kt_min = std::min(kt_min, p->ph[ph].KT);
+    if (nt < 256 && kt_min >= 4) t.nsplit = std::max(1, std::min(std::min(kt_min / 2, cdiv(512, nt)), 16));
+    return t;
+}
+
+void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
+    const char* x3 = p->precision == MF_PREC_BF16X3 ? "true" : "false";
+    if (p->halo) {
+        const HaloTile t = mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
+        snprintf(buf, cap, "k_conv3x3_halo<%d,%d,%d,%d,%s>", t.ph, t.bn, t.wgm, t.wgn, x3);
+    } else {
+        const ConvTile t = mf_conv_pick_tile(p, batch);
+        snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s>%s", t.bm, t.bn, t.wgm, t.wgn, x3, t.nsplit > 1 ? "+splitk" : "");
+    }
+}
+
+double mf_conv_flops(const ConvPlan* p, int batch) {
+    const mf_conv2d_desc& d = p->d;
+    const double taps = (double)d.kh * d.kw;
+    const double sites = d.transposed ? (double)d.in_h * d.in_w : (double)p->out_h * p->out_w;
+    return 2.0 * batch * sites * d.cin * d.cout * taps;
 }

@@ -69,6 +69,28 @@ extern "C" int mf_conv2d_forward(mf_conv2d* h, const float* x, float* y, int bat
     return mf_act_to_nchw(out, y, batch, s);
 }
 
+extern "C" int mf_conv2d_time(mf_conv2d* h, int batch, int iters, float* ms, void* stream) {
+    MF_REQUIRE(h && ms, "conv2d_time: null argument");
+    MF_REQUIRE(batch > 0 && batch <= h->cap && iters > 0, "conv2d_time: run mf_conv2d_forward at this batch first");
+    hipStream_t s = (hipStream_t)stream;
+    ActView in{&h->in, 0, h->in.C}, out{&h->out, 0, h->plan.d.cout};
+    ActView res = h->plan.d.residual ? ActView{&h->in, 0, h->plan.d.cout} : ActView{};
+    hipEvent_t e0, e1;
+    MF_HIP(hipEventCreate(&e0)); MF_HIP(hipEventCreate(&e1));
+    MF_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) {
+        int rc = mf_conv_launch(&h->plan, in, out, res, batch, s);
+        if (rc) return rc;
+    }
+    MF_HIP(hipEventRecord(e1, s));
+    MF_HIP(hipEventSynchronize(e1));
+    float t = 0.f;
+    MF_HIP(hipEventElapsedTime(&t, e0, e1));
+    *ms = t / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return MF_OK;
+}
+
 extern "C" int mf_conv2d_out_shape(const mf_conv2d* h, int* out_h, int* out_w) {
     MF_REQUIRE(h && out_h && out_w, "conv2d_out_shape: null argument");
     *out_h = h->plan.out_h; *out_w = h->plan.out_w;

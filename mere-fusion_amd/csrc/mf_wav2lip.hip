@@ -382,4 +382,75 @@ extern "C" int mf_wav2lip_read_tap(mf_wav2lip* h, const char* tap, float* dst, i
     return mf_act_to_nchw(it->second, dst, batch, (hipStream_t)stream);
 }
 
+// ---- measurement seam ----------------------------------------------------------------------------
+// launch order of a forward: prep_mel, prep_face, [audio encoder], [face encoder], [decoder], head
+extern "C" int mf_wav2lip_num_layers(const mf_wav2lip* h) { return h ? (int)h->steps.size() + 3 : 0; }
+
+namespace {
+// steps are stored audio(0) / face-enc(1) / decoder(2) in that order already
+const char* kAuxNames[3] = {"prep_mel(nchw->nhwc)", "prep_face(nchw->nhwc)", "output_block.1+sigmoid"};
+const char* kAuxKernels[3] = {"k_nchw_to_act", "k_nchw_to_act", "k_head<32>"};
+}
+
+extern "C" int mf_wav2lip_layer_info(const mf_wav2lip* h, int index, int batch, char* name, int name_cap,
+                                     char* kernel, int kernel_cap, double* flops) {
+    MF_REQUIRE(h && name && kernel && flops, "layer_info: null argument");
+    const int n = (int)h->steps.size();
+    MF_REQUIRE(index >= 0 && index < n + 3, "layer_info: index %d out of range", index);
+    if (index < 2 || index == n + 2) {
+        const int a = index < 2 ? index : 2;
+        snprintf(name, name_cap, "%s", kAuxNames[a]);
+        snprintf(kernel, kernel_cap, "%s", kAuxKernels[a]);
+        *flops = a == 2 ? 2.0 * batch * 96 * 96 * 32 * 3 : 0.0;
+        return MF_OK;
+    }
+    const Step& st = *h->steps[index - 2];
+    snprintf(name, name_cap, "%s", st.name.c_str());
+    mf_conv_kernel_name(&st.plan, batch, kernel, kernel_cap);
+    *flops = mf_conv_flops(&st.plan, batch);
+    return MF_OK;
+}
+
+extern "C" int mf_wav2lip_profile(mf_wav2lip* h, const float* mel, const float* face, float* out, int batch,
+                                  int iters, float* ms_per_layer, void* stream) {
+    MF_REQUIRE(h && mel && face && out && ms_per_layer, "profile: null argument");
+    MF_REQUIRE(batch > 0 && iters > 0, "profile: batch and iters must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = h->ensure_capacity(batch);
+    if (rc) return rc;
+    const int n = (int)h->steps.size() + 3;
+    std::vector<hipEvent_t> e0(n), e1(n);
+    for (int i = 0; i < n; ++i) { MF_HIP(hipEventCreate(&e0[i])); MF_HIP(hipEventCreate(&e1[i])); }
+    std::vector<double> acc(n, 0.0);
+    for (int it = 0; it < iters; ++it) {
+        // one stream, strictly serial: each launch is timed alone (the audio lane is not forked here)
+        MF_HIP(hipEventRecord(e0[0], s));
+        if ((rc = mf_nchw_to_act(mel, 1, *h->mel_in, batch, s))) return rc;
+        MF_HIP(hipEventRecord(e1[0], s));
+        MF_HIP(hipEventRecord(e0[1], s));
+        if ((rc = mf_nchw_to_act(face, 6, *h->face_in, batch, s))) return rc;
+        MF_HIP(hipEventRecord(e1[1], s));
+        for (size_t k = 0; k < h->steps.size(); ++k) {
+            Step& st = *h->steps[k];
+            MF_HIP(hipEventRecord(e0[k + 2], s));
+            if ((rc = mf_conv_launch(&st.plan, st.in, st.out, st.res, batch, s))) return rc;
+            MF_HIP(hipEventRecord(e1[k + 2], s));
+        }
+        MF_HIP(hipEventRecord(e0[n - 1], s));
+        if ((rc = mf_head_1x1_sigmoid(ActView{h->out0, 0, 32}, h->head_w, h->head_b, out, 0, batch, s))) return rc;
+        MF_HIP(hipEventRecord(e1[n - 1], s));
+        MF_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < n; ++i) {
+            float ms = 0.f;
+            MF_HIP(hipEventElapsedTime(&ms, e0[i], e1[i]));
+            acc[i] += ms;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        ms_per_layer[i] = (float)(acc[i] / iters);
+        (void)hipEventDestroy(e0[i]); (void)hipEventDestroy(e1[i]);
+    }
+    return MF_OK;
+}
+
 extern "C" void mf_wav2lip_destroy(mf_wav2lip* h) { delete h; }

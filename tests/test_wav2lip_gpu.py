@@ -142,7 +142,9 @@ def test_linearity_free_properties_at_full_batch(gpu_model_factory, sd0):
     with torch.no_grad():
         full = m(mel, face)
         one = torch.cat([m(mel[i:i + 1], face[i:i + 1]) for i in (0, 7, 15)])
-    assert (full[[0, 7, 15]] - one).abs().max().item() <= 1e-6
+    # tile shapes and split-K depend on the batch size, so the fp32 summation order (and with it the
+    # rounding of every re-split activation) differs: equality holds to the parity bound, not bitwise
+    assert (full[[0, 7, 15]] - one).abs().max().item() <= 2e-4
     assert full.min() >= 0 and full.max() <= 1
 
 
