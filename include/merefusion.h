@@ -82,17 +82,18 @@ int mf_wav2lip_forward_u8(mf_wav2lip* h, const float* mel, const uint8_t* faces_
  * parity tests.  tap: "audio_embedding", "face_encoder_blocks.N", "face_decoder_blocks.N". */
 int mf_wav2lip_read_tap(mf_wav2lip* h, const char* tap, float* dst, int batch, void* stream);
 
-/* Measurement seam for bench.py (roofline): the generator's kernel launches in execution order.
- * layer_info: name = the reference module path ("face_decoder_blocks.4.1"), kernel = the HIP kernel
- * the launch uses at this batch size (as rocprofv3 names it, template arguments without spaces),
- * flops = algorithmic FLOPs of that launch (2 x conv MACs; 0 for the layout/head kernels).
- * profile: runs `iters` forwards WITHOUT the hipGraph, bracketing every launch with hipEvents on
- * the stream it is launched on, and returns the mean milliseconds per launch. */
-int mf_wav2lip_num_layers(const mf_wav2lip* h);
-int mf_wav2lip_layer_info(const mf_wav2lip* h, int index, int batch, char* name, int name_cap,
-                          char* kernel, int kernel_cap, double* flops);
+/* Measurement seam for bench.py (roofline): the generator's KERNEL launches in execution order at a
+ * batch size (a split-K layer is two launches: the MFMA kernel and its combine pass).
+ * launch_info: name = the reference module path ("face_decoder_blocks.4.1"), kernel = the HIP kernel
+ * name as rocprofv3 prints it (template arguments without spaces), flops = algorithmic FLOPs of that
+ * launch (2 x conv MACs; 0 for layout / combine kernels).
+ * profile: runs `iters` forwards WITHOUT the hipGraph on `stream`, a hipEvent before every launch,
+ * and returns the mean milliseconds of each launch. */
+int mf_wav2lip_num_launches(const mf_wav2lip* h, int batch);
+int mf_wav2lip_launch_info(const mf_wav2lip* h, int index, int batch, char* name, int name_cap,
+                           char* kernel, int kernel_cap, double* flops);
 int mf_wav2lip_profile(mf_wav2lip* h, const float* mel, const float* face, float* out, int batch,
-                       int iters, float* ms_per_layer, void* stream);
+                       int iters, float* ms_per_launch, void* stream);
 
 void mf_wav2lip_destroy(mf_wav2lip* h);
 

@@ -33,8 +33,8 @@ SIGNATURES = {
     "mf_wav2lip_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_wav2lip_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_wav2lip_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "mf_wav2lip_num_layers": (C.c_int, [C.c_void_p]),
-    "mf_wav2lip_layer_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
+    "mf_wav2lip_num_launches": (C.c_int, [C.c_void_p, C.c_int]),
+    "mf_wav2lip_launch_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
                                         C.POINTER(C.c_double)]),
     "mf_wav2lip_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.POINTER(C.c_float), C.c_void_p]),

@@ -95,6 +95,7 @@ struct ConvPlan {
     int* goff = nullptr;
     bool halo = false;    // 3x3 s1 p1 on a >= 16x16 map: LDS halo-tile kernel, weights packed [slice][tap][Npad][CK]
     int n_slices = 0;
+    hipEvent_t prof_mid = nullptr;   // measurement only: recorded between the MFMA kernel and its split-K combine
     float* ws = nullptr;  // split-K workspace, grown on the first (eager) launch that needs it
     int64_t ws_cap = 0;
     // host-side phase description, independent of the buffers the layer is later bound to

@@ -618,6 +618,7 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         return rc;
     }
     if (tc.nsplit > 1) {
+        if (p->prof_mid) MF_HIP(hipEventRecord(p->prof_mid, stream));
         ConvArgs e = a;   // unit-grid strides for the combine pass
         e.yi = ob.Wp() * ob.C; e.yj = ob.C;
         const int64_t total = (int64_t)batch * p->out_h * p->out_w * (a.N / 4);
@@ -651,7 +652,7 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision == MF_PREC_BF16X3 ? "true" : "false";
     if (p->halo) {
         const HaloTile t = mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
-        snprintf(buf, cap, "k_conv3x3_halo<%d,%d,%d,%d,%s>", t.ph, t.bn, t.wgm, t.wgn, x3);
+        snprintf(buf, cap, "k_conv3x3_halo<%d,%d,%d,%d,%s,2>", t.ph, t.bn, t.wgm, t.wgn, x3);
     } else {
         const ConvTile t = mf_conv_pick_tile(p, batch);
         snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s>%s", t.bm, t.bn, t.wgm, t.wgn, x3, t.nsplit > 1 ? "+splitk" : "");

@@ -383,28 +383,49 @@ extern "C" int mf_wav2lip_read_tap(mf_wav2lip* h, const char* tap, float* dst, i
 }
 
 // ---- measurement seam ----------------------------------------------------------------------------
-// launch order of a forward: prep_mel, prep_face, [audio encoder], [face encoder], [decoder], head
-extern "C" int mf_wav2lip_num_layers(const mf_wav2lip* h) { return h ? (int)h->steps.size() + 3 : 0; }
-
+// kernel launches of a forward in execution order: prep_mel, prep_face, [audio encoder], [face encoder],
+// [decoder], head; a split-K layer contributes two rows (the MFMA kernel and its combine pass)
 namespace {
-// steps are stored audio(0) / face-enc(1) / decoder(2) in that order already
 const char* kAuxNames[3] = {"prep_mel(nchw->nhwc)", "prep_face(nchw->nhwc)", "output_block.1+sigmoid"};
 const char* kAuxKernels[3] = {"k_nchw_to_act", "k_nchw_to_act", "k_head<32>"};
+
+struct Row { int step; int part; };   // step -1/-2/-3 = aux kernels; part 1 = split-K combine
+std::vector<Row> launch_rows(const mf_wav2lip* h, int batch) {
+    std::vector<Row> rows{{-1, 0}, {-2, 0}};
+    for (size_t k = 0; k < h->steps.size(); ++k) {
+        rows.push_back({(int)k, 0});
+        const ConvPlan& pl = h->steps[k]->plan;
+        if (!pl.halo && mf_conv_pick_tile(&pl, batch).nsplit > 1) rows.push_back({(int)k, 1});
+    }
+    rows.push_back({-3, 0});
+    return rows;
+}
+}  // namespace
+
+extern "C" int mf_wav2lip_num_launches(const mf_wav2lip* h, int batch) {
+    return h && batch > 0 ? (int)launch_rows(h, batch).size() : 0;
 }
 
-extern "C" int mf_wav2lip_layer_info(const mf_wav2lip* h, int index, int batch, char* name, int name_cap,
-                                     char* kernel, int kernel_cap, double* flops) {
-    MF_REQUIRE(h && name && kernel && flops, "layer_info: null argument");
-    const int n = (int)h->steps.size();
-    MF_REQUIRE(index >= 0 && index < n + 3, "layer_info: index %d out of range", index);
-    if (index < 2 || index == n + 2) {
-        const int a = index < 2 ? index : 2;
+extern "C" int mf_wav2lip_launch_info(const mf_wav2lip* h, int index, int batch, char* name, int name_cap,
+                                      char* kernel, int kernel_cap, double* flops) {
+    MF_REQUIRE(h && name && kernel && flops && batch > 0, "launch_info: bad argument");
+    const std::vector<Row> rows = launch_rows(h, batch);
+    MF_REQUIRE(index >= 0 && index < (int)rows.size(), "launch_info: index %d out of range", index);
+    const Row r = rows[index];
+    if (r.step < 0) {
+        const int a = -r.step - 1;
         snprintf(name, name_cap, "%s", kAuxNames[a]);
         snprintf(kernel, kernel_cap, "%s", kAuxKernels[a]);
         *flops = a == 2 ? 2.0 * batch * 96 * 96 * 32 * 3 : 0.0;
         return MF_OK;
     }
-    const Step& st = *h->steps[index - 2];
+    const Step& st = *h->steps[r.step];
+    if (r.part == 1) {
+        snprintf(name, name_cap, "%s (split-K combine)", st.name.c_str());
+        snprintf(kernel, kernel_cap, "k_splitk_epilogue");
+        *flops = 0.0;
+        return MF_OK;
+    }
     snprintf(name, name_cap, "%s", st.name.c_str());
     mf_conv_kernel_name(&st.plan, batch, kernel, kernel_cap);
     *flops = mf_conv_flops(&st.plan, batch);
@@ -412,44 +433,47 @@ extern "C" int mf_wav2lip_layer_info(const mf_wav2lip* h, int index, int batch, 
 }
 
 extern "C" int mf_wav2lip_profile(mf_wav2lip* h, const float* mel, const float* face, float* out, int batch,
-                                  int iters, float* ms_per_layer, void* stream) {
-    MF_REQUIRE(h && mel && face && out && ms_per_layer, "profile: null argument");
+                                  int iters, float* ms_per_launch, void* stream) {
+    MF_REQUIRE(h && mel && face && out && ms_per_launch, "profile: null argument");
     MF_REQUIRE(batch > 0 && iters > 0, "profile: batch and iters must be positive");
     hipStream_t s = (hipStream_t)stream;
     int rc = h->ensure_capacity(batch);
     if (rc) return rc;
-    const int n = (int)h->steps.size() + 3;
-    std::vector<hipEvent_t> e0(n), e1(n);
-    for (int i = 0; i < n; ++i) { MF_HIP(hipEventCreate(&e0[i])); MF_HIP(hipEventCreate(&e1[i])); }
+    const std::vector<Row> rows = launch_rows(h, batch);
+    const int n = (int)rows.size();
+    // one event before every launch + one after the last: duration(i) = ev[i] -> ev[i+1]; everything is
+    // on ONE stream, strictly serial (the audio lane is not forked here), so each kernel is timed alone
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) MF_HIP(hipEventCreate(&e));
     std::vector<double> acc(n, 0.0);
     for (int it = 0; it < iters; ++it) {
-        // one stream, strictly serial: each launch is timed alone (the audio lane is not forked here)
-        MF_HIP(hipEventRecord(e0[0], s));
+        int i = 0;
+        MF_HIP(hipEventRecord(ev[i++], s));
         if ((rc = mf_nchw_to_act(mel, 1, *h->mel_in, batch, s))) return rc;
-        MF_HIP(hipEventRecord(e1[0], s));
-        MF_HIP(hipEventRecord(e0[1], s));
+        MF_HIP(hipEventRecord(ev[i++], s));
         if ((rc = mf_nchw_to_act(face, 6, *h->face_in, batch, s))) return rc;
-        MF_HIP(hipEventRecord(e1[1], s));
         for (size_t k = 0; k < h->steps.size(); ++k) {
             Step& st = *h->steps[k];
-            MF_HIP(hipEventRecord(e0[k + 2], s));
-            if ((rc = mf_conv_launch(&st.plan, st.in, st.out, st.res, batch, s))) return rc;
-            MF_HIP(hipEventRecord(e1[k + 2], s));
+            MF_HIP(hipEventRecord(ev[i++], s));
+            const bool split = i < n && rows[i].part == 1 && rows[i].step == (int)k;
+            st.plan.prof_mid = split ? ev[i++] : nullptr;   // recorded between the MFMA kernel and its combine pass
+            rc = mf_conv_launch(&st.plan, st.in, st.out, st.res, batch, s);
+            st.plan.prof_mid = nullptr;
+            if (rc) return rc;
         }
-        MF_HIP(hipEventRecord(e0[n - 1], s));
+        MF_HIP(hipEventRecord(ev[i++], s));
         if ((rc = mf_head_1x1_sigmoid(ActView{h->out0, 0, 32}, h->head_w, h->head_b, out, 0, batch, s))) return rc;
-        MF_HIP(hipEventRecord(e1[n - 1], s));
+        MF_HIP(hipEventRecord(ev[i++], s));
+        MF_REQUIRE(i == n + 1, "profile: launch table out of sync (%d vs %d)", i, n + 1);
         MF_HIP(hipStreamSynchronize(s));
-        for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) {
             float ms = 0.f;
-            MF_HIP(hipEventElapsedTime(&ms, e0[i], e1[i]));
-            acc[i] += ms;
+            MF_HIP(hipEventElapsedTime(&ms, ev[j], ev[j + 1]));
+            acc[j] += ms;
         }
     }
-    for (int i = 0; i < n; ++i) {
-        ms_per_layer[i] = (float)(acc[i] / iters);
-        (void)hipEventDestroy(e0[i]); (void)hipEventDestroy(e1[i]);
-    }
+    for (int j = 0; j < n; ++j) ms_per_launch[j] = (float)(acc[j] / iters);
+    for (auto& e : ev) (void)hipEventDestroy(e);
     return MF_OK;
 }
 

@@ -63,3 +63,17 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oracle/" not in src or f.endswith(".md"), f
+
+
+def test_dropin_import_paths(lib_built):
+    """The two imports the reference makes (lipreal.py:25, lipasr.py:10) resolve to this repository when
+    mere-fusion_amd/dropin precedes the reference on sys.path."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0] = [%r, %r]; "
+            "from wav2lip.models import Wav2Lip; from wav2lip import audio; "
+            "import mere_fusion_amd.wav2lip.models as M; "
+            "assert Wav2Lip is M.Wav2Lip and hasattr(audio, 'melspectrogram'); print('ok')"
+            % (os.path.join(ROOT, "mere-fusion_amd", "dropin"), ROOT))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/")
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
