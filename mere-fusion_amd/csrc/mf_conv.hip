@@ -85,10 +85,10 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const float (&
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool X3>
+template <int BM, int BN, int WGM, int WGN, bool X3, int BK>
 __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
-    constexpr int BK = X3 ? 32 : 64;
+    static_assert(BK == 32 || BK == 64, "LDS tile depth");
     constexpr int KG = BK / 8;            // 16-byte groups per tile row
     constexpr int ROWB = BK * 2;          // bytes per tile row
     constexpr int RPC = 1024 / ROWB;      // tile rows per 1-KiB DMA chunk
@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     const int tm = t / a.tiles_n, tn = t - tm * a.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // split-K slice of this workgroup
-    const int kt_begin = (int)((int64_t)ph.KT * blockIdx.y / gridDim.y);
-    const int kt_end = (int)((int64_t)ph.KT * (blockIdx.y + 1) / gridDim.y);
+    // split-K slice of this workgroup (ph.KT counts 64-deep packed tiles; this kernel steps BK)
+    const int KTk = ph.KT * (64 / BK);
+    const int kt_begin = (int)((int64_t)KTk * blockIdx.y / gridDim.y);
+    const int kt_end = (int)((int64_t)KTk * (blockIdx.y + 1) / gridDim.y);
 
     for (int i = tid; i < ph.ngroups; i += 256) s_goff[i] = a.goff[ph.goff_begin + i];
 
@@ -147,9 +148,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
         const int kg = (lane % KG) ^ swz<BK>(row);
         int n = n0 + row;
         n = n < a.Npad ? n : a.Npad - 1;
-        wp[i] = a.w_hi + ph.w_off + (int64_t)n * BK + kg * 8;
+        wp[i] = a.w_hi + ph.w_off + (int64_t)n * 64 + kg * 8;   // packed [K/64][Npad][64]
     }
-    const int64_t w_kstep = (int64_t)a.Npad * BK;
+    const int64_t w_kstep = (int64_t)a.Npad * 64;
 
     auto stage = [&](int kt, int s) __attribute__((always_inline)) {
         char* base = smem + s * STAGE;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
         for (int i = 0; i < NWC; ++i) {
             const int c = wave + 4 * i;
             if (WCH % 4 == 0 || c < WCH) {
-                const bf16_t* src = wp[i] + kt * w_kstep;
+                const bf16_t* src = BK == 64 ? wp[i] + kt * w_kstep : wp[i] + (kt >> 1) * w_kstep + (kt & 1) * 32;
                 glds16(src, base + P_BYTES + c * 1024);
                 if (X3) glds16(src + w_delta, base + PLANE + P_BYTES + c * 1024);
             }
@@ -286,16 +287,15 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int n
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int BM, int BN, int WGM, int WGN, bool X3>
+template <int BM, int BN, int WGM, int WGN, bool X3, int BK>
 int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = k_conv_igemm<BM, BN, WGM, WGN, X3>;
+    auto kern = k_conv_igemm<BM, BN, WGM, WGN, X3, BK>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    constexpr int BK = X3 ? 32 : 64;
     const size_t lds = 2 * (size_t)(BM + BN) * BK * 2 * (X3 ? 2 : 1) + (size_t)goff_max * 4;
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, nphase);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
@@ -305,8 +305,11 @@ int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStrea
 
 template <int BM, int BN, int WGM, int WGN>
 int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3, hipStream_t s) {
-    return x3 ? launch_cfg<BM, BN, WGM, WGN, true>(a, nphase, nsplit, goff_max, s)
-              : launch_cfg<BM, BN, WGM, WGN, false>(a, nphase, nsplit, goff_max, s);
+    // bf16x3 doubles the LDS image: 64-deep tiles only where two stages of (hi, lo) still leave >= 2
+    // workgroups per CU (the small tiles of the long-K layers), 32-deep otherwise
+    constexpr bool deep = (BM + BN) <= 128;
+    return x3 ? launch_cfg<BM, BN, WGM, WGN, true, deep ? 64 : 32>(a, nphase, nsplit, goff_max, s)
+              : launch_cfg<BM, BN, WGM, WGN, false, 64>(a, nphase, nsplit, goff_max, s);
 }
 
 int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -402,21 +405,22 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
         }
     }
 
-    const int BK = precision == MF_PREC_BF16X3 ? 32 : 64, KG = BK / 8;
+    const int HCK = precision == MF_PREC_BF16X3 ? 32 : 64;   // channel slice of the halo kernel
+    const int BK = 64, KG = BK / 8;                            // packed K tile of the implicit-GEMM kernel
     p->BK = BK;
     p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
               d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16;
     if (p->halo) {
         // ---- pack for the halo-tile kernel: [slice][tap][Npad][CK], channels past cin are zero --------
-        p->n_slices = cdiv(d.cin, BK);
+        p->n_slices = cdiv(d.cin, HCK);
         p->goff_total = 0;
-        const int64_t total = (int64_t)p->n_slices * 9 * p->Npad * BK;
+        const int64_t total = (int64_t)p->n_slices * 9 * p->Npad * HCK;
         std::vector<bf16_t> hi(total, 0), lo(total, 0);
         for (int c = 0; c < d.cin; ++c)
             for (int tap = 0; tap < 9; ++tap)
                 for (int n = 0; n < d.cout; ++n) {
                     const float wf = weight[(((int64_t)n * d.cin + c) * 3 + tap / 3) * 3 + tap % 3] * scale[n];
-                    const int64_t idx = (((int64_t)(c / BK) * 9 + tap) * p->Npad + n) * BK + c % BK;
+                    const int64_t idx = (((int64_t)(c / HCK) * 9 + tap) * p->Npad + n) * HCK + c % HCK;
                     const bf16_t h = mf_f2bf(wf);
                     hi[idx] = h;
                     lo[idx] = mf_f2bf(wf - mf_bf2f(h));
@@ -432,7 +436,7 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
         p->bound_in_ld = p->bound_in_wp = -1;
         return MF_OK;
     }
-    // ---- pack: per phase [KT][Npad][BK], K groups tap-major (BK = 64 bf16, 32 bf16x3) ----------
+    // ---- pack: per phase [K/64][Npad][64], K groups tap-major ---------------------------------------
     int64_t total = 0;
     int goff_total = 0;
     for (int ph = 0; ph < p->nphase; ++ph) {
@@ -644,7 +648,7 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
     const int nt = tiles(t.bm, t.bn);
     int kt_min = p->ph[0].KT;
     for (int ph = 1; ph < p->nphase; ++ph) kt_min = std::min(kt_min, p->ph[ph].KT);
-    if (nt < 256 && kt_min >= 4) t.nsplit = std::max(1, std::min(std::min(kt_min / 2, cdiv(512, nt)), 16));
+    if (nt < 256 && kt_min >= 2) t.nsplit = std::max(1, std::min(std::min(kt_min, cdiv(512, nt)), 16));
     return t;
 }
 
@@ -655,7 +659,8 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
         snprintf(buf, cap, "k_conv3x3_halo<%d,%d,%d,%d,%s,2>", t.ph, t.bn, t.wgm, t.wgn, x3);
     } else {
         const ConvTile t = mf_conv_pick_tile(p, batch);
-        snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s>%s", t.bm, t.bn, t.wgm, t.wgn, x3, t.nsplit > 1 ? "+splitk" : "");
+        const int bk = (p->precision == MF_PREC_BF16X3 && t.bm + t.bn > 128) ? 32 : 64;
+        snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s,%d>", t.bm, t.bn, t.wgm, t.wgn, x3, bk);
     }
 }
 

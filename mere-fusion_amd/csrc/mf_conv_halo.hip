@@ -322,10 +322,14 @@ int halo_launch_prec(const HaloArgs& a, bool x3, hipStream_t s) {
 
 }  // namespace
 
+// Patch selection: 8x16 pixels x 64 (or 32) channels; maps too small to give every CU a workgroup fall
+// back to 4-row patches and then to 32-channel tiles (4x the workgroups, 1/4 of the MFMAs each).
 HaloTile mf_halo_pick_tile(int H, int W, int N, int batch) {
-    (void)H; (void)W; (void)batch;
-    if (N <= 32) return HaloTile{8, 32, 2, 2};
-    return HaloTile{8, 64, 2, 2};
+    auto wgs = [&](int ph, int bn) { return batch * ((H + ph - 1) / ph) * ((W + PW - 1) / PW) * ((N + bn - 1) / bn); };
+    if (N <= 32) return wgs(8, 32) >= 256 ? HaloTile{8, 32, 2, 2} : HaloTile{4, 32, 2, 2};
+    if (wgs(8, 64) >= 256) return HaloTile{8, 64, 2, 2};
+    if (wgs(4, 64) >= 256) return HaloTile{4, 64, 2, 2};
+    return HaloTile{4, 32, 2, 2};
 }
 
 int mf_halo_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t s) {
@@ -338,7 +342,8 @@ int mf_halo_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t s
 #define MF_HCASE(PH, BN, WGM, WGN) \
     if (t.ph == PH && t.bn == BN) return halo_launch_prec<PH, BN, WGM, WGN>(a, x3, s);
     MF_HCASE(8, 64, 2, 2)
-    MF_HCASE(8, 64, 1, 4)
+    MF_HCASE(4, 64, 2, 2)
+    MF_HCASE(4, 32, 2, 2)
     MF_HCASE(8, 32, 2, 2)
 #undef MF_HCASE
     mf_set_error("halo conv: no kernel for patch %dx16, BN %d", t.ph, t.bn);
