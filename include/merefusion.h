@@ -107,8 +107,8 @@ typedef struct mf_conv2d_desc {
     int pad_h, pad_w;
     int transposed;       /* 0 = Conv2d (conv.py:5), 1 = ConvTranspose2d (conv.py:33) */
     int output_padding;   /* transposed only */
-    int residual;         /* add the layer input before the activation (conv.py:17-18) */
-    int act;              /* 0 none, 1 ReLU, 2 sigmoid */
+    int residual;         /* 1: add the layer input before the activation (conv.py:17-18); 2: after it */
+    int act;              /* 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf), 4 SiLU */
     int in_h, in_w;       /* spatial size of the input this layer is built for */
 } mf_conv2d_desc;
 
@@ -133,6 +133,26 @@ void mf_conv2d_destroy(mf_conv2d* h);
  * pad_mode: 0 = zeros (librosa >= 0.10 default "constant"), 1 = reflect (librosa < 0.10). */
 int mf_melspec(const float* wav, int n, float* out, int pad_mode, void* stream);
 int mf_melspec_frames(int n);
+
+/* ---- MuseTalk Whisper audio features (H3) -------------------------------------------------- */
+typedef struct mf_whisper mf_whisper;
+
+/* Replaces `load_model(path)` of musetalk/whisper/whisper/__init__.py:108-116 for the ENCODER half
+ * (`Whisper.encoder`, model.py:131-171): weights = the encoder state-dict tensors ("conv1.weight",
+ * "blocks.N.attn.query.weight", ...; an "encoder." prefix is accepted); n_head comes from the checkpoint's
+ * dims (6 for tiny); n_state / n_layer are inferred from the tensors, n_ctx is 1500 (30 s). */
+int mf_whisper_create(const mf_tensor* weights, int n_weights, int n_head, int precision, mf_whisper** out);
+int mf_whisper_dims(const mf_whisper* h, int* n_layer, int* n_ctx, int* n_state);
+
+/* Replaces `log_mel_spectrogram(audio)` (whisper/audio.py:92-125): wav device fp32 [n], 160 <= n <= 480000
+ * -> out device fp32 [80, n/160]. */
+int mf_whisper_log_mel(mf_whisper* h, const float* wav, int n, float* out, void* stream);
+
+/* One segment of `transcribe` (transcribe.py:103-126): log-mel, pad to 3000 frames,
+ * `encoder(segment, include_embeddings=True)`.  emb: device fp32 [n_layer+1][1500][n_state]
+ * (= the reference's embeddings[0], model.py:158-168).  n <= 480000 samples (one 30 s segment). */
+int mf_whisper_encode_audio(mf_whisper* h, const float* wav, int n, float* emb, void* stream);
+void mf_whisper_destroy(mf_whisper* h);
 
 #ifdef __cplusplus
 }

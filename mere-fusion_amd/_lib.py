@@ -44,6 +44,11 @@ SIGNATURES = {
     "mf_conv2d_out_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mf_conv2d_time": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "mf_conv2d_destroy": (None, [C.c_void_p]),
+    "mf_whisper_create": (C.c_int, [C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mf_whisper_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mf_whisper_log_mel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mf_whisper_encode_audio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mf_whisper_destroy": (None, [C.c_void_p]),
     "mf_melspec": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_melspec_frames": (C.c_int, [C.c_int]),
 }

@@ -51,7 +51,8 @@ struct ConvArgs {
     int64_t xb; int xi, xj;   // input element strides per (batch, quotient row, quotient col)
     int64_t yb; int yi, yj;   // output strides
     int64_t rb; int ri, rj;   // residual strides
-    int act;                  // 0 none, 1 relu, 2 sigmoid
+    int act;                  // 0 none, 1 relu, 2 sigmoid, 3 gelu(erf), 4 silu
+    int res_after_act;        // residual added after the activation (x = act(conv) + r)
     int tiles_m, tiles_n;
     int goff_total;
     float* ws;                // split-K fp32 partials [split][B][Ho][Wo][N], or null

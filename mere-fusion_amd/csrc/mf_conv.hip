@@ -53,26 +53,36 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ void add_residual(const ConvArgs& a, float (&v)[4], int64_t ro, int c, bool x3) {
+    const uint2 rh = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
+    v[0] += bf2f(rh.x & 0xffffu); v[1] += bf2f(rh.x >> 16);
+    v[2] += bf2f(rh.y & 0xffffu); v[3] += bf2f(rh.y >> 16);
+    if (x3) {
+        const uint2 rl = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
+        v[0] += bf2f(rl.x & 0xffffu); v[1] += bf2f(rl.x >> 16);
+        v[2] += bf2f(rl.y & 0xffffu); v[3] += bf2f(rl.y >> 16);
+    }
+}
+
+// act: 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf form, torch.nn.GELU default), 4 SiLU
 __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const float (&v0)[4], int64_t yo, int64_t ro,
                                                int c, bool x3) {
     float v[4] = {v0[0], v0[1], v0[2], v0[3]};
-    if (a.r_hi) {
-        const uint2 rh = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
-        v[0] += bf2f(rh.x & 0xffffu); v[1] += bf2f(rh.x >> 16);
-        v[2] += bf2f(rh.y & 0xffffu); v[3] += bf2f(rh.y >> 16);
-        if (x3) {
-            const uint2 rl = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
-            v[0] += bf2f(rl.x & 0xffffu); v[1] += bf2f(rl.x >> 16);
-            v[2] += bf2f(rl.y & 0xffffu); v[3] += bf2f(rl.y >> 16);
-        }
-    }
+    if (a.r_hi && !a.res_after_act) add_residual(a, v, ro, c, x3);
     if (a.act == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     } else if (a.act == 2) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+    } else if (a.act == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+    } else if (a.act == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.f + expf(-v[e]));
     }
+    if (a.r_hi && a.res_after_act) add_residual(a, v, ro, c, x3);
     uint32_t h[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
@@ -409,7 +419,7 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     const int BK = 64, KG = BK / 8;                            // packed K tile of the implicit-GEMM kernel
     p->BK = BK;
     p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
-              d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16;
+              d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16 && d.residual != 2 && d.act <= 2;
     if (p->halo) {
         // ---- pack for the halo-tile kernel: [slice][tap][Npad][CK], channels past cin are zero --------
         p->n_slices = cdiv(d.cin, HCK);
@@ -582,6 +592,7 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         a.rb = rb.per_batch(); a.ri = rb.Wp() * rb.C; a.rj = rb.C;
     }
     a.act = p->d.act;
+    a.res_after_act = p->d.residual == 2;
     a.goff_total = p->goff_total;
     int goff_max = 0;
     for (int ph = 0; ph < p->nphase; ++ph) {

@@ -1,0 +1,105 @@
+"""`Audio2Feature` drop-in (musetalk/whisper/audio2feature.py:9-112) over the MI355X Whisper encoder.
+
+museasr.py:26-27 calls `audio_processor.audio2feat(inputs)` with a float32 ndarray and
+`feature2chunks(feature_array=, fps=, batch_size=, start=)`; both keep their signatures and return types
+(numpy (T50, 5, 384) and a list of (50, 384) arrays).  The 30-s-padded encoder runs on the GPU through
+`mf_whisper_encode_audio`; there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ... import _lib
+
+N_SAMPLES_SEGMENT = 480000   # 30 s at 16 kHz = 3000 mel frames (whisper/audio.py:13-19)
+
+
+class Audio2Feature:
+    def __init__(self, whisper_model_type="tiny", model_path="./models/whisper/tiny.pt", state_dict=None, n_head=6,
+                 precision="bf16x3", device="cuda"):
+        """`model_path` is a Whisper checkpoint {dims, model_state_dict} as whisper/__init__.py:108-116 loads it;
+        `state_dict` (encoder tensors) + `n_head` may be given instead (tests, synthetic weights)."""
+        self.whisper_model_type = whisper_model_type
+        if state_dict is None:
+            ckpt = torch.load(model_path, map_location="cpu")
+            n_head = ckpt["dims"]["n_audio_head"]
+            state_dict = {k: v for k, v in ckpt["model_state_dict"].items() if k.startswith("encoder.")}
+        if not torch.cuda.is_available():
+            raise RuntimeError("Audio2Feature needs a HIP device; no CPU path exists here")
+        self.device = torch.device(device)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.init_device(idx)
+        items = [(k.encode(), v.detach().to("cpu", torch.float32).contiguous()) for k, v in state_dict.items()
+                 if k.split(".")[-1] in ("weight", "bias")]
+        arr = (_lib.MfTensor * len(items))()
+        self._keep = items
+        for i, (k, v) in enumerate(items):
+            arr[i].name, arr[i].data, arr[i].ndim = k, v.data_ptr(), v.dim()
+            for d in range(v.dim()):
+                arr[i].shape[d] = v.shape[d]
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mf_whisper_create(arr, len(items), int(n_head), _lib.PRECISIONS[precision], C.byref(h)),
+                       "whisper_create")
+        self._h = h.value
+        nl, nc, ns = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(_lib.lib().mf_whisper_dims(self._h, C.byref(nl), C.byref(nc), C.byref(ns)))
+        self.n_layer, self.n_ctx, self.n_state = nl.value, nc.value, ns.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().mf_whisper_destroy(self._h)
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def log_mel_spectrogram(self, audio):
+        """whisper/audio.py:92-125 for one <=30 s segment: (80, n // 160) float32 tensor on the device."""
+        wav = torch.as_tensor(np.asarray(audio, dtype=np.float32)).to(self.device).contiguous()
+        n = wav.numel()
+        out = torch.empty((80, n // 160), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mf_whisper_log_mel(self._h, wav.data_ptr(), n, out.data_ptr(), self._stream()), "whisper_log_mel")
+        return out
+
+    def audio2feat_device(self, audio):
+        """(T50, n_layer+1, n_state) float32 tensor on the device."""
+        wav = torch.as_tensor(np.asarray(audio, dtype=np.float32)).to(self.device).contiguous()
+        outs = []
+        # transcribe.py:103-126: 3000-frame (480000-sample) segments, each padded to 30 s
+        for s0 in range(0, wav.numel(), N_SAMPLES_SEGMENT):
+            seg = wav[s0:s0 + N_SAMPLES_SEGMENT]
+            n = seg.numel()
+            if n < 160:
+                break
+            emb = torch.empty((self.n_layer + 1, self.n_ctx, self.n_state), dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().mf_whisper_encode_audio(self._h, seg.data_ptr(), n, emb.data_ptr(), self._stream()),
+                           "whisper_encode_audio")
+            frames = n // 160
+            outs.append(emb[:, : int(frames / 2)].permute(1, 0, 2))     # audio2feature.py:104-110
+        return torch.cat(outs, dim=0)
+
+    def audio2feat(self, audio_path):
+        if isinstance(audio_path, str):
+            raise RuntimeError("Audio2Feature.audio2feat: file decoding (ffmpeg) is outside the hot path; pass the "
+                               "float32 waveform as museasr.py:25-26 does")
+        return self.audio2feat_device(audio_path).cpu().numpy()
+
+    # ---- audio2feature.py:16-45, 82-97: index arithmetic only, kept on the host ---------------------------
+    def get_sliced_feature(self, feature_array, vid_idx, audio_feat_length=[2, 2], fps=25):
+        length = len(feature_array)
+        center_idx = int(vid_idx * 50 / fps)
+        left_idx = center_idx - audio_feat_length[0] * 2
+        right_idx = center_idx + (audio_feat_length[1] + 1) * 2
+        selected_idx = [min(length - 1, max(0, idx)) for idx in range(left_idx, right_idx)]
+        selected_feature = np.concatenate([feature_array[i] for i in selected_idx], axis=0).reshape(-1, self.n_state)
+        return selected_feature, selected_idx
+
+    def feature2chunks(self, feature_array, fps, batch_size, audio_feat_length=[2, 2], start=0):
+        return [self.get_sliced_feature(feature_array=feature_array, vid_idx=i + start,
+                                        audio_feat_length=audio_feat_length, fps=fps)[0] for i in range(batch_size)]

@@ -116,3 +116,52 @@ def make_lip_inputs(batch, seed=0):
     masked[:, 48:] = 0
     face = (np.concatenate((masked, u8), axis=3) / 255.0).transpose(0, 3, 1, 2).astype(np.float32)
     return torch.from_numpy(mel), torch.from_numpy(np.ascontiguousarray(face)), u8
+
+
+# ---- Whisper-tiny audio encoder (musetalk/whisper/whisper/model.py:131-171) --------------------------
+# dims of the public "tiny" checkpoint; the reference reads them from the checkpoint (whisper/__init__.py:112)
+WHISPER_TINY = dict(n_mels=80, n_audio_ctx=1500, n_audio_state=384, n_audio_head=6, n_audio_layer=4)
+
+
+def make_whisper_encoder_state_dict(seed=0, dims=WHISPER_TINY):
+    """Seeded encoder weights under the reference's key names (AudioEncoder's own state_dict, i.e. without
+    the 'encoder.' prefix a full Whisper checkpoint carries).  positional_embedding is the model's own
+    sinusoid buffer and is regenerated, not drawn."""
+    rng = np.random.default_rng(7000 + seed)
+    C, M, L = dims["n_audio_state"], dims["n_mels"], dims["n_audio_layer"]
+
+    def f(a):
+        return torch.from_numpy(np.asarray(a, dtype=np.float32))
+
+    def lin(out_f, in_f, gain=1.0):
+        return f(rng.standard_normal((out_f, in_f)) * (gain / np.sqrt(in_f)))
+
+    sd = {
+        "conv1.weight": f(rng.standard_normal((C, M, 3)) * (1.0 / np.sqrt(M * 3))),
+        "conv1.bias": f(rng.standard_normal(C) * 0.05),
+        "conv2.weight": f(rng.standard_normal((C, C, 3)) * (1.4 / np.sqrt(C * 3))),
+        "conv2.bias": f(rng.standard_normal(C) * 0.05),
+    }
+    for i in range(L):
+        p = f"blocks.{i}."
+        sd[p + "attn.query.weight"] = lin(C, C, 1.5); sd[p + "attn.query.bias"] = f(rng.standard_normal(C) * 0.05)
+        sd[p + "attn.key.weight"] = lin(C, C, 1.5)
+        sd[p + "attn.value.weight"] = lin(C, C); sd[p + "attn.value.bias"] = f(rng.standard_normal(C) * 0.05)
+        sd[p + "attn.out.weight"] = lin(C, C, 0.7); sd[p + "attn.out.bias"] = f(rng.standard_normal(C) * 0.05)
+        sd[p + "attn_ln.weight"] = f(rng.uniform(0.8, 1.2, C)); sd[p + "attn_ln.bias"] = f(rng.standard_normal(C) * 0.05)
+        sd[p + "mlp.0.weight"] = lin(4 * C, C); sd[p + "mlp.0.bias"] = f(rng.standard_normal(4 * C) * 0.05)
+        sd[p + "mlp.2.weight"] = lin(C, 4 * C, 0.7); sd[p + "mlp.2.bias"] = f(rng.standard_normal(C) * 0.05)
+        sd[p + "mlp_ln.weight"] = f(rng.uniform(0.8, 1.2, C)); sd[p + "mlp_ln.bias"] = f(rng.standard_normal(C) * 0.05)
+    sd["ln_post.weight"] = f(rng.uniform(0.8, 1.2, C)); sd["ln_post.bias"] = f(rng.standard_normal(C) * 0.05)
+    return sd
+
+
+def make_speech_like_wav(n, seed=0):
+    """Seeded 16 kHz test signal: band-limited noise bursts + a few tones, |x| <= 1 (SURVEY 8d cfg 3 feeds
+    36x320 or 52x320 samples per step)."""
+    rng = np.random.default_rng(9000 + seed)
+    t = np.arange(n) / 16000.0
+    x = 0.08 * rng.standard_normal(n)
+    for f0 in (180.0, 440.0, 1250.0, 3100.0):
+        x += 0.1 * np.sin(2 * np.pi * f0 * t + rng.uniform(0, 6.28)) * (0.5 + 0.5 * np.sin(2 * np.pi * rng.uniform(1, 4) * t))
+    return np.clip(x, -1, 1).astype(np.float32)

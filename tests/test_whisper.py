@@ -1,0 +1,121 @@
+"""MuseTalk Whisper feature path: oracle against the vectors recorded from the real
+reference modules (CPU), HIP path against the oracle and the goldens (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from mere_fusion_amd import weights as W
+from oracle import whisper_ref as R
+
+FEAT_STRIDE = 13
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(os.path.join(GOLDEN, "whisper_golden.npz")))
+
+
+@pytest.fixture(scope="module")
+def wsd():
+    return W.make_whisper_encoder_state_dict(0)
+
+
+def test_mel_filterbank_matches_reference_asset(gold):
+    # audio.py:80-87: the asset IS librosa.filters.mel(sr=16000, n_fft=400, n_mels=80)
+    mine = R.mel_filters()
+    assert mine.shape == gold["mel_filters"].shape == (80, 201) and mine.dtype == np.float32
+    np.testing.assert_allclose(mine, gold["mel_filters"], rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize("n", [16640, 11520])
+def test_oracle_log_mel(gold, n):
+    got = R.log_mel_spectrogram(W.make_speech_like_wav(n, 0)).numpy()
+    assert got.shape == gold[f"logmel_{n}"].shape == (80, n // 160)
+    np.testing.assert_allclose(got, gold[f"logmel_{n}"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("n,B", [(16640, 16), (11520, 8)])
+def test_oracle_audio2feat_and_chunks(gold, wsd, n, B):
+    feat = R.audio2feat(wsd, W.make_speech_like_wav(n, 0))
+    assert list(feat.shape) == list(gold[f"feat_shape_{n}"]) == [n // 320, 5, 384]
+    np.testing.assert_allclose(feat.reshape(-1)[::FEAT_STRIDE], gold[f"feat_sample_{n}"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(feat[:2], gold[f"feat_first_{n}"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(np.abs(feat.astype(np.float64)).sum(), gold[f"feat_abssum_{n}"], rtol=1e-5)
+    # museasr.py:27: feature2chunks(feature_array, fps=opt.fps/2, batch_size, start=stride_left/2)
+    chunks, idxs = R.feature2chunks(feat, fps=25.0, batch_size=B, start=5.0)
+    np.testing.assert_array_equal(np.asarray(idxs), gold[f"chunk_idx_{n}"])
+    assert idxs[0] == list(range(6, 16)) and idxs[-1] == list(range(2 * (B + 4) - 4, 2 * (B + 4) + 6))
+    np.testing.assert_allclose(chunks[-1], gold[f"chunk_last_{n}"], rtol=0, atol=3e-4)
+    assert all(np.array_equal(c, feat[i].reshape(-1, 384)) for c, i in zip(chunks, idxs))
+
+
+def test_sliced_feature_clamps_at_the_edges():
+    feat = np.arange(20 * 5 * 384, dtype=np.float32).reshape(20, 5, 384)
+    _, idx = R.get_sliced_feature(feat, 0)
+    assert idx == [0, 0, 0, 0, 0, 1, 2, 3, 4, 5]
+    _, idx = R.get_sliced_feature(feat, 9)
+    assert idx == [14, 15, 16, 17, 18, 19, 19, 19, 19, 19]
+
+
+# ---- GPU: HIP path vs oracle and goldens -----------------------------------------------------------------
+TOL_LOGMEL = 2e-5      # fp64 DFT vs torch's fp32 stft; log-mel lives in [-1.5, 1.5]
+TOL_FEAT = 2e-3        # bf16x3 through 4 transformer blocks; embeddings reach |x| ~ 6 (relative 3e-4)
+
+
+@pytest.fixture(scope="module")
+def a2f(lib_built, wsd):
+    from mere_fusion_amd.musetalk.whisper.audio2feature import Audio2Feature
+    return Audio2Feature(state_dict=wsd, n_head=6, precision="bf16x3")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [16640, 11520, 480000, 1600])
+def test_hip_log_mel(a2f, gold, n):
+    wav = W.make_speech_like_wav(n, 0)
+    got = a2f.log_mel_spectrogram(wav).cpu().numpy()
+    want = R.log_mel_spectrogram(wav).numpy()
+    assert got.shape == want.shape == (80, n // 160)
+    assert np.abs(got - want).max() <= TOL_LOGMEL
+    if f"logmel_{n}" in gold:
+        assert np.abs(got - gold[f"logmel_{n}"]).max() <= TOL_LOGMEL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,B", [(16640, 16), (11520, 8)])
+def test_hip_audio2feat_vs_oracle_and_golden(a2f, gold, wsd, n, B):
+    wav = W.make_speech_like_wav(n, 0)
+    got = a2f.audio2feat(wav)
+    want = R.audio2feat(wsd, wav)
+    assert got.shape == want.shape == (n // 320, 5, 384) and got.dtype == np.float32
+    err = np.abs(got - want)
+    # per layer: the error must not grow out of the bf16x3 class through the stack
+    for l in range(5):
+        assert err[:, l].max() <= TOL_FEAT, (l, err[:, l].max())
+    np.testing.assert_allclose(got.reshape(-1)[::FEAT_STRIDE], gold[f"feat_sample_{n}"], rtol=0, atol=TOL_FEAT)
+    chunks = a2f.feature2chunks(feature_array=got, fps=25.0, batch_size=B, start=5.0)
+    assert len(chunks) == B and all(c.shape == (50, 384) for c in chunks)
+    np.testing.assert_allclose(chunks[-1], gold[f"chunk_last_{n}"], rtol=0, atol=TOL_FEAT)
+    _, idx = a2f.get_sliced_feature(got, 5.0)
+    assert idx == list(gold[f"chunk_idx_{n}"][0])
+
+
+@pytest.mark.gpu
+def test_hip_audio2feat_other_signal_and_repeatability(a2f, wsd):
+    wav = W.make_speech_like_wav(6400, 3)          # 20 tokens kept
+    a = a2f.audio2feat(wav)
+    b = a2f.audio2feat(wav)
+    assert a.shape == (20, 5, 384) and np.array_equal(a, b)
+    assert np.abs(a - R.audio2feat(wsd, wav)).max() <= TOL_FEAT
+    silent = a2f.audio2feat(np.zeros(3200, np.float32))   # log-mel of silence: all bins at the clamp
+    assert np.isfinite(silent).all() and np.abs(silent - R.audio2feat(wsd, np.zeros(3200, np.float32))).max() <= TOL_FEAT
+
+
+@pytest.mark.gpu
+def test_hip_whisper_error_paths(a2f):
+    with pytest.raises(RuntimeError, match="frames"):
+        a2f.log_mel_spectrogram(np.zeros(480160, np.float32))
+    with pytest.raises(RuntimeError, match="float32 waveform"):
+        a2f.audio2feat("some.wav")
