@@ -110,6 +110,7 @@ typedef struct mf_conv2d_desc {
     int residual;         /* 1: add the layer input before the activation (conv.py:17-18); 2: after it */
     int act;              /* 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf), 4 SiLU */
     int in_h, in_w;       /* spatial size of the input this layer is built for */
+    int upsample;         /* 1: nearest-neighbour 2x upsampling in front of a 3x3 s1 p1 conv (diffusers Upsample2D) */
 } mf_conv2d_desc;
 
 /* weight: host fp32, [cout,cin,kh,kw] (Conv2d) or [cin,cout,kh,kw] (ConvTranspose2d);
@@ -153,6 +154,54 @@ int mf_whisper_log_mel(mf_whisper* h, const float* wav, int n, float* out, void*
  * (= the reference's embeddings[0], model.py:158-168).  n <= 480000 samples (one 30 s segment). */
 int mf_whisper_encode_audio(mf_whisper* h, const float* wav, int n, float* emb, void* stream);
 void mf_whisper_destroy(mf_whisper* h);
+
+/* ---- MuseTalk UNet (H4) and VAE decode (H5) --------------------------------------------------- */
+/* The reference builds both from diffusers with config files it does not ship (musetalk/models/unet.py:34-37,
+ * vae.py:24), so the architecture is a parameter here.  Field meaning = the diffusers config keys. */
+typedef struct mf_unet_config {
+    int in_channels, out_channels;      /* 8, 4 */
+    int n_blocks;                        /* len(block_out_channels), <= 4 */
+    int block_out_channels[4];          /* 320, 640, 1280, 1280 */
+    int layers_per_block;               /* 2 */
+    int cross_attention_dim;            /* 384 */
+    int attention_heads;                /* config key "attention_head_dim": 8 heads */
+    int norm_num_groups;                /* 32 */
+    int down_attn[4], up_attn[4];       /* CrossAttn{Down,Up}Block2D vs {Down,Up}Block2D */
+    int sample_size;                    /* latent H = W: 32 */
+    int ctx_len;                        /* audio tokens per frame: 50 */
+} mf_unet_config;
+
+typedef struct mf_vae_config {
+    int latent_channels, out_channels;  /* 4, 3 */
+    int n_blocks;
+    int block_out_channels[4];          /* 128, 256, 512, 512 */
+    int layers_per_block;               /* 2 */
+    int norm_num_groups;                /* 32 */
+    int sample_size;                    /* latent H = W: 32 */
+    float scaling_factor;               /* 0.18215 */
+} mf_vae_config;
+
+typedef struct mf_unet mf_unet;
+typedef struct mf_vae mf_vae;
+
+/* Replaces `UNet(unet_config, model_path)` (musetalk/models/unet.py:29-44): weights = the
+ * UNet2DConditionModel state dict (diffusers key names).  The timestep is fixed to 0 as musereal.py:59 does;
+ * its embedding is folded into the resnet biases at create time. */
+int mf_unet_create(const mf_unet_config* cfg, const mf_tensor* weights, int n_weights, int precision, int max_batch,
+                   mf_unet** out);
+/* Replaces `pe(audio)` + `unet.model(latent_batch, timesteps, encoder_hidden_states=audio).sample`
+ * (musereal.py:102-107).  latents: device fp32 [B,in_channels,S,S]; audio: device fp32 [B,ctx_len,cross_dim];
+ * add_pe != 0 adds the PositionalEncoding of unet.py:12-27 to `audio` first; out: device fp32 [B,out_channels,S,S]. */
+int mf_unet_forward(mf_unet* h, const float* latents, const float* audio, int add_pe, float* out, int batch, void* stream);
+void mf_unet_destroy(mf_unet* h);
+
+/* Replaces `AutoencoderKL.from_pretrained` for the DECODER half (musetalk/models/vae.py:24,96-108). */
+int mf_vae_create(const mf_vae_config* cfg, const mf_tensor* weights, int n_weights, int precision, int max_batch,
+                  mf_vae** out);
+/* `VAE.decode_latents` (vae.py:96-108): latents device fp32 [B,4,S,S] -> frames device uint8 [B,8S,8S,3] BGR.
+ * image_f32 (optional, may be NULL): the decoder output before post-processing, device fp32 [B,3,8S,8S]. */
+int mf_vae_decode_latents(mf_vae* h, const float* latents, uint8_t* frames, float* image_f32, int batch, void* stream);
+void mf_vae_destroy(mf_vae* h);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,33 @@ class MfTensor(C.Structure):
 class MfConv2dDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "cin", "cout", "kh", "kw", "stride_h", "stride_w", "pad_h", "pad_w", "transposed",
-        "output_padding", "residual", "act", "in_h", "in_w")]
+        "output_padding", "residual", "act", "in_h", "in_w", "upsample")]
+
+
+class MfUnetConfig(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("n_blocks", C.c_int),
+                ("block_out_channels", C.c_int * 4), ("layers_per_block", C.c_int), ("cross_attention_dim", C.c_int),
+                ("attention_heads", C.c_int), ("norm_num_groups", C.c_int), ("down_attn", C.c_int * 4),
+                ("up_attn", C.c_int * 4), ("sample_size", C.c_int), ("ctx_len", C.c_int)]
+
+
+class MfVaeConfig(C.Structure):
+    _fields_ = [("latent_channels", C.c_int), ("out_channels", C.c_int), ("n_blocks", C.c_int),
+                ("block_out_channels", C.c_int * 4), ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int),
+                ("sample_size", C.c_int), ("scaling_factor", C.c_float)]
+
+
+def tensor_array(state_dict):
+    """(ctypes array of MfTensor, keep-alive list) for a {name: fp32 cpu tensor} dict."""
+    import torch
+    items = [(k.encode(), v.detach().to("cpu", torch.float32).contiguous()) for k, v in state_dict.items()
+             if torch.is_tensor(v) and v.is_floating_point()]
+    arr = (MfTensor * len(items))()
+    for i, (k, v) in enumerate(items):
+        arr[i].name, arr[i].data, arr[i].ndim = k, v.data_ptr(), v.dim()
+        for d in range(min(v.dim(), 4)):
+            arr[i].shape[d] = v.shape[d]
+    return arr, items
 
 
 # every symbol include/merefusion.h declares: (restype, argtypes)
@@ -49,6 +75,12 @@ SIGNATURES = {
     "mf_whisper_log_mel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mf_whisper_encode_audio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mf_whisper_destroy": (None, [C.c_void_p]),
+    "mf_unet_create": (C.c_int, [C.POINTER(MfUnetConfig), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mf_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mf_unet_destroy": (None, [C.c_void_p]),
+    "mf_vae_create": (C.c_int, [C.POINTER(MfVaeConfig), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mf_vae_decode_latents": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mf_vae_destroy": (None, [C.c_void_p]),
     "mf_melspec": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_melspec_frames": (C.c_int, [C.c_int]),
 }

@@ -11,6 +11,7 @@
 #pragma once
 #include "mf_common.h"
 #include <vector>
+#include <utility>
 
 struct ActBuf {
     int C = 0, H = 0, W = 0, halo = 0;
@@ -55,6 +56,9 @@ struct ConvArgs {
     int res_after_act;        // residual added after the activation (x = act(conv) + r)
     int tiles_m, tiles_n;
     int goff_total;
+    // grouped launch (attention: one GEMM per (batch, head) on blockIdx.z): element offsets per group
+    int zgroups, zheads;
+    int64_t zx_b, zx_h, zw, zy_b, zy_h;
     float* ws;                // split-K fp32 partials [split][B][Ho][Wo][N], or null
     int64_t ws_split, wsb; int wsi, wsj;
     ConvPhase ph[MF_MAX_PHASE];
@@ -96,11 +100,15 @@ struct ConvPlan {
     int* goff = nullptr;
     bool halo = false;    // 3x3 s1 p1 on a >= 16x16 map: LDS halo-tile kernel, weights packed [slice][tap][Npad][CK]
     int n_slices = 0;
+    int groups_cap = 1;   // grouped GEMM shells: packed operands the weight buffers hold
     hipEvent_t prof_mid = nullptr;   // measurement only: recorded between the MFMA kernel and its split-K combine
     float* ws = nullptr;  // split-K workspace, grown on the first (eager) launch that needs it
     int64_t ws_cap = 0;
     // host-side phase description, independent of the buffers the layer is later bound to
-    struct Tap { int dy, dx; };               // input displacement in pixels relative to anchor
+    struct Tap {                              // input displacement in pixels relative to anchor
+        int dy, dx;
+        std::vector<std::pair<int, int>> src;  // kernel taps (ky, kx) summed into this tap; empty = derived
+    };
     std::vector<std::vector<Tap>> phase_taps; // per phase
     std::vector<int> phase_oy, phase_ox;      // output pixel offset of the phase
     int out_step = 1;                         // output pixel stride of the quotient grid
@@ -129,6 +137,17 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap);
 ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch);
 // Algorithmic FLOPs of the layer (2 x MACs of the convolution itself; BN/ReLU/residual excluded).
 double mf_conv_flops(const ConvPlan* p, int batch);
+
+// Grouped GEMM on raw pointers (attention): for group z = (b, h), b = z / heads:
+//   out[z][m][n] = sum_k x[b*zx_b + h*zx_h + m*x_row + k] * B_z[n][k],  B_z = plan weights + z*zw
+// written at y + b*zy_b + h*zy_h + m*y_row + n.  The plan is a mf_gemm_plan_create shell whose packed weights
+// hold `groups` consecutive operands.  No split-K, no residual.
+struct GroupedGemm {
+    const bf16_t* x_hi; const bf16_t* x_lo; int64_t zx_b, zx_h; int x_row;
+    bf16_t* y_hi; bf16_t* y_lo; int64_t zy_b, zy_h; int y_row;
+    int M, groups, heads;
+};
+int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream);
 
 // Enqueues the layer.  res may have buf == nullptr.
 int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,

@@ -117,7 +117,14 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const ConvPhase ph = a.ph[blockIdx.z];
+    ConvPhase ph = a.ph[a.zgroups ? 0 : blockIdx.z];
+    int64_t zx = 0, zy = 0;
+    if (a.zgroups) {   // attention: blockIdx.z = (batch, head); operand bases move, geometry does not
+        const int zb = blockIdx.z / a.zheads, zh = blockIdx.z - zb * a.zheads;
+        zx = zb * a.zx_b + zh * a.zx_h;
+        zy = zb * a.zy_b + zh * a.zy_h;
+        ph.w_off += (int64_t)blockIdx.z * a.zw;
+    }
 
     // XCD-aware tile order: the dispatcher round-robins blockIdx over the 8 XCDs; give each XCD a
     // contiguous run of tiles (n fastest) so the N tiles of one pixel tile share an L2.
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
         const int b = m / a.HqWq;
         const int rem = m - b * a.HqWq;
         const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
-        xp[i] = a.x_hi + ((int64_t)b * a.xb + (int64_t)qi * a.xi + (int64_t)qj * a.xj);
+        xp[i] = a.x_hi + (zx + (int64_t)b * a.xb + (int64_t)qi * a.xi + (int64_t)qj * a.xj);
     }
     const bf16_t* wp[NWC];
     const int64_t w_delta = X3 ? (a.w_lo - a.w_hi) : 0;
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
             }
             continue;
         }
-        const int64_t yo = (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
+        const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
         const int64_t ro = (int64_t)b * a.rb + (int64_t)qi * a.ri + (int64_t)qj * a.rj;
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
@@ -307,7 +314,7 @@ int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStrea
         attr_done = true;
     }
     const size_t lds = 2 * (size_t)(BM + BN) * BK * 2 * (X3 ? 2 : 1) + (size_t)goff_max * 4;
-    dim3 grid(a.tiles_m * a.tiles_n, nsplit, nphase);
+    dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.zgroups ? a.zgroups : nphase);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     MF_HIP(hipGetLastError());
     return MF_OK;
@@ -330,7 +337,6 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
                         const float* bn_gamma, const float* bn_beta, const float* bn_mean,
                         const float* bn_var, int precision) {
     MF_REQUIRE(d.cin > 0 && d.cout > 0 && d.kh > 0 && d.kw > 0, "conv: bad channel/kernel size");
-    MF_REQUIRE(d.cout % 4 == 0, "conv: cout=%d must be a multiple of 4 for the MFMA path", d.cout);
     MF_REQUIRE(d.stride_h > 0 && d.stride_w > 0 && d.in_h > 0 && d.in_w > 0, "conv: bad stride/input size");
     MF_REQUIRE(precision == MF_PREC_BF16 || precision == MF_PREC_BF16X3, "conv: unknown precision %d", precision);
     p->d = d;
@@ -339,7 +345,33 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     const int cpg = p->cin_pad / 8;
     p->phase_taps.clear(); p->phase_oy.clear(); p->phase_ox.clear();
 
-    if (!d.transposed) {
+    if (d.upsample) {
+        MF_REQUIRE(!d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 && d.pad_w == 1,
+                   "conv: upsample is built for 3x3 stride-1 pad-1 convolutions");
+        // nearest 2x upsampling folded into the gather: output pixel (2i+py, 2j+px) reads input rows
+        // i-1..i (py=0) or i..i+1 (py=1); kernel taps that land on the same input pixel are summed, so each of
+        // the 4 phases is a 2x2 convolution on the INPUT grid (16 tap-products per input pixel instead of 36)
+        p->out_h = 2 * d.in_h; p->out_w = 2 * d.in_w;
+        p->Hq = d.in_h; p->Wq = d.in_w; p->out_step = 2; p->in_step_h = p->in_step_w = 1;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                std::vector<ConvPlan::Tap> taps;
+                for (int ty = 0; ty < 2; ++ty)
+                    for (int tx = 0; tx < 2; ++tx) {
+                        ConvPlan::Tap t{py + ty - 1, px + tx - 1, {}};
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx) {
+                                // floor((p + k - 1) / 2) for p in {0,1}, k in {0,1,2}
+                                const int dy = (py + ky - 1 + 2) / 2 - 1, dx = (px + kx - 1 + 2) / 2 - 1;
+                                if (dy == t.dy && dx == t.dx) t.src.push_back({ky, kx});
+                            }
+                        taps.push_back(t);
+                    }
+                p->phase_taps.push_back(taps);
+                p->phase_oy.push_back(py); p->phase_ox.push_back(px);
+            }
+        p->in_halo_need = 1;
+    } else if (!d.transposed) {
         p->out_h = (d.in_h + 2 * d.pad_h - d.kh) / d.stride_h + 1;
         p->out_w = (d.in_w + 2 * d.pad_w - d.kw) / d.stride_w + 1;
         MF_REQUIRE(p->out_h > 0 && p->out_w > 0, "conv: empty output");
@@ -419,7 +451,8 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     const int BK = 64, KG = BK / 8;                            // packed K tile of the implicit-GEMM kernel
     p->BK = BK;
     p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
-              d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16 && d.residual != 2 && d.act <= 2;
+              d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16 && d.residual != 2 && d.act <= 2 && !d.upsample &&
+              d.cin <= 256 && d.cout <= 256 && d.cout % 4 == 0;   // wide layers: weights must be shared through LDS
     if (p->halo) {
         // ---- pack for the halo-tile kernel: [slice][tap][Npad][CK], channels past cin are zero --------
         p->n_slices = cdiv(d.cin, HCK);
@@ -465,31 +498,33 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     std::vector<bf16_t> hi(total, 0), lo(total, 0);
     const int k = d.kh;  // (transposed: square)
     for (int ph = 0; ph < p->nphase; ++ph) {
-        const auto& taps = p->phase_taps[ph];
+        auto& taps = p->phase_taps[ph];
         for (size_t ti = 0; ti < taps.size(); ++ti) {
-            int ky, kx;
-            if (!d.transposed) {
-                ky = taps[ti].dy + d.pad_h; kx = taps[ti].dx + d.pad_w;
-            } else if (d.stride_h == 1) {
-                ky = p->phase_oy[ph]; kx = p->phase_ox[ph];
-            } else {
-                ky = p->phase_oy[ph] + d.pad_h - taps[ti].dy * d.stride_h;
-                kx = p->phase_ox[ph] + d.pad_w - taps[ti].dx * d.stride_w;
+            if (taps[ti].src.empty()) {   // the kernel tap this gather tap stands for
+                int ky, kx;
+                if (!d.transposed) {
+                    ky = taps[ti].dy + d.pad_h; kx = taps[ti].dx + d.pad_w;
+                } else if (d.stride_h == 1) {
+                    ky = p->phase_oy[ph]; kx = p->phase_ox[ph];
+                } else {
+                    ky = p->phase_oy[ph] + d.pad_h - taps[ti].dy * d.stride_h;
+                    kx = p->phase_ox[ph] + d.pad_w - taps[ti].dx * d.stride_w;
+                }
+                taps[ti].src.push_back({ky, kx});
             }
-            for (int c = 0; c < d.cin; ++c) {
-                const int g = (int)ti * cpg + c / 8;
-                const int kt = g / KG, e = (g % KG) * 8 + c % 8;
-                for (int n = 0; n < d.cout; ++n) {
-                    const float w = d.transposed
-                        ? weight[(((int64_t)c * d.cout + n) * k + ky) * k + kx]
-                        : weight[(((int64_t)n * d.cin + c) * d.kh + ky) * d.kw + kx];
-                    const float wf = w * scale[n];
-                    const int64_t idx = p->ph[ph].w_off + ((int64_t)kt * p->Npad + n) * BK + e;
+            for (int n = 0; n < d.cout; ++n)
+                for (int c = 0; c < d.cin; ++c) {
+                    double w = 0.0;
+                    for (const auto& kk : taps[ti].src)
+                        w += d.transposed ? weight[(((int64_t)c * d.cout + n) * k + kk.first) * k + kk.second]
+                                          : weight[(((int64_t)n * d.cin + c) * d.kh + kk.first) * d.kw + kk.second];
+                    const float wf = (float)(w * (double)scale[n]);
+                    const int g = (int)ti * cpg + c / 8;
+                    const int64_t idx = p->ph[ph].w_off + ((int64_t)(g / KG) * p->Npad + n) * BK + (g % KG) * 8 + c % 8;
                     const bf16_t h = mf_f2bf(wf);
                     hi[idx] = h;
                     lo[idx] = mf_f2bf(wf - mf_bf2f(h));
                 }
-            }
         }
     }
     MF_HIP(hipMalloc(&p->w_hi, total * sizeof(bf16_t)));
@@ -545,7 +580,9 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
     const ActBuf& ob = *out.buf;
     MF_REQUIRE(p->bound_in_ld == ib.C && p->bound_in_wp == ib.Wp(), "conv: plan not bound to this input geometry");
     MF_REQUIRE(in.C >= p->cin_pad && in.coff % 8 == 0 && in.coff + in.C <= ib.C, "conv: bad input view");
-    MF_REQUIRE(out.C == p->d.cout && out.coff % 4 == 0 && out.coff + out.C <= ob.C, "conv: bad output view");
+    // the epilogue stores channel quads: a cout that is not a multiple of 4 spills zero-weight channels
+    // into the next (up to 3) channels of the buffer, which must exist
+    MF_REQUIRE(out.C == p->d.cout && out.coff % 4 == 0 && out.coff + (out.C + 3) / 4 * 4 <= ob.C, "conv: bad output view");
     MF_REQUIRE(ob.H == p->out_h && ob.W == p->out_w, "conv: output buffer %dx%d != %dx%d", ob.H, ob.W, p->out_h, p->out_w);
     const bool x3 = p->precision == MF_PREC_BF16X3;
     MF_REQUIRE(!x3 || (ib.lo && ob.lo), "conv: BF16X3 needs lo planes");
@@ -642,6 +679,38 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         MF_HIP(hipGetLastError());
     }
     return MF_OK;
+}
+
+int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream) {
+    MF_REQUIRE(!p->halo && p->nphase == 1 && p->bound_in_ld > 0, "grouped gemm: plan must be a bound mf_gemm_plan_create shell");
+    const bool x3 = p->precision == MF_PREC_BF16X3;
+    ConvArgs a{};
+    a.x_hi = g.x_hi; a.x_lo = x3 ? g.x_lo : nullptr;
+    a.w_hi = p->w_hi; a.w_lo = p->w_lo; a.bias = p->bias; a.goff = p->goff;
+    a.M = g.M; a.N = p->d.cout; a.Npad = p->Npad;
+    a.HqWq = g.M; a.Wq = g.M;          // rows are linear: (b, i, j) = (0, 0, m)
+    a.xb = 0; a.xi = 0; a.xj = g.x_row;
+    a.y_hi = g.y_hi; a.y_lo = x3 ? g.y_lo : nullptr;
+    a.yb = 0; a.yi = 0; a.yj = g.y_row;
+    a.act = 0;
+    a.goff_total = p->goff_total;
+    a.ph[0] = p->ph[0];
+    a.zgroups = g.groups; a.zheads = g.heads;
+    a.zx_b = g.zx_b; a.zx_h = g.zx_h; a.zy_b = g.zy_b; a.zy_h = g.zy_h;
+    a.zw = (int64_t)p->ph[0].KT * p->Npad * 64;
+    const int M = g.M, N = a.N;
+    int rc = MF_ERR_INVALID;
+#define MF_GCASE(BM, BN, WGM, WGN)                                                         \
+    { a.tiles_m = cdiv(M, BM); a.tiles_n = cdiv(N, BN);                                    \
+      rc = launch_prec<BM, BN, WGM, WGN>(a, 1, 1, p->ph[0].ngroups, x3, stream); }
+    if (N <= 16) MF_GCASE(128, 16, 4, 1)
+    else if (N <= 32) MF_GCASE(128, 32, 4, 1)
+    else if (M <= 16) MF_GCASE(16, 64, 1, 4)
+    else if (cdiv(M, 128) * cdiv(N, 128) * g.groups >= 512 && N % 128 == 0) MF_GCASE(128, 128, 2, 2)
+    else if (cdiv(M, 128) * cdiv(N, 64) * g.groups >= 512) MF_GCASE(128, 64, 2, 2)
+    else MF_GCASE(64, 64, 2, 2)
+#undef MF_GCASE
+    return rc;
 }
 
 // Tile selection: the largest tile that still yields >= ~2 workgroups per CU (256 CUs); layers that

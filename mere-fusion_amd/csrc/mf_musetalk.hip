@@ -1,0 +1,611 @@
+// MuseTalk UNet (one conditional evaluation at t = 0) and SD-VAE decoder on gfx950 (H4, H5):
+// musereal.py:102-108 -> musetalk/models/unet.py:29-44, vae.py:96-108 -> diffusers UNet2DConditionModel /
+// AutoencoderKL (un-vendored; architecture per include/merefusion.h mf_unet_config / mf_vae_config).
+//
+// Both networks are static schedules of the same fused building blocks as the Wav2Lip generator:
+//   * every Conv2d / Linear is an MFMA convolution (3x3 halo-tile or implicit GEMM, 1x1 = GEMM) with
+//     bias / residual / SiLU epilogues; the t = 0 time embedding is a per-channel constant folded into
+//     each resnet's conv1 bias at create time;
+//   * `torch.cat([hidden, skip])` of the up path is free: producer layers write channel slices of one buffer;
+//   * nearest-2x upsample + conv3x3 runs as 4 sub-pixel phases of pre-summed 2x2 taps (2.25x fewer FLOPs);
+//   * attention = grouped (batch x head) GEMMs with device-packed K / V^T operands + fp32 row softmax;
+//   * GroupNorm(+SiLU) = fp64 statistics pass + one apply pass.
+#include "mf_nn.h"
+#include "mf_aux.h"
+#include <cmath>
+#include <cstdlib>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace {
+
+typedef std::function<int(int, hipStream_t)> Op;
+
+struct Net {
+    int precision = MF_PREC_BF16X3;
+    int cap = 1;
+    std::map<std::string, const mf_tensor*> sd;
+    std::vector<std::unique_ptr<ActBuf>> bufs;
+    std::vector<std::unique_ptr<ConvPlan>> plans;
+    std::vector<void*> dev;
+    std::vector<Op> ops;
+    std::map<std::tuple<std::string, int, int, int, int>, ActBuf*> scratch;
+    std::map<std::tuple<int, int, int, int>, std::pair<ConvPlan*, ConvPlan*>> attn_plans;   // (dh, Tq, Tk, heads)
+    double* gn_stats = nullptr;
+    std::map<int, hipGraphExec_t> graphs;
+    hipStream_t cap_stream = nullptr;
+    bool use_graph = true;
+    std::string err;
+
+    ~Net() {
+        for (auto& g : graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
+        for (auto& p : plans) mf_conv_plan_destroy(p.get());
+        for (auto& b : bufs) { if (b->hi) (void)hipFree(b->hi); if (b->lo) (void)hipFree(b->lo); }
+        for (void* d : dev) (void)hipFree(d);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    }
+
+    // ---- resources ----------------------------------------------------------------------------------------
+    ActBuf* buf(int C, int H, int W, int halo) {
+        bufs.emplace_back(new ActBuf());
+        ActBuf* b = bufs.back().get();
+        b->C = (C + 7) / 8 * 8; b->H = H; b->W = W; b->halo = halo;
+        const size_t bytes = ((size_t)cap * b->per_batch() + 64) * sizeof(bf16_t);
+        if (hipMalloc(&b->hi, bytes) != hipSuccess || hipMemset(b->hi, 0, bytes) != hipSuccess) { err = "hipMalloc failed for an activation buffer"; return nullptr; }
+        if (precision == MF_PREC_BF16X3 && (hipMalloc(&b->lo, bytes) != hipSuccess || hipMemset(b->lo, 0, bytes) != hipSuccess)) { err = "hipMalloc failed for an activation buffer"; return nullptr; }
+        return b;
+    }
+    // scratch reused by every block that asks for the same (slot, shape): blocks run one after another
+    ActBuf* tmp(const std::string& slot, int C, int H, int W, int halo) {
+        auto key = std::make_tuple(slot, C, H, W, halo);
+        auto it = scratch.find(key);
+        if (it != scratch.end()) return it->second;
+        ActBuf* b = buf(C, H, W, halo);
+        scratch[key] = b;
+        return b;
+    }
+    float* upload(const float* host, size_t n) {
+        float* d = nullptr;
+        if (hipMalloc(&d, n * sizeof(float)) != hipSuccess || hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "upload failed"; return nullptr; }
+        dev.push_back(d);
+        return d;
+    }
+    const float* T(const std::string& k, int64_t numel) {
+        auto it = sd.find(k);
+        if (it == sd.end()) { err = "state dict has no tensor '" + k + "'"; return nullptr; }
+        int64_t n = 1;
+        for (int i = 0; i < it->second->ndim; ++i) n *= it->second->shape[i];
+        if (n != numel) { err = "tensor '" + k + "' has " + std::to_string(n) + " elements, expected " + std::to_string(numel); return nullptr; }
+        return it->second->data;
+    }
+    bool has(const std::string& k) const { return sd.count(k) != 0; }
+    ConvPlan* new_plan() { plans.emplace_back(new ConvPlan()); return plans.back().get(); }
+
+    // ---- ops ----------------------------------------------------------------------------------------------
+    // Conv2d / Linear `name` (k x k, stride, pad), optional SiLU etc., optional residual view, optional
+    // nearest-2x upsample in front, optional per-channel constant added to the bias, optional input scale.
+    int conv(const std::string& name, ActView in, ActView out, int cin, int cout, int k, int stride, int pad, int act,
+             ActView res, int upsample = 0, const std::vector<float>* extra_bias = nullptr, float w_scale = 1.f, bool bias = true) {
+        const float* w = T(name + ".weight", (int64_t)cin * cout * k * k);
+        const float* b = bias ? T(name + ".bias", cout) : nullptr;
+        if (!w || (bias && !b)) return MF_ERR_INVALID;
+        std::vector<float> bb(cout, 0.f), ws;
+        for (int i = 0; i < cout; ++i) bb[i] = (b ? b[i] : 0.f) + (extra_bias ? (*extra_bias)[i] : 0.f);
+        if (w_scale != 1.f) {
+            ws.assign(w, w + (size_t)cin * cout * k * k);
+            for (auto& v : ws) v *= w_scale;
+            w = ws.data();
+        }
+        mf_conv2d_desc d{};
+        d.cin = cin; d.cout = cout; d.kh = d.kw = k; d.stride_h = d.stride_w = stride; d.pad_h = d.pad_w = pad;
+        d.act = act; d.residual = res.buf ? 1 : 0; d.in_h = in.buf->H; d.in_w = in.buf->W; d.upsample = upsample;
+        ConvPlan* p = new_plan();
+        int rc = mf_conv_plan_create(p, d, w, bb.data(), nullptr, nullptr, nullptr, nullptr, precision);
+        if (rc) return rc;
+        if ((rc = mf_conv_bind(p, *in.buf))) return rc;
+        ops.push_back([p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
+        return MF_OK;
+    }
+    int gn(const std::string& name, ActView in, ActView out, int groups, float eps, bool silu) {
+        const float* g = T(name + ".weight", in.C);
+        const float* b = T(name + ".bias", in.C);
+        if (!g || !b) return MF_ERR_INVALID;
+        float* dg = upload(g, in.C);
+        float* db = upload(b, in.C);
+        if (!dg || !db) return MF_ERR_HIP;
+        double* st = gn_stats;
+        ops.push_back([=](int B, hipStream_t s) { return mf_groupnorm(in, out, dg, db, groups, eps, silu, st, B, s); });
+        return MF_OK;
+    }
+    int ln(const std::string& name, ActView in, ActView out) {
+        const float* g = T(name + ".weight", in.C);
+        const float* b = T(name + ".bias", in.C);
+        if (!g || !b) return MF_ERR_INVALID;
+        float* dg = upload(g, in.C);
+        float* db = upload(b, in.C);
+        if (!dg || !db) return MF_ERR_HIP;
+        ops.push_back([=](int B, hipStream_t s) { return mf_layernorm(in, out, dg, db, 1e-5f, B, s); });
+        return MF_OK;
+    }
+    // softmax(q k^T * dh^-0.5) v for `heads` heads; q / k / v / out are views of contiguous (halo 0) token buffers
+    int attention(ActView q, ActView k, ActView v, ActView out, int heads) {
+        const int C = q.C, dh = C / heads;
+        const int Tq = q.buf->H * q.buf->W, Tk = k.buf->H * k.buf->W;
+        if (q.buf->halo || k.buf->halo || v.buf->halo || out.buf->halo || dh % 8 || k.C != C || v.C != C || out.C != C) {
+            err = "attention: needs contiguous token buffers and a head dim that is a multiple of 8";
+            return MF_ERR_INVALID;
+        }
+        const int Tk8 = (Tk + 7) / 8 * 8, Tk64 = (Tk + 63) / 64 * 64;
+        auto key = std::make_tuple(dh, Tq, Tk, heads);
+        if (!attn_plans.count(key)) {
+            ConvPlan* ps = new_plan();
+            ConvPlan* pv = new_plan();
+            int rc;
+            if ((rc = mf_gemm_plan_create_grouped(ps, dh, Tk, Tq, cap * heads, precision))) return rc;
+            if ((rc = mf_gemm_plan_create_grouped(pv, Tk64, dh, Tq, cap * heads, precision))) return rc;
+            // linear rows: the k-group table is just cg*8
+            for (ConvPlan* p : {ps, pv}) {
+                std::vector<int> goff(p->goff_total);
+                for (int g = 0; g < p->goff_total; ++g) goff[g] = (g < p->cin_pad / 8 ? g : 0) * 8;
+                MF_HIP(hipMemcpy(p->goff, goff.data(), goff.size() * sizeof(int), hipMemcpyHostToDevice));
+                p->bound_in_ld = 1; p->bound_in_wp = 1;
+            }
+            attn_plans[key] = {ps, pv};
+        }
+        ConvPlan* ps = attn_plans[key].first;
+        ConvPlan* pv = attn_plans[key].second;
+        ActBuf* sc = tmp("attn.scores", Tk8, heads, Tq, 0);
+        ActBuf* pm = tmp("attn.probs", Tk64, heads, Tq, 0);
+        if (!sc || !pm) return MF_ERR_HIP;
+        const float scale = 1.0f / std::sqrt((float)dh);
+        const bool x3 = precision == MF_PREC_BF16X3;
+        ops.push_back([=](int B, hipStream_t s) {
+            int rc;
+            if ((rc = mf_pack_b_grouped(ps, k.buf->hi + k.coff, x3 ? k.buf->lo + k.coff : nullptr, k.buf->per_batch(), dh,
+                                        k.buf->C, 1, Tk, dh, B * heads, heads, s))) return rc;
+            GroupedGemm g{};
+            g.x_hi = q.buf->hi + q.coff; g.x_lo = x3 ? q.buf->lo + q.coff : nullptr;
+            g.zx_b = q.buf->per_batch(); g.zx_h = dh; g.x_row = q.buf->C;
+            g.y_hi = sc->hi; g.y_lo = sc->lo; g.zy_b = sc->per_batch(); g.zy_h = (int64_t)Tq * sc->C; g.y_row = sc->C;
+            g.M = Tq; g.groups = B * heads; g.heads = heads;
+            if ((rc = mf_gemm_grouped_launch(ps, g, s))) return rc;
+            if ((rc = mf_softmax_rows(ActView{sc, 0, Tk}, ActView{pm, 0, pm->C}, Tk, scale, B, s))) return rc;
+            if ((rc = mf_pack_b_grouped(pv, v.buf->hi + v.coff, x3 ? v.buf->lo + v.coff : nullptr, v.buf->per_batch(), dh,
+                                        1, v.buf->C, dh, Tk, B * heads, heads, s))) return rc;
+            GroupedGemm o{};
+            o.x_hi = pm->hi; o.x_lo = pm->lo; o.zx_b = pm->per_batch(); o.zx_h = (int64_t)Tq * pm->C; o.x_row = pm->C;
+            o.y_hi = out.buf->hi + out.coff; o.y_lo = x3 ? out.buf->lo + out.coff : nullptr;
+            o.zy_b = out.buf->per_batch(); o.zy_h = dh; o.y_row = out.buf->C;
+            o.M = Tq; o.groups = B * heads; o.heads = heads;
+            return mf_gemm_grouped_launch(pv, o, s);
+        });
+        return MF_OK;
+    }
+
+    // ---- blocks -------------------------------------------------------------------------------------------
+    // diffusers ResnetBlock2D; temb_act = silu(time_embedding) on the host (nullptr: VAE)
+    int resnet(const std::string& p, ActView x, ActView y, int cin, int cout, int groups, float eps, const std::vector<float>* temb_act) {
+        const int H = x.buf->H, W = x.buf->W;
+        ActBuf *t1 = tmp("rn.t1", cin, H, W, 1), *c1 = tmp("rn.c1", cout, H, W, 1), *t2 = tmp("rn.t2", cout, H, W, 1);
+        if (!t1 || !c1 || !t2) return MF_ERR_HIP;
+        int rc;
+        if ((rc = gn(p + ".norm1", x, ActView{t1, 0, cin}, groups, eps, true))) return rc;
+        std::vector<float> tb;
+        if (temb_act && has(p + ".time_emb_proj.weight")) {
+            const int td = (int)temb_act->size();
+            const float* w = T(p + ".time_emb_proj.weight", (int64_t)cout * td);
+            const float* b = T(p + ".time_emb_proj.bias", cout);
+            if (!w || !b) return MF_ERR_INVALID;
+            tb.resize(cout);
+            for (int o = 0; o < cout; ++o) {
+                double a = b[o];
+                for (int i = 0; i < td; ++i) a += (double)w[(size_t)o * td + i] * (*temb_act)[i];
+                tb[o] = (float)a;
+            }
+        }
+        if ((rc = conv(p + ".conv1", ActView{t1, 0, cin}, ActView{c1, 0, cout}, cin, cout, 3, 1, 1, 0, ActView{}, 0, tb.empty() ? nullptr : &tb))) return rc;
+        if ((rc = gn(p + ".norm2", ActView{c1, 0, cout}, ActView{t2, 0, cout}, groups, eps, true))) return rc;
+        ActView res = x;
+        if (has(p + ".conv_shortcut.weight")) {
+            ActBuf* sc = tmp("rn.sc", cout, H, W, 1);
+            if (!sc) return MF_ERR_HIP;
+            if ((rc = conv(p + ".conv_shortcut", x, ActView{sc, 0, cout}, cin, cout, 1, 1, 0, 0, ActView{}))) return rc;
+            res = ActView{sc, 0, cout};
+        } else if (cin != cout) {
+            err = p + ": cin != cout but no conv_shortcut in the state dict";
+            return MF_ERR_INVALID;
+        }
+        return conv(p + ".conv2", ActView{t2, 0, cout}, y, cout, cout, 3, 1, 1, 0, res);
+    }
+
+    // diffusers Transformer2DModel (conv projections) with one BasicTransformerBlock; ctx = audio tokens
+    int transformer(const std::string& p, ActView x, ActView y, int C, int heads, int groups, ActView ctx) {
+        const int H = x.buf->H, W = x.buf->W, X = ctx.C;
+        ActBuf *g0 = tmp("xf.gn", C, H, W, 0), *hA = tmp("xf.hA", C, H, W, 0), *hB = tmp("xf.hB", C, H, W, 0);
+        ActBuf *nb = tmp("xf.ln", C, H, W, 0), *qkv = tmp("xf.qkv", 3 * C, H, W, 0), *ao = tmp("xf.ao", C, H, W, 0);
+        ActBuf *kv = tmp("xf.kv", 2 * C, ctx.buf->H, ctx.buf->W, 0), *ff = tmp("xf.ff", 8 * C, H, W, 0), *gg = tmp("xf.geglu", 4 * C, H, W, 0);
+        if (!g0 || !hA || !hB || !nb || !qkv || !ao || !kv || !ff || !gg) return MF_ERR_HIP;
+        const std::string t = p + ".transformer_blocks.0";
+        int rc;
+        if ((rc = gn(p + ".norm", x, ActView{g0, 0, C}, groups, 1e-6f, false))) return rc;
+        if ((rc = conv(p + ".proj_in", ActView{g0, 0, C}, ActView{hA, 0, C}, C, C, 1, 1, 0, 0, ActView{}))) return rc;
+        // self attention: q | k | v in one GEMM (no bias)
+        if ((rc = ln(t + ".norm1", ActView{hA, 0, C}, ActView{nb, 0, C}))) return rc;
+        {
+            const float *wq = T(t + ".attn1.to_q.weight", (int64_t)C * C), *wk = T(t + ".attn1.to_k.weight", (int64_t)C * C),
+                        *wv = T(t + ".attn1.to_v.weight", (int64_t)C * C);
+            if (!wq || !wk || !wv) return MF_ERR_INVALID;
+            std::vector<float> w((size_t)3 * C * C);
+            std::copy(wq, wq + (size_t)C * C, w.begin());
+            std::copy(wk, wk + (size_t)C * C, w.begin() + (size_t)C * C);
+            std::copy(wv, wv + (size_t)C * C, w.begin() + (size_t)2 * C * C);
+            if ((rc = linear_raw(w.data(), nullptr, ActView{nb, 0, C}, ActView{qkv, 0, 3 * C}, C, 3 * C, ActView{}))) return rc;
+        }
+        if ((rc = attention(ActView{qkv, 0, C}, ActView{qkv, C, C}, ActView{qkv, 2 * C, C}, ActView{ao, 0, C}, heads))) return rc;
+        if ((rc = conv(t + ".attn1.to_out.0", ActView{ao, 0, C}, ActView{hB, 0, C}, C, C, 1, 1, 0, 0, ActView{hA, 0, C}))) return rc;
+        // cross attention over the audio tokens: k | v in one GEMM
+        if ((rc = ln(t + ".norm2", ActView{hB, 0, C}, ActView{nb, 0, C}))) return rc;
+        if ((rc = conv(t + ".attn2.to_q", ActView{nb, 0, C}, ActView{qkv, 0, C}, C, C, 1, 1, 0, 0, ActView{}, 0, nullptr, 1.f, false))) return rc;
+        {
+            const float *wk = T(t + ".attn2.to_k.weight", (int64_t)C * X), *wv = T(t + ".attn2.to_v.weight", (int64_t)C * X);
+            if (!wk || !wv) return MF_ERR_INVALID;
+            std::vector<float> w((size_t)2 * C * X);
+            std::copy(wk, wk + (size_t)C * X, w.begin());
+            std::copy(wv, wv + (size_t)C * X, w.begin() + (size_t)C * X);
+            if ((rc = linear_raw(w.data(), nullptr, ctx, ActView{kv, 0, 2 * C}, X, 2 * C, ActView{}))) return rc;
+        }
+        if ((rc = attention(ActView{qkv, 0, C}, ActView{kv, 0, C}, ActView{kv, C, C}, ActView{ao, 0, C}, heads))) return rc;
+        if ((rc = conv(t + ".attn2.to_out.0", ActView{ao, 0, C}, ActView{hA, 0, C}, C, C, 1, 1, 0, 0, ActView{hB, 0, C}))) return rc;
+        // GEGLU feed-forward
+        if ((rc = ln(t + ".norm3", ActView{hA, 0, C}, ActView{nb, 0, C}))) return rc;
+        if ((rc = conv(t + ".ff.net.0.proj", ActView{nb, 0, C}, ActView{ff, 0, 8 * C}, C, 8 * C, 1, 1, 0, 0, ActView{}))) return rc;
+        ops.push_back([=](int B, hipStream_t s) { return mf_geglu(ActView{ff, 0, 8 * C}, ActView{gg, 0, 4 * C}, B, s); });
+        if ((rc = conv(t + ".ff.net.2", ActView{gg, 0, 4 * C}, ActView{hB, 0, C}, 4 * C, C, 1, 1, 0, 0, ActView{hA, 0, C}))) return rc;
+        return conv(p + ".proj_out", ActView{hB, 0, C}, y, C, C, 1, 1, 0, 0, x);
+    }
+
+    int linear_raw(const float* w, const float* b, ActView in, ActView out, int cin, int cout, ActView res) {
+        mf_conv2d_desc d{};
+        d.cin = cin; d.cout = cout; d.kh = d.kw = 1; d.stride_h = d.stride_w = 1; d.residual = res.buf ? 1 : 0;
+        d.in_h = in.buf->H; d.in_w = in.buf->W;
+        ConvPlan* p = new_plan();
+        int rc = mf_conv_plan_create(p, d, w, b, nullptr, nullptr, nullptr, nullptr, precision);
+        if (rc) return rc;
+        if ((rc = mf_conv_bind(p, *in.buf))) return rc;
+        ops.push_back([p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
+        return MF_OK;
+    }
+
+    // ---- execution ----------------------------------------------------------------------------------------
+    int run_body(int B, hipStream_t s) {
+        for (auto& op : ops) { int rc = op(B, s); if (rc) return rc; }
+        return MF_OK;
+    }
+    int run(int B, hipStream_t s) {
+        if (!use_graph) return run_body(B, s);
+        auto it = graphs.find(B);
+        if (it == graphs.end()) { graphs.emplace(B, nullptr); return run_body(B, s); }   // first call eager
+        if (!it->second) {
+            hipGraph_t graph = nullptr;
+            MF_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+            int rc = run_body(B, cap_stream);
+            hipError_t e = hipStreamEndCapture(cap_stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (e != hipSuccess) { mf_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return MF_ERR_HIP; }
+            hipGraphExec_t exec = nullptr;
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { mf_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return MF_ERR_HIP; }
+            it->second = exec;
+        }
+        MF_HIP(hipGraphLaunch(it->second, s));
+        return MF_OK;
+    }
+    int init(const mf_tensor* weights, int n, int prec, int max_batch, int max_groups) {
+        precision = prec; cap = max_batch;
+        for (int i = 0; i < n; ++i) {
+            if (!weights[i].name || !weights[i].data) { mf_set_error("tensor %d has no name/data", i); return MF_ERR_INVALID; }
+            sd[weights[i].name] = &weights[i];
+        }
+        MF_HIP(hipMalloc(&gn_stats, (size_t)max_batch * max_groups * 2 * sizeof(double)));
+        dev.push_back(gn_stats);
+        MF_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+        const char* ng = std::getenv("MF_NO_GRAPH");
+        use_graph = !(ng && ng[0] == '1');
+        return MF_OK;
+    }
+};
+
+#define NET_TRY(expr)                                                                      \
+    do {                                                                                   \
+        int rc_ = (expr);                                                                  \
+        if (rc_ != MF_OK) {                                                                \
+            if (!net.err.empty()) mf_set_error("%s", net.err.c_str());                     \
+            return rc_;                                                                    \
+        }                                                                                  \
+    } while (0)
+
+std::vector<float> silu_vec(const std::vector<float>& v) {
+    std::vector<float> o(v.size());
+    for (size_t i = 0; i < v.size(); ++i) o[i] = (float)((double)v[i] / (1.0 + std::exp(-(double)v[i])));
+    return o;
+}
+
+}  // namespace
+
+// ==========================================================================================================
+struct mf_unet {
+    mf_unet_config cfg{};
+    Net net;
+    ActBuf* in_lat = nullptr;
+    ActBuf* ctx = nullptr;
+    ActBuf* out_buf = nullptr;
+    float* pe = nullptr;       // [ctx_len][cross_dim] positional encoding (unet.py:12-27)
+};
+
+extern "C" int mf_unet_create(const mf_unet_config* c, const mf_tensor* weights, int n_weights, int precision, int max_batch,
+                              mf_unet** out) {
+    MF_REQUIRE(c && weights && out && n_weights > 0 && max_batch > 0, "unet_create: bad argument");
+    MF_REQUIRE(c->n_blocks >= 1 && c->n_blocks <= 4 && c->layers_per_block >= 1, "unet_create: bad block config");
+    *out = nullptr;
+    std::unique_ptr<mf_unet> h(new mf_unet());
+    h->cfg = *c;
+    Net& net = h->net;
+    int rc = net.init(weights, n_weights, precision, max_batch, c->norm_num_groups);
+    if (rc) return rc;
+    const int nb = c->n_blocks, L = c->layers_per_block, G = c->norm_num_groups, heads = c->attention_heads;
+    const int* boc = c->block_out_channels;
+    const int S = c->sample_size, X = c->cross_attention_dim;
+
+    // ---- time embedding at t = 0 (musereal.py:59): cos(0) = 1 for the first half, sin(0) = 0 for the second -----
+    std::vector<float> temb_act;
+    {
+        const int d0 = boc[0], td = 4 * boc[0];
+        const float *w1 = net.T("time_embedding.linear_1.weight", (int64_t)td * d0), *b1 = net.T("time_embedding.linear_1.bias", td);
+        const float *w2 = net.T("time_embedding.linear_2.weight", (int64_t)td * td), *b2 = net.T("time_embedding.linear_2.bias", td);
+        if (!w1 || !b1 || !w2 || !b2) { mf_set_error("%s", net.err.c_str()); return MF_ERR_INVALID; }
+        std::vector<float> e1(td), e2(td);
+        for (int o = 0; o < td; ++o) {
+            double a = b1[o];
+            for (int i = 0; i < d0 / 2; ++i) a += (double)w1[(size_t)o * d0 + i];   // emb = [1]*half + [0]*half
+            e1[o] = (float)a;
+        }
+        e1 = silu_vec(e1);
+        for (int o = 0; o < td; ++o) {
+            double a = b2[o];
+            for (int i = 0; i < td; ++i) a += (double)w2[(size_t)o * td + i] * e1[i];
+            e2[o] = (float)a;
+        }
+        temb_act = silu_vec(e2);
+    }
+
+    // ---- positional encoding table -------------------------------------------------------------------------------
+    {
+        std::vector<float> pe((size_t)c->ctx_len * X);
+        for (int t = 0; t < c->ctx_len; ++t)
+            for (int i = 0; i < X; i += 2) {
+                const float div = std::exp((float)i * (float)(-std::log(10000.0) / X));
+                pe[(size_t)t * X + i] = std::sin((float)t * div);
+                if (i + 1 < X) pe[(size_t)t * X + i + 1] = std::cos((float)t * div);
+            }
+        h->pe = net.upload(pe.data(), pe.size());
+        if (!h->pe) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+    }
+
+    // ---- skip bookkeeping: skip k is consumed by up-resnet (n_skips-1-k); both live in one concat buffer ------------
+    std::vector<int> skip_c, skip_s;   // channels / spatial size of each skip, in production order
+    {
+        int s = S;
+        skip_c.push_back(boc[0]); skip_s.push_back(s);
+        for (int b = 0; b < nb; ++b) {
+            for (int i = 0; i < L; ++i) { skip_c.push_back(boc[b]); skip_s.push_back(s); }
+            if (b < nb - 1) { s /= 2; skip_c.push_back(boc[b]); skip_s.push_back(s); }
+        }
+    }
+    const int n_skips = (int)skip_c.size();
+    // hidden channels entering each up-resnet
+    std::vector<int> up_h(n_skips), up_out(n_skips);
+    {
+        int ch = boc[nb - 1], j = 0;
+        for (int b = 0; b < nb; ++b)
+            for (int i = 0; i < L + 1; ++i, ++j) { up_h[j] = ch; up_out[j] = boc[nb - 1 - b]; ch = boc[nb - 1 - b]; }
+    }
+    std::vector<ActBuf*> cat(n_skips);   // cat[j] = [hidden | skip] read by up-resnet j
+    for (int j = 0; j < n_skips; ++j) {
+        const int k = n_skips - 1 - j;
+        cat[j] = net.buf(up_h[j] + skip_c[k], skip_s[k], skip_s[k], 1);
+        if (!cat[j]) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+    }
+    auto skip_view = [&](int k) { const int j = n_skips - 1 - k; return ActView{cat[j], up_h[j], skip_c[k]}; };
+
+    h->in_lat = net.buf(c->in_channels, S, S, 1);
+    h->ctx = net.buf(X, 1, c->ctx_len, 0);
+    h->out_buf = net.buf(c->out_channels, S, S, 1);
+    if (!h->in_lat || !h->ctx || !h->out_buf) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+    const ActView ctx{h->ctx, 0, X};
+
+    // ---- down path ------------------------------------------------------------------------------------------------
+    int k = 0, s = S, ch = boc[0];
+    NET_TRY(net.conv("conv_in", ActView{h->in_lat, 0, h->in_lat->C}, skip_view(k), c->in_channels, boc[0], 3, 1, 1, 0, ActView{}));
+    ActView x = skip_view(k++);
+    for (int b = 0; b < nb; ++b) {
+        for (int i = 0; i < L; ++i) {
+            const std::string rp = "down_blocks." + std::to_string(b) + ".resnets." + std::to_string(i);
+            if (c->down_attn[b]) {
+                ActBuf* r = net.tmp("down.r", boc[b], s, s, 1);
+                if (!r) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+                NET_TRY(net.resnet(rp, x, ActView{r, 0, boc[b]}, ch, boc[b], G, 1e-5f, &temb_act));
+                NET_TRY(net.transformer("down_blocks." + std::to_string(b) + ".attentions." + std::to_string(i),
+                                        ActView{r, 0, boc[b]}, skip_view(k), boc[b], heads, G, ctx));
+            } else {
+                NET_TRY(net.resnet(rp, x, skip_view(k), ch, boc[b], G, 1e-5f, &temb_act));
+            }
+            ch = boc[b];
+            x = skip_view(k++);
+        }
+        if (b < nb - 1) {
+            // Downsample2D: conv 3x3 stride 2 padding 1
+            ActView o = skip_view(k);
+            NET_TRY(net.conv("down_blocks." + std::to_string(b) + ".downsamplers.0.conv", x, o, ch, ch, 3, 2, 1, 0, ActView{}));
+            s /= 2;
+            x = skip_view(k++);
+        }
+    }
+    // ---- mid ------------------------------------------------------------------------------------------------------
+    {
+        ActBuf *m0 = net.buf(ch, s, s, 1), *m1 = net.buf(ch, s, s, 1);
+        if (!m0 || !m1) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+        NET_TRY(net.resnet("mid_block.resnets.0", x, ActView{m0, 0, ch}, ch, ch, G, 1e-5f, &temb_act));
+        NET_TRY(net.transformer("mid_block.attentions.0", ActView{m0, 0, ch}, ActView{m1, 0, ch}, ch, heads, G, ctx));
+        // the second mid resnet writes the hidden slice of the first up-resnet's concat buffer
+        NET_TRY(net.resnet("mid_block.resnets.1", ActView{m1, 0, ch}, ActView{cat[0], 0, up_h[0]}, ch, ch, G, 1e-5f, &temb_act));
+    }
+    // ---- up path --------------------------------------------------------------------------------------------------
+    int j = 0;
+    ActView last{};
+    for (int b = 0; b < nb; ++b) {
+        const int co = boc[nb - 1 - b];
+        for (int i = 0; i < L + 1; ++i, ++j) {
+            const std::string rp = "up_blocks." + std::to_string(b) + ".resnets." + std::to_string(i);
+            const int cin = cat[j]->C;
+            const bool tail = (i == L);                               // last resnet of the block
+            const bool has_up = b < nb - 1;
+            // where this sub-block's result goes: next concat buffer (same resolution), or a staging buffer in
+            // front of the upsampler, or the final buffer
+            ActView dst;
+            ActBuf* stage = nullptr;
+            if (!tail) dst = ActView{cat[j + 1], 0, up_h[j + 1]};
+            else {
+                stage = net.buf(co, s, s, 1);
+                if (!stage) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+                dst = ActView{stage, 0, co};
+            }
+            if (c->up_attn[b]) {
+                ActBuf* r = net.tmp("up.r", co, s, s, 1);
+                if (!r) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+                NET_TRY(net.resnet(rp, ActView{cat[j], 0, cin}, ActView{r, 0, co}, cin, co, G, 1e-5f, &temb_act));
+                NET_TRY(net.transformer("up_blocks." + std::to_string(b) + ".attentions." + std::to_string(i), ActView{r, 0, co}, dst, co, heads, G, ctx));
+            } else {
+                NET_TRY(net.resnet(rp, ActView{cat[j], 0, cin}, dst, cin, co, G, 1e-5f, &temb_act));
+            }
+            if (tail && has_up) {
+                // Upsample2D: nearest 2x + conv 3x3, written into the hidden slice of the next concat buffer
+                NET_TRY(net.conv("up_blocks." + std::to_string(b) + ".upsamplers.0.conv", dst, ActView{cat[j + 1], 0, up_h[j + 1]}, co, co, 3, 1, 1, 0, ActView{}, 1));
+                s *= 2;
+            }
+            last = dst;
+        }
+    }
+    {
+        ActBuf* t = net.buf(boc[0], S, S, 1);
+        if (!t) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+        NET_TRY(net.gn("conv_norm_out", last, ActView{t, 0, boc[0]}, G, 1e-5f, true));
+        NET_TRY(net.conv("conv_out", ActView{t, 0, boc[0]}, ActView{h->out_buf, 0, c->out_channels}, boc[0], c->out_channels, 3, 1, 1, 0, ActView{}));
+    }
+    *out = h.release();
+    return MF_OK;
+}
+
+extern "C" int mf_unet_forward(mf_unet* h, const float* latents, const float* audio, int add_pe, float* out, int batch, void* stream) {
+    MF_REQUIRE(h && latents && audio && out, "unet_forward: null argument");
+    MF_REQUIRE(batch > 0 && batch <= h->net.cap, "unet_forward: batch %d exceeds the handle's max_batch %d", batch, h->net.cap);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = mf_nchw_to_act(latents, h->cfg.in_channels, *h->in_lat, batch, s))) return rc;
+    if ((rc = mf_rows_from_f32(audio, add_pe ? h->pe : nullptr, ActView{h->ctx, 0, h->cfg.cross_attention_dim}, batch, s))) return rc;
+    if ((rc = h->net.run(batch, s))) return rc;
+    return mf_act_to_nchw(ActView{h->out_buf, 0, h->cfg.out_channels}, out, batch, s);
+}
+
+extern "C" void mf_unet_destroy(mf_unet* h) { delete h; }
+
+// ==========================================================================================================
+struct mf_vae {
+    mf_vae_config cfg{};
+    Net net;
+    ActBuf* in_lat = nullptr;
+    ActBuf* out_buf = nullptr;
+};
+
+extern "C" int mf_vae_create(const mf_vae_config* c, const mf_tensor* weights, int n_weights, int precision, int max_batch,
+                             mf_vae** out) {
+    MF_REQUIRE(c && weights && out && n_weights > 0 && max_batch > 0, "vae_create: bad argument");
+    MF_REQUIRE(c->n_blocks >= 1 && c->n_blocks <= 4 && c->scaling_factor > 0.f, "vae_create: bad config");
+    *out = nullptr;
+    std::unique_ptr<mf_vae> h(new mf_vae());
+    h->cfg = *c;
+    Net& net = h->net;
+    int rc = net.init(weights, n_weights, precision, max_batch, c->norm_num_groups);
+    if (rc) return rc;
+    const int nb = c->n_blocks, L = c->layers_per_block, G = c->norm_num_groups, Z = c->latent_channels;
+    const int* boc = c->block_out_channels;
+    int s = c->sample_size, ch = boc[nb - 1];
+    h->in_lat = net.buf(Z, s, s, 1);
+    ActBuf *pq = net.buf(Z, s, s, 1), *x0 = net.buf(ch, s, s, 1), *x1 = net.buf(ch, s, s, 1);
+    if (!h->in_lat || !pq || !x0 || !x1) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+    // latents = (1 / scaling_factor) * latents (vae.py:102) folded into post_quant_conv's weights
+    NET_TRY(net.conv("post_quant_conv", ActView{h->in_lat, 0, h->in_lat->C}, ActView{pq, 0, Z}, Z, Z, 1, 1, 0, 0, ActView{}, 0, nullptr, 1.f / c->scaling_factor));
+    NET_TRY(net.conv("decoder.conv_in", ActView{pq, 0, pq->C}, ActView{x0, 0, ch}, Z, ch, 3, 1, 1, 0, ActView{}));
+    NET_TRY(net.resnet("decoder.mid_block.resnets.0", ActView{x0, 0, ch}, ActView{x1, 0, ch}, ch, ch, G, 1e-6f, nullptr));
+    {   // single-head attention over all channels, with residual
+        const std::string a = "decoder.mid_block.attentions.0";
+        ActBuf *g0 = net.tmp("va.gn", ch, s, s, 0), *qkv = net.tmp("va.qkv", 3 * ch, s, s, 0), *ao = net.tmp("va.ao", ch, s, s, 0);
+        if (!g0 || !qkv || !ao) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+        NET_TRY(net.gn(a + ".group_norm", ActView{x1, 0, ch}, ActView{g0, 0, ch}, G, 1e-6f, false));
+        const float *wq = net.T(a + ".to_q.weight", (int64_t)ch * ch), *wk = net.T(a + ".to_k.weight", (int64_t)ch * ch), *wv = net.T(a + ".to_v.weight", (int64_t)ch * ch);
+        const float *bq = net.T(a + ".to_q.bias", ch), *bk = net.T(a + ".to_k.bias", ch), *bv = net.T(a + ".to_v.bias", ch);
+        if (!wq || !wk || !wv || !bq || !bk || !bv) { mf_set_error("%s", net.err.c_str()); return MF_ERR_INVALID; }
+        std::vector<float> w((size_t)3 * ch * ch), b((size_t)3 * ch);
+        std::copy(wq, wq + (size_t)ch * ch, w.begin()); std::copy(wk, wk + (size_t)ch * ch, w.begin() + (size_t)ch * ch);
+        std::copy(wv, wv + (size_t)ch * ch, w.begin() + (size_t)2 * ch * ch);
+        std::copy(bq, bq + ch, b.begin()); std::copy(bk, bk + ch, b.begin() + ch); std::copy(bv, bv + ch, b.begin() + 2 * ch);
+        NET_TRY(net.linear_raw(w.data(), b.data(), ActView{g0, 0, ch}, ActView{qkv, 0, 3 * ch}, ch, 3 * ch, ActView{}));
+        NET_TRY(net.attention(ActView{qkv, 0, ch}, ActView{qkv, ch, ch}, ActView{qkv, 2 * ch, ch}, ActView{ao, 0, ch}, 1));
+        NET_TRY(net.conv(a + ".to_out.0", ActView{ao, 0, ch}, ActView{x0, 0, ch}, ch, ch, 1, 1, 0, 0, ActView{x1, 0, ch}));
+    }
+    NET_TRY(net.resnet("decoder.mid_block.resnets.1", ActView{x0, 0, ch}, ActView{x1, 0, ch}, ch, ch, G, 1e-6f, nullptr));
+    ActView x{x1, 0, ch};
+    for (int b = 0; b < nb; ++b) {
+        const int co = boc[nb - 1 - b];
+        for (int i = 0; i < L + 1; ++i) {
+            ActBuf* y = net.buf(co, s, s, 1);
+            if (!y) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+            NET_TRY(net.resnet("decoder.up_blocks." + std::to_string(b) + ".resnets." + std::to_string(i), x, ActView{y, 0, co}, ch, co, G, 1e-6f, nullptr));
+            ch = co;
+            x = ActView{y, 0, co};
+        }
+        if (b < nb - 1) {
+            ActBuf* y = net.buf(ch, 2 * s, 2 * s, 1);
+            if (!y) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+            NET_TRY(net.conv("decoder.up_blocks." + std::to_string(b) + ".upsamplers.0.conv", x, ActView{y, 0, ch}, ch, ch, 3, 1, 1, 0, ActView{}, 1));
+            s *= 2;
+            x = ActView{y, 0, ch};
+        }
+    }
+    ActBuf* t = net.buf(ch, s, s, 1);
+    h->out_buf = net.buf(c->out_channels, s, s, 1);
+    if (!t || !h->out_buf) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+    NET_TRY(net.gn("decoder.conv_norm_out", x, ActView{t, 0, ch}, G, 1e-6f, true));
+    NET_TRY(net.conv("decoder.conv_out", ActView{t, 0, ch}, ActView{h->out_buf, 0, c->out_channels}, ch, c->out_channels, 3, 1, 1, 0, ActView{}));
+    *out = h.release();
+    return MF_OK;
+}
+
+extern "C" int mf_vae_decode_latents(mf_vae* h, const float* latents, uint8_t* frames, float* image_f32, int batch, void* stream) {
+    MF_REQUIRE(h && latents && (frames || image_f32), "vae_decode_latents: null argument");
+    MF_REQUIRE(batch > 0 && batch <= h->net.cap, "vae_decode_latents: batch %d exceeds the handle's max_batch %d", batch, h->net.cap);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = mf_nchw_to_act(latents, h->cfg.latent_channels, *h->in_lat, batch, s))) return rc;
+    if ((rc = h->net.run(batch, s))) return rc;
+    const ActView o{h->out_buf, 0, h->cfg.out_channels};
+    if (image_f32 && (rc = mf_act_to_nchw(o, image_f32, batch, s))) return rc;
+    if (frames && (rc = mf_vae_post_u8(o, frames, batch, s))) return rc;
+    return MF_OK;
+}
+
+extern "C" void mf_vae_destroy(mf_vae* h) { delete h; }

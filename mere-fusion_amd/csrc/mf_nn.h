@@ -25,4 +25,26 @@ int mf_gemm_plan_create(ConvPlan* p, int K, int N, int T, int precision);
 // (hi + lo) planes of the interior of a view -> fp32 [batch][T][C] row-major
 int mf_rows_to_f32(const ActView& x, float* dst, int batch, hipStream_t s);
 
+// fp32 [batch][T][C] row-major (+ optional addend [T][C], e.g. a positional encoding) -> planes of a view
+int mf_rows_from_f32(const float* src, const float* addend, const ActView& y, int batch, hipStream_t s);
+
+// GroupNorm over (H*W x C/groups) per (batch, group), optional SiLU, on any view (fp64 sums, fp32 apply).
+// `stats` is a device scratch of batch*groups*2 doubles owned by the caller.
+int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, int groups, float eps,
+                 bool silu, double* stats, int batch, hipStream_t s);
+
+// GEGLU (diffusers): y[t][c] = x[t][c] * gelu(x[t][C + c]) for c < C = x.C / 2
+int mf_geglu(const ActView& x, const ActView& y, int batch, hipStream_t s);
+
+// Packs `groups` = batch*heads B operands at once (see mf_pack_b): group z = (b, h) reads
+// src[b*sb + h*sh + n*stride_n + k*stride_k] into plan weights + z * (KT*Npad*64).
+int mf_pack_b_grouped(ConvPlan* plan, const bf16_t* src_hi, const bf16_t* src_lo, int64_t sb, int64_t sh, int64_t stride_n,
+                      int64_t stride_k, int N, int K, int groups, int heads, hipStream_t s);
+// a mf_gemm_plan_create shell with room for `groups` packed operands
+int mf_gemm_plan_create_grouped(ConvPlan* p, int K, int N, int T, int groups, int precision);
+
+// image = (x / 2 + 0.5).clamp(0, 1); (image * 255).round() -> uint8 [B][H][W][3] with the channel order reversed
+// (RGB -> BGR): the tail of VAE.decode_latents, musetalk/models/vae.py:104-107
+int mf_vae_post_u8(const ActView& x, uint8_t* dst, int batch, hipStream_t s);
+
 inline int64_t mf_interior(const ActBuf& b) { return ((int64_t)b.halo * b.Wp() + b.halo) * b.C; }

@@ -2,6 +2,7 @@
 // latency/HBM-bound helpers around the MFMA GEMMs; math in fp32, storage in bf16 (hi, lo) planes.
 #include "mf_nn.h"
 #include <vector>
+#include <algorithm>
 
 namespace {
 
@@ -36,14 +37,26 @@ __device__ __forceinline__ void st(bf16_t* hi, bf16_t* lo, int64_t o, float v) {
 
 constexpr int MAXPL = 32;   // channels per lane held in registers: C <= 2048
 
-// one wave per token; rows are addressed as base + b*batch_stride + t*row_stride
-__global__ __launch_bounds__(256) void k_layernorm(const bf16_t* xh, const bf16_t* xl, int64_t xb, int xs,
-                                                   bf16_t* yh, bf16_t* yl, int64_t yb, int ys, const float* gamma,
-                                                   const float* beta, float eps, int C, int T, int total) {
+// token t of batch b of a (possibly padded) H x W image view
+struct Rows {
+    const bf16_t* hi; const bf16_t* lo;
+    int64_t bstride; int W, Wp, halo, C, T;
+    __host__ __device__ int64_t off(int b, int t) const {
+        const int y = t / W, x = t - y * W;
+        return (int64_t)b * bstride + ((int64_t)(y + halo) * Wp + x + halo) * C;
+    }
+};
+
+// one wave per token
+__global__ __launch_bounds__(256) void k_layernorm(Rows X, Rows Y, const float* gamma, const float* beta, float eps,
+                                                   int C, int total) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= total) return;
+    const int T = X.T;
     const int b = row / T, t = row - b * T;
-    const int64_t xo = (int64_t)b * xb + (int64_t)t * xs, yo = (int64_t)b * yb + (int64_t)t * ys;
+    const bf16_t *xh = X.hi, *xl = X.lo;
+    bf16_t *yh = const_cast<bf16_t*>(Y.hi), *yl = const_cast<bf16_t*>(Y.lo);
+    const int64_t xo = X.off(b, t), yo = Y.off(b, t);
     float v[MAXPL];
     float s = 0.f;
 #pragma unroll
@@ -68,13 +81,14 @@ __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* xh, const bf16_
     }
 }
 
-__global__ __launch_bounds__(256) void k_softmax_rows(const bf16_t* sh, const bf16_t* sl, int64_t sb, int ss,
-                                                      bf16_t* ph, bf16_t* pl, int64_t pb, int ps, int n_keys,
-                                                      int n_out, float scale, int T, int total) {
+__global__ __launch_bounds__(256) void k_softmax_rows(Rows S, Rows P, int n_keys, int n_out, float scale, int total) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= total) return;
+    const int T = S.T;
     const int b = row / T, t = row - b * T;
-    const int64_t so = (int64_t)b * sb + (int64_t)t * ss, po = (int64_t)b * pb + (int64_t)t * ps;
+    const bf16_t *sh = S.hi, *sl = S.lo;
+    bf16_t *ph = const_cast<bf16_t*>(P.hi), *pl = const_cast<bf16_t*>(P.lo);
+    const int64_t so = S.off(b, t), po = P.off(b, t);
     float v[MAXPL];
     float m = -3.0e38f;
 #pragma unroll
@@ -114,46 +128,211 @@ __global__ __launch_bounds__(256) void k_pack_b(const bf16_t* sh, const bf16_t* 
     if (dl) dl[idx] = in ? sl[so] : (bf16_t)0;
 }
 
-__global__ __launch_bounds__(256) void k_rows_to_f32(const bf16_t* xh, const bf16_t* xl, int64_t xb, int xs, int C,
-                                                     int T, float* dst, int64_t total) {
+__global__ __launch_bounds__(256) void k_rows_to_f32(Rows X, int C, float* dst, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % C);
     const int64_t r = idx / C;
-    const int t = (int)(r % T), b = (int)(r / T);
-    dst[idx] = ld(xh, xl, (int64_t)b * xb + (int64_t)t * xs + c);
+    const int t = (int)(r % X.T), b = (int)(r / X.T);
+    dst[idx] = ld(X.hi, X.lo, X.off(b, t) + c);
 }
 
-struct Rows { const bf16_t* hi; const bf16_t* lo; int64_t bstride; int rstride; int T; };
+__global__ __launch_bounds__(256) void k_rows_from_f32(const float* src, const float* addend, Rows Y, int C, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int64_t r = idx / C;
+    const int t = (int)(r % Y.T), b = (int)(r / Y.T);
+    float v = src[idx];
+    if (addend) v += addend[(int64_t)t * C + c];
+    st(const_cast<bf16_t*>(Y.hi), const_cast<bf16_t*>(Y.lo), Y.off(b, t) + c, v);
+}
+
+// GroupNorm statistics: grid (batch*groups, splits); fp64 sum and sum of squares via atomics
+__global__ __launch_bounds__(256) void k_gn_stats(Rows X, int groups, int cpg, double* stats) {
+    const int bg = blockIdx.x, b = bg / groups, g = bg - b * groups;
+    const int T = X.T;
+    const int per = (T + gridDim.y - 1) / gridDim.y;
+    const int t0 = blockIdx.y * per, t1 = min(T, t0 + per);
+    double s = 0.0, q = 0.0;
+    for (int t = t0 + (int)threadIdx.x; t < t1; t += 256) {
+        const int64_t o = X.off(b, t) + g * cpg;
+        for (int c = 0; c < cpg; ++c) {
+            const double v = (double)ld(X.hi, X.lo, o + c);
+            s += v; q += v * v;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    __shared__ double sh[8];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[2 * w] = s; sh[2 * w + 1] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[2 * bg], sh[0] + sh[2] + sh[4] + sh[6]);
+        atomicAdd(&stats[2 * bg + 1], sh[1] + sh[3] + sh[5] + sh[7]);
+    }
+}
+
+// one thread per (token, 8 channels)
+__global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* gamma, const float* beta, const double* stats,
+                                                  int groups, int cpg, int C, float eps, int silu, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = C / 8;
+    const int c0 = (int)(idx % c8) * 8;
+    const int64_t r = idx / c8;
+    const int t = (int)(r % X.T), b = (int)(r / X.T);
+    const int64_t xo = X.off(b, t) + c0, yo = Y.off(b, t) + c0;
+    const double n = (double)X.T * cpg;
+    const uint4 vh = *reinterpret_cast<const uint4*>(X.hi + xo);
+    uint4 vl = make_uint4(0, 0, 0, 0);
+    if (X.lo) vl = *reinterpret_cast<const uint4*>(X.lo + xo);
+    const uint32_t hh[4] = {vh.x, vh.y, vh.z, vh.w}, ll[4] = {vl.x, vl.y, vl.z, vl.w};
+    uint32_t oh[4], ol[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float out2[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = c0 + 2 * e + k;
+            const int g = c / cpg;
+            const double mean = stats[2 * (b * groups + g)] / n;
+            const double var = fmax(stats[2 * (b * groups + g) + 1] / n - mean * mean, 0.0);
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float x = nbf2f(k ? hh[e] >> 16 : hh[e] & 0xffffu) + nbf2f(k ? ll[e] >> 16 : ll[e] & 0xffffu);
+            float v = (x - (float)mean) * rstd * gamma[c] + beta[c];
+            if (silu) v = v / (1.f + expf(-v));
+            out2[k] = v;
+        }
+        const uint32_t h0 = nf2bf(out2[0]), h1 = nf2bf(out2[1]);
+        oh[e] = h0 | (h1 << 16);
+        ol[e] = nf2bf(out2[0] - nbf2f(h0)) | (nf2bf(out2[1] - nbf2f(h1)) << 16);
+    }
+    *reinterpret_cast<uint4*>(const_cast<bf16_t*>(Y.hi) + yo) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+    if (Y.lo) *reinterpret_cast<uint4*>(const_cast<bf16_t*>(Y.lo) + yo) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+}
+
+__global__ __launch_bounds__(256) void k_geglu(Rows X, Rows Y, int C, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int64_t r = idx / C;
+    const int t = (int)(r % X.T), b = (int)(r / X.T);
+    const int64_t xo = X.off(b, t);
+    const float a = ld(X.hi, X.lo, xo + c), g = ld(X.hi, X.lo, xo + C + c);
+    st(const_cast<bf16_t*>(Y.hi), const_cast<bf16_t*>(Y.lo), Y.off(b, t) + c, a * (0.5f * g * (1.f + erff(g * 0.70710678118654752f))));
+}
+
+__global__ __launch_bounds__(256) void k_pack_b_grouped(const bf16_t* sh, const bf16_t* sl, int64_t sb, int64_t shd,
+                                                        int64_t stride_n, int64_t stride_k, int N, int K, int Npad, int heads,
+                                                        int64_t per_group, bf16_t* dh, bf16_t* dl, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int z = (int)(idx / per_group);
+    const int64_t w = idx - (int64_t)z * per_group;
+    const int e = (int)(w & 63);
+    const int64_t r = w >> 6;
+    const int n = (int)(r % Npad);
+    const int k = (int)(r / Npad) * 64 + e;
+    const bool in = n < N && k < K;
+    const int zb = z / heads, zh = z - zb * heads;
+    const int64_t so = zb * sb + zh * shd + (int64_t)n * stride_n + (int64_t)k * stride_k;
+    dh[idx] = in ? sh[so] : (bf16_t)0;
+    if (dl) dl[idx] = in ? sl[so] : (bf16_t)0;
+}
+
+__global__ __launch_bounds__(256) void k_vae_post(Rows X, int H, int W, uint8_t* dst, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread per pixel
+    if (idx >= total) return;
+    const int t = (int)(idx % X.T), b = (int)(idx / X.T);
+    const int64_t o = X.off(b, t);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = ld(X.hi, X.lo, o + c) / 2.f + 0.5f;
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        dst[idx * 3 + (2 - c)] = (uint8_t)rintf(v * 255.f);   // numpy round (half to even), RGB -> BGR
+    }
+}
+
 Rows rows_of(const ActView& v) {
     const ActBuf& b = *v.buf;
-    const int64_t base = mf_interior(b) + v.coff;
-    return Rows{b.hi + base, b.lo ? b.lo + base : nullptr, b.per_batch(), b.C, b.W};
+    return Rows{b.hi + v.coff, b.lo ? b.lo + v.coff : nullptr, b.per_batch(), b.W, b.Wp(), b.halo, b.C, b.H * b.W};
 }
 
 }  // namespace
 
 int mf_layernorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, float eps, int batch,
                  hipStream_t s) {
-    MF_REQUIRE(x.buf->H == 1 && y.buf->H == 1 && x.buf->W == y.buf->W && x.C == y.C, "layernorm: shape mismatch");
+    MF_REQUIRE(x.buf->H * x.buf->W == y.buf->H * y.buf->W && x.C == y.C, "layernorm: shape mismatch");
     MF_REQUIRE(x.C <= 64 * MAXPL, "layernorm: C=%d exceeds %d", x.C, 64 * MAXPL);
     const Rows xr = rows_of(x), yr = rows_of(y);
     const int total = batch * xr.T;
-    hipLaunchKernelGGL(k_layernorm, dim3((total + 3) / 4), dim3(256), 0, s, xr.hi, xr.lo, xr.bstride, xr.rstride,
-                       const_cast<bf16_t*>(yr.hi), const_cast<bf16_t*>(yr.lo), yr.bstride, yr.rstride, gamma, beta,
-                       eps, x.C, xr.T, total);
+    hipLaunchKernelGGL(k_layernorm, dim3((total + 3) / 4), dim3(256), 0, s, xr, yr, gamma, beta, eps, x.C, total);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
 
 int mf_softmax_rows(const ActView& scores, const ActView& probs, int n_keys, float scale, int batch, hipStream_t s) {
-    MF_REQUIRE(scores.buf->W == probs.buf->W && scores.C >= n_keys && probs.C >= n_keys, "softmax: shape mismatch");
+    MF_REQUIRE(scores.buf->H * scores.buf->W == probs.buf->H * probs.buf->W && scores.C >= n_keys && probs.C >= n_keys, "softmax: shape mismatch");
     MF_REQUIRE(probs.C <= 64 * MAXPL, "softmax: row length %d exceeds %d", probs.C, 64 * MAXPL);
     const Rows sr = rows_of(scores), pr = rows_of(probs);
     const int total = batch * sr.T;
-    hipLaunchKernelGGL(k_softmax_rows, dim3((total + 3) / 4), dim3(256), 0, s, sr.hi, sr.lo, sr.bstride, sr.rstride,
-                       const_cast<bf16_t*>(pr.hi), const_cast<bf16_t*>(pr.lo), pr.bstride, pr.rstride, n_keys, probs.C,
-                       scale, sr.T, total);
+    hipLaunchKernelGGL(k_softmax_rows, dim3((total + 3) / 4), dim3(256), 0, s, sr, pr, n_keys, probs.C, scale, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+int mf_rows_from_f32(const float* src, const float* addend, const ActView& y, int batch, hipStream_t s) {
+    const Rows yr = rows_of(y);
+    const int64_t total = (int64_t)batch * yr.T * y.C;
+    hipLaunchKernelGGL(k_rows_from_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, addend, yr, y.C, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, int groups, float eps,
+                 bool silu, double* stats, int batch, hipStream_t s) {
+    MF_REQUIRE(x.C == y.C && x.C % groups == 0 && x.C % 8 == 0 && x.coff % 8 == 0 && y.coff % 8 == 0, "groupnorm: C=%d groups=%d", x.C, groups);
+    MF_REQUIRE(x.buf->H == y.buf->H && x.buf->W == y.buf->W, "groupnorm: spatial mismatch");
+    const Rows xr = rows_of(x), yr = rows_of(y);
+    const int cpg = x.C / groups;
+    MF_HIP(hipMemsetAsync(stats, 0, (size_t)batch * groups * 2 * sizeof(double), s));
+    const int splits = std::max(1, std::min(64, xr.T * cpg / 8192));
+    hipLaunchKernelGGL(k_gn_stats, dim3(batch * groups, splits), dim3(256), 0, s, xr, groups, cpg, stats);
+    MF_HIP(hipGetLastError());
+    const int64_t total = (int64_t)batch * xr.T * (x.C / 8);
+    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xr, yr, gamma, beta, stats, groups,
+                       cpg, x.C, eps, silu ? 1 : 0, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+int mf_geglu(const ActView& x, const ActView& y, int batch, hipStream_t s) {
+    MF_REQUIRE(x.C == 2 * y.C, "geglu: input must have twice the output channels");
+    const Rows xr = rows_of(x), yr = rows_of(y);
+    const int64_t total = (int64_t)batch * xr.T * y.C;
+    hipLaunchKernelGGL(k_geglu, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xr, yr, y.C, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+int mf_vae_post_u8(const ActView& x, uint8_t* dst, int batch, hipStream_t s) {
+    MF_REQUIRE(x.C >= 3, "vae_post: need 3 channels");
+    const Rows xr = rows_of(x);
+    const int64_t total = (int64_t)batch * xr.T;
+    hipLaunchKernelGGL(k_vae_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xr, x.buf->H, x.buf->W, dst, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+int mf_pack_b_grouped(ConvPlan* plan, const bf16_t* src_hi, const bf16_t* src_lo, int64_t sb, int64_t sh, int64_t stride_n,
+                      int64_t stride_k, int N, int K, int groups, int heads, hipStream_t s) {
+    MF_REQUIRE(N <= plan->Npad && K <= plan->ph[0].KT * 64 && groups <= plan->groups_cap, "pack_b: does not fit the plan");
+    const int64_t per_group = (int64_t)plan->ph[0].KT * plan->Npad * 64;
+    const int64_t total = per_group * groups;
+    hipLaunchKernelGGL(k_pack_b_grouped, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src_hi, src_lo, sb, sh,
+                       stride_n, stride_k, N, K, plan->Npad, heads, per_group, plan->w_hi, plan->w_lo, total);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
@@ -169,7 +348,11 @@ int mf_pack_b(ConvPlan* plan, const bf16_t* src_hi, const bf16_t* src_lo, int64_
 }
 
 int mf_gemm_plan_create(ConvPlan* p, int K, int N, int T, int precision) {
-    MF_REQUIRE(K % 8 == 0 && N % 4 == 0 && K > 0 && N > 0 && T > 0, "gemm plan: K=%d must be a multiple of 8, N=%d of 4", K, N);
+    return mf_gemm_plan_create_grouped(p, K, N, T, 1, precision);
+}
+
+int mf_gemm_plan_create_grouped(ConvPlan* p, int K, int N, int T, int groups, int precision) {
+    MF_REQUIRE(K % 8 == 0 && K > 0 && N > 0 && T > 0 && groups > 0, "gemm plan: K=%d must be a multiple of 8", K);
     mf_conv2d_desc d{};
     d.cin = K; d.cout = N; d.kh = d.kw = 1; d.stride_h = d.stride_w = 1; d.in_h = 1; d.in_w = T;
     p->d = d;
@@ -185,7 +368,8 @@ int mf_gemm_plan_create(ConvPlan* p, int K, int N, int T, int precision) {
     const int KT = (K / 8 + 7) / 8;
     p->ph[0] = ConvPhase{0, KT * 8, KT, 0, 0, 0};
     p->goff_total = KT * 8;
-    const int64_t total = (int64_t)KT * p->Npad * 64;
+    p->groups_cap = groups;
+    const int64_t total = (int64_t)KT * p->Npad * 64 * groups;
     MF_HIP(hipMalloc(&p->w_hi, total * sizeof(bf16_t)));
     MF_HIP(hipMemset(p->w_hi, 0, total * sizeof(bf16_t)));
     if (precision == MF_PREC_BF16X3) {
@@ -202,8 +386,7 @@ int mf_gemm_plan_create(ConvPlan* p, int K, int N, int T, int precision) {
 int mf_rows_to_f32(const ActView& x, float* dst, int batch, hipStream_t s) {
     const Rows xr = rows_of(x);
     const int64_t total = (int64_t)batch * xr.T * x.C;
-    hipLaunchKernelGGL(k_rows_to_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xr.hi, xr.lo, xr.bstride,
-                       xr.rstride, x.C, xr.T, dst, total);
+    hipLaunchKernelGGL(k_rows_to_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xr, x.C, dst, total);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

@@ -165,3 +165,114 @@ def make_speech_like_wav(n, seed=0):
     for f0 in (180.0, 440.0, 1250.0, 3100.0):
         x += 0.1 * np.sin(2 * np.pi * f0 * t + rng.uniform(0, 6.28)) * (0.5 + 0.5 * np.sin(2 * np.pi * rng.uniform(1, 4) * t))
     return np.clip(x, -1, 1).astype(np.float32)
+
+
+# ---- MuseTalk UNet2DConditionModel / AutoencoderKL decoder (diffusers key names) -----
+def _mt_gen(seed):
+    rng = np.random.default_rng(seed)
+
+    def f(a):
+        return torch.from_numpy(np.asarray(a, dtype=np.float32))
+
+    def conv(sd, p, ci, co, k, gain=1.0, bias=True):
+        # float32 draws: the full-size UNet has 860 M parameters
+        sd[p + ".weight"] = torch.from_numpy(rng.standard_normal((co, ci, k, k), dtype=np.float32) * np.float32(gain / np.sqrt(ci * k * k)))
+        if bias:
+            sd[p + ".bias"] = f(rng.standard_normal(co) * 0.05)
+
+    def lin(sd, p, ci, co, gain=1.0, bias=True):
+        sd[p + ".weight"] = torch.from_numpy(rng.standard_normal((co, ci), dtype=np.float32) * np.float32(gain / np.sqrt(ci)))
+        if bias:
+            sd[p + ".bias"] = f(rng.standard_normal(co) * 0.05)
+
+    def norm(sd, p, c):
+        sd[p + ".weight"] = f(rng.uniform(0.8, 1.2, c))
+        sd[p + ".bias"] = f(rng.standard_normal(c) * 0.05)
+
+    def resnet(sd, p, ci, co, temb=None):
+        norm(sd, p + ".norm1", ci); conv(sd, p + ".conv1", ci, co, 3, 1.4)
+        if temb:
+            lin(sd, p + ".time_emb_proj", temb, co)
+        norm(sd, p + ".norm2", co); conv(sd, p + ".conv2", co, co, 3, 0.7)
+        if ci != co:
+            conv(sd, p + ".conv_shortcut", ci, co, 1)
+
+    return rng, f, conv, lin, norm, resnet
+
+
+def make_musetalk_unet_state_dict(cfg, seed=0):
+    u = cfg["unet"] if "unet" in cfg else cfg
+    rng, f, conv, lin, norm, resnet = _mt_gen(11000 + seed)
+    boc, L, X = u["block_out_channels"], u["layers_per_block"], u["cross_attention_dim"]
+    temb = boc[0] * 4
+    sd = {}
+
+    def xf(p, c):
+        norm(sd, p + ".norm", c); conv(sd, p + ".proj_in", c, c, 1)
+        t = p + ".transformer_blocks.0"
+        norm(sd, t + ".norm1", c)
+        for n_ in ("to_q", "to_k", "to_v"):
+            lin(sd, t + ".attn1." + n_, c, c, 1.3, bias=False)
+        lin(sd, t + ".attn1.to_out.0", c, c, 0.7)
+        norm(sd, t + ".norm2", c)
+        lin(sd, t + ".attn2.to_q", c, c, 1.3, bias=False)
+        lin(sd, t + ".attn2.to_k", X, c, 1.3, bias=False); lin(sd, t + ".attn2.to_v", X, c, 1.0, bias=False)
+        lin(sd, t + ".attn2.to_out.0", c, c, 0.7)
+        norm(sd, t + ".norm3", c)
+        lin(sd, t + ".ff.net.0.proj", c, 8 * c); lin(sd, t + ".ff.net.2", 4 * c, c, 0.7)
+        conv(sd, p + ".proj_out", c, c, 1, 0.7)
+
+    lin(sd, "time_embedding.linear_1", boc[0], temb); lin(sd, "time_embedding.linear_2", temb, temb)
+    conv(sd, "conv_in", u["in_channels"], boc[0], 3)
+    chans, c = [boc[0]], boc[0]
+    for b, co in enumerate(boc):
+        for i in range(L):
+            resnet(sd, f"down_blocks.{b}.resnets.{i}", c, co, temb); c = co
+            if u["down_attn"][b]:
+                xf(f"down_blocks.{b}.attentions.{i}", c)
+            chans.append(c)
+        if b < len(boc) - 1:
+            conv(sd, f"down_blocks.{b}.downsamplers.0.conv", c, c, 3); chans.append(c)
+    resnet(sd, "mid_block.resnets.0", c, c, temb); xf("mid_block.attentions.0", c); resnet(sd, "mid_block.resnets.1", c, c, temb)
+    for b, co in enumerate(reversed(boc)):
+        for i in range(L + 1):
+            resnet(sd, f"up_blocks.{b}.resnets.{i}", c + chans.pop(), co, temb); c = co
+            if u["up_attn"][b]:
+                xf(f"up_blocks.{b}.attentions.{i}", c)
+        if b < len(boc) - 1:
+            conv(sd, f"up_blocks.{b}.upsamplers.0.conv", c, c, 3)
+    norm(sd, "conv_norm_out", c); conv(sd, "conv_out", c, u["out_channels"], 3, 0.5)
+    return sd
+
+
+def make_musetalk_vae_state_dict(cfg, seed=0):
+    v = cfg["vae"] if "vae" in cfg else cfg
+    rng, f, conv, lin, norm, resnet = _mt_gen(12000 + seed)
+    boc, L, Z = v["block_out_channels"], v["layers_per_block"], v["latent_channels"]
+    sd = {}
+    conv(sd, "post_quant_conv", Z, Z, 1, 2.0)
+    c = boc[-1]
+    conv(sd, "decoder.conv_in", Z, c, 3)
+    resnet(sd, "decoder.mid_block.resnets.0", c, c)
+    a = "decoder.mid_block.attentions.0"
+    norm(sd, a + ".group_norm", c)
+    for n_ in ("to_q", "to_k", "to_v"):
+        lin(sd, a + "." + n_, c, c, 1.3)
+    lin(sd, a + ".to_out.0", c, c, 0.7)
+    resnet(sd, "decoder.mid_block.resnets.1", c, c)
+    for b, co in enumerate(reversed(boc)):
+        for i in range(L + 1):
+            resnet(sd, f"decoder.up_blocks.{b}.resnets.{i}", c, co); c = co
+        if b < len(boc) - 1:
+            conv(sd, f"decoder.up_blocks.{b}.upsamplers.0.conv", c, c, 3)
+    norm(sd, "decoder.conv_norm_out", c); conv(sd, "decoder.conv_out", c, v["out_channels"], 3, 1.2)
+    return sd
+
+
+def make_musetalk_inputs(batch, seed=0, hw=32):
+    """cfg-3 inputs: latents [B,8,hw,hw] ~ N(0,1)*0.18215-scaled pairs (vae.py:117-121),
+    whisper chunks [B,50,384] ~ N(0,1) before the positional encoding."""
+    rng = np.random.default_rng(13000 + seed)
+    lat = (rng.standard_normal((batch, 8, hw, hw)) * 0.9).astype(np.float32)
+    aud = rng.standard_normal((batch, 50, 384)).astype(np.float32)
+    return torch.from_numpy(lat), torch.from_numpy(aud)

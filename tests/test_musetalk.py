@@ -1,0 +1,142 @@
+"""MuseTalk UNet + VAE decode: oracle self-checks on CPU, HIP vs oracle on GPU.
+
+PARITY UNPINNED: diffusers and the model configs are absent (oracle/musetalk_ref.py header), so the oracle is
+this repository's restatement; what IS pinned to the reference is the seam arithmetic around it
+(PositionalEncoding, t = 0, decode_latents post-processing) and the analytic MAC count of SURVEY Appendix C."""
+import numpy as np
+import pytest
+import torch
+
+from mere_fusion_amd import weights as W
+from oracle import musetalk_ref as R
+
+CFG = R.MUSETALK_SMALL
+
+
+def test_mac_count_matches_survey_appendix_c():
+    m = R.count_macs(R.MUSETALK_V1)
+    assert abs(m["unet"] / 1e9 - 88.9) < 0.5 and abs(m["vae"] / 1e9 - 311.0) < 1.0   # "UNet ~ 88.9 GMAC, VAE decoder ~ 311 GMAC"
+
+
+def test_positional_encoding_kat():
+    pe = R.positional_encoding(50)
+    assert pe.shape == (50, 384) and pe[0, 0] == 0 and pe[0, 1] == 1            # sin(0), cos(0)
+    np.testing.assert_allclose(pe[3, 0].item(), np.sin(3.0), rtol=1e-6)
+    x = torch.zeros(2, 50, 384)
+    assert torch.equal(R.add_positional_encoding(x)[1], pe)
+
+
+def test_timestep_zero_embedding():
+    e = R.timestep_embedding(torch.tensor([0]), 320)
+    assert torch.equal(e[0, :160], torch.ones(160)) and torch.equal(e[0, 160:], torch.zeros(160))
+
+
+def test_decode_postprocessing_kat():
+    # vae.py:104-107 on a decoder stub: /2+0.5, clamp, *255 round, RGB -> BGR
+    img = torch.tensor([[[[-1.2]], [[0.0]], [[0.999]]]])        # R, G, B = -1.2, 0, 0.999
+    x = (img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+    out = (x * 255).round().astype("uint8")[..., ::-1]
+    assert out.tolist() == [[[[255, 128, 0]]]]                     # B=254.87->255, G=127.5->128 (half to even), R=0
+
+
+@pytest.fixture(scope="module")
+def small():
+    torch.set_num_threads(8)
+    usd = W.make_musetalk_unet_state_dict(CFG, 0)
+    vsd = W.make_musetalk_vae_state_dict(CFG, 0)
+    return usd, vsd
+
+
+def test_oracle_small_step_shapes(small):
+    usd, vsd = small
+    lat, aud = W.make_musetalk_inputs(1, 0)
+    img, pred = R.musetalk_step(usd, vsd, CFG, lat, aud)
+    assert pred.shape == (1, 4, 32, 32) and img.shape == (1, 256, 256, 3) and img.dtype == np.uint8
+    assert 30 < img.std() < 110 and 0.2 < pred.std() < 3
+    # batch independence of the restatement
+    lat2, aud2 = W.make_musetalk_inputs(2, 0)
+    p2 = R.unet_forward(usd, CFG["unet"], lat2, torch.tensor([0]), R.add_positional_encoding(aud2))
+    p1 = R.unet_forward(usd, CFG["unet"], lat2[1:], torch.tensor([0]), R.add_positional_encoding(aud2[1:]))
+    assert (p2[1:] - p1).abs().max() < 1e-4
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------
+TOL_LATENT = 2e-3     # bf16x3 through ~60 convs / 16 attention blocks; latents are O(1)
+TOL_IMAGE = 4e-3      # decoder output before clamp, values in about [-4, 4]
+
+
+def _cfg_json(c):
+    return dict(in_channels=c["in_channels"], out_channels=c["out_channels"], block_out_channels=list(c["block_out_channels"]),
+                layers_per_block=c["layers_per_block"], cross_attention_dim=c["cross_attention_dim"],
+                attention_head_dim=c["attention_heads"], norm_num_groups=c["norm_num_groups"],
+                down_attn=c["down_attn"], up_attn=c["up_attn"], sample_size=32)
+
+
+@pytest.fixture(scope="module")
+def hip_small(lib_built, small):
+    from mere_fusion_amd.musetalk.models.unet import UNet
+    from mere_fusion_amd.musetalk.models.vae import VAE
+    usd, vsd = small
+    unet = UNet(_cfg_json(CFG["unet"]), usd, max_batch=4)
+    vc = dict(CFG["vae"]); vc["block_out_channels"] = list(vc["block_out_channels"])
+    vae = VAE(config=vc, state_dict=vsd, max_batch=4)
+    return unet, vae
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 3])
+def test_hip_unet_vs_oracle(hip_small, small, batch):
+    unet, _ = hip_small
+    usd, _ = small
+    lat, aud = W.make_musetalk_inputs(batch, batch)
+    want = R.unet_forward(usd, CFG["unet"], lat, torch.tensor([0]), R.add_positional_encoding(aud))
+    got = unet.model(lat.cuda(), torch.tensor([0]).cuda(), encoder_hidden_states=unet.pe(aud.cuda())).sample.cpu()
+    assert got.shape == want.shape == (batch, 4, 32, 32)
+    err = (got - want).abs().max().item()
+    assert err <= TOL_LATENT, err
+
+
+@pytest.mark.gpu
+def test_hip_vae_vs_oracle(hip_small, small):
+    _, vae = hip_small
+    _, vsd = small
+    torch.manual_seed(0)
+    lat = torch.randn(2, 4, 32, 32) * 0.2
+    want_img = R.vae_decode(vsd, CFG["vae"], lat / CFG["vae"]["scaling_factor"])
+    want_u8 = R.decode_latents(vsd, CFG["vae"], lat)
+    frames, image = vae.decode_latents_device(lat.cuda(), want_image=True)
+    assert (image.cpu() - want_img).abs().max().item() <= TOL_IMAGE
+    got = frames.cpu().numpy()
+    assert got.shape == want_u8.shape == (2, 256, 256, 3) and got.dtype == np.uint8
+    diff = np.abs(got.astype(int) - want_u8.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02        # rounding boundaries only
+    assert np.array_equal(vae.decode_latents(lat.cuda()), got)  # the reference-shaped call: numpy uint8 BGR
+
+
+@pytest.mark.gpu
+def test_hip_musetalk_step_and_replay(hip_small, small):
+    """musereal.py:100-108 end to end; call 1 eager, call 2 captures the hipGraphs, call 3 replays."""
+    unet, vae = hip_small
+    usd, vsd = small
+    lat, aud = W.make_musetalk_inputs(2, 7)
+    want, _ = R.musetalk_step(usd, vsd, CFG, lat, aud)
+    outs = []
+    for _ in range(3):
+        pred = unet.model(lat.cuda(), torch.tensor([0]).cuda(), encoder_hidden_states=unet.pe(aud.cuda())).sample
+        outs.append(vae.decode_latents(pred))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    diff = np.abs(outs[0].astype(int) - want.astype(int))
+    assert diff.max() <= 2 and (diff > 0).mean() < 0.05
+
+
+@pytest.mark.gpu
+def test_hip_unet_rejects_other_timesteps_and_cpu(hip_small):
+    unet, vae = hip_small
+    lat, aud = W.make_musetalk_inputs(1, 0)
+    with pytest.raises(RuntimeError, match="timesteps"):
+        unet.model(lat.cuda(), torch.tensor([10]).cuda(), encoder_hidden_states=aud.cuda())
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        unet.model(lat, torch.tensor([0]), encoder_hidden_states=aud)
+    with pytest.raises(RuntimeError, match="max_batch"):
+        l8, a8 = W.make_musetalk_inputs(8, 0)
+        unet.model(l8.cuda(), torch.tensor([0]).cuda(), encoder_hidden_states=a8.cuda())
