@@ -148,30 +148,67 @@ __global__ __launch_bounds__(256) void k_rows_from_f32(const float* src, const f
     st(const_cast<bf16_t*>(Y.hi), const_cast<bf16_t*>(Y.lo), Y.off(b, t) + c, v);
 }
 
-// GroupNorm statistics: grid (batch*groups, splits); fp64 sum and sum of squares via atomics
-__global__ __launch_bounds__(256) void k_gn_stats(Rows X, int groups, int cpg, double* stats) {
-    const int bg = blockIdx.x, b = bg / groups, g = bg - b * groups;
-    const int T = X.T;
-    const int per = (T + gridDim.y - 1) / gridDim.y;
-    const int t0 = blockIdx.y * per, t1 = min(T, t0 + per);
-    double s = 0.0, q = 0.0;
-    for (int t = t0 + (int)threadIdx.x; t < t1; t += 256) {
-        const int64_t o = X.off(b, t) + g * cpg;
-        for (int c = 0; c < cpg; ++c) {
-            const double v = (double)ld(X.hi, X.lo, o + c);
-            s += v; q += v * v;
+// GroupNorm statistics.  grid (pixel blocks, batch); thread (k = tid % c8, pp = tid / c8) owns the 16-byte channel
+// chunk k (and k + 256, ... for very wide tensors) and walks the block's pixels pp, pp + PPI, ...: for one pixel
+// the active threads read one contiguous row of the NHWC tensor.  Per-channel fp32 partials over <= 64 pixels,
+// then fp64: LDS bins per group, one global fp64 atomic per (workgroup, group).
+constexpr int GN_MAXCOL = 2;     // chunk columns per thread: C <= 8 * 256 * 2 = 4096
+__global__ __launch_bounds__(256) void k_gn_stats(Rows X, int groups, int cpg, int C, int P, double* stats) {
+    __shared__ double bins[2 * 64];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int c8 = C / 8;
+    const int cols = c8 < 256 ? c8 : 256;
+    const int ppi = 256 / cols;                     // pixels walked in parallel
+    const int k0 = tid % cols, pp = tid / cols;
+    const int t0 = blockIdx.x * P, t1 = min(X.T, t0 + P);
+    for (int i = tid; i < 2 * groups; i += 256) bins[i] = 0.0;
+    __syncthreads();
+    float s[GN_MAXCOL][8], q[GN_MAXCOL][8];
+#pragma unroll
+    for (int j = 0; j < GN_MAXCOL; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[j][e] = 0.f; q[j][e] = 0.f; }
+    if (pp < ppi) {
+        for (int t = t0 + pp; t < t1; t += ppi) {
+            const int64_t o = X.off(b, t);
+#pragma unroll
+            for (int j = 0; j < GN_MAXCOL; ++j) {
+                const int k = k0 + 256 * j;
+                if (k >= c8) break;
+                const uint4 vh = *reinterpret_cast<const uint4*>(X.hi + o + k * 8);
+                uint4 vl = make_uint4(0, 0, 0, 0);
+                if (X.lo) vl = *reinterpret_cast<const uint4*>(X.lo + o + k * 8);
+                const uint32_t hh[4] = {vh.x, vh.y, vh.z, vh.w}, ll[4] = {vl.x, vl.y, vl.z, vl.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v0 = nbf2f(hh[e] & 0xffffu) + nbf2f(ll[e] & 0xffffu);
+                    const float v1 = nbf2f(hh[e] >> 16) + nbf2f(ll[e] >> 16);
+                    s[j][2 * e] += v0; q[j][2 * e] += v0 * v0;
+                    s[j][2 * e + 1] += v1; q[j][2 * e + 1] += v1 * v1;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GN_MAXCOL; ++j) {
+            const int k = k0 + 256 * j;
+            if (k >= c8) break;
+            // channels of this chunk -> groups (cpg may be smaller or larger than 8, and need not divide it)
+            int g_cur = (k * 8) / cpg;
+            double as = 0.0, aq = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int g = (k * 8 + e) / cpg;
+                if (g != g_cur) {
+                    atomicAdd(&bins[2 * g_cur], as); atomicAdd(&bins[2 * g_cur + 1], aq);
+                    g_cur = g; as = 0.0; aq = 0.0;
+                }
+                as += (double)s[j][e]; aq += (double)q[j][e];
+            }
+            atomicAdd(&bins[2 * g_cur], as); atomicAdd(&bins[2 * g_cur + 1], aq);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-    __shared__ double sh[8];
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sh[2 * w] = s; sh[2 * w + 1] = q; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&stats[2 * bg], sh[0] + sh[2] + sh[4] + sh[6]);
-        atomicAdd(&stats[2 * bg + 1], sh[1] + sh[3] + sh[5] + sh[7]);
-    }
+    for (int i = tid; i < 2 * groups; i += 256) atomicAdd(&stats[2 * (b * groups) + i], bins[i]);
 }
 
 // one thread per (token, 8 channels)
@@ -298,8 +335,11 @@ int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const f
     const Rows xr = rows_of(x), yr = rows_of(y);
     const int cpg = x.C / groups;
     MF_HIP(hipMemsetAsync(stats, 0, (size_t)batch * groups * 2 * sizeof(double), s));
-    const int splits = std::max(1, std::min(64, xr.T * cpg / 8192));
-    hipLaunchKernelGGL(k_gn_stats, dim3(batch * groups, splits), dim3(256), 0, s, xr, groups, cpg, stats);
+    MF_REQUIRE(groups <= 64 && x.C <= 8 * 256 * GN_MAXCOL, "groupnorm: groups=%d / C=%d beyond the kernel's limits", groups, x.C);
+    // pixels per workgroup: enough workgroups to fill the chip, at most 64 pixels per thread column
+    const int cols = std::min(256, x.C / 8), ppi = 256 / cols;
+    int P = std::max(ppi, std::min(64 * ppi, (xr.T * batch + 1023) / 1024));
+    hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, cpg, x.C, P, stats);
     MF_HIP(hipGetLastError());
     const int64_t total = (int64_t)batch * xr.T * (x.C / 8);
     hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xr, yr, gamma, beta, stats, groups,
