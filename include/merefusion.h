@@ -193,6 +193,12 @@ int mf_unet_create(const mf_unet_config* cfg, const mf_tensor* weights, int n_we
  * (musereal.py:102-107).  latents: device fp32 [B,in_channels,S,S]; audio: device fp32 [B,ctx_len,cross_dim];
  * add_pe != 0 adds the PositionalEncoding of unet.py:12-27 to `audio` first; out: device fp32 [B,out_channels,S,S]. */
 int mf_unet_forward(mf_unet* h, const float* latents, const float* audio, int add_pe, float* out, int batch, void* stream);
+/* Measurement seam (bench.py roofline): the schedule's ops in execution order on the buffers of the last forward.
+ * op_info: name = the diffusers module path, kernel = HIP kernel(s) it launches, flops_per_frame = 2 x MACs.
+ * profile: every op alone between two hipEvents on `stream`, hipGraph off; mean milliseconds per op. */
+int mf_unet_num_ops(const mf_unet* h);
+int mf_unet_op_info(const mf_unet* h, int i, char* name, int ncap, char* kernel, int kcap, double* flops_per_frame);
+int mf_unet_profile(mf_unet* h, int batch, int iters, float* ms_per_op, void* stream);
 void mf_unet_destroy(mf_unet* h);
 
 /* Replaces `AutoencoderKL.from_pretrained` for the DECODER half (musetalk/models/vae.py:24,96-108). */
@@ -201,6 +207,9 @@ int mf_vae_create(const mf_vae_config* cfg, const mf_tensor* weights, int n_weig
 /* `VAE.decode_latents` (vae.py:96-108): latents device fp32 [B,4,S,S] -> frames device uint8 [B,8S,8S,3] BGR.
  * image_f32 (optional, may be NULL): the decoder output before post-processing, device fp32 [B,3,8S,8S]. */
 int mf_vae_decode_latents(mf_vae* h, const float* latents, uint8_t* frames, float* image_f32, int batch, void* stream);
+int mf_vae_num_ops(const mf_vae* h);
+int mf_vae_op_info(const mf_vae* h, int i, char* name, int ncap, char* kernel, int kcap, double* flops_per_frame);
+int mf_vae_profile(mf_vae* h, int batch, int iters, float* ms_per_op, void* stream);
 void mf_vae_destroy(mf_vae* h);
 
 #ifdef __cplusplus

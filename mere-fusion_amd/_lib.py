@@ -77,9 +77,15 @@ SIGNATURES = {
     "mf_whisper_destroy": (None, [C.c_void_p]),
     "mf_unet_create": (C.c_int, [C.POINTER(MfUnetConfig), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mf_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mf_unet_num_ops": (C.c_int, [C.c_void_p]),
+    "mf_unet_op_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double)]),
+    "mf_unet_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "mf_unet_destroy": (None, [C.c_void_p]),
     "mf_vae_create": (C.c_int, [C.POINTER(MfVaeConfig), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mf_vae_decode_latents": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mf_vae_num_ops": (C.c_int, [C.c_void_p]),
+    "mf_vae_op_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double)]),
+    "mf_vae_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "mf_vae_destroy": (None, [C.c_void_p]),
     "mf_melspec": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_melspec_frames": (C.c_int, [C.c_int]),

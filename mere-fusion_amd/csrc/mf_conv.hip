@@ -22,6 +22,7 @@
 // over blockIdx.y; their fp32 partial tiles are combined by k_splitk_epilogue.
 #include "mf_conv.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 
@@ -713,6 +714,16 @@ int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream
     return rc;
 }
 
+// minimum number of workgroups for which the 128x128 / 128x64 tile is preferred (tunable for experiments)
+static int tile_threshold(int which) {
+    static int th[2] = {-1, -1};
+    if (th[0] < 0) {
+        const char* a = getenv("MF_TILE_T128"); const char* b = getenv("MF_TILE_T64");
+        th[0] = a ? atoi(a) : 512; th[1] = b ? atoi(b) : 512;
+    }
+    return th[which];
+}
+
 // Tile selection: the largest tile that still yields >= ~2 workgroups per CU (256 CUs); layers that
 // cannot fill the chip with output tiles and have a long contraction are additionally split along K.
 ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
@@ -722,13 +733,14 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
     if (N <= 16) t = {128, 16, 4, 1, 1};
     else if (N <= 32) t = {128, 32, 4, 1, 1};
     else if (M <= 16) t = {16, 64, 1, 4, 1};
-    else if (tiles(128, 128) >= 512 && N % 128 == 0) t = {128, 128, 2, 2, 1};
-    else if (tiles(128, 64) >= 512) t = {128, 64, 2, 2, 1};
+    else if (tiles(128, 128) >= tile_threshold(0) && N % 128 == 0) t = {128, 128, 2, 2, 1};
+    else if (tiles(128, 64) >= tile_threshold(1)) t = {128, 64, 2, 2, 1};
     else t = {64, 64, 2, 2, 1};
     const int nt = tiles(t.bm, t.bn);
     int kt_min = p->ph[0].KT;
     for (int ph = 1; ph < p->nphase; ++ph) kt_min = std::min(kt_min, p->ph[ph].KT);
-    if (nt < 256 && kt_min >= 2) t.nsplit = std::max(1, std::min(std::min(kt_min, cdiv(512, nt)), 16));
+    static const int split_nt = [] { const char* e = getenv("MF_SPLIT_NT"); return e ? atoi(e) : 256; }();
+    if (nt < split_nt && kt_min >= 2) t.nsplit = std::max(1, std::min(std::min(kt_min, cdiv(2 * split_nt, nt)), 16));
     return t;
 }
 

@@ -33,11 +33,14 @@ struct Net {
     std::vector<std::unique_ptr<ConvPlan>> plans;
     std::vector<void*> dev;
     std::vector<Op> ops;
+    struct OpInfo { std::string name, kernel; double flops_per_frame; };
+    std::vector<OpInfo> info;   // parallel to ops (measurement seam)
     std::map<std::tuple<std::string, int, int, int, int>, ActBuf*> scratch;
     std::map<std::tuple<int, int, int, int>, std::pair<ConvPlan*, ConvPlan*>> attn_plans;   // (dh, Tq, Tk, heads)
     double* gn_stats = nullptr;
     std::map<int, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     bool use_graph = true;
     std::string err;
 
@@ -47,6 +50,8 @@ struct Net {
         for (auto& b : bufs) { if (b->hi) (void)hipFree(b->hi); if (b->lo) (void)hipFree(b->lo); }
         for (void* d : dev) (void)hipFree(d);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (ev_in) (void)hipEventDestroy(ev_in);
+        if (ev_out) (void)hipEventDestroy(ev_out);
     }
 
     // ---- resources ----------------------------------------------------------------------------------------
@@ -85,6 +90,11 @@ struct Net {
     bool has(const std::string& k) const { return sd.count(k) != 0; }
     ConvPlan* new_plan() { plans.emplace_back(new ConvPlan()); return plans.back().get(); }
 
+    void push(const std::string& name, const std::string& kernel, double flops, Op op) {
+        ops.push_back(std::move(op));
+        info.push_back(OpInfo{name, kernel, flops});
+    }
+
     // ---- ops ----------------------------------------------------------------------------------------------
     // Conv2d / Linear `name` (k x k, stride, pad), optional SiLU etc., optional residual view, optional
     // nearest-2x upsample in front, optional per-channel constant added to the bias, optional input scale.
@@ -107,7 +117,9 @@ struct Net {
         int rc = mf_conv_plan_create(p, d, w, bb.data(), nullptr, nullptr, nullptr, nullptr, precision);
         if (rc) return rc;
         if ((rc = mf_conv_bind(p, *in.buf))) return rc;
-        ops.push_back([p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
+        char kn[96];
+        mf_conv_kernel_name(p, cap, kn, sizeof(kn));
+        push(name, kn, mf_conv_flops(p, 1), [p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
         return MF_OK;
     }
     int gn(const std::string& name, ActView in, ActView out, int groups, float eps, bool silu) {
@@ -118,7 +130,7 @@ struct Net {
         float* db = upload(b, in.C);
         if (!dg || !db) return MF_ERR_HIP;
         double* st = gn_stats;
-        ops.push_back([=](int B, hipStream_t s) { return mf_groupnorm(in, out, dg, db, groups, eps, silu, st, B, s); });
+        push(name, "k_gn_stats+k_gn_apply", 0.0, [=](int B, hipStream_t s) { return mf_groupnorm(in, out, dg, db, groups, eps, silu, st, B, s); });
         return MF_OK;
     }
     int ln(const std::string& name, ActView in, ActView out) {
@@ -128,7 +140,7 @@ struct Net {
         float* dg = upload(g, in.C);
         float* db = upload(b, in.C);
         if (!dg || !db) return MF_ERR_HIP;
-        ops.push_back([=](int B, hipStream_t s) { return mf_layernorm(in, out, dg, db, 1e-5f, B, s); });
+        push(name, "k_layernorm", 0.0, [=](int B, hipStream_t s) { return mf_layernorm(in, out, dg, db, 1e-5f, B, s); });
         return MF_OK;
     }
     // softmax(q k^T * dh^-0.5) v for `heads` heads; q / k / v / out are views of contiguous (halo 0) token buffers
@@ -163,7 +175,8 @@ struct Net {
         if (!sc || !pm) return MF_ERR_HIP;
         const float scale = 1.0f / std::sqrt((float)dh);
         const bool x3 = precision == MF_PREC_BF16X3;
-        ops.push_back([=](int B, hipStream_t s) {
+        push("attention " + std::to_string(Tq) + "x" + std::to_string(Tk) + " heads " + std::to_string(heads) + " dh " + std::to_string(dh),
+             "pack+gemm+softmax+pack+gemm", 4.0 * Tq * Tk * C, [=](int B, hipStream_t s) {
             int rc;
             if ((rc = mf_pack_b_grouped(ps, k.buf->hi + k.coff, x3 ? k.buf->lo + k.coff : nullptr, k.buf->per_batch(), dh,
                                         k.buf->C, 1, Tk, dh, B * heads, heads, s))) return rc;
@@ -263,7 +276,7 @@ struct Net {
         // GEGLU feed-forward
         if ((rc = ln(t + ".norm3", ActView{hA, 0, C}, ActView{nb, 0, C}))) return rc;
         if ((rc = conv(t + ".ff.net.0.proj", ActView{nb, 0, C}, ActView{ff, 0, 8 * C}, C, 8 * C, 1, 1, 0, 0, ActView{}))) return rc;
-        ops.push_back([=](int B, hipStream_t s) { return mf_geglu(ActView{ff, 0, 8 * C}, ActView{gg, 0, 4 * C}, B, s); });
+        push(t + ".ff.geglu", "k_geglu", 0.0, [=](int B, hipStream_t s) { return mf_geglu(ActView{ff, 0, 8 * C}, ActView{gg, 0, 4 * C}, B, s); });
         if ((rc = conv(t + ".ff.net.2", ActView{gg, 0, 4 * C}, ActView{hB, 0, C}, 4 * C, C, 1, 1, 0, 0, ActView{hA, 0, C}))) return rc;
         return conv(p + ".proj_out", ActView{hB, 0, C}, y, C, C, 1, 1, 0, 0, x);
     }
@@ -276,7 +289,38 @@ struct Net {
         int rc = mf_conv_plan_create(p, d, w, b, nullptr, nullptr, nullptr, nullptr, precision);
         if (rc) return rc;
         if ((rc = mf_conv_bind(p, *in.buf))) return rc;
-        ops.push_back([p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
+        char kn[96];
+        mf_conv_kernel_name(p, cap, kn, sizeof(kn));
+        push("fused linear " + std::to_string(cin) + "->" + std::to_string(cout), kn, mf_conv_flops(p, 1),
+             [p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
+        return MF_OK;
+    }
+
+    // measurement seam: every op alone between two hipEvents on `s`, no graph
+    int profile(int B, int iters, float* ms, hipStream_t s) {
+        const int n = (int)ops.size();
+        std::vector<hipEvent_t> ev(n + 1);
+        for (auto& e : ev) MF_HIP(hipEventCreate(&e));
+        std::vector<double> acc(n, 0.0);
+        for (int it = 0; it < iters; ++it) {
+            for (int i = 0; i < n; ++i) {
+                MF_HIP(hipEventRecord(ev[i], s));
+                int rc = ops[i](B, s);
+                if (rc) return rc;
+            }
+            MF_HIP(hipEventRecord(ev[n], s));
+            MF_HIP(hipStreamSynchronize(s));
+            for (int i = 0; i < n; ++i) { float t = 0.f; MF_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1])); acc[i] += t; }
+        }
+        for (int i = 0; i < n; ++i) ms[i] = (float)(acc[i] / iters);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        return MF_OK;
+    }
+    int op_info(int i, char* name, int ncap, char* kernel, int kcap, double* flops) const {
+        MF_REQUIRE(i >= 0 && i < (int)info.size() && name && kernel && flops, "op_info: bad argument");
+        snprintf(name, ncap, "%s", info[i].name.c_str());
+        snprintf(kernel, kcap, "%s", info[i].kernel.c_str());
+        *flops = info[i].flops_per_frame;
         return MF_OK;
     }
 
@@ -302,7 +346,13 @@ struct Net {
             if (e != hipSuccess) { mf_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return MF_ERR_HIP; }
             it->second = exec;
         }
-        MF_HIP(hipGraphLaunch(it->second, s));
+        // the graph replays on the handle's own stream, fenced by events against the caller's stream: the
+        // caller usually hands in the legacy NULL stream, whose implicit ordering a graph launch does not inherit
+        MF_HIP(hipEventRecord(ev_in, s));
+        MF_HIP(hipStreamWaitEvent(cap_stream, ev_in, 0));
+        MF_HIP(hipGraphLaunch(it->second, cap_stream));
+        MF_HIP(hipEventRecord(ev_out, cap_stream));
+        MF_HIP(hipStreamWaitEvent(s, ev_out, 0));
         return MF_OK;
     }
     int init(const mf_tensor* weights, int n, int prec, int max_batch, int max_groups) {
@@ -314,6 +364,8 @@ struct Net {
         MF_HIP(hipMalloc(&gn_stats, (size_t)max_batch * max_groups * 2 * sizeof(double)));
         dev.push_back(gn_stats);
         MF_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+        MF_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+        MF_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
         const char* ng = std::getenv("MF_NO_GRAPH");
         use_graph = !(ng && ng[0] == '1');
         return MF_OK;
@@ -521,6 +573,15 @@ extern "C" int mf_unet_forward(mf_unet* h, const float* latents, const float* au
     return mf_act_to_nchw(ActView{h->out_buf, 0, h->cfg.out_channels}, out, batch, s);
 }
 
+extern "C" int mf_unet_num_ops(const mf_unet* h) { return h ? (int)h->net.ops.size() : 0; }
+extern "C" int mf_unet_op_info(const mf_unet* h, int i, char* name, int ncap, char* kernel, int kcap, double* flops_per_frame) {
+    MF_REQUIRE(h, "unet_op_info: null handle");
+    return h->net.op_info(i, name, ncap, kernel, kcap, flops_per_frame);
+}
+extern "C" int mf_unet_profile(mf_unet* h, int batch, int iters, float* ms_per_op, void* stream) {
+    MF_REQUIRE(h && ms_per_op && batch > 0 && batch <= h->net.cap && iters > 0, "unet_profile: bad argument");
+    return h->net.profile(batch, iters, ms_per_op, (hipStream_t)stream);
+}
 extern "C" void mf_unet_destroy(mf_unet* h) { delete h; }
 
 // ==========================================================================================================
@@ -608,4 +669,13 @@ extern "C" int mf_vae_decode_latents(mf_vae* h, const float* latents, uint8_t* f
     return MF_OK;
 }
 
+extern "C" int mf_vae_num_ops(const mf_vae* h) { return h ? (int)h->net.ops.size() : 0; }
+extern "C" int mf_vae_op_info(const mf_vae* h, int i, char* name, int ncap, char* kernel, int kcap, double* flops_per_frame) {
+    MF_REQUIRE(h, "vae_op_info: null handle");
+    return h->net.op_info(i, name, ncap, kernel, kcap, flops_per_frame);
+}
+extern "C" int mf_vae_profile(mf_vae* h, int batch, int iters, float* ms_per_op, void* stream) {
+    MF_REQUIRE(h && ms_per_op && batch > 0 && batch <= h->net.cap && iters > 0, "vae_profile: bad argument");
+    return h->net.profile(batch, iters, ms_per_op, (hipStream_t)stream);
+}
 extern "C" void mf_vae_destroy(mf_vae* h) { delete h; }

@@ -211,9 +211,27 @@ __global__ __launch_bounds__(256) void k_gn_stats(Rows X, int groups, int cpg, i
     for (int i = tid; i < 2 * groups; i += 256) atomicAdd(&stats[2 * (b * groups) + i], bins[i]);
 }
 
-// one thread per (token, 8 channels)
-__global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* gamma, const float* beta, const double* stats,
-                                                  int groups, int cpg, int C, float eps, int silu, int64_t total) {
+// zeroes the statistics scratch (a kernel rather than hipMemsetAsync: memset nodes inside a captured hipGraph
+// were observed to misbehave next to other graphs on ROCm 7.2 -- DESIGN.md "hipGraph notes")
+__global__ void k_zero_f64(double* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
+// (sum, sumsq) fp64 -> (mean, rstd) fp32 per (batch, group), written over the first half of the stats buffer
+__global__ void k_gn_finalize(double* stats, double n, float eps, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double mean = stats[2 * i] / n;
+    const double var = fmax(stats[2 * i + 1] / n - mean * mean, 0.0);
+    float2 r = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    // in place: entry i's 16 bytes are read before its first 8 bytes are overwritten by the same thread
+    reinterpret_cast<float2*>(stats)[2 * i] = r;
+}
+
+// one thread per (token, 8 channels): y = (x - mean) * rstd * gamma + beta [, SiLU]
+__global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const double* stats, int groups, int cpg, int C, int silu, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c8 = C / 8;
@@ -221,12 +239,18 @@ __global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* g
     const int64_t r = idx / c8;
     const int t = (int)(r % X.T), b = (int)(r / X.T);
     const int64_t xo = X.off(b, t) + c0, yo = Y.off(b, t) + c0;
-    const double n = (double)X.T * cpg;
+    const float2* mr = reinterpret_cast<const float2*>(stats);
     const uint4 vh = *reinterpret_cast<const uint4*>(X.hi + xo);
     uint4 vl = make_uint4(0, 0, 0, 0);
     if (X.lo) vl = *reinterpret_cast<const uint4*>(X.lo + xo);
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
+    const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
     const uint32_t hh[4] = {vh.x, vh.y, vh.z, vh.w}, ll[4] = {vl.x, vl.y, vl.z, vl.w};
     uint32_t oh[4], ol[4];
+    int g_prev = -1;
+    float2 st2 = make_float2(0.f, 1.f);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float out2[2];
@@ -234,12 +258,10 @@ __global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* g
         for (int k = 0; k < 2; ++k) {
             const int c = c0 + 2 * e + k;
             const int g = c / cpg;
-            const double mean = stats[2 * (b * groups + g)] / n;
-            const double var = fmax(stats[2 * (b * groups + g) + 1] / n - mean * mean, 0.0);
-            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            if (g != g_prev) { st2 = mr[2 * (b * groups + g)]; g_prev = g; }
             const float x = nbf2f(k ? hh[e] >> 16 : hh[e] & 0xffffu) + nbf2f(k ? ll[e] >> 16 : ll[e] & 0xffffu);
-            float v = (x - (float)mean) * rstd * gamma[c] + beta[c];
-            if (silu) v = v / (1.f + expf(-v));
+            float v = (x - st2.x) * st2.y * gm[2 * e + k] + bt[2 * e + k];
+            if (silu) v = v / (1.f + __expf(-v));
             out2[k] = v;
         }
         const uint32_t h0 = nf2bf(out2[0]), h1 = nf2bf(out2[1]);
@@ -334,16 +356,19 @@ int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const f
     MF_REQUIRE(x.buf->H == y.buf->H && x.buf->W == y.buf->W, "groupnorm: spatial mismatch");
     const Rows xr = rows_of(x), yr = rows_of(y);
     const int cpg = x.C / groups;
-    MF_HIP(hipMemsetAsync(stats, 0, (size_t)batch * groups * 2 * sizeof(double), s));
+    hipLaunchKernelGGL(k_zero_f64, dim3((batch * groups * 2 + 255) / 256), dim3(256), 0, s, stats, batch * groups * 2);
+    MF_HIP(hipGetLastError());
     MF_REQUIRE(groups <= 64 && x.C <= 8 * 256 * GN_MAXCOL, "groupnorm: groups=%d / C=%d beyond the kernel's limits", groups, x.C);
     // pixels per workgroup: enough workgroups to fill the chip, at most 64 pixels per thread column
     const int cols = std::min(256, x.C / 8), ppi = 256 / cols;
     int P = std::max(ppi, std::min(64 * ppi, (xr.T * batch + 1023) / 1024));
     hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, cpg, x.C, P, stats);
     MF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_gn_finalize, dim3((batch * groups + 63) / 64), dim3(64), 0, s, stats, (double)xr.T * cpg, eps, batch * groups);
+    MF_HIP(hipGetLastError());
     const int64_t total = (int64_t)batch * xr.T * (x.C / 8);
     hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xr, yr, gamma, beta, stats, groups,
-                       cpg, x.C, eps, silu ? 1 : 0, total);
+                       cpg, x.C, silu ? 1 : 0, total);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

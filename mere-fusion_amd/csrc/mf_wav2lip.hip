@@ -113,7 +113,7 @@ struct mf_wav2lip {
     std::map<int, hipGraphExec_t> graphs;
     hipStream_t side = nullptr;       // audio-encoder lane
     hipStream_t cap_stream = nullptr; // capture origin
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_gin = nullptr, ev_gout = nullptr;
     bool use_graph = true;
 
     ~mf_wav2lip() {
@@ -126,6 +126,8 @@ struct mf_wav2lip {
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_gin) (void)hipEventDestroy(ev_gin);
+        if (ev_gout) (void)hipEventDestroy(ev_gout);
     }
     void free_bufs() {
         for (auto& b : bufs) {
@@ -252,7 +254,12 @@ int mf_wav2lip::run(int batch, hipStream_t s) {
         if (e != hipSuccess) { mf_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return MF_ERR_HIP; }
         it->second = exec;
     }
-    MF_HIP(hipGraphLaunch(it->second, s));
+    // replay on the handle's own stream, fenced by events against the caller's (usually the legacy NULL) stream
+    MF_HIP(hipEventRecord(ev_gin, s));
+    MF_HIP(hipStreamWaitEvent(cap_stream, ev_gin, 0));
+    MF_HIP(hipGraphLaunch(it->second, cap_stream));
+    MF_HIP(hipEventRecord(ev_gout, cap_stream));
+    MF_HIP(hipStreamWaitEvent(s, ev_gout, 0));
     return MF_OK;
 }
 
@@ -279,6 +286,8 @@ extern "C" int mf_wav2lip_create(const mf_tensor* weights, int n_weights, int pr
     MF_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
     MF_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     MF_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    MF_HIP(hipEventCreateWithFlags(&h->ev_gin, hipEventDisableTiming));
+    MF_HIP(hipEventCreateWithFlags(&h->ev_gout, hipEventDisableTiming));
 
     // ---- buffers ---------------------------------------------------------------------------
     h->mel_in = h->new_buf(8, 80, 16, 1);     // 1 real channel, padded to an 8-channel group

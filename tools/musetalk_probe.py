@@ -43,6 +43,27 @@ for name, fn in (("unet", lambda: unet.model(latd, t0d, encoder_hidden_states=au
     for _ in range(a.iters): fn()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.iters
     print(f"{name}: {dt * 1e3:.2f} ms per batch of {a.batch} -> {a.batch / dt:.1f} frames/s", flush=True)
+import ctypes as C
+from mere_fusion_amd import _lib
+l = _lib.lib()
+if os.environ.get("MF_PROFILE_OPS"):
+    for tag, h, nops, info, prof in (("unet", unet.model._h, l.mf_unet_num_ops, l.mf_unet_op_info, l.mf_unet_profile),
+                                     ("vae", vae._h, l.mf_vae_num_ops, l.mf_vae_op_info, l.mf_vae_profile)):
+        n = nops(h); ms = (C.c_float * n)()
+        _lib.check(prof(h, a.batch, 3, ms, None))
+        rows = []
+        for i in range(n):
+            nm, kn, fl = C.create_string_buffer(160), C.create_string_buffer(96), C.c_double()
+            info(h, i, nm, 160, kn, 96, C.byref(fl)); rows.append((nm.value.decode(), kn.value.decode(), fl.value * a.batch, ms[i]))
+        tot = sum(r[3] for r in rows)
+        print(f"---- {tag}: {n} ops, sum {tot:.2f} ms")
+        bykind = {}
+        for nm, kn, fl, t in rows:
+            k = bykind.setdefault(kn, [0.0, 0.0, 0]); k[0] += t; k[1] += fl; k[2] += 1
+        for kn, (t, fl, cnt) in sorted(bykind.items(), key=lambda x: -x[1][0]):
+            print(f"   {kn:44s} n={cnt:3d} {t:8.3f} ms {100 * t / tot:5.1f} %  {fl / (t * 1e-3) / 1e12 if t else 0:7.1f} TF")
+        for nm, kn, fl, t in sorted(rows, key=lambda r: -r[3])[:12]:
+            print(f"   top: {t * 1e3:8.1f} us {fl / 1e9:8.1f} GF {fl / (t * 1e-3) / 1e12:6.1f} TF  {kn:40s} {nm}")
 m = R.count_macs(cfg)
 print(f"algorithmic GFLOP/frame: unet {2 * m['unet'] / 1e9:.1f}, vae {2 * m['vae'] / 1e9:.1f}; at the step rate: {2 * (m['unet'] + m['vae']) * a.batch / dt / 1e12:.1f} TFLOP/s")
 if a.check:
