@@ -4,10 +4,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch: the Wav2Lip generator
-(wav2lip/models/wav2lip.py:87-125 as called at lipreal.py:124-125) on a batch of 16 mel chunks +
-16 face crops already resident in HBM -- BASELINE.json configs[1].  One process per GPU; sessions
-are independent so ranks share nothing but the barrier and the MAX of the elapsed time ("weak").
+BASELINE.json's metric is "lip-sync frames/sec @256x256": the headline workload is configs[2], the MuseTalk
+step of musereal.py:100-108 -- pe(audio) -> UNet(t=0) -> VAE.decode_latents -> uint8 256x256 BGR frames --
+on a batch of 8 latents + 8 Whisper chunks already resident in HBM (the reference's own
+"actual avg infer fps" brackets exactly this, musereal.py:99-115).  `--workload wav2lip` selects
+configs[1] instead (Wav2Lip generator 96x96, batch 16), which is also reported in the default line
+under "wav2lip".  One process per GPU; sessions are independent so ranks share nothing but the barrier and the
+MAX of the elapsed time ("weak").
 Rank 0 prints ONE JSON line.  Extra objects on that line:
   roofline     : the dominant HIP kernel's algorithmic TFLOP/s (HIP events around every launch,
                  mf_wav2lip_profile) against the dense MFMA peak of the arithmetic mode
@@ -74,6 +77,76 @@ class Runner:
         return rows
 
 
+class MuseTalkRunner:
+    """musereal.py:100-108 on resident device tensors through the drop-in objects (C ABI underneath)."""
+
+    def __init__(self, precision, batch, device, seed=0):
+        from mere_fusion_amd.musetalk.models.unet import UNet
+        from mere_fusion_amd.musetalk.models.vae import VAE
+        from oracle.musetalk_ref import MUSETALK_V1      # the config table only (no oracle arithmetic)
+        self.cfg = MUSETALK_V1
+        u = self.cfg["unet"]
+        ucfg = dict(in_channels=u["in_channels"], out_channels=u["out_channels"], block_out_channels=list(u["block_out_channels"]),
+                    layers_per_block=u["layers_per_block"], cross_attention_dim=u["cross_attention_dim"],
+                    attention_head_dim=u["attention_heads"], norm_num_groups=u["norm_num_groups"], down_attn=u["down_attn"],
+                    up_attn=u["up_attn"], sample_size=32)
+        self.usd = W.make_musetalk_unet_state_dict(self.cfg, 0)
+        self.vsd = W.make_musetalk_vae_state_dict(self.cfg, 0)
+        with torch.cuda.device(device):
+            self.unet = UNet(ucfg, self.usd, precision=precision, max_batch=batch)
+            vc = dict(self.cfg["vae"]); vc["block_out_channels"] = list(vc["block_out_channels"])
+            self.vae = VAE(config=vc, state_dict=self.vsd, precision=precision, max_batch=batch)
+        lat, aud = W.make_musetalk_inputs(batch, seed)
+        self.lat_cpu, self.aud_cpu = lat, aud
+        self.lat, self.aud = lat.to(device), aud.to(device)
+        self.t0 = torch.tensor([0], device=device)
+        self.batch = batch
+
+    def step(self):
+        pred = self.unet.model(self.lat, self.t0, encoder_hidden_states=self.unet.pe(self.aud)).sample
+        return self.vae.decode_latents_device(pred)
+
+    def profile(self, iters):
+        l = _lib.lib()
+        rows = []
+        for tag, h, nops, info, prof in (("unet", self.unet.model._h, l.mf_unet_num_ops, l.mf_unet_op_info, l.mf_unet_profile),
+                                         ("vae", self.vae._h, l.mf_vae_num_ops, l.mf_vae_op_info, l.mf_vae_profile)):
+            n = nops(h)
+            ms = (C.c_float * n)()
+            _lib.check(prof(h, self.batch, iters, ms, None), tag + "_profile")
+            for i in range(n):
+                nm, kn, fl = C.create_string_buffer(160), C.create_string_buffer(96), C.c_double()
+                _lib.check(info(h, i, nm, 160, kn, 96, C.byref(fl)))
+                rows.append(dict(layer=f"{tag}:{nm.value.decode()}", kernel=kn.value.decode(), flops=fl.value * self.batch, ms=float(ms[i])))
+        return rows
+
+    def parity(self):
+        from oracle import musetalk_ref as R
+        torch.set_num_threads(host_threads(0))
+        want_u8, want_pred = R.musetalk_step(self.usd, self.vsd, self.cfg, self.lat_cpu[:1], self.aud_cpu[:1])
+        pred = self.unet.model(self.lat[:1], self.t0, encoder_hidden_states=self.unet.pe(self.aud[:1])).sample
+        got = self.vae.decode_latents(pred)
+        d = np.abs(got.astype(int) - want_u8.astype(int))
+        return {"latent_linf_vs_oracle": float((pred.cpu() - want_pred).abs().max()), "u8_max_diff": int(d.max()),
+                "u8_differing_pixels": float((d > 0).mean()), "oracle": "parity unpinned (diffusers absent): oracle/musetalk_ref.py"}
+
+    def cpu_baseline(self, seconds, threads):
+        from oracle import musetalk_ref as R
+        torch.set_num_threads(host_threads(threads))
+        R.musetalk_step(self.usd, self.vsd, self.cfg, self.lat_cpu[:1], self.aud_cpu[:1])
+        n, t0 = 0, time.perf_counter()
+        while True:
+            R.musetalk_step(self.usd, self.vsd, self.cfg, self.lat_cpu[:1], self.aud_cpu[:1])
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= seconds and n >= 2:
+                break
+        m = R.count_macs(self.cfg)
+        return {"value": round(n / el, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} single-frame steps of the fp32 oracle (oracle/musetalk_ref.py: UNet + VAE decode), {el:.1f} s",
+                "gflops": round(n * 2 * (m["unet"] + m["vae"]) / 1e9 / el, 1)}
+
+
 class MultiSession:
     """S independent talking-head sessions on one GPU, one hipStream + one generator handle each
     (BASELINE.json configs[3] per-GPU shape: lipreal.py runs one inference loop per session)."""
@@ -91,9 +164,11 @@ class MultiSession:
             r.step()
 
 
-def roofline(rows, precision):
+def roofline(rows, precision, only_mfma=False):
     by = {}
     for r in rows:
+        if only_mfma and not r["kernel"].startswith("k_conv"):
+            continue
         k = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, launches=0))
         k["ms"] += r["ms"]; k["flops"] += r["flops"]; k["launches"] += 1
     dom = max(by, key=lambda k: by[k]["ms"])
@@ -166,19 +241,71 @@ def cpu_baseline(batch, seconds, threads):
             "gflops": round(n * batch * GFLOP_PER_FRAME / el, 1)}
 
 
+def wav2lip_report(args, device, world, rank, value=None, ms_per_step=None, run=None):
+    """The configs[1] leg (Wav2Lip generator, B=16).  Headline when --workload wav2lip, else an extra object."""
+    run = run or Runner(args.precision, args.w2l_batch, device, seed=rank)
+    if value is None:
+        steps = args.steps if args.workload == "wav2lip" else 200
+        el = harness.timed_steps(run.step, steps, 20, sync_fn=torch.cuda.synchronize)
+        value, ms_per_step = args.w2l_batch * steps / el, el / steps * 1e3
+    out = {"value": round(value, 1), "unit": "frames/s", "ms_per_step": round(ms_per_step, 4), "dtype": args.precision,
+           "workload": "Wav2Lip generator 96x96, batch=16 mel-chunks, inputs resident in HBM (BASELINE.json configs[1])",
+           "net_tflops": round(value / world * GFLOP_PER_FRAME / 1e3, 2)}
+    rows = run.profile(args.profile_iters)
+    rf, by = roofline(rows, args.precision)
+    out["roofline"] = rf
+    out["parity"] = {"linf_vs_oracle": parity_error(run.model), "tolerance": 1e-3 if args.precision == "bf16x3" else 8e-2,
+                     "oracle": "pinned to the reference (tests/golden/wav2lip_golden.npz)"}
+    if args.dump_layers:
+        with open(args.dump_layers, "w") as f:
+            json.dump({"rows": rows, "by_kernel": by}, f, indent=1)
+    if world == 1:
+        other = "bf16" if args.precision == "bf16x3" else "bf16x3"
+        alt = Runner(other, args.w2l_batch, device)
+        el2 = harness.timed_steps(alt.step, 100, 20, sync_fn=torch.cuda.synchronize)
+        v2 = args.w2l_batch * 100 / el2
+        rf2, _ = roofline(alt.profile(args.profile_iters), other)
+        out["alt"] = {"dtype": other, "value": round(v2, 1), "unit": "frames/s", "net_tflops": round(v2 * GFLOP_PER_FRAME / 1e3, 2),
+                      "linf_vs_oracle": parity_error(alt.model),
+                      "roofline": {k: rf2[k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us")}}
+        del alt
+        if args.sessions > 0:
+            ms_ = MultiSession(args.precision, args.w2l_batch, device, args.sessions)
+            el3 = harness.timed_steps(ms_.step, 50, 5, sync_fn=torch.cuda.synchronize)
+            v3 = args.sessions * args.w2l_batch * 50 / el3
+            big = Runner(args.precision, args.w2l_batch * args.sessions, device)
+            el4 = harness.timed_steps(big.step, 50, 5, sync_fn=torch.cuda.synchronize)
+            v4 = args.sessions * args.w2l_batch * 50 / el4
+            out["multi_session"] = {
+                "sessions_per_gpu": args.sessions, "batch_per_session": args.w2l_batch,
+                "streams": {"value": round(v3, 1), "unit": "frames/s", "note": "one hipStream + handle per session (configs[3] per-GPU shape)"},
+                "cross_session_batch": {"value": round(v4, 1), "unit": "frames/s", "note": f"one launch chain over {args.w2l_batch * args.sessions} frames"}}
+            del ms_, big
+        if args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args.w2l_batch, min(args.cpu_seconds, 8.0), args.cpu_threads)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 40 for musetalk, 200 for wav2lip)")
+    ap.add_argument("--warmup", type=int, default=0, help="untimed warm-up steps (default: 5 / 20)")
+    ap.add_argument("--workload", default="musetalk", choices=["musetalk", "wav2lip"])
+    ap.add_argument("--batch", type=int, default=8, help="MuseTalk frames per step (configs[2]: 8)")
+    ap.add_argument("--w2l-batch", type=int, default=16, help="Wav2Lip frames per step (configs[1]: 16)")
     ap.add_argument("--precision", default=os.environ.get("MF_PRECISION", "bf16x3"), choices=sorted(MFMA_PASSES))
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 skips the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 skips the CPU baseline legs")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = cores available to this process (capped at 64)")
-    ap.add_argument("--profile-iters", type=int, default=10)
-    ap.add_argument("--dump-layers", default=None, help="write the per-launch table (JSON) to this path")
-    ap.add_argument("--sessions", type=int, default=8, help="concurrent sessions/GPU for the extra multi_session leg (0 = skip)")
+    ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--dump-layers", default=None, help="write the per-launch tables (JSON) to this path")
+    ap.add_argument("--sessions", type=int, default=8, help="concurrent Wav2Lip sessions/GPU for the multi_session leg (0 = skip)")
+    ap.add_argument("--extras", type=int, default=1, help="0: only the headline workload (no second workload, alt mode, CPU legs)")
     args = ap.parse_args()
+    if args.steps <= 0:
+        args.steps = 40 if args.workload == "musetalk" else 200
+    if args.warmup <= 0:
+        args.warmup = 5 if args.workload == "musetalk" else 20
 
     rank, local_rank, world = harness.init_dist("nccl")
     if world != args.gpus:
@@ -187,58 +314,75 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to measure")
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
+    extras = bool(args.extras) and world == 1
 
-    run = Runner(args.precision, args.batch, device, seed=rank)
-    elapsed = harness.timed_steps(run.step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=device)
-    value = harness.aggregate_value(args.batch, args.steps, elapsed, world)
-    ms_per_step = elapsed / args.steps * 1e3
-
-    if rank == 0:
-        line = {
-            "metric": "lip-sync frames/sec", "value": round(value, 1), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "Wav2Lip generator 96x96, batch=16 mel-chunks per GPU, inputs resident in HBM "
-                                   "(BASELINE.json configs[1]); seeded random-init weights",
-                       "batch_per_gpu": args.batch, "sessions_at_25fps": round(value / 25.0, 1),
-                       "parallelism": f"{world} independent replicas, sessions sharded by GPU, no collective"},
-            "net_tflops": round(value * GFLOP_PER_FRAME / 1e3, 2),
-        }
-        rows = run.profile(args.profile_iters)
-        rf, by = roofline(rows, args.precision)
-        line["roofline"] = rf
-        line["parity"] = {"linf_vs_oracle": parity_error(run.model), "tolerance": 1e-3 if args.precision == "bf16x3" else 8e-2}
-        if args.dump_layers:
-            with open(args.dump_layers, "w") as f:
-                json.dump({"rows": rows, "by_kernel": by}, f, indent=1)
-        if world == 1:
-            other = "bf16" if args.precision == "bf16x3" else "bf16x3"
-            alt = Runner(other, args.batch, device)
-            el2 = harness.timed_steps(alt.step, max(args.steps // 2, 1), args.warmup, sync_fn=torch.cuda.synchronize)
-            v2 = args.batch * max(args.steps // 2, 1) / el2
-            rf2, _ = roofline(alt.profile(args.profile_iters), other)
-            line["alt"] = {"dtype": other, "value": round(v2, 1), "unit": "frames/s",
-                           "net_tflops": round(v2 * GFLOP_PER_FRAME / 1e3, 2),
-                           "linf_vs_oracle": parity_error(alt.model),
-                           "roofline": {k: rf2[k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us")}}
-            if args.sessions > 0:
-                ms_ = MultiSession(args.precision, args.batch, device, args.sessions)
-                el3 = harness.timed_steps(ms_.step, max(args.steps // 4, 1), 5, sync_fn=torch.cuda.synchronize)
-                v3 = args.sessions * args.batch * max(args.steps // 4, 1) / el3
-                big = Runner(args.precision, args.batch * args.sessions, device)
-                el4 = harness.timed_steps(big.step, max(args.steps // 4, 1), 5, sync_fn=torch.cuda.synchronize)
-                v4 = args.sessions * args.batch * max(args.steps // 4, 1) / el4
-                line["multi_session"] = {
-                    "sessions_per_gpu": args.sessions, "batch_per_session": args.batch,
-                    "streams": {"value": round(v3, 1), "unit": "frames/s", "net_tflops": round(v3 * GFLOP_PER_FRAME / 1e3, 1),
-                                "note": "one hipStream + handle per session, B=16 each (configs[3] per-GPU shape)"},
-                    "cross_session_batch": {"value": round(v4, 1), "unit": "frames/s", "net_tflops": round(v4 * GFLOP_PER_FRAME / 1e3, 1),
-                                            "note": f"one launch chain over {args.batch * args.sessions} frames"}}
-                del ms_, big
-            if args.cpu_seconds > 0:
-                line["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_seconds, args.cpu_threads)
-        print(json.dumps(line), flush=True)
+    if args.workload == "wav2lip":
+        run = Runner(args.precision, args.w2l_batch, device, seed=rank)
+        elapsed = harness.timed_steps(run.step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=device)
+        value = harness.aggregate_value(args.w2l_batch, args.steps, elapsed, world)
+        if rank == 0:
+            if not extras:
+                args.sessions, args.cpu_seconds = 0, 0
+            rep = wav2lip_report(args, device, world, rank, value, elapsed / args.steps * 1e3, run)
+            line = {"metric": "lip-sync frames/sec", "value": rep["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                    "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                    "config": {"workload": rep["workload"] + "; seeded random-init weights", "batch_per_gpu": args.w2l_batch,
+                               "sessions_at_25fps": round(value / 25.0, 1),
+                               "parallelism": f"{world} independent replicas, sessions sharded by GPU, no collective"}}
+            for k in ("roofline", "parity", "alt", "multi_session", "cpu_baseline"):
+                if k in rep:
+                    line[k] = rep[k]
+            print(json.dumps(line), flush=True)
+    else:
+        run = MuseTalkRunner(args.precision, args.batch, device, seed=rank)
+        elapsed = harness.timed_steps(run.step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=device)
+        value = harness.aggregate_value(args.batch, args.steps, elapsed, world)
+        if rank == 0:
+            from oracle.musetalk_ref import count_macs
+            m = count_macs(run.cfg)
+            gf_frame = 2 * (m["unet"] + m["vae"]) / 1e9
+            line = {"metric": "lip-sync frames/sec @256x256", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                    "config": {"workload": "MuseTalk step 256x256: pe(audio) + UNet(t=0) + VAE decode to uint8 frames, batch=8 latents + "
+                                           "Whisper chunks per GPU, inputs resident in HBM (BASELINE.json configs[2]); assumed MuseTalk-v1 / "
+                                           "sd-vae-ft-mse architecture, seeded random-init weights",
+                               "batch_per_gpu": args.batch, "sessions_at_25fps": round(value / 25.0, 1),
+                               "sessions_at_25fps_per_8gpu_node_if_linear": round(8 * value / world / 25.0, 1),
+                               "algorithmic_gflop_per_frame": round(gf_frame, 1),
+                               "parallelism": f"{world} independent replicas, sessions sharded by GPU, no collective"},
+                    "net_tflops": round(value / world * gf_frame / 1e3, 1)}
+            rows = run.profile(args.profile_iters)
+            rf, by = roofline(rows, args.precision, only_mfma=True)
+            line["roofline"] = rf
+            conv_rows = [r for r in rows if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
+            if conv_rows:
+                t = sum(r["ms"] for r in conv_rows); f = sum(r["flops"] for r in conv_rows)
+                line["unet_conv_blocks"] = {"achieved_tflops": round(f / (t * 1e-3) / 1e12, 1), "ms": round(t, 3),
+                                            "mfma_issue_frac_of_bf16_peak": round(MFMA_PASSES[args.precision] * f / (t * 1e-3) / 1e12 / BF16_DENSE_PEAK_TF, 3)}
+            line["parity"] = run.parity()
+            if args.dump_layers:
+                with open(args.dump_layers, "w") as f_:
+                    json.dump({"musetalk_rows": rows, "by_kernel": by}, f_, indent=1)
+            if extras:
+                if args.cpu_seconds > 0:
+                    line["cpu_baseline"] = run.cpu_baseline(args.cpu_seconds, args.cpu_threads)
+                usd, vsd = run.usd, run.vsd
+                del run
+                torch.cuda.empty_cache()
+                other = "bf16" if args.precision == "bf16x3" else "bf16x3"
+                alt = MuseTalkRunner(other, args.batch, device)
+                el2 = harness.timed_steps(alt.step, max(args.steps // 2, 1), 3, sync_fn=torch.cuda.synchronize)
+                par = alt.parity()
+                line["alt"] = {"dtype": other, "value": round(args.batch * max(args.steps // 2, 1) / el2, 1), "unit": "frames/s",
+                               "latent_linf_vs_oracle": par["latent_linf_vs_oracle"], "u8_max_diff": par["u8_max_diff"]}
+                del alt
+                torch.cuda.empty_cache()
+                dl = args.dump_layers
+                args.dump_layers = dl + ".wav2lip.json" if dl else None
+                line["wav2lip"] = wav2lip_report(args, device, world, rank)
+            print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
