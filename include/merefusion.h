@@ -135,6 +135,15 @@ void mf_conv2d_destroy(mf_conv2d* h);
 int mf_melspec(const float* wav, int n, float* out, int pad_mode, void* stream);
 int mf_melspec_frames(int n);
 
+/* ---- fused multi-head attention (test seam of the kernel both transformer stages run on) ---- */
+/* out = softmax(q k^T / sqrt(head_dim)) v per (batch, head): the `Attention` of the diffusers
+ * BasicTransformerBlock that musetalk/models/unet.py:36-47 instantiates (attn1: tk == tq; attn2: tk = audio
+ * tokens) and `MultiHeadAttention.qkv_attention` of musetalk/whisper/whisper/model.py:62-93.
+ * q, out: device fp32 [batch][tq][heads*head_dim]; k, v: device fp32 [batch][tk][heads*head_dim];
+ * head_dim in {40, 64, 80, 160}.  Synchronises the stream before returning. */
+int mf_attention_forward(const float* q, const float* k, const float* v, float* out, int batch, int tq, int tk,
+                         int heads, int head_dim, int precision, void* stream);
+
 /* ---- MuseTalk Whisper audio features (H3) -------------------------------------------------- */
 typedef struct mf_whisper mf_whisper;
 

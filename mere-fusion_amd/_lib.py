@@ -89,6 +89,7 @@ SIGNATURES = {
     "mf_vae_destroy": (None, [C.c_void_p]),
     "mf_melspec": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_melspec_frames": (C.c_int, [C.c_int]),
+    "mf_attention_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
 }
 
 _lib = None

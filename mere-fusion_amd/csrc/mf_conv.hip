@@ -96,10 +96,18 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const float (&
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool X3, int BK>
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NST = LDS ring depth.  2: DMA of tile k+1 under the MFMAs of tile k, drained at a __syncthreads().
+// >= 3: NST-1 tiles in flight; each wave waits only for ITS OWN share of the tile it is about to read
+// (counted s_waitcnt vmcnt, every wave issues the same number of DMA instructions per tile) and a raw
+// s_barrier publishes it -- nothing ever drains the queue inside the loop.
+template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST>
 __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     static_assert(BK == 32 || BK == 64, "LDS tile depth");
+    static_assert(NST >= 2 && NST <= 4, "ring depth");
     constexpr int KG = BK / 8;            // 16-byte groups per tile row
     constexpr int ROWB = BK * 2;          // bytes per tile row
     constexpr int RPC = 1024 / ROWB;      // tile rows per 1-KiB DMA chunk
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     constexpr int NPC = (PCH + 3) / 4, NWC = (WCH + 3) / 4;                  // ... per wave
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* s_goff = reinterpret_cast<int*>(smem + 2 * STAGE);
+    int* s_goff = reinterpret_cast<int*>(smem + NST * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -232,14 +240,35 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     };
 
     __syncthreads();   // s_goff visible
-    if (kt_begin < kt_end) {
-        stage(kt_begin, 0);
-        __syncthreads();   // drains the DMA (vmcnt) and publishes stage 0
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const int s = (kt - kt_begin) & 1;
-            if (kt + 1 < kt_end) stage(kt + 1, s ^ 1);   // DMA of the next tile flies under the MFMAs
-            compute(s);
-            __syncthreads();
+    const int nk = kt_end - kt_begin;
+    if (NST == 2) {
+        if (nk > 0) {
+            stage(kt_begin, 0);
+            __syncthreads();   // drains the DMA (vmcnt) and publishes stage 0
+            for (int kt = kt_begin; kt < kt_end; ++kt) {
+                const int s = (kt - kt_begin) & 1;
+                if (kt + 1 < kt_end) stage(kt + 1, s ^ 1);   // DMA of the next tile flies under the MFMAs
+                compute(s);
+                __syncthreads();
+            }
+        }
+    } else {
+        static_assert(NST == 2 || (PCH % 4 == 0 && WCH % 4 == 0), "counted waits need the same DMA count in every wave");
+        constexpr int L = (NPC + NWC) * NP;          // DMA instructions per wave per tile
+        static_assert(L * (NST - 2) <= 63, "vmcnt field");
+#pragma unroll
+        for (int i = 0; i < NST - 1; ++i)
+            if (i < nk) stage(kt_begin + i, i);
+        int slot = 0;
+        for (int i = 0; i < nk; ++i) {
+            const int newer = nk - 1 - i;            // tiles after i; min(newer, NST-2) of them are in flight
+            if (newer >= NST - 2) wait_vm<L * (NST - 2)>();
+            else if (NST == 4 && newer == 1) wait_vm<L>();
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();            // tile i landed for every wave; slot (i-1)%NST is free
+            if (i + NST - 1 < nk) stage(kt_begin + i + NST - 1, (slot + NST - 1) % NST);
+            compute(slot);
+            slot = slot + 1 == NST ? 0 : slot + 1;
         }
     }
 
@@ -306,19 +335,38 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int n
 namespace {
 
 template <int BM, int BN, int WGM, int WGN, bool X3, int BK>
-int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStream_t s) {
+struct RingDepth {
+    static constexpr int stage_bytes = (BM + BN) * BK * 2 * (X3 ? 2 : 1);
+    static constexpr int RPC = 1024 / (BK * 2);
+    static constexpr bool countable = (BM / RPC) % 4 == 0 && (BN / RPC) % 4 == 0;
+    // deepest ring (<= 4) that leaves room for two workgroups per CU when a stage is small, one otherwise
+    static constexpr int value = !countable ? 2 : (4 * stage_bytes <= 72 * 1024 ? 4 : (3 * stage_bytes <= 76 * 1024 ? 3 : (4 * stage_bytes <= 150 * 1024 ? 4 : (3 * stage_bytes <= 150 * 1024 ? 3 : 2))));
+};
+
+template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST>
+int launch_cfg_n(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = k_conv_igemm<BM, BN, WGM, WGN, X3, BK>;
+    auto kern = k_conv_igemm<BM, BN, WGM, WGN, X3, BK, NST>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    const size_t lds = 2 * (size_t)(BM + BN) * BK * 2 * (X3 ? 2 : 1) + (size_t)goff_max * 4;
+    const size_t lds = (size_t)NST * (BM + BN) * BK * 2 * (X3 ? 2 : 1) + (size_t)goff_max * 4;
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.zgroups ? a.zgroups : nphase);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     MF_HIP(hipGetLastError());
     return MF_OK;
+}
+
+template <int BM, int BN, int WGM, int WGN, bool X3, int BK>
+int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStream_t s) {
+    // Measured on MI355X (profiles/r01_ring_ab.md): the double buffer wins on the MuseTalk / Wav2Lip shapes because the
+    // deeper ring halves the workgroups per CU; MF_RING=deep keeps the 3/4-stage ring reachable for A/B runs.
+    static const bool deep = [] { const char* e = getenv("MF_RING"); return e && !strcmp(e, "deep"); }();
+    constexpr int NST = RingDepth<BM, BN, WGM, WGN, X3, BK>::value;
+    if (deep && NST != 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, NST>(a, nphase, nsplit, goff_max, s);
+    return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2>(a, nphase, nsplit, goff_max, s);
 }
 
 template <int BM, int BN, int WGM, int WGN>

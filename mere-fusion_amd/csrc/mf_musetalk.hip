@@ -14,6 +14,7 @@
 #include "mf_aux.h"
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
@@ -150,6 +151,14 @@ struct Net {
         if (q.buf->halo || k.buf->halo || v.buf->halo || out.buf->halo || dh % 8 || k.C != C || v.C != C || out.C != C) {
             err = "attention: needs contiguous token buffers and a head dim that is a multiple of 8";
             return MF_ERR_INVALID;
+        }
+        // one fused kernel (mf_attn.hip) for the UNet's head dims; MF_ATTN=composite keeps the five-launch path for A/B
+        static const bool composite = [] { const char* e = getenv("MF_ATTN"); return e && !strcmp(e, "composite"); }();
+        if (mf_attention_supported(dh) && !composite) {
+            const int prec = precision;
+            push("attention " + std::to_string(Tq) + "x" + std::to_string(Tk) + " heads " + std::to_string(heads) + " dh " + std::to_string(dh),
+                 "k_attention", 4.0 * Tq * Tk * C, [=](int B, hipStream_t s) { return mf_attention(q, k, v, out, heads, B, prec, s); });
+            return MF_OK;
         }
         const int Tk8 = (Tk + 7) / 8 * 8, Tk64 = (Tk + 63) / 64 * 64;
         auto key = std::make_tuple(dh, Tq, Tk, heads);

@@ -47,4 +47,9 @@ int mf_gemm_plan_create_grouped(ConvPlan* p, int K, int N, int T, int groups, in
 // (RGB -> BGR): the tail of VAE.decode_latents, musetalk/models/vae.py:104-107
 int mf_vae_post_u8(const ActView& x, uint8_t* dst, int batch, hipStream_t s);
 
+// Fused softmax(q k^T / sqrt(dh)) v (mf_attn.hip) on contiguous (halo 0) token buffers; head dims 40 / 64 / 80 / 160.
+bool mf_attention_supported(int dh);
+int mf_attention(const ActView& q, const ActView& k, const ActView& v, const ActView& out, int heads, int batch, int precision,
+                 hipStream_t s);
+
 inline int64_t mf_interior(const ActBuf& b) { return ((int64_t)b.halo * b.Wp() + b.halo) * b.C; }

@@ -80,17 +80,22 @@ def _resnet(sd, p, x, temb_act, groups, eps):
     return x + h
 
 
-def _attention(sd, p, x, ctx, heads):
-    """diffusers Attention: to_q/to_k/to_v (no bias in the UNet), scale = dim_head**-0.5, to_out.0."""
-    q, k, v = _lin(sd, p + ".to_q", x), _lin(sd, p + ".to_k", ctx), _lin(sd, p + ".to_v", ctx)
+def attention_core(q, k, v, heads):
+    """softmax(q k^T * dim_head**-0.5) v per head on [B, T, heads*dim_head] tensors (diffusers Attention /
+    whisper model.py:82-93 qkv_attention, which splits the same scale as dim_head**-0.25 on q and k)."""
     B, T, C = q.shape
     dh = C // heads
     q = q.view(B, T, heads, dh).transpose(1, 2)
     k = k.view(B, -1, heads, dh).transpose(1, 2)
     v = v.view(B, -1, heads, dh).transpose(1, 2)
     w = torch.softmax((q @ k.transpose(-1, -2)) * dh ** -0.5, dim=-1)
-    o = (w @ v).transpose(1, 2).reshape(B, T, C)
-    return _lin(sd, p + ".to_out.0", o)
+    return (w @ v).transpose(1, 2).reshape(B, T, C)
+
+
+def _attention(sd, p, x, ctx, heads):
+    """diffusers Attention: to_q/to_k/to_v (no bias in the UNet), scale = dim_head**-0.5, to_out.0."""
+    q, k, v = _lin(sd, p + ".to_q", x), _lin(sd, p + ".to_k", ctx), _lin(sd, p + ".to_v", ctx)
+    return _lin(sd, p + ".to_out.0", attention_core(q, k, v, heads))
 
 
 def _transformer(sd, p, x, ctx, heads, groups):
