@@ -327,13 +327,17 @@ int mf_attention(const ActView& q, const ActView& k, const ActView& v, const Act
     const int C = q.C, dh = C / heads;
     MF_REQUIRE(heads > 0 && C % heads == 0 && k.C == C && v.C == C && out.C == C, "attention: channel mismatch");
     MF_REQUIRE(mf_attention_supported(dh), "attention: no fused kernel for head dim %d", dh);
-    MF_REQUIRE(!q.buf->halo && !k.buf->halo && !v.buf->halo && !out.buf->halo, "attention: needs contiguous token buffers");
+    // tokens must be contiguous rows: halo-free buffers, or single-row sequences (their interior is one contiguous run)
+    for (const ActBuf* b : {q.buf, k.buf, v.buf, out.buf})
+        MF_REQUIRE(b->halo == 0 || b->H == 1, "attention: needs contiguous token buffers");
     MF_REQUIRE(q.coff % 8 == 0 && k.coff % 8 == 0 && v.coff % 8 == 0 && out.coff % 8 == 0, "attention: views must start on 8-channel groups");
     const bool x3 = precision == MF_PREC_BF16X3;
     AttnArgs a{};
-    a.q_hi = q.buf->hi + q.coff; a.k_hi = k.buf->hi + k.coff; a.v_hi = v.buf->hi + v.coff; a.o_hi = out.buf->hi + out.coff;
+    const int64_t qo = mf_interior(*q.buf) + q.coff, ko = mf_interior(*k.buf) + k.coff, vo = mf_interior(*v.buf) + v.coff,
+                  oo = mf_interior(*out.buf) + out.coff;
+    a.q_hi = q.buf->hi + qo; a.k_hi = k.buf->hi + ko; a.v_hi = v.buf->hi + vo; a.o_hi = out.buf->hi + oo;
     if (x3) {
-        a.q_lo = q.buf->lo + q.coff; a.k_lo = k.buf->lo + k.coff; a.v_lo = v.buf->lo + v.coff; a.o_lo = out.buf->lo + out.coff;
+        a.q_lo = q.buf->lo + qo; a.k_lo = k.buf->lo + ko; a.v_lo = v.buf->lo + vo; a.o_lo = out.buf->lo + oo;
     }
     a.q_b = q.buf->per_batch(); a.k_b = k.buf->per_batch(); a.v_b = v.buf->per_batch(); a.o_b = out.buf->per_batch();
     a.q_row = q.buf->C; a.k_row = k.buf->C; a.v_row = v.buf->C; a.o_row = out.buf->C;

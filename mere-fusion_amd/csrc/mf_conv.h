@@ -55,6 +55,8 @@ struct ConvArgs {
     int act;                  // 0 none, 1 relu, 2 sigmoid, 3 gelu(erf), 4 silu
     int res_after_act;        // residual added after the activation (x = act(conv) + r)
     int tiles_m, tiles_n;
+    unsigned long long* dbg;  // MF_DBG_TIMES: 4 s_memtime stamps per workgroup, or null
+    int m_fastest;            // XCD tile order: pixel tiles fastest (weight-heavy layers), see k_conv_igemm
     int goff_total;
     // grouped launch (attention: one GEMM per (batch, head) on blockIdx.z): element offsets per group
     int zgroups, zheads;

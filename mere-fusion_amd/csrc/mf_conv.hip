@@ -104,8 +104,10 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // (counted s_waitcnt vmcnt, every wave issues the same number of DMA instructions per tile) and a raw
 // s_barrier publishes it -- nothing ever drains the queue inside the loop.
 template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST>
-__global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
-    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a) {
+    constexpr int NW = WGM * WGN;         // waves per workgroup
+    constexpr int NT = NW * 64;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(BK == 32 || BK == 64, "LDS tile depth");
     static_assert(NST >= 2 && NST <= 4, "ring depth");
     constexpr int KG = BK / 8;            // 16-byte groups per tile row
@@ -119,10 +121,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     constexpr int PLANE = P_BYTES + W_BYTES;
     constexpr int STAGE = PLANE * NP;
     constexpr int PCH = (BM + RPC - 1) / RPC, WCH = (BN + RPC - 1) / RPC;   // DMA chunks per tile
-    constexpr int NPC = (PCH + 3) / 4, NWC = (WCH + 3) / 4;                  // ... per wave
+    constexpr int NPC = (PCH + NW - 1) / NW, NWC = (WCH + NW - 1) / NW;      // ... per wave
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* s_goff = reinterpret_cast<int*>(smem + NST * STAGE);
+    // MF_DBG_TIMES: s_memtime stamps of (entry, loop start, loop end, exit) per workgroup
+    unsigned long long* dbg = a.dbg ? a.dbg + 4 * ((size_t)blockIdx.x + gridDim.x * ((size_t)blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
+    if (dbg && threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memtime();
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,7 +146,12 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     const int bid = blockIdx.x;
     const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tm = t / a.tiles_n, tn = t - tm * a.tiles_n;
+    // n fastest: the N tiles of one pixel tile share the activations in one L2.  m fastest (weights outweigh the
+    // activations: the UNet's small maps): an XCD walks all pixel tiles of one or two channel tiles, so each XCD pulls
+    // its slice of the weights from HBM once instead of every XCD pulling all of them.
+    int tm, tn;
+    if (a.m_fastest) { tn = t / a.tiles_m; tm = t - tn * a.tiles_m; }
+    else { tm = t / a.tiles_n; tn = t - tm * a.tiles_n; }
     const int m0 = tm * BM, n0 = tn * BN;
 
     // split-K slice of this workgroup (ph.KT counts 64-deep packed tiles; this kernel steps BK)
@@ -149,15 +159,15 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     const int kt_begin = (int)((int64_t)KTk * blockIdx.y / gridDim.y);
     const int kt_end = (int)((int64_t)KTk * (blockIdx.y + 1) / gridDim.y);
 
-    for (int i = tid; i < ph.ngroups; i += 256) s_goff[i] = a.goff[ph.goff_begin + i];
+    for (int i = tid; i < ph.ngroups; i += NT) s_goff[i] = a.goff[ph.goff_begin + i];
 
-    // ---- DMA assignment: wave w moves chunks w, w+4, ... of each tile -------------------------
+    // ---- DMA assignment: wave w moves chunks w, w+NW, ... of each tile -------------------------
     const bf16_t* xp[NPC];
     int p_kg[NPC];
     const int64_t x_delta = X3 ? (a.x_lo - a.x_hi) : 0;
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
-        const int row = (wave + 4 * i) * RPC + lane / KG;
+        const int row = (wave + NW * i) * RPC + lane / KG;
         p_kg[i] = (lane % KG) ^ swz<BK>(row);
         int m = m0 + row;
         m = m < a.M ? m : a.M - 1;
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     const int64_t w_delta = X3 ? (a.w_lo - a.w_hi) : 0;
 #pragma unroll
     for (int i = 0; i < NWC; ++i) {
-        const int row = (wave + 4 * i) * RPC + lane / KG;
+        const int row = (wave + NW * i) * RPC + lane / KG;
         const int kg = (lane % KG) ^ swz<BK>(row);
         int n = n0 + row;
         n = n < a.Npad ? n : a.Npad - 1;
@@ -182,8 +192,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
         char* base = smem + s * STAGE;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
-            const int c = wave + 4 * i;
-            if (PCH % 4 == 0 || c < PCH) {
+            const int c = wave + NW * i;
+            if (PCH % NW == 0 || c < PCH) {
                 const bf16_t* src = xp[i] + s_goff[kt * KG + p_kg[i]];
                 glds16(src, base + c * 1024);
                 if (X3) glds16(src + x_delta, base + PLANE + c * 1024);
@@ -191,8 +201,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NWC; ++i) {
-            const int c = wave + 4 * i;
-            if (WCH % 4 == 0 || c < WCH) {
+            const int c = wave + NW * i;
+            if (WCH % NW == 0 || c < WCH) {
                 const bf16_t* src = BK == 64 ? wp[i] + kt * w_kstep : wp[i] + (kt >> 1) * w_kstep + (kt & 1) * 32;
                 glds16(src, base + P_BYTES + c * 1024);
                 if (X3) glds16(src + w_delta, base + PLANE + P_BYTES + c * 1024);
@@ -240,6 +250,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     };
 
     __syncthreads();   // s_goff visible
+    if (dbg && threadIdx.x == 0) dbg[1] = __builtin_amdgcn_s_memtime();
     const int nk = kt_end - kt_begin;
     if (NST == 2) {
         if (nk > 0) {
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
             }
         }
     } else {
-        static_assert(NST == 2 || (PCH % 4 == 0 && WCH % 4 == 0), "counted waits need the same DMA count in every wave");
+        static_assert(NST == 2 || (PCH % NW == 0 && WCH % NW == 0), "counted waits need the same DMA count in every wave");
         constexpr int L = (NPC + NWC) * NP;          // DMA instructions per wave per tile
         static_assert(L * (NST - 2) <= 63, "vmcnt field");
 #pragma unroll
@@ -273,6 +284,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
+    if (dbg && threadIdx.x == 0) dbg[2] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
         const int m = m0 + pm0 + j * 16 + fr;
@@ -303,6 +315,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
             epilogue_store(a, v, yo, ro, c, X3);
         }
     }
+    if (dbg && threadIdx.x == 0) dbg[3] = __builtin_amdgcn_s_memtime();
 }
 
 // Combines the split-K partial tiles: one thread per (output pixel, 4 channels).
@@ -338,7 +351,7 @@ template <int BM, int BN, int WGM, int WGN, bool X3, int BK>
 struct RingDepth {
     static constexpr int stage_bytes = (BM + BN) * BK * 2 * (X3 ? 2 : 1);
     static constexpr int RPC = 1024 / (BK * 2);
-    static constexpr bool countable = (BM / RPC) % 4 == 0 && (BN / RPC) % 4 == 0;
+    static constexpr bool countable = (BM / RPC) % (WGM * WGN) == 0 && (BN / RPC) % (WGM * WGN) == 0;
     // deepest ring (<= 4) that leaves room for two workgroups per CU when a stage is small, one otherwise
     static constexpr int value = !countable ? 2 : (4 * stage_bytes <= 72 * 1024 ? 4 : (3 * stage_bytes <= 76 * 1024 ? 3 : (4 * stage_bytes <= 150 * 1024 ? 4 : (3 * stage_bytes <= 150 * 1024 ? 3 : 2))));
 };
@@ -354,7 +367,7 @@ int launch_cfg_n(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStr
     }
     const size_t lds = (size_t)NST * (BM + BN) * BK * 2 * (X3 ? 2 : 1) + (size_t)goff_max * 4;
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.zgroups ? a.zgroups : nphase);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, a);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
@@ -690,6 +703,19 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
 
     const ConvTile tc = mf_conv_pick_tile(p, batch);
     a.tiles_m = cdiv(a.M, tc.bm); a.tiles_n = cdiv(a.N, tc.bn);
+    {
+        // XCD tile order by which operand is heavier: weights N x K vs the input tensor M x Cin (both x planes)
+        static const int order = [] { const char* e = getenv("MF_TILE_ORDER"); return !e ? 0 : (e[0] == 'm' ? 1 : 2); }();
+        const int64_t w_elems = (int64_t)a.Npad * p->ph[0].KT * 64 * p->nphase;
+        const int64_t x_elems = (int64_t)batch * ib.H * ib.W * in.C;
+        a.m_fastest = order ? order == 1 : w_elems > x_elems;
+        static const bool dbg_times = getenv("MF_DBG_TIMES") != nullptr;
+        if (dbg_times) {
+            static unsigned long long* dbg_buf = nullptr;
+            if (!dbg_buf) MF_HIP(hipMalloc(&dbg_buf, (size_t)4 * 65536 * sizeof(unsigned long long)));
+            a.dbg = (int64_t)a.tiles_m * a.tiles_n * tc.nsplit * p->nphase <= 65536 ? dbg_buf : nullptr;
+        }
+    }
     if (tc.nsplit > 1) {
         // fp32 partial tiles [split][B][Ho][Wo][N]; combined by k_splitk_epilogue below
         const int64_t per_split = (int64_t)batch * p->out_h * p->out_w * a.N;
@@ -710,6 +736,8 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
     MF_CASE(128, 16, 4, 1)
     MF_CASE(128, 32, 4, 1)
     MF_CASE(16, 64, 1, 4)
+    MF_CASE(256, 256, 2, 4)
+    MF_CASE(256, 128, 4, 2)
     MF_CASE(128, 128, 2, 2)
     MF_CASE(128, 64, 2, 2)
     MF_CASE(64, 64, 2, 2)
@@ -717,6 +745,27 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
     if (rc != MF_OK) {
         if (rc == MF_ERR_INVALID) mf_set_error("conv: no kernel for tile %dx%d", tc.bm, tc.bn);
         return rc;
+    }
+    if (a.dbg) {
+        static int reports = 0;
+        if (++reports > 3 && reports <= 5) {   // skip the warm-up launches
+            MF_HIP(hipStreamSynchronize(stream));
+            const size_t nwg = (size_t)a.tiles_m * a.tiles_n * tc.nsplit * p->nphase;
+            std::vector<unsigned long long> t(4 * nwg);
+            MF_HIP(hipMemcpy(t.data(), a.dbg, t.size() * sizeof(t[0]), hipMemcpyDeviceToHost));
+            unsigned long long lo = ~0ull, hi = 0;
+            std::vector<double> d[3], start, end;
+            for (size_t w = 0; w < nwg; ++w) {
+                lo = std::min(lo, t[4 * w]); hi = std::max(hi, t[4 * w + 3]);
+                for (int k = 0; k < 3; ++k) d[k].push_back((double)(t[4 * w + k + 1] - t[4 * w + k]));
+            }
+            for (size_t w = 0; w < nwg; ++w) { start.push_back((double)(t[4 * w] - lo)); end.push_back((double)(t[4 * w + 3] - lo)); }
+            auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            auto mx = [](const std::vector<double>& v) { return *std::max_element(v.begin(), v.end()); };
+            fprintf(stderr, "[MF_DBG_TIMES] %zu WGs tile %dx%d split %d: span %llu ticks; prologue med %.0f max %.0f; loop med %.0f max %.0f; "
+                            "epilogue med %.0f max %.0f; WG start med %.0f max %.0f; WG end med %.0f\n",
+                    nwg, tc.bm, tc.bn, tc.nsplit, hi - lo, med(d[0]), mx(d[0]), med(d[1]), mx(d[1]), med(d[2]), mx(d[2]), med(start), mx(start), med(end));
+        }
     }
     if (tc.nsplit > 1) {
         if (p->prof_mid) MF_HIP(hipEventRecord(p->prof_mid, stream));
@@ -762,33 +811,55 @@ int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream
     return rc;
 }
 
-// minimum number of workgroups for which the 128x128 / 128x64 tile is preferred (tunable for experiments)
-static int tile_threshold(int which) {
-    static int th[2] = {-1, -1};
-    if (th[0] < 0) {
-        const char* a = getenv("MF_TILE_T128"); const char* b = getenv("MF_TILE_T64");
-        th[0] = a ? atoi(a) : 512; th[1] = b ? atoi(b) : 512;
-    }
-    return th[which];
-}
-
-// Tile selection: the largest tile that still yields >= ~2 workgroups per CU (256 CUs); layers that
-// cannot fill the chip with output tiles and have a long contraction are additionally split along K.
+// Tile / split-K selection by a cost model of the loop (profiles/r01_igemm_bandwidth_study.md): a workgroup streams
+// (BM + BN) x K/S operand elements at min(per-CU DMA rate, chip L2->LDS rate / resident workgroups); workgroups run in
+// rounds of (256 CUs x resident per CU); a split pays the fp32 partial round trip and one more launch.  Constants were
+// fitted to 386 measured (shape, tile, split) points of the MuseTalk UNet / VAE layers (mean loss vs the best measured
+// configuration 3.5 %).
 ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
     const int M = batch * p->Hq * p->Wq, N = p->d.cout;
-    auto tiles = [&](int bm, int bn) { return cdiv(M, bm) * cdiv(N, bn) * p->nphase; };
+    int kt_min = p->ph[0].KT;
+    double kt_sum = 0;
+    for (int ph = 0; ph < p->nphase; ++ph) { kt_min = std::min(kt_min, p->ph[ph].KT); kt_sum += p->ph[ph].KT; }
     ConvTile t;
     if (N <= 16) t = {128, 16, 4, 1, 1};
     else if (N <= 32) t = {128, 32, 4, 1, 1};
     else if (M <= 16) t = {16, 64, 1, 4, 1};
-    else if (tiles(128, 128) >= tile_threshold(0) && N % 128 == 0) t = {128, 128, 2, 2, 1};
-    else if (tiles(128, 64) >= tile_threshold(1)) t = {128, 64, 2, 2, 1};
     else t = {64, 64, 2, 2, 1};
-    const int nt = tiles(t.bm, t.bn);
-    int kt_min = p->ph[0].KT;
-    for (int ph = 1; ph < p->nphase; ++ph) kt_min = std::min(kt_min, p->ph[ph].KT);
-    static const int split_nt = [] { const char* e = getenv("MF_SPLIT_NT"); return e ? atoi(e) : 256; }();
-    if (nt < split_nt && kt_min >= 2) t.nsplit = std::max(1, std::min(std::min(kt_min, cdiv(2 * split_nt, nt)), 16));
+    const bool modelled = N > 32 && M > 16;
+    // exploration knobs (tools/unet_shape_sweep.py): MF_FORCE_TILE=128x64, MF_FORCE_SPLIT=4
+    static const int force_tile = [] { const char* e = getenv("MF_FORCE_TILE"); int a = 0, b = 0; return e && sscanf(e, "%dx%d", &a, &b) == 2 ? a * 1000 + b : 0; }();
+    static const int force_split = [] { const char* e = getenv("MF_FORCE_SPLIT"); return e ? atoi(e) : 0; }();
+    struct Cand { int bm, bn, wgm, wgn, resident; };
+    static const Cand cands[] = {{64, 64, 2, 2, 2}, {128, 64, 2, 2, 2}, {128, 128, 2, 2, 2}, {256, 128, 4, 2, 1}, {256, 256, 2, 4, 1}};
+    static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    if (modelled) {
+        const double planes = p->precision == MF_PREC_BF16X3 ? 2.0 : 1.0;
+        const double Kavg = kt_sum / p->nphase * 64.0;
+        const double PW = 46e9, CHIP = 10.5e12, EPI_BW = 2.5e12, EPI_FIX = 6e-6, WG_FIX = 2e-6;
+        const int fs = force_split ? std::max(1, std::min(std::min(kt_min, force_split), 16)) : 0;
+        double best = 1e30;
+        for (const Cand& c : cands) {
+            if (force_tile && (c.bm != force_tile / 1000 || c.bn != force_tile % 1000)) continue;
+            if (c.bn == 128 && c.bm == 128 && N % 128) continue;
+            for (int si = 0; si < (fs ? 1 : (int)(sizeof(splits) / sizeof(splits[0]))); ++si) {
+                const int S = fs ? fs : splits[si];
+                if (S > kt_min) continue;
+                if (c.bm == 256 && Kavg / S < 1024 && !force_tile) continue;   // too few K tiles to amortise a 256-wide prologue / epilogue
+                const double wg = (double)cdiv(M, c.bm) * cdiv(N, c.bn) * p->nphase * S;
+                const double slots = 256.0 * c.resident;
+                const double rate = std::min(PW, CHIP / std::min(wg, slots));
+                const double bytes_wg = (double)(c.bm + c.bn) * (Kavg / S) * 2.0 * planes;
+                double cost = std::ceil(wg / slots) * (bytes_wg / rate + WG_FIX);
+                if (S > 1) cost += S * (double)M * N * p->nphase * 4.0 * 2.0 / EPI_BW + EPI_FIX;
+                if (cost < best) { best = cost; t = {c.bm, c.bn, c.wgm, c.wgn, S}; }
+            }
+        }
+        return t;
+    }
+    const int nt = cdiv(M, t.bm) * cdiv(N, t.bn) * p->nphase;
+    if (nt < 256 && kt_min >= 2) t.nsplit = std::max(1, std::min(std::min(kt_min, cdiv(512, nt)), 16));
+    if (force_split) t.nsplit = std::max(1, std::min(std::min(kt_min, force_split), 16));
     return t;
 }
 

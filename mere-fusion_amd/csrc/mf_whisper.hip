@@ -8,6 +8,8 @@
 #include "mf_nn.h"
 #include "mf_aux.h"
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <string>
@@ -151,6 +153,8 @@ struct mf_whisper {
     std::vector<Layer> layers;
     float* raw = nullptr;       // [80][3000] fp32 scratch of the log-mel
     unsigned* gmax = nullptr;
+    bool fused_attn = true;     // one k_attention launch per layer; false (MF_ATTN=composite or an unsupported head dim):
+                                // per-head pack + GEMM + softmax + pack + GEMM
 
     ~mf_whisper() {
         for (auto& p : plans) mf_conv_plan_destroy(p.get());
@@ -246,15 +250,21 @@ int mf_whisper::encode(float* emb, hipStream_t s) {
         Layer& L = layers[l];
         if ((rc = mf_layernorm(W(x), W(ln), L.ln1_g, L.ln1_b, 1e-5f, 1, s))) return rc;
         if ((rc = mf_conv_launch(L.qkv, W(ln), W(qkv), ActView{}, 1, s))) return rc;
-        const int64_t q0 = mf_interior(*qkv);
-        for (int h = 0; h < n_head; ++h) {
-            // scores[i][j] = q_i . k_j : keys packed as the GEMM's weight operand
-            if ((rc = mf_pack_b(scores, qkv->hi + q0 + C + h * dh, qkv->lo ? qkv->lo + q0 + C + h * dh : nullptr, qkv->C, 1, T, dh, s))) return rc;
-            if ((rc = mf_conv_launch(scores, ActView{qkv, h * dh, dh}, ActView{sc, 0, T}, ActView{}, 1, s))) return rc;
-            if ((rc = mf_softmax_rows(ActView{sc, 0, T}, W(pm), T, scale, 1, s))) return rc;
-            // out[i][d] = sum_j p[i][j] v[j][d] : V^T packed as the weight operand
-            if ((rc = mf_pack_b(pv, qkv->hi + q0 + 2 * C + h * dh, qkv->lo ? qkv->lo + q0 + 2 * C + h * dh : nullptr, 1, qkv->C, dh, T, s))) return rc;
-            if ((rc = mf_conv_launch(pv, W(pm), ActView{ao, h * dh, dh}, ActView{}, 1, s))) return rc;
+        // softmax(q k^T * dh^-0.5) v, all heads in one fused launch (mf_attn.hip); model.py:91-93 applies the same
+        // scale as dh^-0.25 on q and on k
+        if (fused_attn) {
+            if ((rc = mf_attention(ActView{qkv, 0, C}, ActView{qkv, C, C}, ActView{qkv, 2 * C, C}, ActView{ao, 0, C}, n_head, 1, precision, s))) return rc;
+        } else {
+            const int64_t q0 = mf_interior(*qkv);
+            for (int h = 0; h < n_head; ++h) {
+                // scores[i][j] = q_i . k_j : keys packed as the GEMM's weight operand
+                if ((rc = mf_pack_b(scores, qkv->hi + q0 + C + h * dh, qkv->lo ? qkv->lo + q0 + C + h * dh : nullptr, qkv->C, 1, T, dh, s))) return rc;
+                if ((rc = mf_conv_launch(scores, ActView{qkv, h * dh, dh}, ActView{sc, 0, T}, ActView{}, 1, s))) return rc;
+                if ((rc = mf_softmax_rows(ActView{sc, 0, T}, W(pm), T, scale, 1, s))) return rc;
+                // out[i][d] = sum_j p[i][j] v[j][d] : V^T packed as the weight operand
+                if ((rc = mf_pack_b(pv, qkv->hi + q0 + 2 * C + h * dh, qkv->lo ? qkv->lo + q0 + 2 * C + h * dh : nullptr, 1, qkv->C, dh, T, s))) return rc;
+                if ((rc = mf_conv_launch(pv, W(pm), ActView{ao, h * dh, dh}, ActView{}, 1, s))) return rc;
+            }
         }
         if ((rc = mf_conv_launch(L.out, W(ao), W(y), W(x), 1, s))) return rc;                 // x + attn(ln(x))
         if ((rc = mf_layernorm(W(y), W(ln), L.ln2_g, L.ln2_b, 1e-5f, 1, s))) return rc;
@@ -286,6 +296,10 @@ extern "C" int mf_whisper_create(const mf_tensor* weights, int n_weights, int n_
     h->n_head = n_head;
     MF_REQUIRE(h->n_mels == W_MELS, "whisper_create: n_mels=%d, only 80 is supported (audio.py:76)", h->n_mels);
     MF_REQUIRE(h->C % n_head == 0 && (h->C / n_head) % 8 == 0, "whisper_create: head dim must be a multiple of 8");
+    {
+        const char* e = getenv("MF_ATTN");
+        h->fused_attn = mf_attention_supported(h->C / n_head) && !(e && !strcmp(e, "composite"));
+    }
     int L = 0;
     while (sd.count("blocks." + std::to_string(L) + ".attn.query.weight")) ++L;
     MF_REQUIRE(L > 0, "whisper_create: no encoder blocks in the state dict");
