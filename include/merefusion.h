@@ -108,7 +108,8 @@ typedef struct mf_conv2d_desc {
     int transposed;       /* 0 = Conv2d (conv.py:5), 1 = ConvTranspose2d (conv.py:33) */
     int output_padding;   /* transposed only */
     int residual;         /* 1: add the layer input before the activation (conv.py:17-18); 2: after it */
-    int act;              /* 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf), 4 SiLU */
+    int act;              /* 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf), 4 SiLU, 5 GEGLU: y = x[:, :cout/2] * gelu(x[:, cout/2:])
+                           * (diffusers GEGLU of the UNet feed-forward), cout % 32 == 0, the output has cout/2 channels */
     int in_h, in_w;       /* spatial size of the input this layer is built for */
     int upsample;         /* 1: nearest-neighbour 2x upsampling in front of a 3x3 s1 p1 conv (diffusers Upsample2D) */
 } mf_conv2d_desc;

@@ -66,6 +66,8 @@ __device__ __forceinline__ void add_residual(const ConvArgs& a, float (&v)[4], i
 }
 
 // act: 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf form, torch.nn.GELU default), 4 SiLU
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
+
 __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const float (&v0)[4], int64_t yo, int64_t ro,
                                                int c, bool x3) {
     float v[4] = {v0[0], v0[1], v0[2], v0[3]};
@@ -306,6 +308,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
         }
         const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
         const int64_t ro = (int64_t)b * a.rb + (int64_t)qi * a.ri + (int64_t)qj * a.rj;
+        if (FN % 2 == 0 && a.act == 5) {
+            // GEGLU: GEMM rows alternate 16 value channels / their 16 gate channels (packed that way at plan creation),
+            // so fragment i holds the values and fragment i + 1 the gates of the same 4 output channels of this lane
+#pragma unroll
+            for (int i = 0; i + 1 < FN; i += 2) {
+                const int c = n0 + cn0 + i * 16 + fk * 4;
+                if (c >= a.N) continue;
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
+                const float4 bg = *reinterpret_cast<const float4*>(a.bias + c + 16);
+                const float v[4] = {(acc[i][j][0] + bv.x) * gelu_erf(acc[i + 1][j][0] + bg.x), (acc[i][j][1] + bv.y) * gelu_erf(acc[i + 1][j][1] + bg.y),
+                                    (acc[i][j][2] + bv.z) * gelu_erf(acc[i + 1][j][2] + bg.z), (acc[i][j][3] + bv.w) * gelu_erf(acc[i + 1][j][3] + bg.w)};
+                epilogue_store(a, v, yo, ro, (n0 + cn0 + i * 16) / 2 + fk * 4, X3);
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
             const int c = n0 + cn0 + i * 16 + fk * 4;
@@ -323,8 +340,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int nsplit, int Ho, int Wo, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    const int nq = a.N >> 2;
-    const int c = (int)(idx % nq) * 4;
+    const bool geglu = a.act == 5;
+    const int nq = (geglu ? a.N >> 1 : a.N) >> 2;         // output channel quads
+    const int co = (int)(idx % nq) * 4;                   // output channel
+    const int c = geglu ? (co >> 4) * 32 + (co & 15) : co; // GEMM row of its value (GEGLU: the gate sits 16 rows on)
     int64_t p = idx / nq;
     const int ox = (int)(p % Wo); p /= Wo;
     const int oy = (int)(p % Ho);
@@ -335,11 +354,19 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int n
         const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)k * a.ws_split);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    const float v[4] = {s.x, s.y, s.z, s.w};
+    float v[4] = {s.x, s.y, s.z, s.w};
+    if (geglu) {
+        float4 g = *reinterpret_cast<const float4*>(a.bias + c + 16);
+        for (int k = 0; k < nsplit; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(w + 16 + (int64_t)k * a.ws_split);
+            g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+        }
+        v[0] *= gelu_erf(g.x); v[1] *= gelu_erf(g.y); v[2] *= gelu_erf(g.z); v[3] *= gelu_erf(g.w);
+    }
     // y/r strides of the UNIT output grid are passed in (yi, yj) / (ri, rj) by the launcher
     const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
     const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)ox * a.rj;
-    epilogue_store(a, v, yo, ro, c, a.y_lo != nullptr);
+    epilogue_store(a, v, yo, ro, co, a.y_lo != nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -401,6 +428,22 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     MF_REQUIRE(d.cin > 0 && d.cout > 0 && d.kh > 0 && d.kw > 0, "conv: bad channel/kernel size");
     MF_REQUIRE(d.stride_h > 0 && d.stride_w > 0 && d.in_h > 0 && d.in_w > 0, "conv: bad stride/input size");
     MF_REQUIRE(precision == MF_PREC_BF16 || precision == MF_PREC_BF16X3, "conv: unknown precision %d", precision);
+    std::vector<float> gw, gb;
+    if (d.act == 5) {
+        // GEGLU (diffusers): out = x[:, :cout/2] * gelu(x[:, cout/2:]).  Rows are re-ordered into alternating blocks of 16
+        // value channels and their 16 gate channels, so one lane of the accumulator tile holds a value and its gate.
+        MF_REQUIRE(!d.transposed && !bn_gamma && !d.residual && d.cout % 32 == 0, "conv: GEGLU needs a plain conv with cout %% 32 == 0");
+        const size_t row = (size_t)d.cin * d.kh * d.kw;
+        gw.resize(row * d.cout); gb.assign(d.cout, 0.f);
+        for (int r = 0; r < d.cout; ++r) {
+            const int q = r / 32, u = r % 32;
+            const int src = u < 16 ? 16 * q + u : d.cout / 2 + 16 * q + (u - 16);
+            std::copy(weight + row * src, weight + row * (src + 1), gw.begin() + row * r);
+            if (bias) gb[r] = bias[src];
+        }
+        weight = gw.data();
+        bias = gb.data();
+    }
     p->d = d;
     p->precision = precision;
     p->cin_pad = (d.cin + 7) / 8 * 8;
@@ -515,6 +558,11 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
               d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16 && d.residual != 2 && d.act <= 2 && !d.upsample &&
               d.cin <= 256 && d.cout <= 256 && d.cout % 4 == 0;   // wide layers: weights must be shared through LDS
+    {
+        // MF_HALO_MAXC=n: halo kernel only up to n input channels (A/B against the 8-wave implicit-GEMM tiles)
+        static const int maxc = [] { const char* e = getenv("MF_HALO_MAXC"); return e ? atoi(e) : 256; }();
+        if (d.cin > maxc) p->halo = false;
+    }
     if (p->halo) {
         // ---- pack for the halo-tile kernel: [slice][tap][Npad][CK], channels past cin are zero --------
         p->n_slices = cdiv(d.cin, HCK);
@@ -644,7 +692,7 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
     MF_REQUIRE(in.C >= p->cin_pad && in.coff % 8 == 0 && in.coff + in.C <= ib.C, "conv: bad input view");
     // the epilogue stores channel quads: a cout that is not a multiple of 4 spills zero-weight channels
     // into the next (up to 3) channels of the buffer, which must exist
-    MF_REQUIRE(out.C == p->d.cout && out.coff % 4 == 0 && out.coff + (out.C + 3) / 4 * 4 <= ob.C, "conv: bad output view");
+    MF_REQUIRE(out.C == (p->d.act == 5 ? p->d.cout / 2 : p->d.cout) && out.coff % 4 == 0 && out.coff + (out.C + 3) / 4 * 4 <= ob.C, "conv: bad output view");
     MF_REQUIRE(ob.H == p->out_h && ob.W == p->out_w, "conv: output buffer %dx%d != %dx%d", ob.H, ob.W, p->out_h, p->out_w);
     const bool x3 = p->precision == MF_PREC_BF16X3;
     MF_REQUIRE(!x3 || (ib.lo && ob.lo), "conv: BF16X3 needs lo planes");
@@ -771,7 +819,7 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         if (p->prof_mid) MF_HIP(hipEventRecord(p->prof_mid, stream));
         ConvArgs e = a;   // unit-grid strides for the combine pass
         e.yi = ob.Wp() * ob.C; e.yj = ob.C;
-        const int64_t total = (int64_t)batch * p->out_h * p->out_w * (a.N / 4);
+        const int64_t total = (int64_t)batch * p->out_h * p->out_w * ((a.act == 5 ? a.N / 2 : a.N) / 4);
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e,
                            tc.nsplit, p->out_h, p->out_w, total);
         MF_HIP(hipGetLastError());
@@ -824,9 +872,9 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
     ConvTile t;
     if (N <= 16) t = {128, 16, 4, 1, 1};
     else if (N <= 32) t = {128, 32, 4, 1, 1};
-    else if (M <= 16) t = {16, 64, 1, 4, 1};
+    else if (M <= 16 && p->d.act != 5) t = {16, 64, 1, 4, 1};   // (its 16-channel wave tile cannot pair GEGLU blocks)
     else t = {64, 64, 2, 2, 1};
-    const bool modelled = N > 32 && M > 16;
+    const bool modelled = N > 32 && (M > 16 || p->d.act == 5);
     // exploration knobs (tools/unet_shape_sweep.py): MF_FORCE_TILE=128x64, MF_FORCE_SPLIT=4
     static const int force_tile = [] { const char* e = getenv("MF_FORCE_TILE"); int a = 0, b = 0; return e && sscanf(e, "%dx%d", &a, &b) == 2 ? a * 1000 + b : 0; }();
     static const int force_split = [] { const char* e = getenv("MF_FORCE_SPLIT"); return e ? atoi(e) : 0; }();

@@ -6,6 +6,8 @@
 #include <memory>
 #include <algorithm>
 
+static int out_channels(const mf_conv2d_desc& d) { return d.act == 5 ? d.cout / 2 : d.cout; }   // GEGLU halves the channels
+
 struct mf_conv2d {
     ConvPlan plan;
     ActBuf in, out;
@@ -34,7 +36,7 @@ extern "C" int mf_conv2d_create(const mf_conv2d_desc* desc, const float* weight,
                    "conv2d_create: residual needs matching input/output shapes");
     h->in.C = h->plan.cin_pad; h->in.H = desc->in_h; h->in.W = desc->in_w;
     h->in.halo = std::max(1, h->plan.in_halo_need);
-    h->out.C = (desc->cout + 7) / 8 * 8; h->out.H = h->plan.out_h; h->out.W = h->plan.out_w; h->out.halo = 1;
+    h->out.C = (out_channels(*desc) + 7) / 8 * 8; h->out.H = h->plan.out_h; h->out.W = h->plan.out_w; h->out.halo = 1;
     if ((rc = mf_conv_bind(&h->plan, h->in))) return rc;
     *out = h.release();
     return MF_OK;
@@ -63,7 +65,7 @@ extern "C" int mf_conv2d_forward(mf_conv2d* h, const float* x, float* y, int bat
     }
     int rc;
     if ((rc = mf_nchw_to_act(x, h->plan.d.cin, h->in, batch, s))) return rc;
-    ActView in{&h->in, 0, h->in.C}, out{&h->out, 0, h->plan.d.cout};
+    ActView in{&h->in, 0, h->in.C}, out{&h->out, 0, out_channels(h->plan.d)};
     ActView res = h->plan.d.residual ? ActView{&h->in, 0, h->plan.d.cout} : ActView{};
     if ((rc = mf_conv_launch(&h->plan, in, out, res, batch, s))) return rc;
     return mf_act_to_nchw(out, y, batch, s);
@@ -73,7 +75,7 @@ extern "C" int mf_conv2d_time(mf_conv2d* h, int batch, int iters, float* ms, voi
     MF_REQUIRE(h && ms, "conv2d_time: null argument");
     MF_REQUIRE(batch > 0 && batch <= h->cap && iters > 0, "conv2d_time: run mf_conv2d_forward at this batch first");
     hipStream_t s = (hipStream_t)stream;
-    ActView in{&h->in, 0, h->in.C}, out{&h->out, 0, h->plan.d.cout};
+    ActView in{&h->in, 0, h->in.C}, out{&h->out, 0, out_channels(h->plan.d)};
     ActView res = h->plan.d.residual ? ActView{&h->in, 0, h->plan.d.cout} : ActView{};
     hipEvent_t e0, e1;
     MF_HIP(hipEventCreate(&e0)); MF_HIP(hipEventCreate(&e1));

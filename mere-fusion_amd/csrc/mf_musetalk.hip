@@ -249,8 +249,8 @@ struct Net {
         const int H = x.buf->H, W = x.buf->W, X = ctx.C;
         ActBuf *g0 = tmp("xf.gn", C, H, W, 0), *hA = tmp("xf.hA", C, H, W, 0), *hB = tmp("xf.hB", C, H, W, 0);
         ActBuf *nb = tmp("xf.ln", C, H, W, 0), *qkv = tmp("xf.qkv", 3 * C, H, W, 0), *ao = tmp("xf.ao", C, H, W, 0);
-        ActBuf *kv = tmp("xf.kv", 2 * C, ctx.buf->H, ctx.buf->W, 0), *ff = tmp("xf.ff", 8 * C, H, W, 0), *gg = tmp("xf.geglu", 4 * C, H, W, 0);
-        if (!g0 || !hA || !hB || !nb || !qkv || !ao || !kv || !ff || !gg) return MF_ERR_HIP;
+        ActBuf *kv = tmp("xf.kv", 2 * C, ctx.buf->H, ctx.buf->W, 0), *gg = tmp("xf.geglu", 4 * C, H, W, 0);
+        if (!g0 || !hA || !hB || !nb || !qkv || !ao || !kv || !gg) return MF_ERR_HIP;
         const std::string t = p + ".transformer_blocks.0";
         int rc;
         if ((rc = gn(p + ".norm", x, ActView{g0, 0, C}, groups, 1e-6f, false))) return rc;
@@ -284,8 +284,8 @@ struct Net {
         if ((rc = conv(t + ".attn2.to_out.0", ActView{ao, 0, C}, ActView{hA, 0, C}, C, C, 1, 1, 0, 0, ActView{hB, 0, C}))) return rc;
         // GEGLU feed-forward
         if ((rc = ln(t + ".norm3", ActView{hA, 0, C}, ActView{nb, 0, C}))) return rc;
-        if ((rc = conv(t + ".ff.net.0.proj", ActView{nb, 0, C}, ActView{ff, 0, 8 * C}, C, 8 * C, 1, 1, 0, 0, ActView{}))) return rc;
-        push(t + ".ff.geglu", "k_geglu", 0.0, [=](int B, hipStream_t s) { return mf_geglu(ActView{ff, 0, 8 * C}, ActView{gg, 0, 4 * C}, B, s); });
+        // GEGLU in the GEMM epilogue (act 5): the 8C-wide projection never reaches HBM, only value * gelu(gate)
+        if ((rc = conv(t + ".ff.net.0.proj", ActView{nb, 0, C}, ActView{gg, 0, 4 * C}, C, 8 * C, 1, 1, 0, 5, ActView{}))) return rc;
         if ((rc = conv(t + ".ff.net.2", ActView{gg, 0, 4 * C}, ActView{hB, 0, C}, 4 * C, C, 1, 1, 0, 0, ActView{hA, 0, C}))) return rc;
         return conv(p + ".proj_out", ActView{hB, 0, C}, y, C, C, 1, 1, 0, 0, x);
     }

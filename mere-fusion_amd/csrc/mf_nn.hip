@@ -81,6 +81,67 @@ __global__ __launch_bounds__(256) void k_layernorm(Rows X, Rows Y, const float* 
     }
 }
 
+// one wave per token, 8 channels (16 bytes per plane) per lane and step: C % 8 == 0, views 16-byte aligned
+template <int NCH>
+__global__ __launch_bounds__(256) void k_layernorm_v8(Rows X, Rows Y, const float* gamma, const float* beta, float eps, int C, int total) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= total) return;
+    const int T = X.T;
+    const int b = row / T, t = row - b * T;
+    const int64_t xo = X.off(b, t), yo = Y.off(b, t);
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c < C) {
+            const uint4 h = *reinterpret_cast<const uint4*>(X.hi + xo + c);
+            const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[j][2 * e] = nbf2f(hw[e] & 0xffffu); v[j][2 * e + 1] = nbf2f(hw[e] >> 16); }
+            if (X.lo) {
+                const uint4 l = *reinterpret_cast<const uint4*>(X.lo + xo + c);
+                const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[j][2 * e] += nbf2f(lw[e] & 0xffffu); v[j][2 * e + 1] += nbf2f(lw[e] >> 16); }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[j][e];
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        if ((lane + 64 * j) * 8 < C) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mean; q += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    bf16_t *yh = const_cast<bf16_t*>(Y.hi), *yl = const_cast<bf16_t*>(Y.lo);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c < C) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            uint32_t hb[8], lb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float o = (v[j][e] - mean) * rstd * gg[e] + bb[e];
+                hb[e] = nf2bf(o);
+                lb[e] = nf2bf(o - nbf2f(hb[e]));
+            }
+            *reinterpret_cast<uint4*>(yh + yo + c) = make_uint4(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16));
+            if (yl) *reinterpret_cast<uint4*>(yl + yo + c) = make_uint4(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_softmax_rows(Rows S, Rows P, int n_keys, int n_out, float scale, int total) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= total) return;
@@ -327,7 +388,12 @@ int mf_layernorm(const ActView& x, const ActView& y, const float* gamma, const f
     MF_REQUIRE(x.C <= 64 * MAXPL, "layernorm: C=%d exceeds %d", x.C, 64 * MAXPL);
     const Rows xr = rows_of(x), yr = rows_of(y);
     const int total = batch * xr.T;
-    hipLaunchKernelGGL(k_layernorm, dim3((total + 3) / 4), dim3(256), 0, s, xr, yr, gamma, beta, eps, x.C, total);
+    const bool vec = x.C % 8 == 0 && x.coff % 8 == 0 && y.coff % 8 == 0 && x.buf->C % 8 == 0 && y.buf->C % 8 == 0 && x.C <= 2048;
+    const dim3 grid((total + 3) / 4), block(256);
+    if (vec && x.C <= 512) hipLaunchKernelGGL(k_layernorm_v8<1>, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total);
+    else if (vec && x.C <= 1024) hipLaunchKernelGGL(k_layernorm_v8<2>, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total);
+    else if (vec) hipLaunchKernelGGL(k_layernorm_v8<4>, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total);
+    else hipLaunchKernelGGL(k_layernorm, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

@@ -144,3 +144,43 @@ def test_hip_unet_rejects_other_timesteps_and_cpu(hip_small):
     with pytest.raises(RuntimeError, match="max_batch"):
         l8, a8 = W.make_musetalk_inputs(8, 0)
         unet.model(l8.cuda(), torch.tensor([0]).cuda(), encoder_hidden_states=a8.cuda())
+
+
+# ---- GEGLU fused into the feed-forward projection (conv act 5) -------------------------------------------------
+def _hip_conv1x1(w, b, x, act, precision="bf16x3"):
+    """y = act(conv1x1(x)) through mf_conv2d_*: w [cout, cin], x [B, cin, H, W] -> [B, cout or cout/2, H, W]."""
+    import ctypes as C
+    from mere_fusion_amd import _lib
+    l = _lib.lib()
+    _lib.init_device(0)
+    cout, cin = w.shape
+    d = _lib.MfConv2dDesc(cin=cin, cout=cout, kh=1, kw=1, stride_h=1, stride_w=1, pad_h=0, pad_w=0, transposed=0,
+                          output_padding=0, residual=0, act=act, in_h=x.shape[2], in_w=x.shape[3])
+    h = C.c_void_p()
+    wk, bk = w.reshape(cout, cin, 1, 1).contiguous(), b.contiguous()
+    _lib.check(l.mf_conv2d_create(C.byref(d), C.c_void_p(wk.data_ptr()), C.c_void_p(bk.data_ptr()), None, None, None, None,
+                                  _lib.PRECISIONS[precision], C.byref(h)))
+    xd = x.cuda().contiguous()
+    y = torch.empty((x.shape[0], cout // 2 if act == 5 else cout, x.shape[2], x.shape[3]), device="cuda")
+    _lib.check(l.mf_conv2d_forward(h, C.c_void_p(xd.data_ptr()), C.c_void_p(y.data_ptr()), x.shape[0], None))
+    torch.cuda.synchronize()
+    l.mf_conv2d_destroy(h)
+    return y.cpu()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 64, 512, 8, 8), (8, 320, 2560, 32, 32), (1, 1280, 10240, 4, 4), (3, 96, 768, 5, 7)],
+                         ids=lambda s: "b%d_c%d_n%d_%dx%d" % s)
+def test_hip_geglu_projection(lib_built, shape):
+    """diffusers GEGLU (`hidden, gate = proj(x).chunk(2, -1); hidden * gelu(gate)`) as the GEMM epilogue; covers the
+    one-pass tiles, the 256-wide tiles and the split-K combine (the 4x4 map of the 1280-channel blocks)."""
+    b, cin, cout, hh, ww = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.3
+    x = torch.randn(b, cin, hh, ww, generator=g)
+    proj = torch.einsum("oc,bchw->bohw", w.double(), x.double()) + bias.double()[None, :, None, None]
+    want = (proj[:, :cout // 2] * torch.nn.functional.gelu(proj[:, cout // 2:])).float()
+    got = _hip_conv1x1(w, bias, x, 5)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 2e-4
