@@ -49,8 +49,9 @@ __device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
 }  // namespace
 
 template <int PH, int BN, int WGM, int WGN, bool X3, int NST>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const HaloArgs a) {
-    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN == 4 ? 2 : 1) void k_conv3x3_halo(const HaloArgs a) {
+    constexpr int NW = WGM * WGN;                           // waves per workgroup
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int CK = X3 ? 32 : 64;
     constexpr int KG = CK / 8, ROWB = CK * 2, RPC = 1024 / ROWB;
     constexpr int NP = X3 ? 2 : 1;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const HaloArgs a) {
     constexpr int HW = PW + 2, HROWS = (PH + 2) * HW;
     constexpr int HCH = (HROWS + RPC - 1) / RPC;           // 1-KiB DMA chunks of the halo image
     constexpr int H_BYTES = HCH * 1024;
-    constexpr int NHC = (HCH + 3) / 4;
+    constexpr int NHC = (HCH + NW - 1) / NW;
     constexpr int FM = PH / WGM;                            // patch rows (= pixel fragments) per wave
     constexpr int FN = BN / WGN / 16;                       // 16-channel fragment rows per wave
     static_assert(FN >= 1 && FM >= 1, "wave tile must hold a fragment");
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const HaloArgs a) {
     const int64_t x_delta = X3 ? (a.x_lo - a.x_hi) : 0;
 #pragma unroll
     for (int i = 0; i < NHC; ++i) {
-        int hr = (wave + 4 * i) * RPC + lane / KG;
+        int hr = (wave + NW * i) * RPC + lane / KG;
         const int kg = (lane % KG) ^ hswz<CK>(hr % HW);
         hr = hr < HROWS ? hr : HROWS - 1;
         const int hy = hr / HW, hx = hr - hy * HW;
@@ -102,8 +103,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const HaloArgs a) {
         char* base = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < NHC; ++i) {
-            const int c = wave + 4 * i;
-            if (HCH % 4 == 0 || c < HCH) {
+            const int c = wave + NW * i;
+            if (HCH % NW == 0 || c < HCH) {
                 const bf16_t* src = hp[i] + slice * CK;
                 hglds16(src, base + c * 1024);
                 if (X3) hglds16(src + x_delta, base + H_BYTES + c * 1024);
@@ -307,7 +308,7 @@ int halo_launch_cfg(const HaloArgs& a, hipStream_t s) {
     constexpr int CK = X3 ? 32 : 64, RPC = 1024 / (CK * 2), NP = X3 ? 2 : 1;
     constexpr int HCH = ((PH + 2) * (PW + 2) + RPC - 1) / RPC;
     const size_t lds = (size_t)NST * NP * HCH * 1024;
-    hipLaunchKernelGGL(kern, dim3(a.n_patches * a.tiles_n), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.n_patches * a.tiles_n), dim3(WGM * WGN * 64), lds, s, a);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
@@ -327,6 +328,10 @@ int halo_launch_prec(const HaloArgs& a, bool x3, hipStream_t s) {
 HaloTile mf_halo_pick_tile(int H, int W, int N, int batch) {
     auto wgs = [&](int ph, int bn) { return batch * ((H + ph - 1) / ph) * ((W + PW - 1) / PW) * ((N + bn - 1) / bn); };
     if (N <= 32) return wgs(8, 32) >= 256 ? HaloTile{8, 32, 2, 2} : HaloTile{4, 32, 2, 2};
+    // 16 x 16 patch, 8 waves (the weight stream shared by twice the pixels): measured 4 % SLOWER than the 8-row patch on
+    // the VAE's 128 / 256-channel layers and on Wav2Lip's 96^2 layers, so it stays opt-in (MF_HALO_PH16=1)
+    static const int big = [] { const char* e = getenv("MF_HALO_PH16"); return e ? atoi(e) : 0; }();
+    if (big && wgs(16, 64) >= 512) return HaloTile{16, 64, 4, 2};
     if (wgs(8, 64) >= 256) return HaloTile{8, 64, 2, 2};
     if (wgs(4, 64) >= 256) return HaloTile{4, 64, 2, 2};
     return HaloTile{4, 32, 2, 2};
@@ -341,6 +346,7 @@ int mf_halo_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t s
     a.tiles_n = (a.N + t.bn - 1) / t.bn;
 #define MF_HCASE(PH, BN, WGM, WGN) \
     if (t.ph == PH && t.bn == BN) return halo_launch_prec<PH, BN, WGM, WGN>(a, x3, s);
+    MF_HCASE(16, 64, 4, 2)
     MF_HCASE(8, 64, 2, 2)
     MF_HCASE(4, 64, 2, 2)
     MF_HCASE(4, 32, 2, 2)
