@@ -39,6 +39,9 @@ struct Net {
     std::map<std::tuple<std::string, int, int, int, int>, ActBuf*> scratch;
     std::map<std::tuple<int, int, int, int>, std::pair<ConvPlan*, ConvPlan*>> attn_plans;   // (dh, Tq, Tk, heads)
     double* gn_stats = nullptr;
+    static constexpr int GN_MAX_OPS = 96;
+    size_t gn_slice = 0;
+    int gn_count = 0;
     std::map<int, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -130,7 +133,8 @@ struct Net {
         float* dg = upload(g, in.C);
         float* db = upload(b, in.C);
         if (!dg || !db) return MF_ERR_HIP;
-        double* st = gn_stats;
+        if (gn_count >= GN_MAX_OPS) { err = "more GroupNorm layers than GN_MAX_OPS"; return MF_ERR_INVALID; }
+        double* st = gn_stats + (size_t)(gn_count++) * gn_slice;
         push(name, "k_gn_stats+k_gn_apply", 0.0, [=](int B, hipStream_t s) { return mf_groupnorm(in, out, dg, db, groups, eps, silu, st, B, s); });
         return MF_OK;
     }
@@ -370,8 +374,16 @@ struct Net {
             if (!weights[i].name || !weights[i].data) { mf_set_error("tensor %d has no name/data", i); return MF_ERR_INVALID; }
             sd[weights[i].name] = &weights[i];
         }
-        MF_HIP(hipMalloc(&gn_stats, (size_t)max_batch * max_groups * 2 * sizeof(double)));
+        // one slice of fp64 (sum, sum of squares) per GroupNorm op; the whole array is zeroed by ONE kernel at the head
+        // of the op list, so a GroupNorm is two launches (statistics, apply) instead of four
+        gn_slice = (size_t)max_batch * max_groups * 2;
+        MF_HIP(hipMalloc(&gn_stats, GN_MAX_OPS * gn_slice * sizeof(double)));
         dev.push_back(gn_stats);
+        {
+            double* st = gn_stats;
+            const int n = (int)(GN_MAX_OPS * gn_slice);
+            push("groupnorm statistics reset", "k_zero_f64", 0.0, [=](int, hipStream_t s) { return mf_zero_f64(st, n, s); });
+        }
         MF_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
         MF_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
         MF_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));

@@ -28,8 +28,10 @@ int mf_rows_to_f32(const ActView& x, float* dst, int batch, hipStream_t s);
 // fp32 [batch][T][C] row-major (+ optional addend [T][C], e.g. a positional encoding) -> planes of a view
 int mf_rows_from_f32(const float* src, const float* addend, const ActView& y, int batch, hipStream_t s);
 
-// GroupNorm over (H*W x C/groups) per (batch, group), optional SiLU, on any view (fp64 sums, fp32 apply).
-// `stats` is a device scratch of batch*groups*2 doubles owned by the caller.
+// GroupNorm over (H*W x C/groups) per (batch, group), optional SiLU, on any view (fp64 sums, fp32 apply): two launches.
+// `stats` is a device scratch of batch*groups*2 doubles owned by the caller and must be ZERO on entry (mf_zero_f64;
+// a kernel, not hipMemsetAsync -- memset nodes corrupted captured graphs on ROCm 7.2).
+int mf_zero_f64(double* p, int n, hipStream_t s);
 int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, int groups, float eps,
                  bool silu, double* stats, int batch, hipStream_t s);
 

@@ -279,20 +279,10 @@ __global__ void k_zero_f64(double* p, int n) {
     if (i < n) p[i] = 0.0;
 }
 
-// (sum, sumsq) fp64 -> (mean, rstd) fp32 per (batch, group), written over the first half of the stats buffer
-__global__ void k_gn_finalize(double* stats, double n, float eps, int total) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const double mean = stats[2 * i] / n;
-    const double var = fmax(stats[2 * i + 1] / n - mean * mean, 0.0);
-    float2 r = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
-    // in place: entry i's 16 bytes are read before its first 8 bytes are overwritten by the same thread
-    reinterpret_cast<float2*>(stats)[2 * i] = r;
-}
-
 // one thread per (token, 8 channels): y = (x - mean) * rstd * gamma + beta [, SiLU]
 __global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  const double* stats, int groups, int cpg, int C, int silu, int64_t total) {
+                                                  const double* stats, double inv_n, float eps, int groups, int cpg, int C, int silu,
+                                                  int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c8 = C / 8;
@@ -300,7 +290,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* _
     const int64_t r = idx / c8;
     const int t = (int)(r % X.T), b = (int)(r / X.T);
     const int64_t xo = X.off(b, t) + c0, yo = Y.off(b, t) + c0;
-    const float2* mr = reinterpret_cast<const float2*>(stats);
+
     const uint4 vh = *reinterpret_cast<const uint4*>(X.hi + xo);
     uint4 vl = make_uint4(0, 0, 0, 0);
     if (X.lo) vl = *reinterpret_cast<const uint4*>(X.lo + xo);
@@ -319,7 +309,14 @@ __global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* _
         for (int k = 0; k < 2; ++k) {
             const int c = c0 + 2 * e + k;
             const int g = c / cpg;
-            if (g != g_prev) { st2 = mr[2 * (b * groups + g)]; g_prev = g; }
+            if (g != g_prev) {
+                // finalise (sum, sum of squares) -> (mean, rstd): a handful of fp64 ops per thread and group
+                const double2 sq = *reinterpret_cast<const double2*>(stats + 2 * (b * groups + g));
+                const double mean = sq.x * inv_n;
+                const double var = fmax(sq.y * inv_n - mean * mean, 0.0);
+                st2 = make_float2((float)mean, rsqrtf((float)var + eps));
+                g_prev = g;
+            }
             const float x = nbf2f(k ? hh[e] >> 16 : hh[e] & 0xffffu) + nbf2f(k ? ll[e] >> 16 : ll[e] & 0xffffu);
             float v = (x - st2.x) * st2.y * gm[2 * e + k] + bt[2 * e + k];
             if (silu) v = v / (1.f + __expf(-v));
@@ -416,25 +413,27 @@ int mf_rows_from_f32(const float* src, const float* addend, const ActView& y, in
     return MF_OK;
 }
 
+int mf_zero_f64(double* p, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_zero_f64, dim3((n + 255) / 256), dim3(256), 0, s, p, n);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
 int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, int groups, float eps,
                  bool silu, double* stats, int batch, hipStream_t s) {
     MF_REQUIRE(x.C == y.C && x.C % groups == 0 && x.C % 8 == 0 && x.coff % 8 == 0 && y.coff % 8 == 0, "groupnorm: C=%d groups=%d", x.C, groups);
     MF_REQUIRE(x.buf->H == y.buf->H && x.buf->W == y.buf->W, "groupnorm: spatial mismatch");
     const Rows xr = rows_of(x), yr = rows_of(y);
     const int cpg = x.C / groups;
-    hipLaunchKernelGGL(k_zero_f64, dim3((batch * groups * 2 + 255) / 256), dim3(256), 0, s, stats, batch * groups * 2);
-    MF_HIP(hipGetLastError());
     MF_REQUIRE(groups <= 64 && x.C <= 8 * 256 * GN_MAXCOL, "groupnorm: groups=%d / C=%d beyond the kernel's limits", groups, x.C);
     // pixels per workgroup: enough workgroups to fill the chip, at most 64 pixels per thread column
     const int cols = std::min(256, x.C / 8), ppi = 256 / cols;
     int P = std::max(ppi, std::min(64 * ppi, (xr.T * batch + 1023) / 1024));
     hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, cpg, x.C, P, stats);
     MF_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_gn_finalize, dim3((batch * groups + 63) / 64), dim3(64), 0, s, stats, (double)xr.T * cpg, eps, batch * groups);
-    MF_HIP(hipGetLastError());
     const int64_t total = (int64_t)batch * xr.T * (x.C / 8);
-    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xr, yr, gamma, beta, stats, groups,
-                       cpg, x.C, silu ? 1 : 0, total);
+    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xr, yr, gamma, beta, stats,
+                       1.0 / ((double)xr.T * cpg), eps, groups, cpg, x.C, silu ? 1 : 0, total);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
