@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -287,15 +288,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
 
     // ---- epilogue ---------------------------------------------------------------------------
     if (dbg && threadIdx.x == 0) dbg[2] = __builtin_amdgcn_s_memtime();
+    if (a.ws) {
+        // split-K: fp32 partial tile, combined by k_splitk_epilogue
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const int m = m0 + pm0 + j * 16 + fr;
-        if (m >= a.M) continue;
-        const int b = m / a.HqWq;
-        const int rem = m - b * a.HqWq;
-        const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
-        if (a.ws) {
-            // split-K: fp32 partial tile, combined by k_splitk_epilogue
+        for (int j = 0; j < FM; ++j) {
+            const int m = m0 + pm0 + j * 16 + fr;
+            if (m >= a.M) continue;
+            const int b = m / a.HqWq;
+            const int rem = m - b * a.HqWq;
+            const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
             float* wo = a.ws + (int64_t)blockIdx.y * a.ws_split + (int64_t)b * a.wsb + (int64_t)qi * a.wsi +
                         (int64_t)qj * a.wsj + ph.ws_off;
 #pragma unroll
@@ -304,32 +305,107 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
                 if (c >= a.N) continue;
                 *reinterpret_cast<float4*>(wo + c) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             }
-            continue;
         }
-        const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
-        const int64_t ro = (int64_t)b * a.rb + (int64_t)qi * a.ri + (int64_t)qj * a.rj;
-        if (FN % 2 == 0 && a.act == 5) {
-            // GEGLU: GEMM rows alternate 16 value channels / their 16 gate channels (packed that way at plan creation),
-            // so fragment i holds the values and fragment i + 1 the gates of the same 4 output channels of this lane
+        if (dbg && threadIdx.x == 0) dbg[3] = __builtin_amdgcn_s_memtime();
+        return;
+    }
+    // Bias quads of this lane, fetched once and with clamped (never branched-around) addresses; the activation is a
+    // compile-time parameter of the body below.  Both keep the per-fragment code straight-line, so the residual loads of a
+    // pixel row are issued together instead of one global round trip per 4 channels.
+    float4 bq[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        int c = n0 + cn0 + i * 16 + fk * 4;
+        c = c < a.Npad - 3 ? c : a.Npad - 4;
+        bq[i] = *reinterpret_cast<const float4*>(a.bias + c);
+    }
+    const int ACT = a.act;
+    if (FN % 2 == 0 && ACT == 5) {
+        // GEGLU: GEMM rows alternate 16 value channels / their 16 gate channels (packed that way at plan creation), so
+        // fragment i holds the values and fragment i + 1 the gates of the same 4 output channels of this lane
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = m0 + pm0 + j * 16 + fr;
+            if (m >= a.M) continue;
+            const int b = m / a.HqWq;
+            const int rem = m - b * a.HqWq;
+            const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+            const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
 #pragma unroll
             for (int i = 0; i + 1 < FN; i += 2) {
                 const int c = n0 + cn0 + i * 16 + fk * 4;
                 if (c >= a.N) continue;
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
-                const float4 bg = *reinterpret_cast<const float4*>(a.bias + c + 16);
-                const float v[4] = {(acc[i][j][0] + bv.x) * gelu_erf(acc[i + 1][j][0] + bg.x), (acc[i][j][1] + bv.y) * gelu_erf(acc[i + 1][j][1] + bg.y),
-                                    (acc[i][j][2] + bv.z) * gelu_erf(acc[i + 1][j][2] + bg.z), (acc[i][j][3] + bv.w) * gelu_erf(acc[i + 1][j][3] + bg.w)};
-                epilogue_store(a, v, yo, ro, (n0 + cn0 + i * 16) / 2 + fk * 4, X3);
-            }
-            continue;
-        }
+                const float v[4] = {(acc[i][j][0] + bq[i].x) * gelu_erf(acc[i + 1][j][0] + bq[i + 1].x), (acc[i][j][1] + bq[i].y) * gelu_erf(acc[i + 1][j][1] + bq[i + 1].y),
+                                    (acc[i][j][2] + bq[i].z) * gelu_erf(acc[i + 1][j][2] + bq[i + 1].z), (acc[i][j][3] + bq[i].w) * gelu_erf(acc[i + 1][j][3] + bq[i + 1].w)};
+                const int co = (n0 + cn0 + i * 16) / 2 + fk * 4;
+                uint32_t h[4];
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            const int c = n0 + cn0 + i * 16 + fk * 4;
-            if (c >= a.N) continue;
-            const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
-            const float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-            epilogue_store(a, v, yo, ro, c, X3);
+                for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
+                *reinterpret_cast<uint2*>(a.y_hi + yo + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                if (X3) {
+                    uint32_t l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
+                    *reinterpret_cast<uint2*>(a.y_lo + yo + co) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                }
+            }
+        }
+    } else {
+        constexpr bool GEGLU = false;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = m0 + pm0 + j * 16 + fr;
+            if (m >= a.M) continue;
+            const int b = m / a.HqWq;
+            const int rem = m - b * a.HqWq;
+            const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+            const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
+            const int64_t ro = (int64_t)b * a.rb + (int64_t)qi * a.ri + (int64_t)qj * a.rj;
+            uint2 rh[FN], rl[FN];
+            const bool has_res = !GEGLU && a.r_hi != nullptr;
+            if (has_res) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    int c = n0 + cn0 + i * 16 + fk * 4;
+                    c = c < a.N ? c : 0;
+                    rh[i] = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
+                    if (X3) rl[i] = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int c = n0 + cn0 + i * 16 + fk * 4;
+                float v[4] = {acc[i][j][0] + bq[i].x, acc[i][j][1] + bq[i].y, acc[i][j][2] + bq[i].z, acc[i][j][3] + bq[i].w};
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
+                if (has_res) {
+                    r[0] = bf2f(rh[i].x & 0xffffu); r[1] = bf2f(rh[i].x >> 16); r[2] = bf2f(rh[i].y & 0xffffu); r[3] = bf2f(rh[i].y >> 16);
+                    if (X3) {
+                        r[0] += bf2f(rl[i].x & 0xffffu); r[1] += bf2f(rl[i].x >> 16); r[2] += bf2f(rl[i].y & 0xffffu); r[3] += bf2f(rl[i].y >> 16);
+                    }
+                }
+                const bool after = a.res_after_act;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[e] + (after ? 0.f : r[e]);
+                    if (ACT == 1) x = fmaxf(x, 0.f);
+                    else if (ACT == 2) x = 1.f / (1.f + __expf(-x));
+                    else if (ACT == 3) x = gelu_erf(x);
+                    else if (ACT == 4) x = x / (1.f + expf(-x));
+                    v[e] = x + (after ? r[e] : 0.f);
+                }
+                if (c >= a.N) continue;
+                const int co = GEGLU ? (n0 + cn0 + i * 16) / 2 + fk * 4 : c;
+                uint32_t h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
+                *reinterpret_cast<uint2*>(a.y_hi + yo + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                if (X3) {
+                    uint32_t l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
+                    *reinterpret_cast<uint2*>(a.y_lo + yo + co) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                }
+            }
         }
     }
     if (dbg && threadIdx.x == 0) dbg[3] = __builtin_amdgcn_s_memtime();
