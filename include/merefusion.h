@@ -222,6 +222,45 @@ int mf_vae_op_info(const mf_vae* h, int i, char* name, int ncap, char* kernel, i
 int mf_vae_profile(mf_vae* h, int batch, int iters, float* ms_per_op, void* stream);
 void mf_vae_destroy(mf_vae* h);
 
+/* ---- ER-NeRF inference kernels (H6): the functions of the reference's four torch extensions ------------------
+ * Same argument order and in-place output conventions as the pybind entry points the Python wrappers call, so
+ * `ernerf/raymarching/raymarching.py`, `gridencoder/grid.py`, `shencoder/sphere_harmonics.py`, `freqencoder/freq.py`
+ * run unchanged on top of them.  All pointers are device fp32 / int32 / uint8 unless
+ * noted; all calls are asynchronous on `stream`. */
+
+/* `_backend.near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars)` (raymarching.py:44 ->
+ * kernel_near_far_from_aabb, raymarching.cu:92-145).  rays_o/d [N,3], aabb [6]; a miss writes FLT_MAX to both. */
+int mf_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t n_rays, float min_near,
+                          float* nears, float* fars, void* stream);
+/* `_backend.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
+ * density_bitfield, near, far, xyzs, dirs, deltas, noises)` (raymarching.py:393 -> kernel_march_rays,
+ * raymarching.cu:828-929).  xyzs/dirs [n_alive*n_step,3] and deltas [n_alive*n_step,2] must be zero-filled by the
+ * caller (raymarching.py:383-385): dt == 0 marks "no sample". */
+int mf_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_alive, const float* rays_t, const float* rays_o,
+                  const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t cascades, uint32_t grid_size,
+                  const uint8_t* density_bitfield, const float* nears, const float* fars, float* xyzs, float* dirs,
+                  float* deltas, const float* noises, void* stream);
+/* `_backend.composite_rays_triplane(...)` (raymarching.py:666 -> kernel_composite_rays_triplane,
+ * raymarching.cu:2142-2249): updates rays_alive (-1 = terminated), rays_t and the [N]-sized accumulators in place. */
+int mf_composite_rays_triplane(uint32_t n_alive, uint32_t n_step, float T_thresh, int* rays_alive, float* rays_t,
+                               const float* sigmas, const float* rgbs, const float* deltas, const float* ambs_aud,
+                               const float* ambs_eye, const float* uncertainties, float* weights_sum, float* depth,
+                               float* image, float* amb_aud_sum, float* amb_eye_sum, float* uncertainty_sum, void* stream);
+/* `_backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
+ * align_corners)` (grid.py:49 -> kernel_grid, gridencoder.cu:76-165), inference only (no dy_dx).
+ * inputs [B,D] in [0,1]; embeddings [offsets[L], C]; offsets_host: HOST int32 [L+1]; S = log2(per_level_scale);
+ * outputs [L,B,C] as the extension writes it, or -- out_blc != 0 -- [B, L*C], the layout grid.py:52 permutes to.
+ * D in {2,3}, C in {1,2,4,8}, L <= 32. */
+int mf_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B,
+                           uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                           int out_blc, void* stream);
+/* `_backend.sh_encode_forward(inputs, outputs, B, input_dim, degree, dy_dx)` (sphere_harmonics.py:32 -> kernel_sh,
+ * shencoder.cu:28-110), inference only; inputs [B,3], outputs [B,degree^2], degree 1..4. */
+int mf_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t degree, void* stream);
+/* `_backend.freq_encode_forward(inputs, B, input_dim, degree, output_dim, outputs)` (freq.py:29 -> kernel_freq,
+ * freqencoder.cu:30-58); outputs [B, D + 2*D*degree]. */
+int mf_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t degree, uint32_t C, float* outputs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,13 @@ SIGNATURES = {
     "mf_melspec": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_melspec_frames": (C.c_int, [C.c_int]),
     "mf_attention_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
+    "mf_near_far_from_aabb": (C.c_int, [C.c_void_p] * 3 + [C.c_uint32, C.c_float] + [C.c_void_p] * 3),
+    "mf_march_rays": (C.c_int, [C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]
+                      + [C.c_void_p] * 8),
+    "mf_composite_rays_triplane": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float] + [C.c_void_p] * 15),
+    "mf_grid_encode_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_uint32] * 4 + [C.c_float, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
+    "mf_sh_encode_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "mf_freq_encode_forward": (C.c_int, [C.c_void_p] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,375 @@
+"""ER-NeRF inference kernels (SURVEY 8a rows a16-a19, a21, a22's frequency encoder).
+
+CPU: the plain-C oracle (oracle/ernerf_ref.c, PARITY UNPINNED -- the CUDA reference cannot run here) against hand-derived
+known answers.  GPU: the HIP kernels, called through the extension-module shims the reference's wrappers import
+(`_raymarching_face`, `_gridencoder`, `_shencoder`, `_freqencoder`), against the oracle on the same seeded inputs:
+bit-exact wherever only +,-,*,/ and exact libm calls are involved (both sides are built without FMA contraction), a written
+tolerance where expf / sinf are."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+FLT_MAX = np.finfo(np.float32).max
+
+
+@pytest.fixture(scope="module")
+def ref():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "libernerfref.so"))
+    lib.ref_morton3d.restype = C.c_uint32
+    lib.ref_morton3d.argtypes = [C.c_uint32] * 3
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+F = lambda *s: np.zeros(s, np.float32)
+
+
+# ---- oracle wrappers (numpy in, numpy out) ----------------------------------------------------------------------------
+def o_near_far(ref, ro, rd, aabb, min_near):
+    n = ro.shape[0]
+    nears, fars = F(n), F(n)
+    ref.ref_near_far_from_aabb(_p(ro), _p(rd), _p(aabb), C.c_uint32(n), C.c_float(min_near), _p(nears), _p(fars))
+    return nears, fars
+
+
+def o_march(ref, n_step, alive, rays_t, ro, rd, bound, dt_gamma, max_steps, cascades, H, grid, nears, fars, noises):
+    na = alive.shape[0]
+    xyzs, dirs, deltas = F(na * n_step, 3), F(na * n_step, 3), F(na * n_step, 2)
+    ref.ref_march_rays(C.c_uint32(na), C.c_uint32(n_step), _p(alive), _p(rays_t), _p(ro), _p(rd), C.c_float(bound), C.c_float(dt_gamma),
+                       C.c_uint32(max_steps), C.c_uint32(cascades), C.c_uint32(H), _p(grid), _p(nears), _p(fars), _p(xyzs), _p(dirs),
+                       _p(deltas), _p(noises))
+    return xyzs, dirs, deltas
+
+
+def o_composite(ref, n_step, T_thresh, alive, rays_t, sig, rgb, deltas, aa, ae, unc, acc):
+    alive, rays_t = alive.copy(), rays_t.copy()
+    acc = {k: v.copy() for k, v in acc.items()}
+    ref.ref_composite_rays_triplane(C.c_uint32(alive.shape[0]), C.c_uint32(n_step), C.c_float(T_thresh), _p(alive), _p(rays_t), _p(sig),
+                                    _p(rgb), _p(deltas), _p(aa), _p(ae), _p(unc), _p(acc["weights_sum"]), _p(acc["depth"]), _p(acc["image"]),
+                                    _p(acc["amb_aud_sum"]), _p(acc["amb_eye_sum"]), _p(acc["uncertainty_sum"]))
+    return alive, rays_t, acc
+
+
+def o_grid(ref, x, emb, offsets, D, Cc, S, H, gridtype, align):
+    B, L = x.shape[0], offsets.shape[0] - 1
+    out = F(L, B, Cc)
+    ref.ref_grid_encode_forward(_p(x), _p(emb), _p(offsets), _p(out), C.c_uint32(B), C.c_uint32(D), C.c_uint32(Cc), C.c_uint32(L),
+                                C.c_float(S), C.c_uint32(H), C.c_uint32(gridtype), C.c_int(align))
+    return out
+
+
+def o_sh(ref, d, degree):
+    out = F(d.shape[0], degree * degree)
+    ref.ref_sh_encode_forward(_p(d), _p(out), C.c_uint32(d.shape[0]), C.c_uint32(degree))
+    return out
+
+
+def o_freq(ref, x, deg):
+    B, D = x.shape
+    Cc = D + 2 * D * deg
+    out = F(B, Cc)
+    ref.ref_freq_encode_forward(_p(x), C.c_uint32(B), C.c_uint32(D), C.c_uint32(deg), C.c_uint32(Cc), _p(out))
+    return out
+
+
+def grid_offsets(D, L, H, per_level_scale, log2_hashmap, align=False):
+    """GridEncoder.__init__, grid.py:108-123."""
+    offs, off = [], 0
+    for i in range(L):
+        res = int(np.ceil(H * per_level_scale ** i))
+        n = min(2 ** log2_hashmap, (res if align else res + 1) ** D)
+        n = int(np.ceil(n / 8) * 8)
+        offs.append(off)
+        off += n
+    offs.append(off)
+    return np.array(offs, np.int32)
+
+
+# ---- CPU known-answer tests ------------------------------------------------------------------------------------------------
+AABB = np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32)      # aabb_infer at bound 1, renderer.py:86-89
+
+
+def test_oracle_near_far_kats(ref):
+    ro = np.array([[-2, 0, 0], [-2, 0, 0], [0, 0, 0], [0, 2, 0]], np.float32)
+    rd = np.array([[1, 1e-9, 1e-9], [0, 1, 1e-9], [1e-9, 1e-9, 1], [1, 1e-9, 1e-9]], np.float32)
+    nears, fars = o_near_far(ref, ro, rd, AABB, 0.05)
+    assert nears[0] == 1.0 and fars[0] == 3.0                                  # enters x = -1 at t = 1, leaves x = 1 at t = 3
+    assert nears[1] == FLT_MAX and fars[1] == FLT_MAX                          # parallel to the box, outside its x slab
+    assert nears[2] == np.float32(0.05) and fars[2] == 1.0                     # origin inside: near clamps to min_near
+    assert nears[3] == FLT_MAX                                                 # above the y slab, moving along x
+
+
+def test_oracle_morton_kats(ref):
+    assert [ref.ref_morton3d(1, 0, 0), ref.ref_morton3d(0, 1, 0), ref.ref_morton3d(0, 0, 1)] == [1, 2, 4]
+    assert ref.ref_morton3d(3, 3, 3) == 63 and ref.ref_morton3d(127, 127, 127) == 2 ** 21 - 1
+    assert ref.ref_morton3d(5, 0, 0) == 0b1000001                             # x bits land on positions 0, 3, 6, ...
+
+
+def test_oracle_sh_kats(ref):
+    out = o_sh(ref, np.array([[0, 0, 1], [1, 0, 0]], np.float32), 4)
+    c = 0.5 * np.sqrt(1 / np.pi)
+    np.testing.assert_allclose(out[:, 0], c, rtol=1e-7)
+    np.testing.assert_allclose(out[0, 2], np.sqrt(3 / (4 * np.pi)), rtol=1e-6)               # Y_1^0 at the pole
+    np.testing.assert_allclose(out[0, 6], 0.25 * np.sqrt(5 / np.pi) * 2, rtol=1e-6)          # Y_2^0 = sqrt(5/pi)/4 (3z^2-1)
+    np.testing.assert_allclose(out[0, 12], 0.25 * np.sqrt(7 / np.pi) * 2, rtol=1e-6)         # Y_3^0 = sqrt(7/pi)/4 (5z^3-3z)
+    np.testing.assert_allclose(out[1, 3], -np.sqrt(3 / (4 * np.pi)), rtol=1e-6)
+    assert out[0, 1] == 0 and out[0, 3] == 0 and out[0, 4] == 0
+
+
+def test_oracle_freq_kats(ref):
+    x = np.array([[0.25, -0.5]], np.float32)
+    out = o_freq(ref, x, 3)
+    assert out.shape == (1, 14)
+    want = [0.25, -0.5]
+    for f in range(3):
+        for ph in (0, np.pi / 2):                                              # freq.py: [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]
+            want += [np.sin(0.25 * 2 ** f + ph), np.sin(-0.5 * 2 ** f + ph)]
+    np.testing.assert_allclose(out[0], np.array(want, np.float32), atol=1e-6)
+
+
+def test_oracle_grid_reproduces_affine_tables(ref):
+    # dense (tiled) levels holding an affine function of the vertex index: bilinear interpolation must return the same affine
+    # function of the continuous position x * scale + 0.5 (gridencoder.cu:131-137)
+    D, L, H, pls = 2, 3, 8, 2.0
+    offs = grid_offsets(D, L, H, pls, 19)
+    emb = np.zeros((offs[-1], 1), np.float32)
+    for l in range(L):
+        res = int(np.ceil(np.exp2(l * np.log2(pls)) * H - 1.0)) + 1
+        for j in range(res + 1):
+            for i in range(res + 1):
+                idx = i + j * (res + 1)
+                if idx < offs[l + 1] - offs[l]:
+                    emb[offs[l] + idx, 0] = 0.5 * i - 0.25 * j + 3
+    x = np.random.default_rng(0).random((64, 2), np.float32) * 0.98
+    out = o_grid(ref, x, emb, offs, D, 1, float(np.log2(pls)), H, 1, 0)
+    for l in range(L):
+        scale = np.float32(np.exp2(np.float32(l) * np.float32(np.log2(pls))) * H - 1.0)
+        pos = x * scale + 0.5
+        np.testing.assert_allclose(out[l, :, 0], 0.5 * pos[:, 0] - 0.25 * pos[:, 1] + 3, rtol=2e-6)
+    oob = o_grid(ref, np.array([[1.5, 0.2], [0.3, -0.1]], np.float32), emb, offs, D, 1, 1.0, H, 1, 0)
+    assert (oob == 0).all()                                                    # gridencoder.cu:98-116
+
+
+def test_oracle_composite_closed_form(ref):
+    n_step = 3
+    alive = np.array([0, 1], np.int32)
+    rays_t = np.array([0.1, 0.2], np.float32)
+    sig = np.array([[2.0, 0, 0], [1.0, 3.0, 0.5]], np.float32)
+    deltas = np.array([[[0.5, 0.6], [0, 0], [0, 0]], [[0.1, 0.3], [0.1, 0.4], [0.1, 0.5]]], np.float32)
+    rgb = np.full((2, n_step, 3), 0.5, np.float32)
+    one = np.ones((2, n_step), np.float32)
+    acc = dict(weights_sum=F(2), depth=F(2), image=F(2, 3), amb_aud_sum=F(2), amb_eye_sum=F(2), uncertainty_sum=F(2))
+    a2, t2, acc2 = o_composite(ref, n_step, 1e-4, alive, rays_t, sig, rgb, deltas, one, 2 * one, one, acc)
+    a0 = 1 - np.exp(-1.0)
+    np.testing.assert_allclose(acc2["weights_sum"][0], a0, rtol=1e-6)
+    np.testing.assert_allclose(acc2["image"][0], 0.5 * a0, rtol=1e-6)
+    np.testing.assert_allclose(acc2["depth"][0], a0 * 0.6, rtol=1e-6)
+    assert a2[0] == -1 and t2[0] == np.float32(0.1)                            # dt == 0 at step 1: terminated, rays_t untouched
+    al = 1 - np.exp(-np.array([0.1, 0.3, 0.05]))
+    w = np.array([al[0], al[1] * (1 - al[0]), al[2] * (1 - al[0] - al[1] * (1 - al[0]))])
+    np.testing.assert_allclose(acc2["weights_sum"][1], w.sum(), rtol=1e-6)
+    np.testing.assert_allclose(acc2["depth"][1], (w * [0.3, 0.4, 0.5]).sum(), rtol=1e-6)
+    assert a2[1] == 1 and t2[1] == np.float32(0.5)                             # survived all steps: rays_t = last t
+    assert acc2["amb_aud_sum"][1] == 3 and acc2["amb_eye_sum"][1] == 6          # ambient terms are plain sums (raymarching.cu:2207-2208)
+
+
+def _scene(n_rays, seed, H=128, cascades=1, density=0.3):
+    rng = np.random.default_rng(seed)
+    ro = (rng.standard_normal((n_rays, 3)) * 0.1 + [0, 0, -2.2]).astype(np.float32)
+    target = rng.uniform(-0.9, 0.9, (n_rays, 3)).astype(np.float32) * [1, 0.5, 1]
+    rd = target - ro
+    rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    grid = (rng.random(cascades * H ** 3 // 8) < density).astype(np.uint8) * rng.integers(1, 256, cascades * H ** 3 // 8).astype(np.uint8)
+    return ro, rd, grid
+
+
+def test_oracle_march_empty_and_full_grid(ref):
+    ro, rd, _ = _scene(64, 1)
+    nears, fars = o_near_far(ref, ro, rd, AABB, 0.05)
+    alive = np.arange(64, dtype=np.int32)
+    noises = np.zeros(64, np.float32)
+    empty = np.zeros(128 ** 3 // 8, np.uint8)
+    xyzs, dirs, deltas = o_march(ref, 4, alive, nears, ro, rd, 1.0, 1 / 256, 16, 1, 128, empty, nears, fars, noises)
+    assert (deltas == 0).all() and (xyzs == 0).all()                            # nothing occupied: no samples
+    full = np.full(128 ** 3 // 8, 255, np.uint8)
+    xyzs, dirs, deltas = o_march(ref, 4, alive, nears, ro, rd, 1.0, 1 / 256, 16, 1, 128, full, nears, fars, noises)
+    hit = fars > nears + 0.5
+    d = deltas.reshape(64, 4, 2)
+    dt_max = np.float32(2 * np.sqrt(3) / 128)
+    assert (d[hit, :, 0] > 0).all() and (d[hit, :, 0] <= dt_max * 1.0001).all()
+    np.testing.assert_allclose(d[hit, 0, 1], nears[hit] + d[hit, 0, 0], rtol=1e-6)   # first sample sits at t = near
+    p = xyzs.reshape(64, 4, 3)[hit, 0]
+    np.testing.assert_allclose(p, np.clip(ro[hit] + nears[hit, None] * rd[hit], -1, 1), atol=1e-6)
+    np.testing.assert_array_equal(dirs.reshape(64, 4, 3)[hit, 2], rd[hit])
+
+
+# ---- GPU parity ----------------------------------------------------------------------------------------------------------
+def _mods():
+    sys.path.insert(0, os.path.join(ROOT, "mere-fusion_amd", "dropin"))
+    import _freqencoder, _gridencoder, _raymarching_face, _shencoder
+    return _raymarching_face, _gridencoder, _shencoder, _freqencoder
+
+
+def _cu(a):
+    return torch.from_numpy(a).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rays,cascades,n_step", [(4096, 1, 1), (4096, 1, 8), (1000, 2, 3), (262144, 1, 2)])
+def test_hip_near_far_and_march_bit_exact(lib_built, ref, n_rays, cascades, n_step):
+    rm = _mods()[0]
+    ro, rd, grid = _scene(n_rays, n_rays + cascades, cascades=cascades)
+    bound = float(2 ** (cascades - 1))
+    aabb = AABB * bound
+    nears_o, fars_o = o_near_far(ref, ro, rd, aabb, 0.05)
+    d_ro, d_rd = _cu(ro), _cu(rd)
+    nears, fars = torch.empty(n_rays, device="cuda"), torch.empty(n_rays, device="cuda")
+    rm.near_far_from_aabb(d_ro, d_rd, _cu(aabb), n_rays, 0.05, nears, fars)
+    np.testing.assert_array_equal(nears.cpu().numpy(), nears_o)
+    np.testing.assert_array_equal(fars.cpu().numpy(), fars_o)
+    rng = np.random.default_rng(7)
+    alive = rng.permutation(n_rays).astype(np.int32)[: max(1, n_rays * 3 // 4)]
+    noises = rng.random(alive.shape[0], np.float32)
+    rays_t = nears_o.copy()
+    want = o_march(ref, n_step, alive, rays_t, ro, rd, bound, 1 / 256, 16, cascades, 128, grid, nears_o, fars_o, noises)
+    na = alive.shape[0]
+    xyzs, dirs, deltas = (torch.zeros(na * n_step, k, device="cuda") for k in (3, 3, 2))
+    rm.march_rays(na, n_step, _cu(alive), _cu(rays_t), d_ro, d_rd, bound, 1 / 256, 16, cascades, 128, _cu(grid), nears, fars, xyzs, dirs,
+                  deltas, _cu(noises))
+    for got, w, name in zip((xyzs, dirs, deltas), want, ("xyzs", "dirs", "deltas")):
+        np.testing.assert_array_equal(got.cpu().numpy(), w, err_msg=name)
+    assert (want[2][:, 0] > 0).mean() > 0.05                                   # the scene does produce samples
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_alive,n_step", [(5000, 1), (5000, 4), (100000, 8)])
+def test_hip_composite_matches_oracle(lib_built, ref, n_alive, n_step):
+    rm = _mods()[0]
+    rng = np.random.default_rng(n_alive + n_step)
+    N = n_alive * 2
+    alive = rng.permutation(N).astype(np.int32)[:n_alive]
+    rays_t = rng.random(N, np.float32)
+    sig = (rng.random((n_alive, n_step), np.float32) * 40).astype(np.float32)
+    rgb = rng.random((n_alive, n_step, 3), np.float32)
+    dt = (rng.random((n_alive, n_step), np.float32) * 0.03 + 0.001).astype(np.float32)
+    dt[rng.random((n_alive, n_step)) < 0.1] = 0                                # "no sample" markers
+    deltas = np.stack([dt, np.cumsum(dt, 1) + 0.2], -1).astype(np.float32)
+    aa, ae, unc = (rng.random((n_alive, n_step), np.float32) for _ in range(3))
+    acc = dict(weights_sum=(rng.random(N, np.float32) * 0.999).astype(np.float32), depth=rng.random(N, np.float32), image=rng.random((N, 3), np.float32),
+               amb_aud_sum=rng.random(N, np.float32), amb_eye_sum=rng.random(N, np.float32), uncertainty_sum=rng.random(N, np.float32))
+    a_o, t_o, acc_o = o_composite(ref, n_step, 1e-4, alive, rays_t, sig, rgb, deltas, aa, ae, unc, acc)
+    d_alive, d_t = _cu(alive.copy()), _cu(rays_t.copy())
+    d_acc = {k: _cu(v.copy()) for k, v in acc.items()}
+    rm.composite_rays_triplane(n_alive, n_step, 1e-4, d_alive, d_t, _cu(sig), _cu(rgb), _cu(deltas), _cu(aa), _cu(ae), _cu(unc), d_acc["weights_sum"],
+                               d_acc["depth"], d_acc["image"], d_acc["amb_aud_sum"], d_acc["amb_eye_sum"], d_acc["uncertainty_sum"])
+    # __expf vs libm expf: a couple of ulp per alpha, accumulated over <= 8 steps; T_thresh decisions are far from the noise
+    np.testing.assert_array_equal(d_alive.cpu().numpy(), a_o)
+    np.testing.assert_array_equal(d_t.cpu().numpy(), t_o)
+    for k in acc:
+        np.testing.assert_allclose(d_acc[k].cpu().numpy(), acc_o[k], rtol=2e-6, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,Cc,L,H,pls,log2h,gridtype,align", [(2, 1, 12, 64, 1.31951, 14, 0, False), (2, 2, 16, 16, 1.38, 17, 1, False),
+                                                                (3, 2, 8, 16, 1.5, 12, 0, False), (2, 4, 4, 8, 2.0, 10, 0, True), (3, 8, 3, 4, 2.0, 19, 1, False)])
+def test_hip_grid_encoder_bit_exact(lib_built, ref, D, Cc, L, H, pls, log2h, gridtype, align):
+    ge = _mods()[1]
+    rng = np.random.default_rng(D * 100 + Cc)
+    offs = grid_offsets(D, L, H, pls, log2h, align)
+    emb = rng.uniform(-1e-1, 1e-1, (offs[-1], Cc)).astype(np.float32)
+    B = 20000
+    x = rng.random((B, D), np.float32)
+    x[:7] = [[0.0] * D, [1.0] * D, [1.0000001] * D, [-1e-7] * D, [0.5] * D, [0.999999] * D, [1e-7] * D]   # edges and out-of-range rows
+    S = float(np.log2(pls))
+    want = o_grid(ref, x, emb, offs, D, Cc, S, H, gridtype, int(align))
+    out = torch.empty(L, B, Cc, device="cuda")
+    ge.grid_encode_forward(_cu(x), _cu(emb), _cu(offs), out, B, D, Cc, L, S, H, None, gridtype, align)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    out2 = torch.empty(B, L * Cc, device="cuda")
+    ge.grid_encode_forward_blc(_cu(x), _cu(emb), _cu(offs), out2, B, D, Cc, L, S, H, gridtype, align)
+    np.testing.assert_array_equal(out2.cpu().numpy(), want.transpose(1, 0, 2).reshape(B, L * Cc))      # grid.py:52
+
+
+@pytest.mark.gpu
+def test_hip_sh_and_freq_encoders(lib_built, ref):
+    _, _, sh, fq = _mods()
+    rng = np.random.default_rng(3)
+    d = rng.standard_normal((50000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for degree in (1, 2, 3, 4):
+        out = torch.empty(d.shape[0], degree * degree, device="cuda")
+        sh.sh_encode_forward(_cu(d), out, d.shape[0], 3, degree, None)
+        np.testing.assert_array_equal(out.cpu().numpy(), o_sh(ref, d, degree))
+    for D, deg in ((2, 8), (6, 3), (3, 10)):                                    # forward_torso uses freq(2, 8) and freq(6, 3), network.py
+        x = rng.uniform(-1, 1, (4000, D)).astype(np.float32)
+        Cc = D + 2 * D * deg
+        out = torch.empty(4000, Cc, device="cuda")
+        fq.freq_encode_forward(_cu(x), 4000, D, deg, Cc, out)
+        want = o_freq(ref, x, deg)
+        # __sinf: absolute error ~ 2^-21 * |argument| (arguments reach 2^9); the identity columns are exact
+        np.testing.assert_array_equal(out.cpu().numpy()[:, :D], want[:, :D])
+        assert np.abs(out.cpu().numpy() - want).max() <= 5e-4 * (2.0 ** deg / 512) + 2e-6
+
+
+@pytest.mark.gpu
+def test_hip_shims_reject_cpu_tensors_and_training_calls(lib_built):
+    rm, ge, sh, fq = _mods()
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        rm.near_far_from_aabb(torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(6), 4, 0.05, torch.zeros(4), torch.zeros(4))
+    with pytest.raises(RuntimeError, match="training"):
+        rm.march_rays_train()
+    with pytest.raises(RuntimeError, match="training"):
+        ge.grid_encode_backward()
+    x = torch.zeros(4, 3, device="cuda")
+    with pytest.raises(RuntimeError, match="degree"):
+        sh.sh_encode_forward(x, torch.zeros(4, 25, device="cuda"), 4, 3, 5, None)
+
+
+@pytest.mark.gpu
+def test_hip_render_loop_properties_full_size(lib_built):
+    """cfg 5 size (512 x 512 rays): march -> (synthetic sigma / rgb) -> composite until no ray is alive, renderer.py:246-270.
+    Size-independent invariants: weights in [0, 1], every ray ends terminated, depth within [near, far], image within [0, 1]."""
+    rm = _mods()[0]
+    N = 512 * 512
+    ro, rd, grid = _scene(N, 5, density=0.5)
+    d_ro, d_rd, d_grid = _cu(ro), _cu(rd), _cu(grid)
+    nears, fars = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    rm.near_far_from_aabb(d_ro, d_rd, _cu(AABB), N, 0.05, nears, fars)
+    acc = {k: torch.zeros(N, device="cuda") for k in ("weights_sum", "depth", "amb_aud_sum", "amb_eye_sum", "uncertainty_sum")}
+    image = torch.zeros(N, 3, device="cuda")
+    alive = torch.arange(N, dtype=torch.int32, device="cuda")
+    rays_t = nears.clone()
+    step, max_steps = 0, 16
+    while step < max_steps:
+        if step > 0:
+            alive = alive[alive >= 0].contiguous()
+        n_alive = alive.shape[0]
+        if n_alive == 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        xyzs, dirs, deltas = (torch.zeros(n_alive * n_step, k, device="cuda") for k in (3, 3, 2))
+        rm.march_rays(n_alive, n_step, alive, rays_t, d_ro, d_rd, 1.0, 1 / 256, max_steps, 1, 128, d_grid, nears, fars, xyzs, dirs, deltas,
+                      torch.rand(n_alive, device="cuda"))
+        sig = (xyzs.abs().sum(1) * 30 + 5).contiguous()
+        rgb = (xyzs * 0.5 + 0.5).clamp(0, 1).contiguous()
+        z = torch.zeros(n_alive * n_step, device="cuda")
+        rm.composite_rays_triplane(n_alive, n_step, 1e-4, alive, rays_t, sig, rgb, deltas, z, z, z, acc["weights_sum"], acc["depth"], image,
+                                   acc["amb_aud_sum"], acc["amb_eye_sum"], acc["uncertainty_sum"])
+        step += n_step
+    w = acc["weights_sum"].cpu().numpy()
+    assert w.min() >= 0 and w.max() <= 1 + 1e-5 and (w > 0.5).mean() > 0.3
+    img = image.cpu().numpy()
+    assert img.min() >= 0 and img.max() <= 1 + 1e-5
+    hit = w > 1e-3
+    dep = acc["depth"].cpu().numpy()[hit] / w[hit]
+    assert (dep >= nears.cpu().numpy()[hit] - 1e-4).all() and (dep <= fars.cpu().numpy()[hit] + 0.05).all()
