@@ -261,6 +261,34 @@ int mf_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32
  * freqencoder.cu:30-58); outputs [B, D + 2*D*degree]. */
 int mf_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t degree, uint32_t C, float* outputs, void* stream);
 
+/* ---- ER-NeRF radiance field (H6) ---------------------------------------------------------- */
+typedef struct mf_nerf_field mf_nerf_field;
+typedef struct mf_nerf_field_config {
+    float bound;                 /* opt.bound (app.py:603): positions live in [-bound, bound] */
+    int num_levels;              /* 12 (network.py:122) */
+    int level_dim;               /* 1 */
+    int base_resolution;         /* 64 */
+    float log2_per_level_scale;  /* S of grid.py:33 */
+    int offsets[33];             /* GridEncoder.offsets (grid.py:108-123), num_levels + 1 entries */
+    int audio_dim;               /* 32 */
+    int geo_feat_dim;            /* 64 */
+    int hidden_dim;              /* 64 */
+    int individual_dim;          /* opt.ind_dim, 4 */
+    int exp_eye;                 /* opt.exp_eye */
+} mf_nerf_field_config;
+/* Replaces the inference half of `NeRFNetwork` (network.py:93-160): weights = the state-dict tensors
+ * "encoder_{xy,yz,xz}.embeddings", "{sigma_net,color_net,aud_ch_att_net,eye_att_net}.net.N.weight" (fp32, host). */
+int mf_nerf_field_create(const mf_nerf_field_config* cfg, const mf_tensor* weights, int n_weights, int precision,
+                         int max_samples, mf_nerf_field** out);
+/* Replaces `self.forward(xyzs, dirs, enc_a, ind_code, eye)` (renderer.py:260 -> network.py:249-277, density :280-308).
+ * xyzs, dirs: device fp32 [M,3]; enc_a: device fp32 [32]; ind_code: device fp32 [individual_dim] or NULL; eye: the
+ * scalar of opt.exp_eye.  Outputs (device fp32): sigmas [M], rgbs [M,3], amb_aud [M] (= ||aud_ch_att||), amb_eye [M],
+ * uncertainty [M] (ln 2 in test mode, may be NULL). */
+int mf_nerf_field_forward(mf_nerf_field* h, const float* xyzs, const float* dirs, const float* enc_a, const float* ind_code,
+                          float eye, int n_samples, float* sigmas, float* rgbs, float* amb_aud, float* amb_eye,
+                          float* uncertainty, void* stream);
+void mf_nerf_field_destroy(mf_nerf_field* h);
+
 #ifdef __cplusplus
 }
 #endif

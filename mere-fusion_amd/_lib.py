@@ -31,6 +31,12 @@ class MfUnetConfig(C.Structure):
                 ("up_attn", C.c_int * 4), ("sample_size", C.c_int), ("ctx_len", C.c_int)]
 
 
+class MfNerfFieldConfig(C.Structure):
+    _fields_ = [("bound", C.c_float), ("num_levels", C.c_int), ("level_dim", C.c_int), ("base_resolution", C.c_int),
+                ("log2_per_level_scale", C.c_float), ("offsets", C.c_int * 33), ("audio_dim", C.c_int), ("geo_feat_dim", C.c_int),
+                ("hidden_dim", C.c_int), ("individual_dim", C.c_int), ("exp_eye", C.c_int)]
+
+
 class MfVaeConfig(C.Structure):
     _fields_ = [("latent_channels", C.c_int), ("out_channels", C.c_int), ("n_blocks", C.c_int),
                 ("block_out_channels", C.c_int * 4), ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int),
@@ -97,6 +103,9 @@ SIGNATURES = {
     "mf_grid_encode_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_uint32] * 4 + [C.c_float, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "mf_sh_encode_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "mf_freq_encode_forward": (C.c_int, [C.c_void_p] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]),
+    "mf_nerf_field_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mf_nerf_field_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 6),
+    "mf_nerf_field_destroy": (None, [C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,300 @@
+// ER-NeRF radiance field on gfx950: tri-plane hash-grid features -> audio / eye attention -> sigma MLP -> colour MLP.
+//
+// Replaces `NeRFNetwork.forward` + `density` + `encode_x` (reference: ernerf/nerf_triplane/network.py:204-219, 249-308) for the
+// inference call `self.forward(xyzs, dirs, enc_a, ind_code, eye)` of the render loop (renderer.py:260): per sample 36 grid
+// features, SH(dir), and ten bias-free Linear layers (23 184 MACs).
+//
+// The reference runs ~10 tiny cuBLAS GEMMs plus cat / repeat / elementwise passes per loop iteration.  Here the samples are a
+// token sequence ([M/1024] "images" of 1 x 1024 tokens) and every Linear is a 1x1 convolution on the MFMA implicit-GEMM kernel
+// (mf_conv.hip) with its ReLU / sigmoid epilogue; the torch.cat calls disappear because producers write channel slices of the
+// consumer's input buffer:
+//     SI [72] = [ enc_x 36 | enc_a * aud_ch_att 32 | e * eye_att 1 | 0 0 0 ]        <- sigma_net input   (network.py:287-296)
+//     CI [96] = [ h0 | geo_feat 64 | 0 x7 | SH 16 | ind_code 4 | 0 x4 ]             <- colour_net input  (network.py:262-269)
+// sigma_net's last layer writes its 65 outputs straight into CI[0..64]; colour_net's weight columns are permuted to that layout
+// (and zero on h0), so geo_feat is never copied.
+#include "mf_nn.h"
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+extern "C" int mf_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B,
+                                      uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                      int out_blc, void* stream);
+
+namespace {
+
+constexpr int TW = 1024;          // tokens per "image" of the token buffers
+constexpr int ENC = 36, AUD = 32, GEO = 64, SHD = 16;
+constexpr int SI_C = 72, CI_C = 96, CI_SH = 72, CI_IND = 88;
+
+__device__ __forceinline__ uint32_t qf2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float qbf2f(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ void put(bf16_t* hi, bf16_t* lo, int64_t o, float v) {
+    const uint32_t h = qf2bf(v);
+    hi[o] = (bf16_t)h;
+    if (lo) lo[o] = (bf16_t)qf2bf(v - qbf2f(h));
+}
+__device__ __forceinline__ float get(const bf16_t* hi, const bf16_t* lo, int64_t o) {
+    float v = qbf2f(hi[o]);
+    if (lo) v += qbf2f(lo[o]);
+    return v;
+}
+
+// per sample: plane coordinates mapped to [0, 1] (grid.py:144 + network.py:204-208), SH basis of the view direction
+// (shencoder.cu:50-68, degree 4) and the individual code into the colour-net input
+__global__ __launch_bounds__(256) void k_nf_prep(const float* __restrict__ xyzs, const float* __restrict__ dirs, const float* __restrict__ ind,
+                                                 int n_ind, float bound, int M, float* coords, bf16_t* ci_hi, bf16_t* ci_lo) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float inv = 1.f / (2.f * bound);
+    const float x = (xyzs[3 * m] + bound) * inv, y = (xyzs[3 * m + 1] + bound) * inv, z = (xyzs[3 * m + 2] + bound) * inv;
+    float* cxy = coords + (size_t)m * 2;
+    float* cyz = coords + (size_t)M * 2 + (size_t)m * 2;
+    float* cxz = coords + (size_t)M * 4 + (size_t)m * 2;
+    cxy[0] = x; cxy[1] = y;
+    cyz[0] = y; cyz[1] = z;
+    cxz[0] = x; cxz[1] = z;
+    const float dx = dirs[3 * m], dy = dirs[3 * m + 1], dz = dirs[3 * m + 2];
+    const float xy = dx * dy, xz = dx * dz, yz = dy * dz, x2 = dx * dx, y2 = dy * dy, z2 = dz * dz;
+    float sh[SHD];
+    sh[0] = 0.28209479177387814f;
+    sh[1] = -0.48860251190291987f * dy; sh[2] = 0.48860251190291987f * dz; sh[3] = -0.48860251190291987f * dx;
+    sh[4] = 1.0925484305920792f * xy; sh[5] = -1.0925484305920792f * yz; sh[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    sh[7] = -1.0925484305920792f * xz; sh[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    sh[9] = 0.59004358992664352f * dy * (-3.0f * x2 + y2); sh[10] = 2.8906114426405538f * xy * dz;
+    sh[11] = 0.45704579946446572f * dy * (1.0f - 5.0f * z2); sh[12] = 0.3731763325901154f * dz * (5.0f * z2 - 3.0f);
+    sh[13] = 0.45704579946446572f * dx * (1.0f - 5.0f * z2); sh[14] = 1.4453057213202769f * dz * (x2 - y2);
+    sh[15] = 0.59004358992664352f * dx * (-x2 + 3.0f * y2);
+    const int64_t o = (int64_t)m * CI_C;
+#pragma unroll
+    for (int i = 0; i < SHD; ++i) put(ci_hi, ci_lo, o + CI_SH + i, sh[i]);
+    for (int i = 0; i < 8; ++i) put(ci_hi, ci_lo, o + CI_IND + i, i < n_ind ? ind[i] : 0.f);
+}
+
+// fp32 grid features [3][M][12] -> SI[m][0..35]
+__global__ __launch_bounds__(256) void k_nf_pack(const float* __restrict__ enc, int M, bf16_t* si_hi, bf16_t* si_lo) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * ENC) return;
+    const int m = (int)(idx / ENC), c = (int)(idx - (int64_t)m * ENC);
+    const int plane = c / 12, l = c - plane * 12;
+    put(si_hi, si_lo, (int64_t)m * SI_C + c, enc[((size_t)plane * M + m) * 12 + l]);
+}
+
+// enc_w = enc_a * aud_ch_att, e * eye_att into the sigma-net input; the two ambient outputs (network.py:284-306)
+__global__ __launch_bounds__(256) void k_nf_mix(const bf16_t* __restrict__ a_hi, const bf16_t* __restrict__ a_lo, const bf16_t* __restrict__ e_hi,
+                                                const bf16_t* __restrict__ e_lo, const float* __restrict__ enc_a, float eye, int has_eye, int M,
+                                                bf16_t* si_hi, bf16_t* si_lo, float* amb_aud, float* amb_eye) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float n2 = 0.f;
+    const int64_t so = (int64_t)m * SI_C + ENC;
+#pragma unroll 8
+    for (int c = 0; c < AUD; ++c) {
+        const float a = get(a_hi, a_lo, (int64_t)m * AUD + c);
+        n2 += a * a;
+        put(si_hi, si_lo, so + c, enc_a[c] * a);
+    }
+    amb_aud[m] = sqrtf(n2);
+    const float ea = has_eye ? get(e_hi, e_lo, (int64_t)m * 8) : 0.f;
+    put(si_hi, si_lo, so + AUD, has_eye ? eye * ea : 0.f);
+    put(si_hi, si_lo, so + AUD + 1, 0.f); put(si_hi, si_lo, so + AUD + 2, 0.f); put(si_hi, si_lo, so + AUD + 3, 0.f);
+    amb_eye[m] = ea;
+}
+
+// sigma = exp(h0) (network.py:300), colour = sigmoid(.) * 1.002 - 0.001 (network.py:272; the sigmoid ran in the GEMM epilogue),
+// uncertainty = log(1 + exp(0)) in test mode (network.py:240-246, 275)
+__global__ __launch_bounds__(256) void k_nf_out(const bf16_t* __restrict__ ci_hi, const bf16_t* __restrict__ ci_lo, const bf16_t* __restrict__ c_hi,
+                                                const bf16_t* __restrict__ c_lo, int M, float* sigmas, float* rgbs, float* unc) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    sigmas[m] = expf(get(ci_hi, ci_lo, (int64_t)m * CI_C));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgbs[3 * m + k] = get(c_hi, c_lo, (int64_t)m * 8 + k) * (1.f + 2.f * 0.001f) - 0.001f;
+    if (unc) unc[m] = 0.69314718055994530942f;
+}
+
+}  // namespace
+
+struct mf_nerf_field {
+    int precision = MF_PREC_BF16X3;
+    mf_nerf_field_config cfg{};
+    int cap_batches = 0;
+    std::vector<std::unique_ptr<ActBuf>> bufs;
+    std::vector<std::unique_ptr<ConvPlan>> plans;
+    std::vector<void*> dev;
+    ActBuf *SI = nullptr, *CI = nullptr, *T1 = nullptr, *AU = nullptr, *T2 = nullptr, *EY = nullptr, *S1 = nullptr, *S2 = nullptr, *C1 = nullptr, *RGB = nullptr;
+    ConvPlan *a1, *a2, *e1, *e2, *s1, *s2, *s3, *c1, *c2;
+    float* emb[3] = {nullptr, nullptr, nullptr};
+    float *coords = nullptr, *enc = nullptr, *d_enc_a = nullptr, *d_ind = nullptr;
+
+    ~mf_nerf_field() {
+        for (auto& p : plans) mf_conv_plan_destroy(p.get());
+        for (auto& b : bufs) { if (b->hi) (void)hipFree(b->hi); if (b->lo) (void)hipFree(b->lo); }
+        for (void* d : dev) (void)hipFree(d);
+    }
+    ActBuf* seq(int C) {
+        bufs.emplace_back(new ActBuf());
+        ActBuf* b = bufs.back().get();
+        b->C = C; b->H = 1; b->W = TW; b->halo = 0;
+        return b;
+    }
+    int alloc() {
+        for (auto& b : bufs) {
+            const size_t bytes = ((size_t)cap_batches * b->per_batch() + 64) * sizeof(bf16_t);
+            MF_HIP(hipMalloc(&b->hi, bytes)); MF_HIP(hipMemset(b->hi, 0, bytes));
+            if (precision == MF_PREC_BF16X3) { MF_HIP(hipMalloc(&b->lo, bytes)); MF_HIP(hipMemset(b->lo, 0, bytes)); }
+        }
+        return MF_OK;
+    }
+    // Linear(cin -> cout, bias=False) (network.py:79) as a 1x1 convolution; `w` is [cout][cin_buf] with the input-channel order of
+    // the buffer view it reads
+    int linear(ConvPlan** out, const std::vector<float>& w, int cin, int cout, int act, ActBuf* in) {
+        plans.emplace_back(new ConvPlan());
+        ConvPlan* p = plans.back().get();
+        mf_conv2d_desc d{};
+        d.cin = cin; d.cout = cout; d.kh = d.kw = 1; d.stride_h = d.stride_w = 1; d.act = act; d.in_h = 1; d.in_w = TW;
+        int rc = mf_conv_plan_create(p, d, w.data(), nullptr, nullptr, nullptr, nullptr, nullptr, precision);
+        if (rc) return rc;
+        if ((rc = mf_conv_bind(p, *in))) return rc;
+        *out = p;
+        return MF_OK;
+    }
+};
+
+static const mf_tensor* nf_find(const std::map<std::string, const mf_tensor*>& sd, const std::string& k, int64_t r, int64_t c) {
+    auto it = sd.find(k);
+    if (it == sd.end()) { mf_set_error("nerf_field_create: tensor '%s' missing", k.c_str()); return nullptr; }
+    const mf_tensor* t = it->second;
+    if (t->ndim != 2 || t->shape[0] != r || t->shape[1] != c) {
+        mf_set_error("nerf_field_create: '%s' has shape [%lld, %lld], expected [%lld, %lld]", k.c_str(), (long long)t->shape[0],
+                     (long long)(t->ndim > 1 ? t->shape[1] : 0), (long long)r, (long long)c);
+        return nullptr;
+    }
+    return t;
+}
+
+extern "C" int mf_nerf_field_create(const mf_nerf_field_config* cfg, const mf_tensor* weights, int n_weights, int precision,
+                                    int max_samples, mf_nerf_field** out) {
+    MF_REQUIRE(cfg && weights && out && n_weights > 0 && max_samples > 0, "nerf_field_create: bad argument");
+    MF_REQUIRE(precision == MF_PREC_BF16 || precision == MF_PREC_BF16X3, "nerf_field_create: unknown precision %d", precision);
+    MF_REQUIRE(cfg->num_levels == 12 && cfg->level_dim == 1 && cfg->audio_dim == AUD && cfg->geo_feat_dim == GEO && cfg->hidden_dim == 64,
+               "nerf_field_create: built for the reference's fixed field (12 levels x 1, audio 32, hidden 64, geo 64: network.py:122-143)");
+    MF_REQUIRE(cfg->individual_dim >= 0 && cfg->individual_dim <= 8 && cfg->bound > 0, "nerf_field_create: individual_dim / bound");
+    *out = nullptr;
+    std::map<std::string, const mf_tensor*> sd;
+    for (int i = 0; i < n_weights; ++i) {
+        MF_REQUIRE(weights[i].name && weights[i].data, "nerf_field_create: tensor %d has no name/data", i);
+        sd[weights[i].name] = &weights[i];
+    }
+    std::unique_ptr<mf_nerf_field> h(new mf_nerf_field());
+    h->precision = precision;
+    h->cfg = *cfg;
+    h->cap_batches = (max_samples + TW - 1) / TW;
+    const int n_emb = cfg->offsets[cfg->num_levels];
+    const int eye = cfg->exp_eye ? 1 : 0, nind = cfg->individual_dim;
+    const int sig_in = ENC + AUD + eye, col_in = SHD + GEO + nind;
+
+    h->SI = h->seq(SI_C); h->CI = h->seq(CI_C); h->T1 = h->seq(64); h->AU = h->seq(AUD); h->T2 = h->seq(16); h->EY = h->seq(8);
+    h->S1 = h->seq(64); h->S2 = h->seq(64); h->C1 = h->seq(64); h->RGB = h->seq(8);
+    int rc = h->alloc();
+    if (rc) return rc;
+    const size_t cap = (size_t)h->cap_batches * TW;
+    MF_HIP(hipMalloc(&h->coords, cap * 6 * sizeof(float))); h->dev.push_back(h->coords);
+    MF_HIP(hipMalloc(&h->enc, cap * ENC * sizeof(float))); h->dev.push_back(h->enc);
+    MF_HIP(hipMalloc(&h->d_enc_a, AUD * sizeof(float))); h->dev.push_back(h->d_enc_a);
+    MF_HIP(hipMalloc(&h->d_ind, 8 * sizeof(float))); h->dev.push_back(h->d_ind);
+    const char* planes[3] = {"encoder_xy.embeddings", "encoder_yz.embeddings", "encoder_xz.embeddings"};
+    for (int p = 0; p < 3; ++p) {
+        const mf_tensor* t = nf_find(sd, planes[p], n_emb, 1);
+        if (!t) return MF_ERR_INVALID;
+        MF_HIP(hipMalloc(&h->emb[p], (size_t)n_emb * sizeof(float))); h->dev.push_back(h->emb[p]);
+        MF_HIP(hipMemcpy(h->emb[p], t->data, (size_t)n_emb * sizeof(float), hipMemcpyHostToDevice));
+    }
+
+    // Linear weights, re-laid onto the channel order of the buffers they read (zero columns for padding / unused channels)
+    auto relay = [&](const char* name, int cout, int cin_ref, int cin_buf, const std::vector<int>& col_of, std::vector<float>& w) -> int {
+        const mf_tensor* t = nf_find(sd, name, cout, cin_ref);
+        if (!t) return MF_ERR_INVALID;
+        const float* src = (const float*)t->data;
+        w.assign((size_t)cout * cin_buf, 0.f);
+        for (int o = 0; o < cout; ++o)
+            for (int i = 0; i < cin_ref; ++i) w[(size_t)o * cin_buf + col_of[i]] = src[(size_t)o * cin_ref + i];
+        return MF_OK;
+    };
+    auto iota = [](int n, int start = 0) { std::vector<int> v(n); for (int i = 0; i < n; ++i) v[i] = start + i; return v; };
+    std::vector<float> w;
+    if ((rc = relay("aud_ch_att_net.net.0.weight", 64, ENC, 40, iota(ENC), w)) || (rc = h->linear(&h->a1, w, 40, 64, 1, h->SI))) return rc;
+    if ((rc = relay("aud_ch_att_net.net.1.weight", AUD, 64, 64, iota(64), w)) || (rc = h->linear(&h->a2, w, 64, AUD, 0, h->T1))) return rc;
+    if (eye) {
+        if ((rc = relay("eye_att_net.net.0.weight", 16, ENC, 40, iota(ENC), w)) || (rc = h->linear(&h->e1, w, 40, 16, 1, h->SI))) return rc;
+        if ((rc = relay("eye_att_net.net.1.weight", 1, 16, 16, iota(16), w)) || (rc = h->linear(&h->e2, w, 16, 1, 2, h->T2))) return rc;
+    }
+    if ((rc = relay("sigma_net.net.0.weight", 64, sig_in, SI_C, iota(sig_in), w)) || (rc = h->linear(&h->s1, w, SI_C, 64, 1, h->SI))) return rc;
+    if ((rc = relay("sigma_net.net.1.weight", 64, 64, 64, iota(64), w)) || (rc = h->linear(&h->s2, w, 64, 64, 1, h->S1))) return rc;
+    if ((rc = relay("sigma_net.net.2.weight", 1 + GEO, 64, 64, iota(64), w)) || (rc = h->linear(&h->s3, w, 64, 1 + GEO, 0, h->S2))) return rc;
+    {
+        // colour-net input order in the reference: [SH 16 | geo 64 | ind] (network.py:265); in CI: geo at 1..64, SH at 72.., ind at 88..
+        std::vector<int> col(col_in);
+        for (int i = 0; i < SHD; ++i) col[i] = CI_SH + i;
+        for (int i = 0; i < GEO; ++i) col[SHD + i] = 1 + i;
+        for (int i = 0; i < nind; ++i) col[SHD + GEO + i] = CI_IND + i;
+        if ((rc = relay("color_net.net.0.weight", 64, col_in, CI_C, col, w)) || (rc = h->linear(&h->c1, w, CI_C, 64, 1, h->CI))) return rc;
+    }
+    if ((rc = relay("color_net.net.1.weight", 3, 64, 64, iota(64), w)) || (rc = h->linear(&h->c2, w, 64, 3, 2, h->C1))) return rc;
+    MF_HIP(hipDeviceSynchronize());
+    *out = h.release();
+    return MF_OK;
+}
+
+extern "C" int mf_nerf_field_forward(mf_nerf_field* h, const float* xyzs, const float* dirs, const float* enc_a, const float* ind_code,
+                                     float eye, int n_samples, float* sigmas, float* rgbs, float* amb_aud, float* amb_eye,
+                                     float* uncertainty, void* stream) {
+    MF_REQUIRE(h && xyzs && dirs && enc_a && sigmas && rgbs && amb_aud && amb_eye, "nerf_field_forward: null argument");
+    MF_REQUIRE(n_samples >= 0 && n_samples <= h->cap_batches * TW, "nerf_field_forward: %d samples exceed the capacity %d", n_samples,
+               h->cap_batches * TW);
+    MF_REQUIRE(h->cfg.individual_dim == 0 || ind_code, "nerf_field_forward: the field was built with an individual code");
+    if (n_samples == 0) return MF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int M = n_samples, nb = (M + TW - 1) / TW, gb = (M + 255) / 256;
+    const bool x3 = h->precision == MF_PREC_BF16X3;
+    const mf_nerf_field_config& c = h->cfg;
+    MF_HIP(hipMemcpyAsync(h->d_enc_a, enc_a, AUD * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (c.individual_dim) MF_HIP(hipMemcpyAsync(h->d_ind, ind_code, c.individual_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_nf_prep, dim3(gb), dim3(256), 0, s, xyzs, dirs, h->d_ind, c.individual_dim, c.bound, M, h->coords, h->CI->hi, h->CI->lo);
+    MF_HIP(hipGetLastError());
+    int rc;
+    for (int p = 0; p < 3; ++p)
+        if ((rc = mf_grid_encode_forward(h->coords + (size_t)p * M * 2, h->emb[p], c.offsets, h->enc + (size_t)p * M * 12, M, 2, 1, 12,
+                                         c.log2_per_level_scale, c.base_resolution, 0, 0, 1, stream)))
+            return rc;
+    hipLaunchKernelGGL(k_nf_pack, dim3((unsigned)(((int64_t)M * ENC + 255) / 256)), dim3(256), 0, s, h->enc, M, h->SI->hi, h->SI->lo);
+    MF_HIP(hipGetLastError());
+    auto V = [](ActBuf* b, int coff, int C) { return ActView{b, coff, C}; };
+    if ((rc = mf_conv_launch(h->a1, V(h->SI, 0, 40), V(h->T1, 0, 64), ActView{}, nb, s))) return rc;
+    if ((rc = mf_conv_launch(h->a2, V(h->T1, 0, 64), V(h->AU, 0, AUD), ActView{}, nb, s))) return rc;
+    if (c.exp_eye) {
+        if ((rc = mf_conv_launch(h->e1, V(h->SI, 0, 40), V(h->T2, 0, 16), ActView{}, nb, s))) return rc;
+        if ((rc = mf_conv_launch(h->e2, V(h->T2, 0, 16), V(h->EY, 0, 1), ActView{}, nb, s))) return rc;
+    }
+    hipLaunchKernelGGL(k_nf_mix, dim3(gb), dim3(256), 0, s, h->AU->hi, h->AU->lo, h->EY->hi, h->EY->lo, h->d_enc_a, eye, c.exp_eye, M, h->SI->hi,
+                       h->SI->lo, amb_aud, amb_eye);
+    MF_HIP(hipGetLastError());
+    if ((rc = mf_conv_launch(h->s1, V(h->SI, 0, SI_C), V(h->S1, 0, 64), ActView{}, nb, s))) return rc;
+    if ((rc = mf_conv_launch(h->s2, V(h->S1, 0, 64), V(h->S2, 0, 64), ActView{}, nb, s))) return rc;
+    if ((rc = mf_conv_launch(h->s3, V(h->S2, 0, 64), V(h->CI, 0, 1 + GEO), ActView{}, nb, s))) return rc;
+    if ((rc = mf_conv_launch(h->c1, V(h->CI, 0, CI_C), V(h->C1, 0, 64), ActView{}, nb, s))) return rc;
+    if ((rc = mf_conv_launch(h->c2, V(h->C1, 0, 64), V(h->RGB, 0, 3), ActView{}, nb, s))) return rc;
+    hipLaunchKernelGGL(k_nf_out, dim3(gb), dim3(256), 0, s, h->CI->hi, x3 ? h->CI->lo : nullptr, h->RGB->hi, x3 ? h->RGB->lo : nullptr, M, sigmas, rgbs,
+                       uncertainty);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+extern "C" void mf_nerf_field_destroy(mf_nerf_field* h) { delete h; }

@@ -276,3 +276,25 @@ def make_musetalk_inputs(batch, seed=0, hw=32):
     lat = (rng.standard_normal((batch, 8, hw, hw)) * 0.9).astype(np.float32)
     aud = rng.standard_normal((batch, 50, 384)).astype(np.float32)
     return torch.from_numpy(lat), torch.from_numpy(aud)
+
+
+# ---- ER-NeRF radiance field (ernerf/nerf_triplane/network.py:93-160) -------------------------------------------------
+def make_ernerf_field_state_dict(n_embeddings, seed=0, individual_dim=4, exp_eye=True):
+    """Seeded stand-in for a trained `NeRFNetwork` checkpoint (missing from the reference checkout, .MISSING_LARGE_BLOBS):
+    the tensors of the inference field with trained-like magnitudes -- grid features O(1) (a fresh GridEncoder starts at
+    1e-4, grid.py:127-129, which would mute every downstream layer), He-scaled bias-free Linears (network.py:79)."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    sd = {}
+    for plane in ("xy", "yz", "xz"):
+        sd[f"encoder_{plane}.embeddings"] = torch.from_numpy(rng.uniform(-1.0, 1.0, (n_embeddings, 1)).astype(np.float32))
+    sig_in = 36 + 32 + (1 if exp_eye else 0)
+
+    def lin(name, dims):
+        for i, (o, c) in enumerate(dims):
+            sd[f"{name}.net.{i}.weight"] = torch.from_numpy((rng.standard_normal((o, c)) * np.sqrt(2.0 / c)).astype(np.float32))
+    lin("sigma_net", [(64, sig_in), (64, 64), (65, 64)])
+    lin("color_net", [(64, 16 + 64 + individual_dim), (3, 64)])
+    lin("aud_ch_att_net", [(64, 36), (32, 64)])
+    lin("eye_att_net", [(16, 36), (1, 16)])
+    return sd

@@ -1,0 +1,79 @@
+"""ORACLE (test infrastructure, not product): torch fp32 restatement of the ER-NeRF radiance field.
+
+Follows ernerf/nerf_triplane/network.py statement by statement: `encode_x` (:211-219, `split_xyz` :204-208), `density`
+(:280-308), `forward` (:249-277), `MLP.forward` (:82-90, bias-free Linears with ReLU between them).  The grid / SH encoders
+are the plain-C restatements of oracle/ernerf_ref.c, called exactly as `GridEncoder.forward` (grid.py:139-154) and
+`SHEncoder.forward` (sphere_harmonics.py:75-86) call their extension.
+
+PARITY UNPINNED: importing the reference's network.py JIT-compiles its CUDA extensions at import (raymarching.py:9-12), which
+this image cannot do, and the trained checkpoint is absent; the pure-torch algebra below is what the reference executes.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _clib():
+    return C.CDLL(os.path.join(HERE, "libernerfref.so"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def grid_encode(x01, emb, offsets, S, H, gridtype=0, align=0):
+    """`_grid_encode.forward` (grid.py:19-58): [B, D] in [0, 1] -> [B, L*C]."""
+    x01 = np.ascontiguousarray(x01, np.float32); emb = np.ascontiguousarray(emb, np.float32); offsets = np.ascontiguousarray(offsets, np.int32)
+    B, D = x01.shape
+    L, Cc = offsets.shape[0] - 1, emb.shape[1]
+    out = np.zeros((L, B, Cc), np.float32)
+    _clib().ref_grid_encode_forward(_p(x01), _p(emb), _p(offsets), _p(out), C.c_uint32(B), C.c_uint32(D), C.c_uint32(Cc), C.c_uint32(L),
+                                    C.c_float(S), C.c_uint32(H), C.c_uint32(gridtype), C.c_int(align))
+    return out.transpose(1, 0, 2).reshape(B, L * Cc)             # grid.py:52
+
+
+def sh_encode(d, degree=4):
+    d = np.ascontiguousarray(d, np.float32)
+    out = np.zeros((d.shape[0], degree * degree), np.float32)
+    _clib().ref_sh_encode_forward(_p(d), _p(out), C.c_uint32(d.shape[0]), C.c_uint32(degree))
+    return out
+
+
+def mlp(sd, name, x):
+    n = sum(1 for k in sd if k.startswith(name + ".net.") and k.endswith(".weight"))
+    for l in range(n):
+        x = x @ sd[f"{name}.net.{l}.weight"].t()
+        if l != n - 1:
+            x = torch.relu(x)
+    return x
+
+
+def field_forward(sd, x, d, enc_a, c, e, offsets, S, H=64, bound=1.0):
+    """NeRFNetwork.forward (network.py:249-277) in test mode.  x, d: [M, 3] tensors; enc_a [1, 32]; c [1, ind] or None; e [1, 1] or None."""
+    xn = x.numpy().astype(np.float32)
+    planes = (xn[:, :2], xn[:, 1:], np.concatenate([xn[:, :1], xn[:, -1:]], -1))      # split_xyz
+    feats = []
+    for name, pl in zip(("xy", "yz", "xz"), planes):
+        x01 = ((pl + np.float32(bound)) / np.float32(2 * bound)).astype(np.float32)   # grid.py:144
+        feats.append(grid_encode(x01, sd[f"encoder_{name}.embeddings"].numpy(), offsets, S, H))
+    enc_x = torch.from_numpy(np.concatenate(feats, -1))
+    aud_ch_att = mlp(sd, "aud_ch_att_net", enc_x)
+    enc_w = enc_a.repeat(enc_x.shape[0], 1) * aud_ch_att
+    if e is not None:
+        eye_att = torch.sigmoid(mlp(sd, "eye_att_net", enc_x))
+        h = torch.cat([enc_x, enc_w, e * eye_att], -1)
+    else:
+        eye_att = torch.zeros(enc_x.shape[0], 1)
+        h = torch.cat([enc_x, enc_w], -1)
+    h = mlp(sd, "sigma_net", h)
+    sigma = torch.exp(h[..., 0])
+    geo_feat = h[..., 1:]
+    enc_d = torch.from_numpy(sh_encode(d.numpy()))
+    hc = torch.cat([enc_d, geo_feat] + ([c.repeat(x.shape[0], 1)] if c is not None else []), -1)
+    color = torch.sigmoid(mlp(sd, "color_net", hc)) * (1 + 2 * 0.001) - 0.001
+    unc = torch.log(1 + torch.exp(torch.zeros(x.shape[0], 1)))
+    return sigma, color, aud_ch_att.norm(dim=-1, keepdim=True), eye_att, unc

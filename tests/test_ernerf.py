@@ -373,3 +373,58 @@ def test_hip_render_loop_properties_full_size(lib_built):
     hit = w > 1e-3
     dep = acc["depth"].cpu().numpy()[hit] / w[hit]
     assert (dep >= nears.cpu().numpy()[hit] - 1e-4).all() and (dep <= fars.cpu().numpy()[hit] + 0.05).all()
+
+
+# ---- radiance field (a18-a20): tri-plane features + attention + sigma / colour MLPs ---------------------------------------------
+def _field_case(M, seed, bound=1.0):
+    from mere_fusion_amd import weights as W
+    from mere_fusion_amd.ernerf.field import grid_geometry
+    offsets, pls = grid_geometry(desired_resolution=512 * bound)
+    sd = W.make_ernerf_field_state_dict(int(offsets[-1]), seed)
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(M, 3, generator=g) * 2 - 1) * torch.tensor([1.0, 0.5, 1.0]) * bound
+    d = torch.randn(M, 3, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    enc_a = torch.randn(1, 32, generator=g)
+    c = torch.randn(1, 4, generator=g) * 0.1
+    e = torch.tensor([[0.4]])
+    return sd, offsets, float(np.log2(pls)), x, d, enc_a, c, e
+
+
+def test_oracle_field_shapes_and_structure(ref):
+    from oracle import ernerf_net_ref as NR
+    sd, offsets, S, x, d, enc_a, c, e = _field_case(300, 0)
+    assert offsets[-1] == sd["encoder_xy.embeddings"].shape[0] and offsets.shape == (13,)
+    sigma, color, aa, ae, unc = NR.field_forward(sd, x, d, enc_a, c, e, offsets, S)
+    assert sigma.shape == (300,) and color.shape == (300, 3) and aa.shape == (300, 1) and ae.shape == (300, 1)
+    assert (sigma > 0).all() and (color > -0.001 - 1e-6).all() and (color < 1.001 + 1e-6).all()
+    assert ((ae > 0) & (ae < 1)).all() and torch.allclose(unc, torch.full((300, 1), float(np.log(2.0))))
+    # the audio branch only enters through enc_a * aud_ch_att: a zero audio feature must equal dropping those 32 columns
+    s0 = NR.field_forward(sd, x, d, torch.zeros(1, 32), c, e, offsets, S)[0]
+    sd2 = dict(sd); sd2["sigma_net.net.0.weight"] = sd["sigma_net.net.0.weight"].clone(); sd2["sigma_net.net.0.weight"][:, 36:68] = 0
+    assert torch.allclose(s0, NR.field_forward(sd2, x, d, enc_a, c, e, offsets, S)[0], rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 1000, 1024, 5000, 262144])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_hip_field_matches_oracle(lib_built, ref, M, precision):
+    from mere_fusion_amd.ernerf.field import HipNeRFField
+    from oracle import ernerf_net_ref as NR
+    if M > 10000 and precision == "bf16":
+        pytest.skip("full-size case once")
+    sd, offsets, S, x, d, enc_a, c, e = _field_case(M, M % 97)
+    f = HipNeRFField(sd, bound=1.0, individual_dim=4, exp_eye=True, precision=precision, max_samples=max(M, 2048))
+    got = f.forward(x.cuda(), d.cuda(), enc_a.cuda(), c.cuda(), e.cuda())
+    n = min(M, 20000)                                                         # oracle on a leading slice of the big case
+    want = NR.field_forward(sd, x[:n], d[:n], enc_a, c, e, offsets, S)
+    # the reference runs these MLPs in fp16 (autocast, utils.py:1200); bf16x3 is tighter than that, plain bf16 comparable
+    tol = 2e-4 if precision == "bf16x3" else 6e-2
+    ls_got, ls_want = torch.log(got[0][:n].cpu()), torch.log(want[0])
+    assert (ls_got - ls_want).abs().max() <= tol * 4, "log sigma"
+    assert (got[1][:n].cpu() - want[1]).abs().max() <= tol, "rgb"
+    assert ((got[2][:n].cpu() - want[2]).abs() / (1 + want[2].abs())).max() <= tol, "ambient_aud"
+    assert (got[3][:n].cpu() - want[3]).abs().max() <= tol, "ambient_eye"
+    assert torch.equal(got[4].cpu(), torch.full((M, 1), float(np.float32(np.log(2.0)))))
+    if M >= 5000:
+        assert torch.isfinite(got[0]).all() and torch.isfinite(got[1]).all()
