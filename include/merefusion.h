@@ -261,6 +261,13 @@ int mf_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32
  * freqencoder.cu:30-58); outputs [B, D + 2*D*degree]. */
 int mf_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t degree, uint32_t C, float* outputs, void* stream);
 
+/* Tail of `run_cuda` (renderer.py:275-280) and the uint8 conversion of nerfreal.py:111, in place:
+ * image[N,3] = clamp(image + (1 - weights_sum) * bg, 0, 1); depth[N] = clamp(depth - near, 0) / (far - near);
+ * frame_u8 (optional, may be NULL) = uint8(image * 255), truncating like ndarray.astype.  bg_color: device fp32 [N,3]
+ * (bg_per_ray != 0), [3], or NULL for the scalar bg_const (`bg_color = 1`, renderer.py:309-310). */
+int mf_nerf_finish(float* image, float* depth, const float* weights_sum, const float* nears, const float* fars, const float* bg_color,
+                   int bg_per_ray, float bg_const, uint32_t n_rays, uint8_t* frame_u8, void* stream);
+
 /* ---- ER-NeRF radiance field (H6) ---------------------------------------------------------- */
 typedef struct mf_nerf_field mf_nerf_field;
 typedef struct mf_nerf_field_config {

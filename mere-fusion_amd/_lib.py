@@ -103,6 +103,7 @@ SIGNATURES = {
     "mf_grid_encode_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_uint32] * 4 + [C.c_float, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "mf_sh_encode_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "mf_freq_encode_forward": (C.c_int, [C.c_void_p] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]),
+    "mf_nerf_finish": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mf_nerf_field_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mf_nerf_field_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 6),
     "mf_nerf_field_destroy": (None, [C.c_void_p]),

@@ -314,6 +314,24 @@ __global__ __launch_bounds__(NT) void k_freq_encode(const float* __restrict__ in
     }
 }
 
+// tail of run_cuda (renderer.py:275-280) + the uint8 conversion of nerfreal.py:111: image = clamp(image + (1 - w) * bg, 0, 1),
+// depth = clamp(depth - near, 0) / (far - near); frame = uint8(image * 255) (numpy astype truncates)
+__global__ __launch_bounds__(NT) void k_nerf_finish(float* image, float* depth, const float* __restrict__ weights_sum,
+                                                    const float* __restrict__ nears, const float* __restrict__ fars,
+                                                    const float* __restrict__ bg, int bg_per_ray, float bg_const, uint32_t N, uint8_t* frame) {
+    const uint32_t n = threadIdx.x + blockIdx.x * NT;
+    if (n >= N) return;
+    const float t = 1 - weights_sum[n];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float b = bg ? (bg_per_ray ? bg[3 * n + k] : bg[k]) : bg_const;
+        const float v = fminf(fmaxf(image[3 * n + k] + t * b, 0.f), 1.f);
+        image[3 * n + k] = v;
+        if (frame) frame[3 * n + k] = (uint8_t)(v * 255.f);
+    }
+    depth[n] = fmaxf(depth[n] - nears[n], 0.f) / (fars[n] - nears[n]);
+}
+
 inline unsigned blocks(uint64_t n) { return (unsigned)((n + NT - 1) / NT); }
 
 }  // namespace
@@ -404,6 +422,16 @@ extern "C" int mf_freq_encode_forward(const float* inputs, uint32_t B, uint32_t 
     MF_REQUIRE(D >= 1 && C == D + D * degree * 2, "freq_encode_forward: output_dim %u != D + 2*D*degree (freq.py:62)", C);
     if ((uint64_t)B * C == 0) return MF_OK;
     hipLaunchKernelGGL(k_freq_encode, dim3(blocks((uint64_t)B * C)), dim3(NT), 0, (hipStream_t)stream, inputs, B, D, C, outputs);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+extern "C" int mf_nerf_finish(float* image, float* depth, const float* weights_sum, const float* nears, const float* fars, const float* bg_color,
+                              int bg_per_ray, float bg_const, uint32_t n_rays, uint8_t* frame_u8, void* stream) {
+    MF_REQUIRE(image && depth && weights_sum && nears && fars, "nerf_finish: null argument");
+    if (n_rays == 0) return MF_OK;
+    hipLaunchKernelGGL(k_nerf_finish, dim3(blocks(n_rays)), dim3(NT), 0, (hipStream_t)stream, image, depth, weights_sum, nears, fars, bg_color,
+                       bg_per_ray, bg_const, n_rays, frame_u8);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

@@ -1,0 +1,70 @@
+"""The head render loop of ER-NeRF on MI355X: the inference branch of `NeRFRenderer.run_cuda`
+(ernerf/nerf_triplane/renderer.py:158-291) over the HIP kernels, one frame per call.
+
+The reference's own renderer keeps working unchanged on top of the extension shims (dropin/_raymarching_face.py ...) and a
+`model.forward = HipNeRFField(...).forward` hook; this module is the same loop without the torch.autograd wrappers, used by
+bench.py / smoke() / the tests, and it is what `nerfreal.py:render` amounts to per frame once torso and audio nets are fixed.
+The compaction `rays_alive[rays_alive >= 0]` (renderer.py:266) and its host sync are kept as in the reference."""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from . import _raymarching_face as rm
+
+
+class HipHeadRenderer:
+    def __init__(self, field, density_bitfield, bound=1.0, min_near=0.05, density_scale=1.0, grid_size=128):
+        import math
+        self.field = field
+        self.bound, self.min_near, self.density_scale, self.grid_size = float(bound), float(min_near), float(density_scale), int(grid_size)
+        self.cascade = 1 + math.ceil(math.log2(bound))                                   # renderer.py:69
+        self.bitfield = density_bitfield.contiguous()
+        b = self.bound
+        self.aabb_infer = torch.tensor([-b, -b / 2, -b, b, b / 2, b], dtype=torch.float32, device=density_bitfield.device)   # renderer.py:86-89
+        self._lib = _lib.lib()
+
+    @torch.no_grad()
+    def run_cuda(self, rays_o, rays_d, enc_a, ind_code, eye, bg_color=None, dt_gamma=1 / 256, max_steps=16, T_thresh=1e-4, perturb=False,
+                 want_u8=False):
+        """rays_o / rays_d: [N, 3] (or [1, N, 3]) CUDA fp32.  Returns image [N, 3] in [0, 1], depth [N], the ambient / weight sums and,
+        with want_u8, the uint8 frame of nerfreal.py:111."""
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N, dev = rays_o.shape[0], rays_o.device
+        nears, fars = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        rm.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, N, self.min_near, nears, fars)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        weights_sum, depth, image = z(N), z(N), z(N, 3)
+        amb_aud_sum, amb_eye_sum, unc_sum = z(N), z(N), z(N)
+        rays_alive = torch.arange(N, dtype=torch.int32, device=dev)
+        rays_t = nears.clone()
+        step = 0
+        trace = []
+        while step < max_steps:
+            n_alive = rays_alive.shape[0]
+            if n_alive <= 0:
+                break
+            n_step = max(min(N // n_alive, 8), 1)                                        # renderer.py:256
+            M = n_alive * n_step
+            xyzs, dirs, deltas = z(M, 3), z(M, 3), z(M, 2)                                # raymarching.py:383-385
+            noises = torch.rand(n_alive, device=dev) if (perturb and step == 0) else z(n_alive)
+            rm.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, dt_gamma, max_steps, self.cascade, self.grid_size,
+                          self.bitfield, nears, fars, xyzs, dirs, deltas, noises)
+            sigmas, rgbs, amb_aud, amb_eye, unc = self.field.forward(xyzs, dirs, enc_a, ind_code, eye)
+            if self.density_scale != 1.0:
+                sigmas = self.density_scale * sigmas
+            rm.composite_rays_triplane(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, amb_aud.view(-1), amb_eye.view(-1),
+                                       unc.view(-1), weights_sum, depth, image, amb_aud_sum, amb_eye_sum, unc_sum)
+            rays_alive = rays_alive[rays_alive >= 0]                                     # renderer.py:266
+            trace.append((n_alive, n_step))
+            step += n_step
+        frame = torch.empty(N, 3, dtype=torch.uint8, device=dev) if want_u8 else None
+        per_ray = torch.is_tensor(bg_color) and bg_color.numel() == 3 * N
+        bg = bg_color.float().contiguous() if torch.is_tensor(bg_color) else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(self._lib.mf_nerf_finish(p(image), p(depth), p(weights_sum), p(nears), p(fars), p(bg), int(per_ray),
+                                            float(1.0 if bg_color is None else (0.0 if bg is not None else bg_color)), N, p(frame),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mf_nerf_finish")
+        return {"image": image, "depth": depth, "ambient_aud": amb_aud_sum, "ambient_eye": amb_eye_sum, "uncertainty": unc_sum,
+                "weights_sum": weights_sum, "frame_u8": frame, "trace": trace}

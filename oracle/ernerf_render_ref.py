@@ -1,0 +1,58 @@
+"""ORACLE (test infrastructure, not product): CPU restatement of the inference branch of `NeRFRenderer.run_cuda`
+(ernerf/nerf_triplane/renderer.py:231-291) over the plain-C kernel restatements (oracle/ernerf_ref.c) and the torch field
+restatement (oracle/ernerf_net_ref.py).  PARITY UNPINNED like its parts.  Only tests/, smoke() and bench.py's cpu_baseline
+leg may import this module."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import ernerf_net_ref as NR
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_p = lambda a: a.ctypes.data_as(C.c_void_p)
+F = lambda *s: np.zeros(s, np.float32)
+
+
+def run_cuda(sd, offsets, S, rays_o, rays_d, enc_a, ind_code, eye, bitfield, bound=1.0, min_near=0.05, bg_color=1.0, dt_gamma=1 / 256,
+             max_steps=16, T_thresh=1e-4, H=128, field=None, density_scale=1.0):
+    lib = C.CDLL(os.path.join(HERE, "libernerfref.so"))
+    ro = np.ascontiguousarray(rays_o, np.float32).reshape(-1, 3); rd = np.ascontiguousarray(rays_d, np.float32).reshape(-1, 3)
+    N = ro.shape[0]
+    cascade = 1 + math.ceil(math.log2(bound))
+    aabb = np.array([-bound, -bound / 2, -bound, bound, bound / 2, bound], np.float32)
+    nears, fars = F(N), F(N)
+    lib.ref_near_far_from_aabb(_p(ro), _p(rd), _p(aabb), C.c_uint32(N), C.c_float(min_near), _p(nears), _p(fars))
+    weights_sum, depth, image = F(N), F(N), F(N, 3)
+    aa_sum, ae_sum, un_sum = F(N), F(N), F(N)
+    alive = np.arange(N, dtype=np.int32)
+    rays_t = nears.copy()
+    step, trace = 0, []
+    field = field or (lambda x, d: NR.field_forward(sd, x, d, enc_a, ind_code, eye, offsets, S, bound=bound))
+    while step < max_steps:
+        n_alive = alive.shape[0]
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        M = n_alive * n_step
+        xyzs, dirs, deltas = F(M, 3), F(M, 3), F(M, 2)
+        noises = F(n_alive)
+        lib.ref_march_rays(C.c_uint32(n_alive), C.c_uint32(n_step), _p(alive), _p(rays_t), _p(ro), _p(rd), C.c_float(bound), C.c_float(dt_gamma),
+                           C.c_uint32(max_steps), C.c_uint32(cascade), C.c_uint32(H), _p(bitfield), _p(nears), _p(fars), _p(xyzs), _p(dirs),
+                           _p(deltas), _p(noises))
+        sig, rgb, aa, ae, un = field(torch.from_numpy(xyzs), torch.from_numpy(dirs))
+        sig, rgb = np.ascontiguousarray((density_scale * sig).numpy(), np.float32), np.ascontiguousarray(rgb.numpy(), np.float32)   # renderer.py:261
+        aa, ae, un = (np.ascontiguousarray(t.numpy().reshape(-1), np.float32) for t in (aa, ae, un))
+        alive = alive.copy()
+        lib.ref_composite_rays_triplane(C.c_uint32(n_alive), C.c_uint32(n_step), C.c_float(T_thresh), _p(alive), _p(rays_t), _p(sig), _p(rgb),
+                                        _p(deltas), _p(aa), _p(ae), _p(un), _p(weights_sum), _p(depth), _p(image), _p(aa_sum), _p(ae_sum), _p(un_sum))
+        alive = alive[alive >= 0]
+        trace.append((n_alive, n_step))
+        step += n_step
+    bg = np.broadcast_to(np.asarray(bg_color, np.float32), (N, 3)) if np.ndim(bg_color) else np.float32(bg_color)
+    img = np.clip(image + (1 - weights_sum)[:, None] * bg, 0, 1).astype(np.float32)            # renderer.py:275-277
+    dep = np.maximum(depth - nears, 0) / (fars - nears)                                       # renderer.py:279
+    return {"image": img, "depth": dep.astype(np.float32), "ambient_aud": aa_sum, "ambient_eye": ae_sum, "weights_sum": weights_sum, "trace": trace,
+            "frame_u8": (img * 255).astype(np.uint8)}

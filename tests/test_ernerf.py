@@ -428,3 +428,73 @@ def test_hip_field_matches_oracle(lib_built, ref, M, precision):
     assert torch.equal(got[4].cpu(), torch.full((M, 1), float(np.float32(np.log(2.0)))))
     if M >= 5000:
         assert torch.isfinite(got[0]).all() and torch.isfinite(got[1]).all()
+
+
+# ---- a15: the head render loop ---------------------------------------------------------------------------------------------------
+def _sphere_bitfield(H=128, radius=0.45):
+    """Occupancy of a ball, in the Morton order march_rays reads (raymarching.cu:889-890)."""
+    i = np.arange(H, dtype=np.uint32)
+    x, y, z = np.meshgrid(i, i, i, indexing="ij")
+    c = (np.stack([x, y, z], -1).astype(np.float32) + 0.5) / H * 2 - 1
+    occ = (np.linalg.norm(c, axis=-1) < radius).reshape(-1)
+
+    def expand(v):
+        v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
+        v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
+        v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
+        v = (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
+        return v
+    m = (expand(x.reshape(-1)) | (expand(y.reshape(-1)) << 1) | (expand(z.reshape(-1)) << 2)).astype(np.int64)
+    bits = np.zeros(H ** 3, np.uint8)
+    bits[m] = occ
+    return np.packbits(bits, bitorder="little")
+
+
+def _camera_rays(W):
+    u = (np.arange(W, dtype=np.float32) + 0.5) / W * 2 - 1
+    px, py = np.meshgrid(u, u)
+    d = np.stack([px * 0.35, py * 0.35, np.ones_like(px)], -1).reshape(-1, 3)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o = np.tile(np.array([[0.02, -0.01, -2.2]], np.float32), (W * W, 1))
+    return o, d
+
+
+def test_sphere_bitfield_matches_oracle_morton(ref):
+    bf = _sphere_bitfield(32, 0.5)
+    idx = ref.ref_morton3d(16, 16, 16)
+    assert bf[idx // 8] & (1 << (idx % 8))                                      # centre voxel occupied
+    idx = ref.ref_morton3d(0, 31, 5)
+    assert not (bf[idx // 8] & (1 << (idx % 8)))                                # corner voxel empty
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W", [48, 512])
+def test_hip_render_loop_matches_oracle(lib_built, ref, W):
+    from mere_fusion_amd.ernerf.field import HipNeRFField
+    from mere_fusion_amd.ernerf.renderer import HipHeadRenderer
+    from oracle import ernerf_render_ref as RR
+    sd, offsets, S, _, _, enc_a, c, e = _field_case(8, 3)
+    sd = {k: (v * 0.35 if k.startswith("sigma_net.net.2") else v) for k, v in sd.items()}          # keep sigma = exp(h0) in a sane range
+    bitfield = _sphere_bitfield()
+    ro, rd = _camera_rays(W)
+    field = HipNeRFField(sd, max_samples=W * W)
+    r = HipHeadRenderer(field, torch.from_numpy(bitfield).cuda(), density_scale=40.0)
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    got = r.run_cuda(_cu(ro), _cu(rd), enc_a.cuda(), c.cuda(), e.cuda(), bg_color=bg, want_u8=True)
+    img = got["image"].cpu().numpy()
+    w = got["weights_sum"].cpu().numpy()
+    assert img.min() >= 0 and img.max() <= 1 and w.max() <= 1 + 1e-5
+    hit = w > 0.5
+    assert 0.02 < hit.mean() < 0.6                                               # the ball covers part of the view
+    np.testing.assert_allclose(img[w == 0], np.broadcast_to([0.1, 0.2, 0.3], img[w == 0].shape), atol=1e-6)   # misses show the background
+    assert np.array_equal(got["frame_u8"].cpu().numpy(), (img * 255).astype(np.uint8))           # nerfreal.py:111 truncation
+    assert sum(a * s for a, s in got["trace"]) <= 16 * W * W
+    if W > 64:
+        return                                                                  # the CPU restatement of the full frame takes minutes
+    want = RR.run_cuda(sd, offsets, S, ro, rd, enc_a, c, e, bitfield, bg_color=np.array([0.1, 0.2, 0.3], np.float32), density_scale=40.0)
+    assert [t[1] for t in got["trace"]] == [t[1] for t in want["trace"]]
+    assert all(abs(a[0] - b[0]) <= max(2, 0.002 * b[0]) for a, b in zip(got["trace"], want["trace"]))   # T_thresh ties may move a ray
+    err = np.abs(img - want["image"]).max(1)
+    assert np.quantile(err, 0.995) <= 1e-3 and err.max() <= 2e-2, (np.quantile(err, 0.995), err.max())
+    derr = np.abs(got["depth"].cpu().numpy() - want["depth"])
+    assert np.quantile(derr, 0.995) <= 1e-3
