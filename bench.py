@@ -286,12 +286,87 @@ def wav2lip_report(args, device, world, rank, value=None, ms_per_step=None, run=
     return out
 
 
+class ErNeRFRunner:
+    """configs[4]: one 512 x 512 head frame per step -- near/far, march -> field -> composite until no ray is alive
+    (renderer.py:231-291), synthetic ball-shaped occupancy grid, seeded field weights, rays resident in HBM."""
+
+    def __init__(self, precision, width, device, seed=0):
+        from mere_fusion_amd.ernerf.field import HipNeRFField, grid_geometry
+        from mere_fusion_amd.ernerf.renderer import HipHeadRenderer
+        self.width = width
+        offsets, pls = grid_geometry()
+        sd = W.make_ernerf_field_state_dict(int(offsets[-1]), seed)
+        self.sd = {k: (v * 0.35 if k.startswith("sigma_net.net.2") else v) for k, v in sd.items()}
+        self.offsets, self.S = offsets, float(np.log2(pls))
+        self.bitfield = W.make_ernerf_sphere_bitfield()
+        ro, rd = W.make_ernerf_camera_rays(width)
+        self.ro_h, self.rd_h = ro, rd
+        self.ro, self.rd = torch.from_numpy(ro).to(device), torch.from_numpy(rd).to(device)
+        g = torch.Generator().manual_seed(seed)
+        self.enc_a, self.ind, self.eye = torch.randn(1, 32, generator=g), torch.randn(1, 4, generator=g) * 0.1, torch.tensor([[0.4]])
+        self.d_enc_a, self.d_ind, self.d_eye = self.enc_a.to(device), self.ind.to(device), self.eye.to(device)
+        self.field = HipNeRFField(self.sd, precision=precision, max_samples=width * width, device=device)
+        self.r = HipHeadRenderer(self.field, torch.from_numpy(self.bitfield).to(device), density_scale=40.0)
+        self.last = None
+
+    def step(self):
+        self.last = self.r.run_cuda(self.ro, self.rd, self.d_enc_a, self.d_ind, self.d_eye, bg_color=1.0, want_u8=True)
+
+    def samples_per_frame(self):
+        return sum(a * s for a, s in self.last["trace"])
+
+    def parity(self, width=48):
+        from mere_fusion_amd.ernerf.field import HipNeRFField
+        from mere_fusion_amd.ernerf.renderer import HipHeadRenderer
+        from oracle import ernerf_render_ref as RR
+        ro, rd = W.make_ernerf_camera_rays(width)
+        dev = self.ro.device
+        r = HipHeadRenderer(self.field, torch.from_numpy(self.bitfield).to(dev), density_scale=40.0)
+        got = r.run_cuda(torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev), self.d_enc_a, self.d_ind, self.d_eye, bg_color=1.0)
+        want = RR.run_cuda(self.sd, self.offsets, self.S, ro, rd, self.enc_a, self.ind, self.eye, self.bitfield, bg_color=1.0, density_scale=40.0)
+        err = np.abs(got["image"].cpu().numpy() - want["image"]).max(1)
+        return {"image_linf_p995_vs_oracle": float(np.quantile(err, 0.995)), "image_linf_max": float(err.max()), "rays": width * width,
+                "oracle": "parity unpinned (CUDA reference cannot run here): oracle/ernerf_render_ref.py"}
+
+    def cpu_baseline(self, seconds, threads, width=64):
+        from oracle import ernerf_render_ref as RR
+        torch.set_num_threads(threads)
+        ro, rd = W.make_ernerf_camera_rays(width)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds or n == 0:
+            RR.run_cuda(self.sd, self.offsets, self.S, ro, rd, self.enc_a, self.ind, self.eye, self.bitfield, bg_color=1.0, density_scale=40.0)
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+        scale = (self.width * self.width) / (width * width)
+        return {"value": round(1.0 / (dt * scale), 3), "unit": "frames/s", "cores": threads, "kind": "port",
+                "sample": f"{n} frames of {width}x{width} rays through the C / torch restatement, scaled by ray count to {self.width}x{self.width}"}
+
+
+def ernerf_report(args, device, world, rank, value=None, ms_per_step=None, run=None):
+    """The configs[4] leg (ER-NeRF 512x512).  Headline when --workload ernerf, else an extra object."""
+    if run is None:
+        run = ErNeRFRunner(args.precision, 512, device, seed=rank)
+        steps = 20
+        el = harness.timed_steps(run.step, steps, 3, sync_fn=torch.cuda.synchronize)
+        value, ms_per_step = steps / el, el / steps * 1e3
+    smp = run.samples_per_frame()
+    rep = {"workload": "ER-NeRF head frame 512x512 rays: near/far + (march -> tri-plane field -> composite) x <= 16 steps, synthetic occupancy, "
+                       "rays resident in HBM (BASELINE.json configs[4])",
+           "value": round(value, 1), "unit": "frames/s", "ms_per_step": round(ms_per_step, 3), "dtype": args.precision,
+           "samples_per_frame": int(smp), "march_iterations": len(run.last["trace"]),
+           "field_tflops_algorithmic": round(smp * 46368 * value / max(world, 1) / 1e12, 2)}
+    rep["parity"] = run.parity()
+    if args.cpu_seconds > 0:
+        rep["cpu_baseline"] = run.cpu_baseline(min(args.cpu_seconds, 10.0), host_threads(args.cpu_threads))
+    return rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 40 for musetalk, 200 for wav2lip)")
     ap.add_argument("--warmup", type=int, default=0, help="untimed warm-up steps (default: 5 / 20)")
-    ap.add_argument("--workload", default="musetalk", choices=["musetalk", "wav2lip"])
+    ap.add_argument("--workload", default="musetalk", choices=["musetalk", "wav2lip", "ernerf"])
     ap.add_argument("--batch", type=int, default=8, help="MuseTalk frames per step (configs[2]: 8)")
     ap.add_argument("--w2l-batch", type=int, default=16, help="Wav2Lip frames per step (configs[1]: 16)")
     ap.add_argument("--precision", default=os.environ.get("MF_PRECISION", "bf16x3"), choices=sorted(MFMA_PASSES))
@@ -303,9 +378,9 @@ def main():
     ap.add_argument("--extras", type=int, default=1, help="0: only the headline workload (no second workload, alt mode, CPU legs)")
     args = ap.parse_args()
     if args.steps <= 0:
-        args.steps = 40 if args.workload == "musetalk" else 200
+        args.steps = {"musetalk": 40, "ernerf": 30}.get(args.workload, 200)
     if args.warmup <= 0:
-        args.warmup = 5 if args.workload == "musetalk" else 20
+        args.warmup = {"musetalk": 5, "ernerf": 3}.get(args.workload, 20)
 
     rank, local_rank, world = harness.init_dist("nccl")
     if world != args.gpus:
@@ -316,7 +391,24 @@ def main():
     torch.cuda.set_device(local_rank)
     extras = bool(args.extras) and world == 1
 
-    if args.workload == "wav2lip":
+    if args.workload == "ernerf":
+        run = ErNeRFRunner(args.precision, 512, device, seed=rank)
+        elapsed = harness.timed_steps(run.step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=device)
+        value = harness.aggregate_value(1, args.steps, elapsed, world)
+        if rank == 0:
+            if not extras:
+                args.cpu_seconds = 0
+            rep = ernerf_report(args, device, world, rank, value, elapsed / args.steps * 1e3, run)
+            line = {"metric": "lip-sync frames/sec", "value": rep["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": args.precision, "data": "synthetic",
+                    "config": {"workload": rep["workload"] + "; seeded random-init field", "sessions_at_25fps": round(value / 25.0, 1),
+                               "parallelism": f"{world} independent replicas, sessions sharded by GPU, no collective"}}
+            for k in ("samples_per_frame", "march_iterations", "field_tflops_algorithmic", "parity", "cpu_baseline"):
+                if k in rep:
+                    line[k] = rep[k]
+            print(json.dumps(line), flush=True)
+    elif args.workload == "wav2lip":
         run = Runner(args.precision, args.w2l_batch, device, seed=rank)
         elapsed = harness.timed_steps(run.step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=device)
         value = harness.aggregate_value(args.w2l_batch, args.steps, elapsed, world)
@@ -382,6 +474,7 @@ def main():
                 dl = args.dump_layers
                 args.dump_layers = dl + ".wav2lip.json" if dl else None
                 line["wav2lip"] = wav2lip_report(args, device, world, rank)
+                line["ernerf"] = ernerf_report(args, device, world, rank)
             print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -119,6 +119,9 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is not built. Run `python -m mere_fusion_amd.build` (needs hipcc); "
                 "this package has no CPU fallback.")
+        # torch first: its wheel carries its own HIP / HSA runtime, and device buffers are torch's.  Loading this library
+        # before torch would bring a second runtime (/opt/rocm) into the process, which then sees no device.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)

@@ -298,3 +298,33 @@ def make_ernerf_field_state_dict(n_embeddings, seed=0, individual_dim=4, exp_eye
     lin("aud_ch_att_net", [(64, 36), (32, 64)])
     lin("eye_att_net", [(16, 36), (1, 16)])
     return sd
+
+
+def make_ernerf_sphere_bitfield(H=128, radius=0.45):
+    """Synthetic `density_bitfield` (renderer.py:113): occupancy of a ball at the origin, one bit per voxel in the Morton order
+    `march_rays` reads (raymarching.cu:56-71, 889-890), cascade 0 only."""
+    i = np.arange(H, dtype=np.uint32)
+    x, y, z = np.meshgrid(i, i, i, indexing="ij")
+    c = (np.stack([x, y, z], -1).astype(np.float32) + 0.5) / H * 2 - 1
+    occ = (np.linalg.norm(c, axis=-1) < radius).reshape(-1)
+
+    def expand(v):
+        v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
+        v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
+        v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
+        v = (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
+        return v
+    m = (expand(x.reshape(-1)) | (expand(y.reshape(-1)) << 1) | (expand(z.reshape(-1)) << 2)).astype(np.int64)
+    bits = np.zeros(H ** 3, np.uint8)
+    bits[m] = occ
+    return np.packbits(bits, bitorder="little")
+
+
+def make_ernerf_camera_rays(W):
+    """W x W pinhole rays looking down +z at the unit box from z = -2.2 (what `get_rays`, utils.py, produces for a frontal pose)."""
+    u = (np.arange(W, dtype=np.float32) + 0.5) / W * 2 - 1
+    px, py = np.meshgrid(u, u)
+    d = np.stack([px * 0.35, py * 0.35, np.ones_like(px)], -1).reshape(-1, 3)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o = np.tile(np.array([[0.02, -0.01, -2.2]], np.float32), (W * W, 1))
+    return o, d

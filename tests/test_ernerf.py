@@ -432,31 +432,13 @@ def test_hip_field_matches_oracle(lib_built, ref, M, precision):
 
 # ---- a15: the head render loop ---------------------------------------------------------------------------------------------------
 def _sphere_bitfield(H=128, radius=0.45):
-    """Occupancy of a ball, in the Morton order march_rays reads (raymarching.cu:889-890)."""
-    i = np.arange(H, dtype=np.uint32)
-    x, y, z = np.meshgrid(i, i, i, indexing="ij")
-    c = (np.stack([x, y, z], -1).astype(np.float32) + 0.5) / H * 2 - 1
-    occ = (np.linalg.norm(c, axis=-1) < radius).reshape(-1)
-
-    def expand(v):
-        v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
-        v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
-        v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
-        v = (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
-        return v
-    m = (expand(x.reshape(-1)) | (expand(y.reshape(-1)) << 1) | (expand(z.reshape(-1)) << 2)).astype(np.int64)
-    bits = np.zeros(H ** 3, np.uint8)
-    bits[m] = occ
-    return np.packbits(bits, bitorder="little")
+    from mere_fusion_amd import weights as W
+    return W.make_ernerf_sphere_bitfield(H, radius)
 
 
-def _camera_rays(W):
-    u = (np.arange(W, dtype=np.float32) + 0.5) / W * 2 - 1
-    px, py = np.meshgrid(u, u)
-    d = np.stack([px * 0.35, py * 0.35, np.ones_like(px)], -1).reshape(-1, 3)
-    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
-    o = np.tile(np.array([[0.02, -0.01, -2.2]], np.float32), (W * W, 1))
-    return o, d
+def _camera_rays(W_):
+    from mere_fusion_amd import weights as W
+    return W.make_ernerf_camera_rays(W_)
 
 
 def test_sphere_bitfield_matches_oracle_morton(ref):
