@@ -328,3 +328,21 @@ def make_ernerf_camera_rays(W):
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     o = np.tile(np.array([[0.02, -0.01, -2.2]], np.float32), (W * W, 1))
     return o, d
+
+
+def make_ernerf_audio_state_dict(template, seed=0):
+    """Seeded tensors for `audio_net.*` / `audio_att_net.*` (network.py:9-66) with the shapes of `template` (a state dict of the
+    reference module or of a fixture): He-scaled weights, small biases, from numpy PCG64 so they do not depend on torch's RNG."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(2000 + seed))
+    sd = {}
+    for k in sorted(template):
+        if not k.startswith(("audio_net.", "audio_att_net.")):
+            continue
+        shape = tuple(template[k].shape)
+        if k.endswith("weight"):
+            fan_in = int(np.prod(shape[1:]))
+            sd[k] = torch.from_numpy((rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32))
+        else:
+            sd[k] = torch.from_numpy((rng.standard_normal(shape) * 0.05).astype(np.float32))
+    return sd

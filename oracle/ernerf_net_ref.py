@@ -5,8 +5,9 @@ Follows ernerf/nerf_triplane/network.py statement by statement: `encode_x` (:211
 are the plain-C restatements of oracle/ernerf_ref.c, called exactly as `GridEncoder.forward` (grid.py:139-154) and
 `SHEncoder.forward` (sphere_harmonics.py:75-86) call their extension.
 
-PARITY UNPINNED: importing the reference's network.py JIT-compiles its CUDA extensions at import (raymarching.py:9-12), which
-this image cannot do, and the trained checkpoint is absent; the pure-torch algebra below is what the reference executes.
+PINNED above the extension boundary: tests/golden/make_ernerf_golden.py runs the reference's own `NeRFNetwork.forward` on the CPU of
+the build container (its CUDA extensions replaced by oracle/ernerf_ref.c) and tests/test_ernerf.py checks this restatement against
+that fixture (sigma rtol 2e-5, colour 2e-6).  The extension kernels themselves stay unpinned (see ernerf_ref.c).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module."""
 import ctypes as C
 import os

@@ -1,6 +1,7 @@
 """ORACLE (test infrastructure, not product): CPU restatement of the inference branch of `NeRFRenderer.run_cuda`
 (ernerf/nerf_triplane/renderer.py:231-291) over the plain-C kernel restatements (oracle/ernerf_ref.c) and the torch field
-restatement (oracle/ernerf_net_ref.py).  PARITY UNPINNED like its parts.  Only tests/, smoke() and bench.py's cpu_baseline
+restatement (oracle/ernerf_net_ref.py).  PINNED above the extension boundary: the fixture of tests/golden/make_ernerf_golden.py holds a
+24 x 24 frame rendered by the reference's own `NeRFRenderer.run_cuda`; this loop reproduces it to 2e-6.  Only tests/, smoke() and bench.py's cpu_baseline
 leg may import this module."""
 import ctypes as C
 import math

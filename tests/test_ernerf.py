@@ -480,3 +480,71 @@ def test_hip_render_loop_matches_oracle(lib_built, ref, W):
     assert np.quantile(err, 0.995) <= 1e-3 and err.max() <= 2e-2, (np.quantile(err, 0.995), err.max())
     derr = np.abs(got["depth"].cpu().numpy() - want["depth"])
     assert np.quantile(derr, 0.995) <= 1e-3
+
+
+# ---- goldens produced by the REFERENCE's own Python (tests/golden/make_ernerf_golden.py) -------------------------------------------
+@pytest.fixture(scope="module")
+def nerf_golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ernerf_golden.npz"))
+
+
+def _golden_field_sd(g):
+    from mere_fusion_amd import weights as W
+    sd = W.make_ernerf_field_state_dict(int(g["offsets"][-1]), 0)
+    return {k: (v * 0.35 if k.startswith("sigma_net.net.2") else v) for k, v in sd.items()}
+
+
+def test_oracle_field_matches_reference_golden(ref, nerf_golden):
+    """Pins oracle/ernerf_net_ref.py to `NeRFNetwork.forward` as the reference executes it (above the extension boundary)."""
+    from mere_fusion_amd.ernerf.field import grid_geometry
+    from oracle import ernerf_net_ref as NR
+    g = nerf_golden
+    offsets, pls = grid_geometry()
+    assert np.array_equal(offsets, g["offsets"]) and np.float32(np.log2(pls)) == g["log2_per_level_scale"]     # GridEncoder.__init__
+    t = lambda k: torch.from_numpy(g[k])
+    got = NR.field_forward(_golden_field_sd(g), t("field_x"), t("field_d"), t("field_enc_a"), t("field_c"), t("field_e"), offsets,
+                           float(g["log2_per_level_scale"]))
+    np.testing.assert_allclose(got[0].numpy(), g["field_sigma"], rtol=2e-5)
+    np.testing.assert_allclose(got[1].numpy(), g["field_color"], atol=2e-6)
+    np.testing.assert_allclose(got[2].numpy(), g["field_amb_aud"], rtol=2e-5)
+    np.testing.assert_allclose(got[3].numpy(), g["field_amb_eye"], atol=2e-6)
+    assert list(g["field_unc_shape"]) == [400, 36, 1] and np.allclose(g["field_unc_first"], np.log(2.0))            # the zeros_like(enc_x) quirk
+
+
+def test_oracle_render_loop_matches_reference_golden(ref, nerf_golden):
+    """Pins oracle/ernerf_render_ref.py to the inference branch of the reference's `run_cuda` (renderer.py:231-291)."""
+    from mere_fusion_amd import weights as W
+    from oracle import ernerf_render_ref as RR
+    g = nerf_golden
+    Wd = int(g["render_W"])
+    ro, rd = W.make_ernerf_camera_rays(Wd)
+    want = RR.run_cuda(_golden_field_sd(g), g["offsets"], float(g["log2_per_level_scale"]), ro, rd, torch.from_numpy(g["enc_audio"]),
+                       torch.from_numpy(g["render_ind_code"])[None], torch.from_numpy(g["field_e"]), W.make_ernerf_sphere_bitfield(),
+                       bg_color=np.array([0.1, 0.2, 0.3], np.float32), density_scale=40.0)
+    np.testing.assert_allclose(want["image"], g["render_image"], atol=2e-6)
+    np.testing.assert_allclose(want["depth"], g["render_depth"], atol=2e-6)
+    np.testing.assert_allclose(want["ambient_aud"], g["render_amb_aud"], rtol=1e-5, atol=1e-5)
+    assert (g["render_image"].std(0) > 0.01).all()                              # the golden frame is not flat
+
+
+@pytest.mark.gpu
+def test_hip_field_and_render_match_reference_golden(lib_built, nerf_golden):
+    from mere_fusion_amd import weights as W
+    from mere_fusion_amd.ernerf.field import HipNeRFField
+    from mere_fusion_amd.ernerf.renderer import HipHeadRenderer
+    g = nerf_golden
+    cu = lambda k: torch.from_numpy(g[k]).cuda()
+    field = HipNeRFField(_golden_field_sd(g), max_samples=4096)
+    sig, rgb, aa, ae, un = field.forward(cu("field_x"), cu("field_d"), cu("field_enc_a"), cu("field_c"), cu("field_e"))
+    assert (torch.log(sig.cpu()) - torch.log(torch.from_numpy(g["field_sigma"]))).abs().max() <= 8e-4
+    assert (rgb.cpu() - torch.from_numpy(g["field_color"])).abs().max() <= 2e-4
+    assert (ae.cpu() - torch.from_numpy(g["field_amb_eye"])).abs().max() <= 2e-4
+    assert ((aa.cpu() - torch.from_numpy(g["field_amb_aud"])).abs() / (1 + torch.from_numpy(g["field_amb_aud"]))).max() <= 2e-4
+    Wd = int(g["render_W"])
+    ro, rd = W.make_ernerf_camera_rays(Wd)
+    r = HipHeadRenderer(field, torch.from_numpy(W.make_ernerf_sphere_bitfield()).cuda(), density_scale=40.0)
+    got = r.run_cuda(_cu(ro), _cu(rd), cu("enc_audio"), torch.from_numpy(g["render_ind_code"])[None].cuda(), cu("field_e"),
+                     bg_color=torch.tensor([0.1, 0.2, 0.3], device="cuda"))
+    err = np.abs(got["image"].cpu().numpy() - g["render_image"]).max(1)
+    assert np.quantile(err, 0.99) <= 1e-3 and err.max() <= 2e-2, (np.quantile(err, 0.99), err.max())
+    assert np.quantile(np.abs(got["depth"].cpu().numpy() - g["render_depth"]), 0.99) <= 1e-3
