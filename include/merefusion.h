@@ -296,6 +296,15 @@ int mf_nerf_field_forward(mf_nerf_field* h, const float* xyzs, const float* dirs
                           float* uncertainty, void* stream);
 void mf_nerf_field_destroy(mf_nerf_field* h);
 
+/* ---- ER-NeRF audio features ------------------------------------------------------------------- */
+typedef struct mf_audio_encoder mf_audio_encoder;
+/* weights: "audio_net.*" and (use_att) "audio_att_net.*" of the NeRFNetwork state dict (network.py:9-66), fp32 host. */
+int mf_audio_encoder_create(const mf_tensor* weights, int n_weights, int use_att, mf_audio_encoder** out);
+/* Replaces `NeRFNetwork.encode_audio(a)` (network.py:222-237): auds device fp32 [n_windows, audio_in_dim, 16]
+ * (8 windows with the attention net, 1 without) -> enc_a device fp32 [32]. */
+int mf_audio_encoder_forward(mf_audio_encoder* h, const float* auds, int n_windows, float* enc_a, void* stream);
+void mf_audio_encoder_destroy(mf_audio_encoder* h);
+
 #ifdef __cplusplus
 }
 #endif

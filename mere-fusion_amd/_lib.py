@@ -107,6 +107,9 @@ SIGNATURES = {
     "mf_nerf_field_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mf_nerf_field_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 6),
     "mf_nerf_field_destroy": (None, [C.c_void_p]),
+    "mf_audio_encoder_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mf_audio_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mf_audio_encoder_destroy": (None, [C.c_void_p]),
 }
 
 _lib = None

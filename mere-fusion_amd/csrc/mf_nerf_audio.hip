@@ -1,0 +1,167 @@
+// ER-NeRF audio feature path on gfx950: AudioNet (4 strided Conv1d + 2 Linear) on each of the 8 windows, then AudioAttNet
+// (5 Conv1d + Linear(8, 8) + softmax) pooling them into one 32-vector.
+//
+// Replaces `NeRFNetwork.encode_audio` (reference: ernerf/nerf_triplane/network.py:222-237 -> AudioNet :40-66, AudioAttNet :9-36),
+// which runs once per frame on an [8, audio_in_dim, 16] window: ~0.3 MFLOP, pure launch latency in the reference (about 25
+// kernels).  Here it is ONE workgroup, fp32, every intermediate in LDS.
+#include "mf_common.h"
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int SEQ = 8, WIN = 16, AUD_DIM = 32;
+constexpr int MAX_ACT = 8 * 64 * 16;     // largest intermediate: 8 windows x 64 channels x 16 steps (the input for in_dim <= 64)
+
+struct Layer { const float* w; const float* b; int cin, cout; };
+struct AudioArgs {
+    Layer conv[4];       // AudioNet.encoder_conv, Conv1d(k3, s2, p1) + LeakyReLU(0.02)
+    Layer fc[2];         // AudioNet.encoder_fc1: Linear + LeakyReLU, Linear
+    Layer att[5];        // AudioAttNet.attentionConvNet, Conv1d(k3, s1, p1) + LeakyReLU(0.02)
+    Layer att_fc;        // AudioAttNet.attentionNet: Linear(8, 8) + Softmax
+    int in_dim, use_att;
+};
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.02f * v; }
+
+// out[n][co][t] = act(b[co] + sum_{ci,k} w[co][ci][k] * in[n][ci][t*stride + k - 1]), zero padding 1
+__device__ void conv1d(const float* in, float* out, const Layer& L, int n, int tin, int stride, bool act) {
+    const int tout = (tin + 2 - 3) / stride + 1;
+    for (int idx = threadIdx.x; idx < n * L.cout * tout; idx += blockDim.x) {
+        const int t = idx % tout, co = (idx / tout) % L.cout, b = idx / (tout * L.cout);
+        float acc = L.b[co];
+        for (int ci = 0; ci < L.cin; ++ci) {
+            const float* wr = L.w + ((size_t)co * L.cin + ci) * 3;
+            const float* xr = in + ((size_t)b * L.cin + ci) * tin;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int ti = t * stride + k - 1;
+                if (ti >= 0 && ti < tin) acc += wr[k] * xr[ti];
+            }
+        }
+        out[idx] = act ? lrelu(acc) : acc;
+    }
+    __syncthreads();
+}
+
+// out[n][o] = act(b[o] + sum_i w[o][i] * in[n][i])
+__device__ void linear(const float* in, float* out, const Layer& L, int n, bool act) {
+    for (int idx = threadIdx.x; idx < n * L.cout; idx += blockDim.x) {
+        const int o = idx % L.cout, b = idx / L.cout;
+        float acc = L.b[o];
+        for (int i = 0; i < L.cin; ++i) acc += L.w[(size_t)o * L.cin + i] * in[(size_t)b * L.cin + i];
+        out[idx] = act ? lrelu(acc) : acc;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_audio_encode(const AudioArgs a, const float* __restrict__ auds, int n_win, float* enc_a) {
+    __shared__ float bufA[MAX_ACT], bufB[MAX_ACT / 2];
+    __shared__ float feat[SEQ * AUD_DIM];
+    // network.py:61-62: the centre 16 steps of the window (win_size 16 -> all of them)
+    for (int i = threadIdx.x; i < n_win * a.in_dim * WIN; i += blockDim.x) bufA[i] = auds[i];
+    __syncthreads();
+    conv1d(bufA, bufB, a.conv[0], n_win, 16, 2, true);
+    conv1d(bufB, bufA, a.conv[1], n_win, 8, 2, true);
+    conv1d(bufA, bufB, a.conv[2], n_win, 4, 2, true);
+    conv1d(bufB, bufA, a.conv[3], n_win, 2, 2, true);        // [n, 64, 1]
+    linear(bufA, bufB, a.fc[0], n_win, true);
+    linear(bufB, feat, a.fc[1], n_win, false);               // [n, 32]
+    if (!a.use_att || n_win != SEQ) {
+        // att == 0: encode_audio returns audio_net's output as is (network.py:230-235); callers pass one window then
+        for (int i = threadIdx.x; i < AUD_DIM; i += blockDim.x) enc_a[i] = feat[i];
+        return;
+    }
+    // AudioAttNet: y = x.permute(0, 2, 1) -> [1, 32, 8]
+    for (int i = threadIdx.x; i < SEQ * AUD_DIM; i += blockDim.x) { const int t = i % SEQ, c = i / SEQ; bufA[c * SEQ + t] = feat[t * AUD_DIM + c]; }
+    __syncthreads();
+    conv1d(bufA, bufB, a.att[0], 1, SEQ, 1, true);
+    conv1d(bufB, bufA, a.att[1], 1, SEQ, 1, true);
+    conv1d(bufA, bufB, a.att[2], 1, SEQ, 1, true);
+    conv1d(bufB, bufA, a.att[3], 1, SEQ, 1, true);
+    conv1d(bufA, bufB, a.att[4], 1, SEQ, 1, true);           // [1, 1, 8]
+    linear(bufB, bufA, a.att_fc, 1, false);                  // [1, 8]
+    if (threadIdx.x == 0) {
+        float m = bufA[0];
+        for (int t = 1; t < SEQ; ++t) m = fmaxf(m, bufA[t]);
+        float s = 0.f;
+        for (int t = 0; t < SEQ; ++t) { bufA[t] = expf(bufA[t] - m); s += bufA[t]; }
+        for (int t = 0; t < SEQ; ++t) bufA[t] /= s;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < AUD_DIM; c += blockDim.x) {    // torch.sum(y * x, dim=1), network.py:36
+        float acc = 0.f;
+        for (int t = 0; t < SEQ; ++t) acc += bufA[t] * feat[t * AUD_DIM + c];
+        enc_a[c] = acc;
+    }
+}
+
+}  // namespace
+
+struct mf_audio_encoder {
+    AudioArgs a{};
+    std::vector<float*> dev;
+    ~mf_audio_encoder() { for (float* d : dev) (void)hipFree(d); }
+};
+
+extern "C" int mf_audio_encoder_create(const mf_tensor* weights, int n_weights, int use_att, mf_audio_encoder** out) {
+    MF_REQUIRE(weights && out && n_weights > 0, "audio_encoder_create: bad argument");
+    *out = nullptr;
+    std::map<std::string, const mf_tensor*> sd;
+    for (int i = 0; i < n_weights; ++i) {
+        MF_REQUIRE(weights[i].name && weights[i].data, "audio_encoder_create: tensor %d has no name/data", i);
+        sd[weights[i].name] = &weights[i];
+    }
+    std::unique_ptr<mf_audio_encoder> h(new mf_audio_encoder());
+    auto up = [&](const std::string& k, int64_t n, const float** dst) -> int {
+        auto it = sd.find(k);
+        if (it == sd.end()) { mf_set_error("audio_encoder_create: tensor '%s' missing", k.c_str()); return MF_ERR_INVALID; }
+        int64_t have = 1;
+        for (int d = 0; d < it->second->ndim; ++d) have *= it->second->shape[d];
+        if (have != n) { mf_set_error("audio_encoder_create: '%s' has %lld elements, expected %lld", k.c_str(), (long long)have, (long long)n); return MF_ERR_INVALID; }
+        float* dptr = nullptr;
+        MF_HIP(hipMalloc(&dptr, n * sizeof(float)));
+        h->dev.push_back(dptr);
+        MF_HIP(hipMemcpy(dptr, it->second->data, n * sizeof(float), hipMemcpyHostToDevice));
+        *dst = dptr;
+        return MF_OK;
+    };
+    auto layer = [&](const std::string& p, int cin, int cout, int k, Layer* L) -> int {
+        L->cin = cin; L->cout = cout;
+        int rc = up(p + ".weight", (int64_t)cout * cin * k, &L->w);
+        return rc ? rc : up(p + ".bias", cout, &L->b);
+    };
+    auto it = sd.find("audio_net.encoder_conv.0.weight");
+    MF_REQUIRE(it != sd.end() && it->second->ndim == 3 && it->second->shape[0] == 32 && it->second->shape[2] == 3,
+               "audio_encoder_create: audio_net.encoder_conv.0.weight [32, in_dim, 3] missing");
+    const int in_dim = (int)it->second->shape[1];
+    MF_REQUIRE(in_dim >= 1 && in_dim <= 64, "audio_encoder_create: audio_in_dim %d (1..64 built: esperanto 44, deepspeech 29, default 32; hubert's 1024 is not)", in_dim);
+    h->a.in_dim = in_dim;
+    h->a.use_att = use_att ? 1 : 0;
+    int rc;
+    const int cc[5] = {in_dim, 32, 32, 64, 64};                 // network.py:46-53 (Sequential indices 0, 2, 4, 6)
+    for (int i = 0; i < 4; ++i)
+        if ((rc = layer("audio_net.encoder_conv." + std::to_string(2 * i), cc[i], cc[i + 1], 3, &h->a.conv[i]))) return rc;
+    if ((rc = layer("audio_net.encoder_fc1.0", 64, 64, 1, &h->a.fc[0])) || (rc = layer("audio_net.encoder_fc1.2", 64, AUD_DIM, 1, &h->a.fc[1]))) return rc;
+    if (use_att) {
+        const int ac[6] = {AUD_DIM, 16, 8, 4, 2, 1};            // network.py:14-24
+        for (int i = 0; i < 5; ++i)
+            if ((rc = layer("audio_att_net.attentionConvNet." + std::to_string(2 * i), ac[i], ac[i + 1], 3, &h->a.att[i]))) return rc;
+        if ((rc = layer("audio_att_net.attentionNet.0", SEQ, SEQ, 1, &h->a.att_fc))) return rc;
+    }
+    *out = h.release();
+    return MF_OK;
+}
+
+extern "C" int mf_audio_encoder_forward(mf_audio_encoder* h, const float* auds, int n_windows, float* enc_a, void* stream) {
+    MF_REQUIRE(h && auds && enc_a, "audio_encoder_forward: null argument");
+    MF_REQUIRE(h->a.use_att ? n_windows == SEQ : n_windows == 1,
+               "audio_encoder_forward: %d windows (the attention net pools exactly 8, network.py:10; without it one window)", n_windows);
+    hipLaunchKernelGGL(k_audio_encode, dim3(1), dim3(256), 0, (hipStream_t)stream, h->a, auds, n_windows, enc_a);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+extern "C" void mf_audio_encoder_destroy(mf_audio_encoder* h) { delete h; }

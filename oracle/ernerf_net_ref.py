@@ -78,3 +78,22 @@ def field_forward(sd, x, d, enc_a, c, e, offsets, S, H=64, bound=1.0):
     color = torch.sigmoid(mlp(sd, "color_net", hc)) * (1 + 2 * 0.001) - 0.001
     unc = torch.log(1 + torch.exp(torch.zeros(x.shape[0], 1)))
     return sigma, color, aud_ch_att.norm(dim=-1, keepdim=True), eye_att, unc
+
+
+def encode_audio(sd, a, att=2):
+    """NeRFNetwork.encode_audio (network.py:222-237) with emb off: AudioNet (:40-66) on every window, AudioAttNet (:9-36) over the 8."""
+    F = torch.nn.functional
+    x = a[:, :, 8 - 8:8 + 8]                                                    # win_size 16
+    for i in (0, 2, 4, 6):
+        x = F.leaky_relu(F.conv1d(x, sd[f"audio_net.encoder_conv.{i}.weight"], sd[f"audio_net.encoder_conv.{i}.bias"], stride=2, padding=1), 0.02)
+    x = x.squeeze(-1)
+    x = F.leaky_relu(F.linear(x, sd["audio_net.encoder_fc1.0.weight"], sd["audio_net.encoder_fc1.0.bias"]), 0.02)
+    x = F.linear(x, sd["audio_net.encoder_fc1.2.weight"], sd["audio_net.encoder_fc1.2.bias"])          # [n, 32]
+    if att <= 0:
+        return x
+    x = x.unsqueeze(0)                                                         # [1, 8, 32]
+    y = x.permute(0, 2, 1)
+    for i in (0, 2, 4, 6, 8):
+        y = F.leaky_relu(F.conv1d(y, sd[f"audio_att_net.attentionConvNet.{i}.weight"], sd[f"audio_att_net.attentionConvNet.{i}.bias"], padding=1), 0.02)
+    y = torch.softmax(F.linear(y.view(1, 8), sd["audio_att_net.attentionNet.0.weight"], sd["audio_att_net.attentionNet.0.bias"]), dim=1).view(1, 8, 1)
+    return torch.sum(y * x, dim=1)

@@ -548,3 +548,34 @@ def test_hip_field_and_render_match_reference_golden(lib_built, nerf_golden):
     err = np.abs(got["image"].cpu().numpy() - g["render_image"]).max(1)
     assert np.quantile(err, 0.99) <= 1e-3 and err.max() <= 2e-2, (np.quantile(err, 0.99), err.max())
     assert np.quantile(np.abs(got["depth"].cpu().numpy() - g["render_depth"]), 0.99) <= 1e-3
+
+
+# ---- a23: audio feature nets --------------------------------------------------------------------------------------------------
+def _audio_sd(g):
+    return {k[len("audio_sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("audio_sd/")}
+
+
+def test_oracle_encode_audio_matches_reference_golden(nerf_golden):
+    from oracle import ernerf_net_ref as NR
+    g = nerf_golden
+    got = NR.encode_audio(_audio_sd(g), torch.from_numpy(g["auds"]))
+    assert got.shape == (1, 32)
+    np.testing.assert_allclose(got.numpy(), g["enc_audio"], rtol=1e-5, atol=1e-6)      # reference: model.encode_audio(auds)
+    assert np.abs(g["enc_audio"]).max() > 0.05
+
+
+@pytest.mark.gpu
+def test_hip_encode_audio_matches_reference_golden(lib_built, nerf_golden):
+    from mere_fusion_amd.ernerf.audio import HipAudioEncoder
+    from oracle import ernerf_net_ref as NR
+    g = nerf_golden
+    sd = _audio_sd(g)
+    enc = HipAudioEncoder(sd, att=2)
+    got = enc.encode_audio(torch.from_numpy(g["auds"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, g["enc_audio"], rtol=2e-5, atol=2e-6)              # fp32 both sides, different summation order
+    one = HipAudioEncoder(sd, att=0)
+    w1 = torch.from_numpy(g["auds"][3:4])
+    np.testing.assert_allclose(one.encode_audio(w1.cuda()).cpu().numpy(), NR.encode_audio(sd, w1, att=0).numpy(), rtol=2e-5, atol=2e-6)
+    with pytest.raises(RuntimeError, match="windows"):
+        enc.encode_audio(torch.zeros(3, 44, 16, device="cuda"))
+    assert enc.encode_audio(None) is None
