@@ -72,10 +72,22 @@ __global__ __launch_bounds__(256) void k_nf_prep(const float* __restrict__ xyzs,
     sh[11] = 0.45704579946446572f * dy * (1.0f - 5.0f * z2); sh[12] = 0.3731763325901154f * dz * (5.0f * z2 - 3.0f);
     sh[13] = 0.45704579946446572f * dx * (1.0f - 5.0f * z2); sh[14] = 1.4453057213202769f * dz * (x2 - y2);
     sh[15] = 0.59004358992664352f * dx * (-x2 + 3.0f * y2);
+    // 16 SH values + 8 individual-code slots per sample as 16-byte stores (CI_SH and CI_IND are multiples of 8 channels)
     const int64_t o = (int64_t)m * CI_C;
+    float v[SHD + 8];
 #pragma unroll
-    for (int i = 0; i < SHD; ++i) put(ci_hi, ci_lo, o + CI_SH + i, sh[i]);
-    for (int i = 0; i < 8; ++i) put(ci_hi, ci_lo, o + CI_IND + i, i < n_ind ? ind[i] : 0.f);
+    for (int i = 0; i < SHD; ++i) v[i] = sh[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[SHD + i] = i < n_ind ? ind[i] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        uint32_t hb[8], lb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hb[e] = qf2bf(v[q * 8 + e]); lb[e] = qf2bf(v[q * 8 + e] - qbf2f(hb[e])); }
+        const int64_t oo = o + (q < 2 ? CI_SH + q * 8 : CI_IND);
+        *reinterpret_cast<uint4*>(ci_hi + oo) = make_uint4(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16));
+        if (ci_lo) *reinterpret_cast<uint4*>(ci_lo + oo) = make_uint4(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16));
+    }
 }
 
 // fp32 grid features [3][M][12] -> SI[m][0..35]
@@ -87,25 +99,26 @@ __global__ __launch_bounds__(256) void k_nf_pack(const float* __restrict__ enc, 
     put(si_hi, si_lo, (int64_t)m * SI_C + c, enc[((size_t)plane * M + m) * 12 + l]);
 }
 
-// enc_w = enc_a * aud_ch_att, e * eye_att into the sigma-net input; the two ambient outputs (network.py:284-306)
+// enc_w = enc_a * aud_ch_att, e * eye_att into the sigma-net input; the two ambient outputs (network.py:284-306).
+// One lane per (sample, audio channel): 32 lanes read / write one sample's 64 contiguous bytes, the norm is a 32-lane butterfly.
 __global__ __launch_bounds__(256) void k_nf_mix(const bf16_t* __restrict__ a_hi, const bf16_t* __restrict__ a_lo, const bf16_t* __restrict__ e_hi,
                                                 const bf16_t* __restrict__ e_lo, const float* __restrict__ enc_a, float eye, int has_eye, int M,
                                                 bf16_t* si_hi, bf16_t* si_lo, float* amb_aud, float* amb_eye) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
-    float n2 = 0.f;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int m = (int)(idx >> 5), c = (int)(idx & 31);
+    const bool live = m < M;
+    const float a = live ? get(a_hi, a_lo, (int64_t)m * AUD + c) : 0.f;
+    float n2 = a * a;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) n2 += __shfl_xor(n2, o, 32);
+    if (!live) return;
     const int64_t so = (int64_t)m * SI_C + ENC;
-#pragma unroll 8
-    for (int c = 0; c < AUD; ++c) {
-        const float a = get(a_hi, a_lo, (int64_t)m * AUD + c);
-        n2 += a * a;
-        put(si_hi, si_lo, so + c, enc_a[c] * a);
+    put(si_hi, si_lo, so + c, enc_a[c] * a);
+    if (c < 4) {
+        const float ea = has_eye ? get(e_hi, e_lo, (int64_t)m * 8) : 0.f;
+        put(si_hi, si_lo, so + AUD + c, (c == 0 && has_eye) ? eye * ea : 0.f);
+        if (c == 0) { amb_aud[m] = sqrtf(n2); amb_eye[m] = ea; }
     }
-    amb_aud[m] = sqrtf(n2);
-    const float ea = has_eye ? get(e_hi, e_lo, (int64_t)m * 8) : 0.f;
-    put(si_hi, si_lo, so + AUD, has_eye ? eye * ea : 0.f);
-    put(si_hi, si_lo, so + AUD + 1, 0.f); put(si_hi, si_lo, so + AUD + 2, 0.f); put(si_hi, si_lo, so + AUD + 3, 0.f);
-    amb_eye[m] = ea;
 }
 
 // sigma = exp(h0) (network.py:300), colour = sigmoid(.) * 1.002 - 0.001 (network.py:272; the sigmoid ran in the GEMM epilogue),
@@ -283,7 +296,7 @@ extern "C" int mf_nerf_field_forward(mf_nerf_field* h, const float* xyzs, const 
         if ((rc = mf_conv_launch(h->e1, V(h->SI, 0, 40), V(h->T2, 0, 16), ActView{}, nb, s))) return rc;
         if ((rc = mf_conv_launch(h->e2, V(h->T2, 0, 16), V(h->EY, 0, 1), ActView{}, nb, s))) return rc;
     }
-    hipLaunchKernelGGL(k_nf_mix, dim3(gb), dim3(256), 0, s, h->AU->hi, h->AU->lo, h->EY->hi, h->EY->lo, h->d_enc_a, eye, c.exp_eye, M, h->SI->hi,
+    hipLaunchKernelGGL(k_nf_mix, dim3((unsigned)(((int64_t)M * 32 + 255) / 256)), dim3(256), 0, s, h->AU->hi, h->AU->lo, h->EY->hi, h->EY->lo, h->d_enc_a, eye, c.exp_eye, M, h->SI->hi,
                        h->SI->lo, amb_aud, amb_eye);
     MF_HIP(hipGetLastError());
     if ((rc = mf_conv_launch(h->s1, V(h->SI, 0, SI_C), V(h->S1, 0, 64), ActView{}, nb, s))) return rc;
