@@ -296,6 +296,31 @@ int mf_nerf_field_forward(mf_nerf_field* h, const float* xyzs, const float* dirs
                           float* uncertainty, void* stream);
 void mf_nerf_field_destroy(mf_nerf_field* h);
 
+/* ---- ER-NeRF torso branch --------------------------------------------------------------------- */
+typedef struct mf_nerf_torso mf_nerf_torso;
+typedef struct mf_nerf_torso_config {
+    float torso_shrink;          /* opt.torso_shrink, 0.8 (app.py:595) */
+    int num_levels;              /* 16: tiled grid of network.py:158 */
+    int level_dim;               /* 2 */
+    int base_resolution;         /* 16 */
+    float log2_per_level_scale;
+    int offsets[33];             /* GridEncoder.offsets of torso_encoder */
+    int individual_dim;          /* opt.ind_dim_torso, 8 */
+    int grid_size;               /* 128: density_grid_torso is grid_size^2 (renderer.py:121) */
+} mf_nerf_torso_config;
+/* weights: "torso_deform_net.net.N.weight", "torso_net.net.N.weight", "torso_encoder.embeddings", "density_grid_torso". */
+int mf_nerf_torso_create(const mf_nerf_torso_config* cfg, const mf_tensor* weights, int n_weights, int precision, int max_pixels,
+                         mf_nerf_torso** out);
+/* Replaces `run_torso` + `forward_torso` (renderer.py:294-352, network.py:166-201) for one frame.
+ * bg_coords: device fp32 [N,2] in [-1,1]; frame_consts_host: HOST fp32 [42 + individual_dim] = FreqEncoder(6,3) of the
+ * wrapped anchors (network.py:175-178) followed by the torso individual code; bg_color as in mf_nerf_finish;
+ * density_thresh = min(opt.density_thresh_torso, mean_density_torso) (renderer.py:325).
+ * bg_out: device fp32 [N,3] = torso_color * torso_alpha + bg * (1 - torso_alpha); torso_alpha [N] and deform [N,2] optional. */
+int mf_nerf_torso_forward(mf_nerf_torso* h, const float* bg_coords, const float* frame_consts_host, const float* bg_color,
+                          int bg_per_ray, float bg_const, float density_thresh, int n_pixels, float* bg_out, float* torso_alpha,
+                          float* deform, void* stream);
+void mf_nerf_torso_destroy(mf_nerf_torso* h);
+
 /* ---- ER-NeRF audio features ------------------------------------------------------------------- */
 typedef struct mf_audio_encoder mf_audio_encoder;
 /* weights: "audio_net.*" and (use_att) "audio_att_net.*" of the NeRFNetwork state dict (network.py:9-66), fp32 host. */

@@ -37,6 +37,11 @@ class MfNerfFieldConfig(C.Structure):
                 ("hidden_dim", C.c_int), ("individual_dim", C.c_int), ("exp_eye", C.c_int)]
 
 
+class MfNerfTorsoConfig(C.Structure):
+    _fields_ = [("torso_shrink", C.c_float), ("num_levels", C.c_int), ("level_dim", C.c_int), ("base_resolution", C.c_int),
+                ("log2_per_level_scale", C.c_float), ("offsets", C.c_int * 33), ("individual_dim", C.c_int), ("grid_size", C.c_int)]
+
+
 class MfVaeConfig(C.Structure):
     _fields_ = [("latent_channels", C.c_int), ("out_channels", C.c_int), ("n_blocks", C.c_int),
                 ("block_out_channels", C.c_int * 4), ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int),
@@ -107,6 +112,9 @@ SIGNATURES = {
     "mf_nerf_field_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mf_nerf_field_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 6),
     "mf_nerf_field_destroy": (None, [C.c_void_p]),
+    "mf_nerf_torso_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mf_nerf_torso_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 4),
+    "mf_nerf_torso_destroy": (None, [C.c_void_p]),
     "mf_audio_encoder_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mf_audio_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mf_audio_encoder_destroy": (None, [C.c_void_p]),

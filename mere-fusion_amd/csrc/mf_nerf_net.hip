@@ -135,19 +135,15 @@ __global__ __launch_bounds__(256) void k_nf_out(const bf16_t* __restrict__ ci_hi
 
 }  // namespace
 
-struct mf_nerf_field {
+// shared by the field and the torso net: token buffers of 1 x TW "images", bias-free Linears as bound 1x1-conv plans
+struct TokenNet {
     int precision = MF_PREC_BF16X3;
-    mf_nerf_field_config cfg{};
     int cap_batches = 0;
     std::vector<std::unique_ptr<ActBuf>> bufs;
     std::vector<std::unique_ptr<ConvPlan>> plans;
     std::vector<void*> dev;
-    ActBuf *SI = nullptr, *CI = nullptr, *T1 = nullptr, *AU = nullptr, *T2 = nullptr, *EY = nullptr, *S1 = nullptr, *S2 = nullptr, *C1 = nullptr, *RGB = nullptr;
-    ConvPlan *a1, *a2, *e1, *e2, *s1, *s2, *s3, *c1, *c2;
-    float* emb[3] = {nullptr, nullptr, nullptr};
-    float *coords = nullptr, *enc = nullptr, *d_enc_a = nullptr, *d_ind = nullptr;
 
-    ~mf_nerf_field() {
+    ~TokenNet() {
         for (auto& p : plans) mf_conv_plan_destroy(p.get());
         for (auto& b : bufs) { if (b->hi) (void)hipFree(b->hi); if (b->lo) (void)hipFree(b->lo); }
         for (void* d : dev) (void)hipFree(d);
@@ -179,6 +175,14 @@ struct mf_nerf_field {
         *out = p;
         return MF_OK;
     }
+};
+
+struct mf_nerf_field : TokenNet {
+    mf_nerf_field_config cfg{};
+    ActBuf *SI = nullptr, *CI = nullptr, *T1 = nullptr, *AU = nullptr, *T2 = nullptr, *EY = nullptr, *S1 = nullptr, *S2 = nullptr, *C1 = nullptr, *RGB = nullptr;
+    ConvPlan *a1, *a2, *e1, *e2, *s1, *s2, *s3, *c1, *c2;
+    float* emb[3] = {nullptr, nullptr, nullptr};
+    float *coords = nullptr, *enc = nullptr, *d_enc_a = nullptr, *d_ind = nullptr;
 };
 
 static const mf_tensor* nf_find(const std::map<std::string, const mf_tensor*>& sd, const std::string& k, int64_t r, int64_t c) {
@@ -311,3 +315,219 @@ extern "C" int mf_nerf_field_forward(mf_nerf_field* h, const float* xyzs, const 
 }
 
 extern "C" void mf_nerf_field_destroy(mf_nerf_field* h) { delete h; }
+
+// =========================================================================================================================
+// Torso branch: `run_torso` (renderer.py:294-352) + `forward_torso` (network.py:166-201).
+//
+// The reference gathers the pixels whose torso occupancy exceeds a threshold (boolean mask -> host sync), runs the deform and
+// colour MLPs on them and scatters back.  Here every pixel goes through the (cheap: 8.6 kMAC) nets and the mask is applied in the
+// final mix, so there is no compaction and no sync.  The per-frame constant part of the MLP inputs -- the frequency-encoded
+// wrapped anchors (42) and the individual code (8) -- never becomes a channel: it is folded into a per-frame BIAS of the first
+// layer of each MLP (W[:, const columns] . const), written into the plans' bias arrays before the launch.
+//     TX [40] = [ freq(x, 8) 34 | 0 x6 ]                         <- deform-net input (+ bias)     (network.py:177-185)
+//     TH [72] = [ tiled-grid(x + dx) 32 | freq(x, 8) 34 | 0 x6 ] <- torso-net input (+ bias)     (network.py:189-196)
+// =========================================================================================================================
+namespace {
+
+constexpr int TX_C = 40, TH_C = 72, FQ = 34, TG = 32, NCONST = 50;
+
+// x = bg_coords * shrink; FreqEncoder(2, 8) (freqencoder.cu:30-58, with the accurate sinf) into TX[0..33] and TH[32..65]
+__global__ __launch_bounds__(256) void k_torso_prep(const float* __restrict__ bg_coords, float shrink, int N, float* xs, bf16_t* tx_hi, bf16_t* tx_lo,
+                                                    bf16_t* th_hi, bf16_t* th_lo) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = (int)(idx / TX_C), c = (int)(idx - (int64_t)n * TX_C);
+    if (n >= N) return;
+    float v = 0.f;
+    if (c < FQ) {
+        if (c < 2) {
+            v = bg_coords[2 * n + c] * shrink;
+            xs[2 * n + c] = v;
+        } else {
+            const int col = c / 2 - 1, d = c & 1, freq = col >> 1;
+            v = sinf(scalbnf(bg_coords[2 * n + d] * shrink, freq) + (float)(col & 1) * 1.57079632679489661923f);
+        }
+        put(th_hi, th_lo, (int64_t)n * TH_C + TG + c, v);
+    } else {
+        put(th_hi, th_lo, (int64_t)n * TH_C + TG + c, 0.f);      // TH[66..71]
+    }
+    put(tx_hi, tx_lo, (int64_t)n * TX_C + c, v);
+}
+
+// x2 = clamp(x + dx, -1, 1) (network.py:187), mapped to [0, 1] for the tiled grid (grid.py:144, bound 1)
+__global__ __launch_bounds__(256) void k_torso_warp(const float* __restrict__ xs, const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo, int N,
+                                                    float* coords01, float* deform) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float dx = get(d_hi, d_lo, (int64_t)n * 8 + k);
+        const float x2 = fminf(fmaxf(xs[2 * n + k] + dx, -1.f), 1.f);
+        coords01[2 * n + k] = (x2 + 1.f) * 0.5f;
+        if (deform) deform[2 * n + k] = dx;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_torso_pack(const float* __restrict__ feat, int N, bf16_t* th_hi, bf16_t* th_lo) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)N * TG) return;
+    const int n = (int)(idx / TG), c = (int)(idx - (int64_t)n * TG);
+    put(th_hi, th_lo, (int64_t)n * TH_C + c, feat[idx]);
+}
+
+// occupancy = grid_sample(density_grid_torso, bg_coords, align_corners=True) (renderer.py:326), mask = occupancy > thresh;
+// alpha / colour = sigmoid(.) * 1.002 - 0.001 (network.py:198-199, the sigmoid ran in the GEMM epilogue);
+// bg = colour * alpha + bg * (1 - alpha) (renderer.py:343)
+__global__ __launch_bounds__(256) void k_torso_mix(const float* __restrict__ bg_coords, const float* __restrict__ density, int G, float thresh,
+                                                   const bf16_t* __restrict__ o_hi, const bf16_t* __restrict__ o_lo, const float* __restrict__ bg,
+                                                   int bg_per_ray, float bg_const, int N, float* out, float* alpha_out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float gx = (bg_coords[2 * n] + 1.f) * 0.5f * (float)(G - 1), gy = (bg_coords[2 * n + 1] + 1.f) * 0.5f * (float)(G - 1);
+    const float fx = floorf(gx), fy = floorf(gy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx = gx - fx, wy = gy - fy;
+    auto at = [&](int y, int x) { return (x >= 0 && x < G && y >= 0 && y < G) ? density[y * G + x] : 0.f; };   // zeros padding
+    const float occ = at(y0, x0) * (1 - wx) * (1 - wy) + at(y0, x0 + 1) * wx * (1 - wy) + at(y0 + 1, x0) * (1 - wx) * wy + at(y0 + 1, x0 + 1) * wx * wy;
+    const bool m = occ > thresh;
+    const float a = m ? get(o_hi, o_lo, (int64_t)n * 8) * 1.002f - 0.001f : 0.f;
+    if (alpha_out) alpha_out[n] = a;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float col = m ? get(o_hi, o_lo, (int64_t)n * 8 + 1 + k) * 1.002f - 0.001f : 0.f;
+        const float b = bg ? (bg_per_ray ? bg[3 * n + k] : bg[k]) : bg_const;
+        out[3 * n + k] = col * a + b * (1.f - a);
+    }
+}
+
+}  // namespace
+
+struct mf_nerf_torso : TokenNet {
+    mf_nerf_torso_config cfg{};
+    ActBuf *TX = nullptr, *TH = nullptr, *D1 = nullptr, *D2 = nullptr, *DX = nullptr, *U1 = nullptr, *U2 = nullptr, *OUT = nullptr;
+    ConvPlan *d1, *d2, *d3, *t1, *t2, *t3;
+    float *emb = nullptr, *density = nullptr, *xs = nullptr, *coords01 = nullptr, *feat = nullptr;
+    std::vector<float> wd_const, wt_const;     // [32][50]: the constant-input columns of the two first layers
+};
+
+extern "C" int mf_nerf_torso_create(const mf_nerf_torso_config* cfg, const mf_tensor* weights, int n_weights, int precision, int max_pixels,
+                                    mf_nerf_torso** out) {
+    MF_REQUIRE(cfg && weights && out && n_weights > 0 && max_pixels > 0, "nerf_torso_create: bad argument");
+    MF_REQUIRE(precision == MF_PREC_BF16 || precision == MF_PREC_BF16X3, "nerf_torso_create: unknown precision %d", precision);
+    MF_REQUIRE(cfg->num_levels == 16 && cfg->level_dim == 2 && cfg->individual_dim >= 0 && cfg->individual_dim <= 8 && cfg->grid_size > 1,
+               "nerf_torso_create: built for the reference's torso nets (tiled grid 16 x 2, ind_dim_torso <= 8: network.py:155-159)");
+    *out = nullptr;
+    std::map<std::string, const mf_tensor*> sd;
+    for (int i = 0; i < n_weights; ++i) {
+        MF_REQUIRE(weights[i].name && weights[i].data, "nerf_torso_create: tensor %d has no name/data", i);
+        sd[weights[i].name] = &weights[i];
+    }
+    std::unique_ptr<mf_nerf_torso> h(new mf_nerf_torso());
+    h->precision = precision;
+    h->cfg = *cfg;
+    h->cap_batches = (max_pixels + TW - 1) / TW;
+    const int nind = cfg->individual_dim, ncst = 42 + nind;                 // anchors freq(6, 3) = 42 (network.py:151) + code
+    const int din = FQ + ncst, tin = TG + FQ + ncst;
+    h->TX = h->seq(TX_C); h->TH = h->seq(TH_C); h->D1 = h->seq(32); h->D2 = h->seq(32); h->DX = h->seq(8); h->U1 = h->seq(32); h->U2 = h->seq(32);
+    h->OUT = h->seq(8);
+    int rc = h->alloc();
+    if (rc) return rc;
+    const size_t cap = (size_t)h->cap_batches * TW;
+    auto dmalloc = [&](float** p, size_t n) -> int { MF_HIP(hipMalloc(p, n * sizeof(float))); h->dev.push_back(*p); return MF_OK; };
+    if ((rc = dmalloc(&h->xs, cap * 2)) || (rc = dmalloc(&h->coords01, cap * 2)) || (rc = dmalloc(&h->feat, cap * TG))) return rc;
+    const int n_emb = cfg->offsets[cfg->num_levels];
+    const mf_tensor* te = nf_find(sd, "torso_encoder.embeddings", n_emb, 2);
+    if (!te) return MF_ERR_INVALID;
+    if ((rc = dmalloc(&h->emb, (size_t)n_emb * 2))) return rc;
+    MF_HIP(hipMemcpy(h->emb, te->data, (size_t)n_emb * 2 * sizeof(float), hipMemcpyHostToDevice));
+    {
+        auto it = sd.find("density_grid_torso");
+        MF_REQUIRE(it != sd.end(), "nerf_torso_create: tensor 'density_grid_torso' missing");
+        int64_t n = 1;
+        for (int d = 0; d < it->second->ndim; ++d) n *= it->second->shape[d];
+        MF_REQUIRE(n == (int64_t)cfg->grid_size * cfg->grid_size, "nerf_torso_create: density_grid_torso has %lld entries, expected %d^2", (long long)n, cfg->grid_size);
+        if ((rc = dmalloc(&h->density, (size_t)n))) return rc;
+        MF_HIP(hipMemcpy(h->density, it->second->data, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    auto first_layer = [&](const char* name, int cin_ref, int var_cols, int cin_buf, const std::vector<int>& col_of, std::vector<float>& w,
+                           std::vector<float>& wconst) -> int {
+        const mf_tensor* t = nf_find(sd, name, 32, cin_ref);
+        if (!t) return MF_ERR_INVALID;
+        const float* src = (const float*)t->data;
+        w.assign((size_t)32 * cin_buf, 0.f);
+        wconst.assign((size_t)32 * NCONST, 0.f);
+        for (int o = 0; o < 32; ++o) {
+            for (int i = 0; i < var_cols; ++i) w[(size_t)o * cin_buf + col_of[i]] = src[(size_t)o * cin_ref + i];
+            for (int i = var_cols; i < cin_ref; ++i) wconst[(size_t)o * NCONST + (i - var_cols)] = src[(size_t)o * cin_ref + i];
+        }
+        return MF_OK;
+    };
+    auto plain = [&](const char* name, int cout, int cin, std::vector<float>& w) -> int {
+        const mf_tensor* t = nf_find(sd, name, cout, cin);
+        if (!t) return MF_ERR_INVALID;
+        w.assign((const float*)t->data, (const float*)t->data + (size_t)cout * cin);
+        return MF_OK;
+    };
+    std::vector<float> w;
+    std::vector<int> col(FQ + TG);
+    for (int i = 0; i < FQ; ++i) col[i] = i;
+    // deform net input order: [freq(x) 34 | anchors 42 | code] (network.py:180-183)
+    if ((rc = first_layer("torso_deform_net.net.0.weight", din, FQ, TX_C, col, w, h->wd_const)) || (rc = h->linear(&h->d1, w, TX_C, 32, 1, h->TX))) return rc;
+    if ((rc = plain("torso_deform_net.net.1.weight", 32, 32, w)) || (rc = h->linear(&h->d2, w, 32, 32, 1, h->D1))) return rc;
+    if ((rc = plain("torso_deform_net.net.2.weight", 2, 32, w)) || (rc = h->linear(&h->d3, w, 32, 2, 0, h->D2))) return rc;
+    // torso net input order: [grid 32 | freq(x) 34 | anchors 42 | code] (network.py:189-194) -- the same layout as TH
+    for (int i = 0; i < TG + FQ; ++i) col[i] = i;
+    if ((rc = first_layer("torso_net.net.0.weight", tin, TG + FQ, TH_C, col, w, h->wt_const)) || (rc = h->linear(&h->t1, w, TH_C, 32, 1, h->TH))) return rc;
+    if ((rc = plain("torso_net.net.1.weight", 32, 32, w)) || (rc = h->linear(&h->t2, w, 32, 32, 1, h->U1))) return rc;
+    if ((rc = plain("torso_net.net.2.weight", 4, 32, w)) || (rc = h->linear(&h->t3, w, 32, 4, 2, h->U2))) return rc;
+    MF_HIP(hipDeviceSynchronize());
+    *out = h.release();
+    return MF_OK;
+}
+
+extern "C" int mf_nerf_torso_forward(mf_nerf_torso* h, const float* bg_coords, const float* frame_consts_host, const float* bg_color,
+                                     int bg_per_ray, float bg_const, float density_thresh, int n_pixels, float* bg_out, float* torso_alpha,
+                                     float* deform, void* stream) {
+    MF_REQUIRE(h && bg_coords && frame_consts_host && bg_out, "nerf_torso_forward: null argument");
+    MF_REQUIRE(n_pixels >= 0 && n_pixels <= h->cap_batches * TW, "nerf_torso_forward: %d pixels exceed the capacity %d", n_pixels, h->cap_batches * TW);
+    if (n_pixels == 0) return MF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int N = n_pixels, nb = (N + TW - 1) / TW, gb = (N + 255) / 256;
+    const int ncst = 42 + h->cfg.individual_dim;
+    // per-frame biases of the two first layers: W[:, constant columns] . [freq(wrapped anchors) | individual code]
+    float bd[32], bt[32];
+    for (int o = 0; o < 32; ++o) {
+        double a = 0, b = 0;
+        for (int i = 0; i < ncst; ++i) {
+            a += (double)h->wd_const[(size_t)o * NCONST + i] * frame_consts_host[i];
+            b += (double)h->wt_const[(size_t)o * NCONST + i] * frame_consts_host[i];
+        }
+        bd[o] = (float)a; bt[o] = (float)b;
+    }
+    MF_HIP(hipMemcpyAsync(h->d1->bias, bd, sizeof(bd), hipMemcpyHostToDevice, s));
+    MF_HIP(hipMemcpyAsync(h->t1->bias, bt, sizeof(bt), hipMemcpyHostToDevice, s));
+    MF_HIP(hipStreamSynchronize(s));     // bd / bt live on this stack frame
+    hipLaunchKernelGGL(k_torso_prep, dim3((unsigned)(((int64_t)N * TX_C + 255) / 256)), dim3(256), 0, s, bg_coords, h->cfg.torso_shrink, N, h->xs,
+                       h->TX->hi, h->TX->lo, h->TH->hi, h->TH->lo);
+    MF_HIP(hipGetLastError());
+    auto V = [](ActBuf* b, int C) { return ActView{b, 0, C}; };
+    int rc;
+    if ((rc = mf_conv_launch(h->d1, V(h->TX, TX_C), V(h->D1, 32), ActView{}, nb, s))) return rc;
+    if ((rc = mf_conv_launch(h->d2, V(h->D1, 32), V(h->D2, 32), ActView{}, nb, s))) return rc;
+    if ((rc = mf_conv_launch(h->d3, V(h->D2, 32), V(h->DX, 2), ActView{}, nb, s))) return rc;
+    hipLaunchKernelGGL(k_torso_warp, dim3(gb), dim3(256), 0, s, h->xs, h->DX->hi, h->DX->lo, N, h->coords01, deform);
+    MF_HIP(hipGetLastError());
+    if ((rc = mf_grid_encode_forward(h->coords01, h->emb, h->cfg.offsets, h->feat, N, 2, 2, 16, h->cfg.log2_per_level_scale, h->cfg.base_resolution, 1, 0,
+                                     1, stream)))
+        return rc;
+    hipLaunchKernelGGL(k_torso_pack, dim3((unsigned)(((int64_t)N * TG + 255) / 256)), dim3(256), 0, s, h->feat, N, h->TH->hi, h->TH->lo);
+    MF_HIP(hipGetLastError());
+    if ((rc = mf_conv_launch(h->t1, V(h->TH, TH_C), V(h->U1, 32), ActView{}, nb, s))) return rc;
+    if ((rc = mf_conv_launch(h->t2, V(h->U1, 32), V(h->U2, 32), ActView{}, nb, s))) return rc;
+    if ((rc = mf_conv_launch(h->t3, V(h->U2, 32), V(h->OUT, 4), ActView{}, nb, s))) return rc;
+    hipLaunchKernelGGL(k_torso_mix, dim3(gb), dim3(256), 0, s, bg_coords, h->density, h->cfg.grid_size, density_thresh, h->OUT->hi, h->OUT->lo, bg_color,
+                       bg_per_ray, bg_const, N, bg_out, torso_alpha);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+extern "C" void mf_nerf_torso_destroy(mf_nerf_torso* h) { delete h; }

@@ -346,3 +346,28 @@ def make_ernerf_audio_state_dict(template, seed=0):
         else:
             sd[k] = torch.from_numpy((rng.standard_normal(shape) * 0.05).astype(np.float32))
     return sd
+
+
+def make_ernerf_torso_state_dict(n_embeddings, seed=0, individual_dim=8, grid_size=128):
+    """Seeded stand-in for the torso tensors of a trained NeRFNetwork(torso=True) (network.py:146-159): He-scaled deform / colour
+    MLPs (the deform net's last layer scaled down so |dx| stays a few percent of the image), O(1) tiled-grid features, a smooth
+    blob as `density_grid_torso`, the default anchor points, small individual codes."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(3000 + seed))
+    sd = {"torso_encoder.embeddings": torch.from_numpy(rng.uniform(-1, 1, (n_embeddings, 2)).astype(np.float32))}
+    din = 34 + 42 + individual_dim
+
+    def lin(name, dims, last_scale=1.0):
+        for i, (o, c) in enumerate(dims):
+            w = rng.standard_normal((o, c)) * np.sqrt(2.0 / c) * (last_scale if i == len(dims) - 1 else 1.0)
+            sd[f"{name}.net.{i}.weight"] = torch.from_numpy(w.astype(np.float32))
+    lin("torso_deform_net", [(32, din), (32, 32), (2, 32)], 0.03)
+    lin("torso_net", [(32, 32 + din), (32, 32), (4, 32)])
+    u = (np.arange(grid_size, dtype=np.float32) + 0.5) / grid_size * 2 - 1
+    yy, xx = np.meshgrid(u, u, indexing="ij")
+    blob = np.clip(1.2 - np.sqrt((xx / 0.7) ** 2 + ((yy - 0.45) / 0.5) ** 2) * 1.5, 0, None)
+    sd["density_grid_torso"] = torch.from_numpy(blob.astype(np.float32).reshape(-1))
+    sd["anchor_points"] = torch.tensor([[0.01, 0.01, 0.1, 1], [-0.1, -0.1, 0.1, 1], [0.1, -0.1, 0.1, 1]], dtype=torch.float32)   # network.py:149
+    if individual_dim:
+        sd["individual_codes_torso"] = torch.from_numpy((rng.standard_normal((4, individual_dim)) * 0.1).astype(np.float32))
+    return sd

@@ -97,3 +97,43 @@ def encode_audio(sd, a, att=2):
         y = F.leaky_relu(F.conv1d(y, sd[f"audio_att_net.attentionConvNet.{i}.weight"], sd[f"audio_att_net.attentionConvNet.{i}.bias"], padding=1), 0.02)
     y = torch.softmax(F.linear(y.view(1, 8), sd["audio_att_net.attentionNet.0.weight"], sd["audio_att_net.attentionNet.0.bias"]), dim=1).view(1, 8, 1)
     return torch.sum(y * x, dim=1)
+
+
+def freq_encode(x, degree):
+    """`_freq_encoder.forward` (freq.py:19-33 -> kernel_freq) via the C restatement: [B, D] -> [B, D + 2 D degree]."""
+    x = np.ascontiguousarray(x, np.float32)
+    B, D = x.shape
+    Cc = D + 2 * D * degree
+    out = np.zeros((B, Cc), np.float32)
+    _clib().ref_freq_encode_forward(_p(x), C.c_uint32(B), C.c_uint32(D), C.c_uint32(degree), C.c_uint32(Cc), _p(out))
+    return out
+
+
+def run_torso(sd, bg_coords, poses, bg_color, offsets, S, torso_shrink=0.8, thresh=0.0, grid_size=128, H=16):
+    """`NeRFRenderer.run_torso` (renderer.py:294-352) + `forward_torso` (network.py:166-201), test mode (individual code 0)."""
+    xy = torch.as_tensor(bg_coords, dtype=torch.float32).reshape(-1, 2)
+    N = xy.shape[0]
+    bg = torch.as_tensor(bg_color, dtype=torch.float32)
+    bg = bg.expand(N, 3) if bg.dim() else bg
+    occ = torch.nn.functional.grid_sample(sd["density_grid_torso"].view(1, 1, grid_size, grid_size), xy.view(1, -1, 1, 2), align_corners=True).view(-1)
+    mask = occ > thresh
+    alpha, color = torch.zeros(N, 1), torch.zeros(N, 3)
+    deform = torch.zeros(N, 2)
+    if mask.any():
+        x = xy[mask] * torso_shrink
+        c = sd["individual_codes_torso"][0:1] if "individual_codes_torso" in sd else None
+        wa = sd["anchor_points"][None, ...] @ torch.as_tensor(poses, dtype=torch.float32).reshape(1, 4, 4).permute(0, 2, 1).inverse()
+        wa = (wa[:, :, :2] / wa[:, :, 3, None] / wa[:, :, 2, None]).view(1, -1)
+        enc_anchor = torch.from_numpy(freq_encode(wa.numpy(), 3))
+        enc_x = torch.from_numpy(freq_encode(x.numpy(), 8))
+        parts = [enc_x, enc_anchor.repeat(x.shape[0], 1)] + ([c.repeat(x.shape[0], 1)] if c is not None else [])
+        h = torch.cat(parts, -1)
+        dx = mlp(sd, "torso_deform_net", h)
+        x2 = (x + dx).clamp(-1, 1)
+        g = torch.from_numpy(grid_encode(((x2.numpy() + np.float32(1)) / np.float32(2)).astype(np.float32), sd["torso_encoder.embeddings"].numpy(), offsets, S, H,
+                                         gridtype=1))
+        o = mlp(sd, "torso_net", torch.cat([g, h], -1))
+        alpha[mask] = torch.sigmoid(o[..., :1]) * (1 + 2 * 0.001) - 0.001
+        color[mask] = torch.sigmoid(o[..., 1:]) * (1 + 2 * 0.001) - 0.001
+        deform[mask] = dx
+    return {"bg_color": color * alpha + bg * (1 - alpha), "torso_alpha": alpha, "deform": deform, "mask": mask}

@@ -74,13 +74,29 @@ def oracle_backends():
     return rm, ge, sh
 
 
-def build_reference_model(sd_field, seed):
+def build_reference_model(sd_field, seed, torso=False):
     net = import_reference()
     rm, ge, sh = oracle_backends()
     importlib.import_module("ernerf.raymarching.raymarching")._backend = rm
     importlib.import_module("ernerf.gridencoder.grid")._backend = ge
     importlib.import_module("ernerf.shencoder.sphere_harmonics")._backend = sh
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "libernerfref.so"))
+
+    def freq_encode_forward(inputs, B, D, degree, Cc, outputs):
+        lib.ref_freq_encode_forward(_p(inputs), C.c_uint32(B), C.c_uint32(D), C.c_uint32(degree), C.c_uint32(Cc), _p(outputs))
+    importlib.import_module("ernerf.freqencoder.freq")._backend = types.SimpleNamespace(freq_encode_forward=freq_encode_forward)
     torch.Tensor.cuda = lambda self, *a, **k: self
+    if torso:
+        opt = argparse.Namespace(asr_model="esperanto", emb=False, att=2, bound=1, min_near=0.05, density_thresh=10, density_thresh_torso=0.01,
+                                 exp_eye=True, test_train=False, smooth_lips=False, torso=True, cuda_ray=True, ind_num=4, ind_dim=4, ind_dim_torso=8,
+                                 train_camera=False, unc_loss=1, torso_shrink=0.8)
+        torch.manual_seed(seed)
+        model = net.NeRFNetwork(opt).eval()
+        own = model.state_dict()
+        for k, v in sd_field.items():
+            assert own[k].shape == v.shape, (k, own[k].shape, v.shape)
+        model.load_state_dict(sd_field, strict=False)
+        return model, None
     opt = argparse.Namespace(asr_model="esperanto", emb=False, att=2, bound=1, min_near=0.05, density_thresh=10, density_thresh_torso=0.01,
                              exp_eye=True, test_train=False, smooth_lips=False, torso=False, cuda_ray=True, ind_num=16, ind_dim=4,
                              train_camera=False, unc_loss=1)
@@ -137,6 +153,23 @@ def main():
     out.update(render_W=np.int32(Wd), render_image=res["image"].reshape(-1, 3).numpy(), render_depth=res["depth"].reshape(-1).numpy(),
                render_amb_aud=res["ambient_aud"].reshape(-1).numpy(), render_amb_eye=res["ambient_eye"].reshape(-1).numpy(),
                render_ind_code=model.individual_codes[0].detach().numpy())
+    # ---- a22: run_torso / forward_torso on 40 x 40 background pixels, reference model built with opt.torso ----
+    from mere_fusion_amd.ernerf.field import grid_geometry as gg
+    t_offsets, t_pls = gg(num_levels=16, base_resolution=16, log2_hashmap_size=16, desired_resolution=2048)
+    tsd = W.make_ernerf_torso_state_dict(int(t_offsets[-1]), seed)
+    tmodel, _ = build_reference_model(tsd, seed, torso=True)
+    assert np.array_equal(tmodel.torso_encoder.offsets.numpy(), t_offsets)
+    Wt = 40
+    u = (torch.arange(Wt, dtype=torch.float32) + 0.5) / Wt * 2 - 1
+    yy, xx = torch.meshgrid(u, u, indexing="ij")
+    bg_coords = torch.stack([xx, yy], -1).reshape(1, -1, 2).contiguous()
+    pose = torch.eye(4); pose[:3, :3] = torch.tensor([[0.98, 0.05, -0.19], [-0.03, 0.995, 0.09], [0.195, -0.083, 0.977]]); pose[:3, 3] = torch.tensor([0.05, -0.02, 0.9])
+    tbg = torch.tensor([0.3, 0.5, 0.7]).expand(Wt * Wt, 3).contiguous()
+    with torch.no_grad():
+        tr = tmodel.run_torso(torch.zeros(1, Wt * Wt, 3), bg_coords, pose[None], 0, tbg)
+    out.update(torso_W=np.int32(Wt), torso_bg_coords=bg_coords.reshape(-1, 2).numpy(), torso_pose=pose.numpy(), torso_bg_in=tbg.numpy(),
+               torso_bg_color=tr["bg_color"].numpy(), torso_alpha=tr["torso_alpha"].numpy(), torso_offsets=t_offsets,
+               torso_log2_per_level_scale=np.float32(np.log2(tmodel.torso_encoder.per_level_scale)))
     path = os.path.join(ROOT, "tests", "golden", "ernerf_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: getattr(v, "shape", None) for k, v in out.items() if not k.startswith("audio_sd/")})

@@ -579,3 +579,55 @@ def test_hip_encode_audio_matches_reference_golden(lib_built, nerf_golden):
     with pytest.raises(RuntimeError, match="windows"):
         enc.encode_audio(torch.zeros(3, 44, 16, device="cuda"))
     assert enc.encode_audio(None) is None
+
+
+# ---- a22: torso branch -----------------------------------------------------------------------------------------------------------
+def _torso_sd(g):
+    from mere_fusion_amd import weights as W
+    return W.make_ernerf_torso_state_dict(int(g["torso_offsets"][-1]), 0)
+
+
+def test_oracle_torso_matches_reference_golden(ref, nerf_golden):
+    """Pins oracle run_torso to the reference's own `run_torso` + `forward_torso` (opt.torso model, extensions backed by the C oracle)."""
+    from oracle import ernerf_net_ref as NR
+    g = nerf_golden
+    got = NR.run_torso(_torso_sd(g), g["torso_bg_coords"], g["torso_pose"], g["torso_bg_in"], g["torso_offsets"], float(g["torso_log2_per_level_scale"]))
+    np.testing.assert_allclose(got["bg_color"].numpy(), g["torso_bg_color"], atol=3e-6)
+    np.testing.assert_allclose(got["torso_alpha"].numpy(), g["torso_alpha"], atol=3e-6)
+    m = got["mask"].numpy()
+    assert 0.15 < m.mean() < 0.85 and (g["torso_alpha"][~m] == 0).all() and g["torso_alpha"][m].std() > 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_hip_torso_matches_reference_golden(lib_built, ref, nerf_golden, precision):
+    from mere_fusion_amd.ernerf.torso import HipTorso
+    g = nerf_golden
+    t = HipTorso(_torso_sd(g), torso_shrink=0.8, individual_dim=8, precision=precision, max_pixels=4096)
+    got = t.run_torso(torch.from_numpy(g["torso_bg_coords"]).cuda(), torch.from_numpy(g["torso_pose"])[None], torch.from_numpy(g["torso_bg_in"]).cuda())
+    tol = 3e-4 if precision == "bf16x3" else 5e-2
+    assert np.abs(got["torso_alpha"].cpu().numpy() - g["torso_alpha"]).max() <= tol
+    assert np.abs(got["bg_color"].cpu().numpy() - g["torso_bg_color"]).max() <= tol
+    # a [3] background and the scalar default take the other two branches of the mix
+    b3 = t.run_torso(torch.from_numpy(g["torso_bg_coords"]).cuda(), torch.from_numpy(g["torso_pose"])[None], torch.tensor([0.3, 0.5, 0.7], device="cuda"))
+    assert torch.allclose(b3["bg_color"], got["bg_color"], atol=1e-6)
+    one = t.run_torso(torch.from_numpy(g["torso_bg_coords"]).cuda(), torch.from_numpy(g["torso_pose"])[None], None)
+    a = got["torso_alpha"]
+    assert torch.allclose(one["bg_color"] - (1 - a), got["bg_color"] - torch.tensor([0.3, 0.5, 0.7], device="cuda") * (1 - a), atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_torso_full_frame_properties(lib_built):
+    from mere_fusion_amd import weights as W
+    from mere_fusion_amd.ernerf.field import grid_geometry
+    from mere_fusion_amd.ernerf.torso import HipTorso
+    offs, _ = grid_geometry(num_levels=16, base_resolution=16, log2_hashmap_size=16, desired_resolution=2048)
+    t = HipTorso(W.make_ernerf_torso_state_dict(int(offs[-1]), 1), max_pixels=512 * 512)
+    u = (torch.arange(512, dtype=torch.float32) + 0.5) / 512 * 2 - 1
+    yy, xx = torch.meshgrid(u, u, indexing="ij")
+    r = t.run_torso(torch.stack([xx, yy], -1).reshape(-1, 2).cuda(), torch.eye(4)[None], None)
+    a = r["torso_alpha"].cpu().numpy()
+    assert a.min() >= -0.001 - 1e-6 and a.max() <= 1.001 + 1e-6 and 0.1 < (a > 0).mean() < 0.9
+    img = r["bg_color"].cpu().numpy()
+    assert np.isfinite(img).all() and img.min() >= -0.01 and img.max() <= 1.01
+    assert np.abs(r["deform"].cpu().numpy()).max() < 0.5
