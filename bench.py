@@ -306,11 +306,33 @@ class ErNeRFRunner:
         self.enc_a, self.ind, self.eye = torch.randn(1, 32, generator=g), torch.randn(1, 4, generator=g) * 0.1, torch.tensor([[0.4]])
         self.d_enc_a, self.d_ind, self.d_eye = self.enc_a.to(device), self.ind.to(device), self.eye.to(device)
         self.field = HipNeRFField(self.sd, precision=precision, max_samples=width * width, device=device)
-        self.r = HipHeadRenderer(self.field, torch.from_numpy(self.bitfield).to(device), density_scale=40.0)
+        # the full nerfreal.py frame: audio window -> enc_a, torso over the background, head loop, uint8 frame
+        from mere_fusion_amd.ernerf.audio import HipAudioEncoder
+        from mere_fusion_amd.ernerf.torso import HipTorso
+        t_offs, _ = grid_geometry(num_levels=16, base_resolution=16, log2_hashmap_size=16, desired_resolution=2048)
+        self.torso = HipTorso(W.make_ernerf_torso_state_dict(int(t_offs[-1]), seed), precision=precision, max_pixels=width * width, device=device)
+        tmpl = {"audio_net.encoder_conv.0.weight": torch.empty(32, 44, 3), "audio_net.encoder_conv.0.bias": torch.empty(32),
+                "audio_net.encoder_conv.2.weight": torch.empty(32, 32, 3), "audio_net.encoder_conv.2.bias": torch.empty(32),
+                "audio_net.encoder_conv.4.weight": torch.empty(64, 32, 3), "audio_net.encoder_conv.4.bias": torch.empty(64),
+                "audio_net.encoder_conv.6.weight": torch.empty(64, 64, 3), "audio_net.encoder_conv.6.bias": torch.empty(64),
+                "audio_net.encoder_fc1.0.weight": torch.empty(64, 64), "audio_net.encoder_fc1.0.bias": torch.empty(64),
+                "audio_net.encoder_fc1.2.weight": torch.empty(32, 64), "audio_net.encoder_fc1.2.bias": torch.empty(32),
+                "audio_att_net.attentionNet.0.weight": torch.empty(8, 8), "audio_att_net.attentionNet.0.bias": torch.empty(8)}
+        for i, (ci, co) in enumerate(((32, 16), (16, 8), (8, 4), (4, 2), (2, 1))):
+            tmpl[f"audio_att_net.attentionConvNet.{2 * i}.weight"] = torch.empty(co, ci, 3)
+            tmpl[f"audio_att_net.attentionConvNet.{2 * i}.bias"] = torch.empty(co)
+        self.audio = HipAudioEncoder(W.make_ernerf_audio_state_dict(tmpl, seed), att=2, device=device)
+        self.auds = torch.randn(8, 44, 16, generator=g).to(device)
+        u = (torch.arange(width, dtype=torch.float32) + 0.5) / width * 2 - 1
+        yy, xx = torch.meshgrid(u, u, indexing="ij")
+        self.bg_coords = torch.stack([xx, yy], -1).reshape(-1, 2).to(device)
+        self.pose = torch.eye(4)[None]
+        self.r = HipHeadRenderer(self.field, torch.from_numpy(self.bitfield).to(device), density_scale=40.0, torso=self.torso, audio=self.audio,
+                                 ind_code=self.d_ind, smooth_lips=True)
         self.last = None
 
     def step(self):
-        self.last = self.r.run_cuda(self.ro, self.rd, self.d_enc_a, self.d_ind, self.d_eye, bg_color=1.0, want_u8=True)
+        self.last = self.r.render(self.ro, self.rd, self.auds, self.bg_coords, self.pose, self.d_eye, bg_color=1.0, want_u8=True)
 
     def samples_per_frame(self):
         return sum(a * s for a, s in self.last["trace"])
@@ -326,7 +348,7 @@ class ErNeRFRunner:
         want = RR.run_cuda(self.sd, self.offsets, self.S, ro, rd, self.enc_a, self.ind, self.eye, self.bitfield, bg_color=1.0, density_scale=40.0)
         err = np.abs(got["image"].cpu().numpy() - want["image"]).max(1)
         return {"image_linf_p995_vs_oracle": float(np.quantile(err, 0.995)), "image_linf_max": float(err.max()), "rays": width * width,
-                "oracle": "parity unpinned (CUDA reference cannot run here): oracle/ernerf_render_ref.py"}
+                "oracle": "oracle/ernerf_render_ref.py, pinned to the reference Python above the extension boundary (tests/golden/make_ernerf_golden.py); CUDA kernels unpinned"}
 
     def cpu_baseline(self, seconds, threads, width=64):
         from oracle import ernerf_render_ref as RR
@@ -350,8 +372,9 @@ def ernerf_report(args, device, world, rank, value=None, ms_per_step=None, run=N
         el = harness.timed_steps(run.step, steps, 3, sync_fn=torch.cuda.synchronize)
         value, ms_per_step = steps / el, el / steps * 1e3
     smp = run.samples_per_frame()
-    rep = {"workload": "ER-NeRF head frame 512x512 rays: near/far + (march -> tri-plane field -> composite) x <= 16 steps, synthetic occupancy, "
-                       "rays resident in HBM (BASELINE.json configs[4])",
+    rep = {"workload": "ER-NeRF frame 512x512 (nerfreal.py path): audio nets -> enc_a, torso deform / colour nets over the background, near/far + "
+                       "(march -> tri-plane field -> composite) x <= 16 steps, uint8 frame; synthetic occupancy, rays resident in HBM "
+                       "(BASELINE.json configs[4])",
            "value": round(value, 1), "unit": "frames/s", "ms_per_step": round(ms_per_step, 3), "dtype": args.precision,
            "samples_per_frame": int(smp), "march_iterations": len(run.last["trace"]),
            "field_tflops_algorithmic": round(smp * 46368 * value / max(world, 1) / 1e12, 2)}

@@ -14,15 +14,30 @@ from . import _raymarching_face as rm
 
 
 class HipHeadRenderer:
-    def __init__(self, field, density_bitfield, bound=1.0, min_near=0.05, density_scale=1.0, grid_size=128):
+    def __init__(self, field, density_bitfield, bound=1.0, min_near=0.05, density_scale=1.0, grid_size=128, torso=None, audio=None,
+                 ind_code=None, smooth_lips=False):
         import math
         self.field = field
+        self.torso, self.audio, self.ind_code, self.smooth_lips, self.enc_a = torso, audio, ind_code, bool(smooth_lips), None
         self.bound, self.min_near, self.density_scale, self.grid_size = float(bound), float(min_near), float(density_scale), int(grid_size)
         self.cascade = 1 + math.ceil(math.log2(bound))                                   # renderer.py:69
         self.bitfield = density_bitfield.contiguous()
         b = self.bound
         self.aabb_infer = torch.tensor([-b, -b / 2, -b, b, b / 2, b], dtype=torch.float32, device=density_bitfield.device)   # renderer.py:86-89
         self._lib = _lib.lib()
+
+    @torch.no_grad()
+    def render(self, rays_o, rays_d, auds, bg_coords, poses, eye, bg_color=None, **kw):
+        """One frame as `NeRFRenderer.render` -> `run_cuda` does it (renderer.py:657-677, 158-291): audio window -> enc_a (+ the lip
+        smoothing EMA of :190-194), fixed individual code 0 (:197-202), head loop, torso / background mix (:272-277)."""
+        enc_a = self.audio.encode_audio(auds) if self.audio is not None else auds
+        if enc_a is not None and self.smooth_lips:
+            if self.enc_a is not None:
+                enc_a = 0.35 * self.enc_a + (1 - 0.35) * enc_a
+            self.enc_a = enc_a
+        if self.torso is not None:
+            bg_color = self.torso.run_torso(bg_coords, poses, bg_color)["bg_color"]
+        return self.run_cuda(rays_o, rays_d, enc_a, self.ind_code, eye, bg_color=bg_color, **kw)
 
     @torch.no_grad()
     def run_cuda(self, rays_o, rays_d, enc_a, ind_code, eye, bg_color=None, dt_gamma=1 / 256, max_steps=16, T_thresh=1e-4, perturb=False,
