@@ -109,6 +109,23 @@ struct Net {
         if (!w || (bias && !b)) return MF_ERR_INVALID;
         std::vector<float> bb(cout, 0.f), ws;
         for (int i = 0; i < cout; ++i) bb[i] = (b ? b[i] : 0.f) + (extra_bias ? (*extra_bias)[i] : 0.f);
+        // A 3x3 layer with a channel count that is not a multiple of 4 (the decoder's conv_out, 128 -> 3) would fall to the
+        // implicit-GEMM kernel and re-gather its input once per tap; one zero-weight channel makes it eligible for the LDS
+        // halo-tile kernel, which reads the input once (330 -> ~90 us at 256x256).
+        if (k == 3 && stride == 1 && pad == 1 && !upsample && cout % 4 && cin >= 16 && cin <= 256 && in.buf->H >= 16 && in.buf->W >= 16 &&
+            !res.buf && out.coff % 4 == 0 && out.coff + (cout + 3) / 4 * 4 <= out.buf->C) {
+            const int cp = (cout + 3) / 4 * 4;
+            const size_t row = (size_t)cin * k * k;
+            std::vector<float> wp(row * cp, 0.f);
+            for (int o = 0; o < cout; ++o)
+                for (size_t i = 0; i < row; ++i) wp[row * o + i] = w[row * o + i] * w_scale;
+            bb.resize(cp, 0.f);
+            ws.swap(wp);
+            w = ws.data();
+            w_scale = 1.f;
+            cout = cp;
+            out.C = cp;
+        }
         if (w_scale != 1.f) {
             ws.assign(w, w + (size_t)cin * cout * k * k);
             for (auto& v : ws) v *= w_scale;
