@@ -1,0 +1,483 @@
+// ER-NeRF radiance field as ONE kernel on gfx950: tri-plane hash-grid gathers, SH, and the nine Linear layers of
+// `NeRFNetwork.forward` / `density` (reference: ernerf/nerf_triplane/network.py:249-308, 23 184 MACs per sample) without a
+// single intermediate in HBM.
+//
+// Why: as separate launches (mf_nerf_net.hip) each Linear moves a [M, 64] (hi, lo) tensor out and back -- at M = 262 144 that
+// is ~70 MB per layer and the nine GEMMs are memory-bound at ~45 us each.  Fused, a sample costs 12 B in and 28 B out.
+//
+// How (wave64, MFMA 16x16x32 bf16, fp32 accumulate, bf16x3 = (hi, lo) operands and 3 MFMAs per product):
+//   * one wave owns 16 samples (one MFMA fragment column block); D[out channel][sample] = W * X^T, so the weights are the MFMA A
+//     operand and a lane of the accumulator tile holds 4 consecutive OUT channels of ONE sample (lane % 16).
+//   * a layer's accumulators ARE the next layer's B operand: the contraction index of a 32-deep step is defined as
+//     (8g + j) <-> channel 16*(2s + j/4) + 4g + j%4, i.e. exactly what lane (sample, g) already holds from blocks 2s and 2s+1
+//     of the previous layer.  Activations never move between lanes or through LDS; the weights are packed on the host in that
+//     K order (mf_nerf_fused_pack).
+//   * torch.cat is an ordering of K blocks: sigma_net reads [enc_x | enc_a * aud_ch_att | e * eye_att], colour_net reads
+//     [geo_feat (sigma_net blocks 0..4, its row 0 = log sigma has zero weights) | SH | individual code].
+//   * every weight fragment (63 x 1 KB x planes) sits in LDS, lane-linear, loaded once per workgroup; workgroups are persistent
+//     over 128-sample tiles (8 waves x 16 samples).
+//   * each lane gathers only the grid features its own B fragments need (channels 4g..4g+3 of each 16-block): 36 bilinear
+//     lookups per sample spread over its 4 lanes, straight from the L2-resident tables.
+#include "mf_nn.h"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+namespace {
+
+constexpr int NLEV = 12;
+constexpr int NSF = 1;          // 16-sample fragments per wave (2 halves the weight reads per MFMA but spills past 256 VGPRs)
+constexpr int TILE = 8 * 16 * NSF;   // samples per workgroup tile
+// fragment table: (first fragment, out blocks, k-steps) per layer, fragment = blk * nks + ks
+enum { L_AUD0, L_AUD1, L_EYE0, L_EYE1, L_SIG0, L_SIG1, L_SIG2, L_COL0, L_COL1, NLAYER };
+constexpr int L_NBLK[NLAYER] = {4, 2, 1, 1, 4, 4, 5, 4, 1};
+constexpr int L_NKS[NLAYER] = {2, 2, 2, 1, 3, 2, 2, 4, 2};
+constexpr int frag_base(int l) { int b = 0; for (int i = 0; i < l; ++i) b += L_NBLK[i] * L_NKS[i]; return b; }
+constexpr int NFRAG = frag_base(NLAYER);      // 63
+
+struct FusedArgs {
+    const float *xyzs, *dirs, *enc_a, *ind;
+    const float* emb[3];
+    const bf16_t* w;                 // packed fragments [NFRAG][planes][64 lanes][8]
+    float scale[NLEV];
+    uint32_t resolution[NLEV], offset[NLEV], hashmap_size[NLEV];
+    float bound, eye;
+    int n_ind, has_eye, M, ntiles;
+    float *sigmas, *rgbs, *amb_aud, *amb_eye, *unc;
+};
+
+__device__ __forceinline__ uint32_t fbf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bff(uint32_t h) { return __uint_as_float(h << 16); }
+
+// a B fragment half (4 channels of one 16-block): bf16 (hi, lo) pairs of 4 fp32 values -> 2 + 2 dwords
+struct Half { uint32_t h[2], l[2]; };
+__device__ __forceinline__ Half pack4(float v0, float v1, float v2, float v3) {
+    const uint32_t a = fbf(v0), b = fbf(v1), c = fbf(v2), d = fbf(v3);
+    Half r;
+    r.h[0] = a | (b << 16); r.h[1] = c | (d << 16);
+    r.l[0] = fbf(v0 - bff(a)) | (fbf(v1 - bff(b)) << 16);
+    r.l[1] = fbf(v2 - bff(c)) | (fbf(v3 - bff(d)) << 16);
+    return r;
+}
+__device__ __forceinline__ Half zero_half() { Half r; r.h[0] = r.h[1] = r.l[0] = r.l[1] = 0u; return r; }
+struct BFrag { bf16x8 hi, lo; };
+__device__ __forceinline__ BFrag join(const Half& p0, const Half& p1) {
+    BFrag f;
+    f.hi = __builtin_bit_cast(bf16x8, u32x4{p0.h[0], p0.h[1], p1.h[0], p1.h[1]});
+    f.lo = __builtin_bit_cast(bf16x8, u32x4{p0.l[0], p0.l[1], p1.l[0], p1.l[1]});
+    return f;
+}
+
+// per-level constants in LDS: the level index differs from lane to lane, which kernel-argument arrays cannot serve
+struct LevelTab { float scale[NLEV]; uint32_t resolution[NLEV], offset[NLEV], hashmap_size[NLEV]; };
+
+// one grid feature: level `lv` of plane table `tab` at (u, v) in [0, 1]^2 (gridencoder.cu:76-165 with D = 2, C = 1, hash grid)
+__device__ __forceinline__ float grid_feat(const LevelTab& a, const float* __restrict__ tab, int lv, float u, float v) {
+    if (u < 0.f || u > 1.f || v < 0.f || v > 1.f) return 0.f;
+    const float scale = a.scale[lv];
+    const uint32_t res = a.resolution[lv], hs = a.hashmap_size[lv];
+    const float* g = tab + a.offset[lv];
+    float pu = u * scale + 0.5f, pv = v * scale + 0.5f;
+    const float fu = floorf(pu), fv = floorf(pv);
+    const uint32_t iu = (uint32_t)fu, iv = (uint32_t)fv;
+    pu -= fu; pv -= fv;
+    float r = 0.f;
+#pragma unroll
+    for (int idx = 0; idx < 4; ++idx) {
+        const uint32_t x = iu + (idx & 1), y = iv + (idx >> 1);
+        const float w = ((idx & 1) ? pu : 1.f - pu) * ((idx >> 1) ? pv : 1.f - pv);
+        // get_grid_index: dense while the running stride fits the table, else the 2-prime hash (gridencoder.cu:54-72)
+        uint32_t index = x, stride = res + 1;
+        if (stride <= hs) { index += y * stride; stride *= res + 1; }
+        if (stride > hs) index = x ^ (y * 2654435761u);
+        r += w * g[index % hs];
+    }
+    return r;
+}
+
+template <bool X3>
+__global__ __launch_bounds__(512) void k_nerf_field_fused(const FusedArgs a) {
+    constexpr int NP = X3 ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // NFRAG * NP KiB of weight fragments
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ LevelTab lt;
+    for (int i = tid; i < NFRAG * NP * 64; i += 512)
+        reinterpret_cast<u32x4*>(smem)[i] = reinterpret_cast<const u32x4*>(a.w)[i];
+    if (tid < NLEV) { lt.scale[tid] = a.scale[tid]; lt.resolution[tid] = a.resolution[tid]; lt.offset[tid] = a.offset[tid]; lt.hashmap_size[tid] = a.hashmap_size[tid]; }
+    __syncthreads();
+    const float* const emb0 = a.emb[0];
+    const float* const emb1 = a.emb[1];
+    const float* const emb2 = a.emb[2];
+
+    auto wfrag = [&](int f, int plane) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8*>(smem + ((size_t)(f * NP + plane) * 64 + lane) * 16);
+    };
+    // acc[blk][sf] += W(layer, blk, ks) * B[sf]
+    auto mma = [&](int f, const BFrag (&b)[NSF], f32x4 (&acc)[NSF]) __attribute__((always_inline)) {
+        const bf16x8 whi = wfrag(f, 0);
+        if constexpr (X3) {
+            const bf16x8 wlo = wfrag(f, 1);
+#pragma unroll
+            for (int sf = 0; sf < NSF; ++sf) {
+                acc[sf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, b[sf].hi, acc[sf], 0, 0, 0);
+                acc[sf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, b[sf].lo, acc[sf], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) acc[sf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, b[sf].hi, acc[sf], 0, 0, 0);
+    };
+    // between layers: stops the scheduler from hoisting the next layers' 1-KiB weight fragments into registers early
+#define LAYER_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+    const float inv2b = 1.f / (2.f * a.bound);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int s0 = tile * TILE + wave * 16 * NSF;
+        // ---- inputs of this lane's two samples ------------------------------------------------------------------
+        float px[NSF], py[NSF], pz[NSF], dx[NSF], dy[NSF], dz[NSF];
+        bool live[NSF];
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) {
+            int m = s0 + sf * 16 + fr;
+            live[sf] = m < a.M;
+            m = live[sf] ? m : a.M - 1;
+            px[sf] = (a.xyzs[3 * m] + a.bound) * inv2b; py[sf] = (a.xyzs[3 * m + 1] + a.bound) * inv2b; pz[sf] = (a.xyzs[3 * m + 2] + a.bound) * inv2b;
+            dx[sf] = a.dirs[3 * m]; dy[sf] = a.dirs[3 * m + 1]; dz[sf] = a.dirs[3 * m + 2];
+        }
+        // enc_x channel c = plane * 12 + level (network.py:204-219): blocks X0 = 0..15, X1 = 16..31, X2 = 32..35
+        auto enc4 = [&](int sf, int c0) __attribute__((always_inline)) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                if (c >= 36) { v[j] = 0.f; continue; }
+                const int plane = c / 12, lv = c - plane * 12;
+                const float u = plane == 1 ? py[sf] : px[sf];                 // xy, yz, xz
+                const float w = plane == 0 ? py[sf] : pz[sf];
+                v[j] = grid_feat(lt, plane == 0 ? emb0 : (plane == 1 ? emb1 : emb2), lv, u, w);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the 16 gathers of one block together, not all 48 of the lane in flight
+            return pack4(v[0], v[1], v[2], v[3]);
+        };
+        Half x0[NSF], x1[NSF], x2[NSF];
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) {
+            x0[sf] = enc4(sf, 4 * g);
+            x1[sf] = enc4(sf, 16 + 4 * g);
+            x2[sf] = g == 0 ? enc4(sf, 32) : zero_half();
+        }
+        const Half Z = zero_half();
+        BFrag bx0[NSF], bx1[NSF];
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) {
+            bx0[sf] = join(x0[sf], x1[sf]);                                      // k-step (X0, X1)
+            bx1[sf] = join(x2[sf], Z);                                           // k-step (X2, 0)
+        }
+
+        // ---- aud_ch_att_net: 36 -> 64 relu -> 32 (network.py:148, 284-285) ---------------------------------------
+        f32x4 h1[4][NSF];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            for (int sf = 0; sf < NSF; ++sf) h1[blk][sf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma(frag_base(L_AUD0) + blk * 2 + 0, bx0, h1[blk]);
+            mma(frag_base(L_AUD0) + blk * 2 + 1, bx1, h1[blk]);
+        }
+        LAYER_FENCE();
+        auto relu_half = [&](const f32x4& v) __attribute__((always_inline)) { return pack4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)); };
+        auto lin_half = [&](const f32x4& v) __attribute__((always_inline)) { return pack4(v[0], v[1], v[2], v[3]); };
+        BFrag t0[NSF], t1[NSF];
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) {
+            t0[sf] = join(relu_half(h1[0][sf]), relu_half(h1[1][sf]));
+            t1[sf] = join(relu_half(h1[2][sf]), relu_half(h1[3][sf]));
+        }
+        LAYER_FENCE();
+        f32x4 aud[2][NSF];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            for (int sf = 0; sf < NSF; ++sf) aud[blk][sf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma(frag_base(L_AUD1) + blk * 2 + 0, t0, aud[blk]);
+            mma(frag_base(L_AUD1) + blk * 2 + 1, t1, aud[blk]);
+        }
+        LAYER_FENCE();
+        // ambient_aud = ||aud_ch_att||_2 (network.py:306): 8 channels in this lane, the other 24 in lanes g' != g of the same sample
+        float amb[NSF];
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) {
+            float n2 = 0.f;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) n2 += aud[blk][sf][e] * aud[blk][sf][e];
+            n2 += __shfl_xor(n2, 16);
+            n2 += __shfl_xor(n2, 32);
+            amb[sf] = sqrtf(n2);
+        }
+        // enc_w = enc_a * aud_ch_att (network.py:286): this lane's channels 16*blk + 4g + e
+        Half ew[2][NSF];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const float4 ea = *reinterpret_cast<const float4*>(a.enc_a + blk * 16 + 4 * g);
+#pragma unroll
+            for (int sf = 0; sf < NSF; ++sf)
+                ew[blk][sf] = pack4(ea.x * aud[blk][sf][0], ea.y * aud[blk][sf][1], ea.z * aud[blk][sf][2], ea.w * aud[blk][sf][3]);
+        }
+
+        LAYER_FENCE();
+        // ---- eye_att_net: 36 -> 16 relu -> 1, sigmoid (network.py:137, 291-292) ----------------------------------
+        float eye_att[NSF];
+        Half eyeh[NSF];
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) { eye_att[sf] = 0.f; eyeh[sf] = Z; }
+        if (a.has_eye) {
+            f32x4 e1[NSF], e2[NSF];
+            BFrag te[NSF];
+#pragma unroll
+            for (int sf = 0; sf < NSF; ++sf) e1[sf] = e2[sf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma(frag_base(L_EYE0) + 0, bx0, e1);
+            mma(frag_base(L_EYE0) + 1, bx1, e1);
+#pragma unroll
+            for (int sf = 0; sf < NSF; ++sf) te[sf] = join(relu_half(e1[sf]), Z);
+            mma(frag_base(L_EYE1), te, e2);
+#pragma unroll
+            for (int sf = 0; sf < NSF; ++sf) {
+                // row 0 of the block lives in lanes g == 0 (element 0); the other lanes hold zero-weight rows
+                const float s = 1.f / (1.f + __expf(-e2[sf][0]));
+                eye_att[sf] = s;
+                eyeh[sf] = g == 0 ? pack4(a.eye * s, 0.f, 0.f, 0.f) : Z;
+            }
+        }
+
+        LAYER_FENCE();
+        // ---- sigma_net: [enc_x 36 | enc_w 32 | e 1] -> 64 -> 64 -> 65 (network.py:139, 294-302) -------------------
+        BFrag bs1[NSF], bs2[NSF];
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) {
+            bs1[sf] = join(x2[sf], ew[0][sf]);                                   // k-step (X2, W0)
+            bs2[sf] = join(ew[1][sf], eyeh[sf]);                                 // k-step (W1, eye)
+        }
+        f32x4 s1[4][NSF];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            for (int sf = 0; sf < NSF; ++sf) s1[blk][sf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma(frag_base(L_SIG0) + blk * 3 + 0, bx0, s1[blk]);
+            mma(frag_base(L_SIG0) + blk * 3 + 1, bs1, s1[blk]);
+            mma(frag_base(L_SIG0) + blk * 3 + 2, bs2, s1[blk]);
+        }
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) {
+            t0[sf] = join(relu_half(s1[0][sf]), relu_half(s1[1][sf]));
+            t1[sf] = join(relu_half(s1[2][sf]), relu_half(s1[3][sf]));
+        }
+        LAYER_FENCE();
+        f32x4 s2[4][NSF];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            for (int sf = 0; sf < NSF; ++sf) s2[blk][sf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma(frag_base(L_SIG1) + blk * 2 + 0, t0, s2[blk]);
+            mma(frag_base(L_SIG1) + blk * 2 + 1, t1, s2[blk]);
+        }
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) {
+            t0[sf] = join(relu_half(s2[0][sf]), relu_half(s2[1][sf]));
+            t1[sf] = join(relu_half(s2[2][sf]), relu_half(s2[3][sf]));
+        }
+        LAYER_FENCE();
+        f32x4 s3[5][NSF];
+#pragma unroll
+        for (int blk = 0; blk < 5; ++blk) {
+            for (int sf = 0; sf < NSF; ++sf) s3[blk][sf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma(frag_base(L_SIG2) + blk * 2 + 0, t0, s3[blk]);
+            mma(frag_base(L_SIG2) + blk * 2 + 1, t1, s3[blk]);
+        }
+        // row 0 = log sigma (lanes g == 0, element 0); rows 1..64 = geo_feat (network.py:300-301)
+
+        LAYER_FENCE();
+        // ---- colour_net: [geo (blocks 0..4) | SH 16 | ind 4] -> 64 -> 3 (network.py:144, 262-272) -----------------
+        Half shh[NSF], indh;
+        {
+            const float4 iv = g == 0 ? make_float4(a.n_ind > 0 ? a.ind[0] : 0.f, a.n_ind > 1 ? a.ind[1] : 0.f, a.n_ind > 2 ? a.ind[2] : 0.f,
+                                                   a.n_ind > 3 ? a.ind[3] : 0.f)
+                                     : (g == 1 ? make_float4(a.n_ind > 4 ? a.ind[4] : 0.f, a.n_ind > 5 ? a.ind[5] : 0.f, a.n_ind > 6 ? a.ind[6] : 0.f,
+                                                             a.n_ind > 7 ? a.ind[7] : 0.f)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f));
+            indh = pack4(iv.x, iv.y, iv.z, iv.w);
+        }
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) {
+            const float x = dx[sf], y = dy[sf], z = dz[sf];
+            const float xy = x * y, xz = x * z, yz = y * z, x2_ = x * x, y2 = y * y, z2 = z * z;
+            float sh[16];
+            sh[0] = 0.28209479177387814f;
+            sh[1] = -0.48860251190291987f * y; sh[2] = 0.48860251190291987f * z; sh[3] = -0.48860251190291987f * x;
+            sh[4] = 1.0925484305920792f * xy; sh[5] = -1.0925484305920792f * yz; sh[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+            sh[7] = -1.0925484305920792f * xz; sh[8] = 0.54627421529603959f * x2_ - 0.54627421529603959f * y2;
+            sh[9] = 0.59004358992664352f * y * (-3.0f * x2_ + y2); sh[10] = 2.8906114426405538f * xy * z;
+            sh[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2); sh[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+            sh[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2); sh[14] = 1.4453057213202769f * z * (x2_ - y2);
+            sh[15] = 0.59004358992664352f * x * (-x2_ + 3.0f * y2);
+            float v0 = sh[0], v1 = sh[1], v2 = sh[2], v3 = sh[3];
+            if (g == 1) { v0 = sh[4]; v1 = sh[5]; v2 = sh[6]; v3 = sh[7]; }
+            if (g == 2) { v0 = sh[8]; v1 = sh[9]; v2 = sh[10]; v3 = sh[11]; }
+            if (g == 3) { v0 = sh[12]; v1 = sh[13]; v2 = sh[14]; v3 = sh[15]; }
+            shh[sf] = pack4(v0, v1, v2, v3);
+        }
+        BFrag c0[NSF], c1[NSF], c2[NSF], c3[NSF];
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) {
+            c0[sf] = join(lin_half(s3[0][sf]), lin_half(s3[1][sf]));
+            c1[sf] = join(lin_half(s3[2][sf]), lin_half(s3[3][sf]));
+            c2[sf] = join(lin_half(s3[4][sf]), shh[sf]);
+            c3[sf] = join(indh, Z);
+        }
+        LAYER_FENCE();
+        f32x4 k1[4][NSF];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            for (int sf = 0; sf < NSF; ++sf) k1[blk][sf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma(frag_base(L_COL0) + blk * 4 + 0, c0, k1[blk]);
+            mma(frag_base(L_COL0) + blk * 4 + 1, c1, k1[blk]);
+            mma(frag_base(L_COL0) + blk * 4 + 2, c2, k1[blk]);
+            mma(frag_base(L_COL0) + blk * 4 + 3, c3, k1[blk]);
+        }
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) {
+            t0[sf] = join(relu_half(k1[0][sf]), relu_half(k1[1][sf]));
+            t1[sf] = join(relu_half(k1[2][sf]), relu_half(k1[3][sf]));
+        }
+        LAYER_FENCE();
+        f32x4 rgb[NSF];
+#pragma unroll
+        for (int sf = 0; sf < NSF; ++sf) rgb[sf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mma(frag_base(L_COL1) + 0, t0, rgb);
+        mma(frag_base(L_COL1) + 1, t1, rgb);
+
+        LAYER_FENCE();
+        // ---- outputs: lanes g == 0 hold row 0 of sigma_net (element 0) and rows 0..2 of colour_net ---------------
+        if (g == 0) {
+#pragma unroll
+            for (int sf = 0; sf < NSF; ++sf) {
+                if (!live[sf]) continue;
+                const int m = s0 + sf * 16 + fr;
+                a.sigmas[m] = expf(s3[0][sf][0]);                                                   // network.py:300
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a.rgbs[3 * m + k] = 1.f / (1.f + __expf(-rgb[sf][k])) * 1.002f - 0.001f;   // network.py:272
+                a.amb_aud[m] = amb[sf];
+                a.amb_eye[m] = eye_att[sf];
+                if (a.unc) a.unc[m] = 0.69314718055994530942f;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ---- host: weight fragments in the kernel's K order ----------------------------------------------------------------------
+// `blocks`: the 16-channel K blocks of a layer in k-step order (pairs), each entry a source column of `w` ([cout][cin]) or -1.
+static void pack_layer(const float* w, int cout, int cin, const std::vector<std::vector<int>>& blocks, int nblk, int nks, bool x3,
+                       std::vector<bf16_t>& dst, int frag0) {
+    const int np = x3 ? 2 : 1;
+    for (int blk = 0; blk < nblk; ++blk)
+        for (int ks = 0; ks < nks; ++ks) {
+            const int f = frag0 + blk * nks + ks;
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 15, g = lane >> 4;
+                for (int j = 0; j < 8; ++j) {
+                    const std::vector<int>& kb = blocks[2 * ks + (j >> 2)];
+                    const int src = kb[4 * g + (j & 3)];
+                    const int row = blk * 16 + m;
+                    const float v = (src >= 0 && row < cout) ? w[(size_t)row * cin + src] : 0.f;
+                    const bf16_t hi = mf_f2bf(v);
+                    dst[((size_t)(f * np + 0) * 64 + lane) * 8 + j] = hi;
+                    if (x3) dst[((size_t)(f * np + 1) * 64 + lane) * 8 + j] = mf_f2bf(v - mf_bf2f(hi));
+                }
+            }
+        }
+}
+
+static std::vector<int> kblock(int first, int n = 16) {   // n real channels first..first+n-1, padded with -1
+    std::vector<int> b(16, -1);
+    for (int i = 0; i < n; ++i) b[i] = first + i;
+    return b;
+}
+
+// weights: the nine [cout][cin] matrices in reference order (aud0, aud1, eye0, eye1, sig0, sig1, sig2, col0, col1; eye* may be null)
+int mf_nerf_fused_pack(const float* const w[9], int n_ind, bool has_eye, bool x3, bf16_t** dev_out) {
+    const int np = x3 ? 2 : 1;
+    std::vector<bf16_t> buf((size_t)NFRAG * np * 64 * 8, 0);
+    const std::vector<int> Z(16, -1);
+    const int sig_in = 36 + 32 + (has_eye ? 1 : 0), col_in = 16 + 64 + n_ind;
+    const std::vector<std::vector<int>> X = {kblock(0), kblock(16), kblock(32, 4), Z};
+    const std::vector<std::vector<int>> H64 = {kblock(0), kblock(16), kblock(32), kblock(48)};
+    pack_layer(w[0], 64, 36, X, 4, 2, x3, buf, frag_base(L_AUD0));
+    pack_layer(w[1], 32, 64, H64, 2, 2, x3, buf, frag_base(L_AUD1));
+    if (has_eye) {
+        pack_layer(w[2], 16, 36, X, 1, 2, x3, buf, frag_base(L_EYE0));
+        pack_layer(w[3], 1, 16, {kblock(0), Z}, 1, 1, x3, buf, frag_base(L_EYE1));
+    }
+    // sigma_net.0: reference columns [enc_x 0..35 | enc_w 36..67 | e 68]; K blocks (X0, X1), (X2, W0), (W1, eye)
+    pack_layer(w[4], 64, sig_in, {kblock(0), kblock(16), kblock(32, 4), kblock(36), kblock(52), has_eye ? kblock(68, 1) : Z}, 4, 3, x3, buf, frag_base(L_SIG0));
+    pack_layer(w[5], 64, 64, H64, 4, 2, x3, buf, frag_base(L_SIG1));
+    pack_layer(w[6], 65, 64, H64, 5, 2, x3, buf, frag_base(L_SIG2));
+    {
+        // colour_net.0: reference columns [SH 0..15 | geo 16..79 | ind 80..]; K blocks = sigma_net rows (row 0 = log sigma -> no column,
+        // row r -> geo r-1 -> column 16 + r - 1), then SH, then the individual code
+        std::vector<std::vector<int>> kb;
+        for (int blk = 0; blk < 5; ++blk) {
+            std::vector<int> b(16, -1);
+            for (int i = 0; i < 16; ++i) {
+                const int r = blk * 16 + i;
+                if (r >= 1 && r <= 64) b[i] = 16 + r - 1;
+            }
+            kb.push_back(b);
+        }
+        kb.push_back(kblock(0));
+        kb.push_back(kblock(80, n_ind));
+        kb.push_back(Z);
+        pack_layer(w[7], 64, col_in, kb, 4, 4, x3, buf, frag_base(L_COL0));
+    }
+    pack_layer(w[8], 3, 64, H64, 1, 2, x3, buf, frag_base(L_COL1));
+    bf16_t* d = nullptr;
+    MF_HIP(hipMalloc(&d, buf.size() * sizeof(bf16_t)));
+    MF_HIP(hipMemcpy(d, buf.data(), buf.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    *dev_out = d;
+    return MF_OK;
+}
+
+int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound,
+                         const float* xyzs, const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M,
+                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s) {
+    FusedArgs a{};
+    a.xyzs = xyzs; a.dirs = dirs; a.enc_a = enc_a; a.ind = ind; a.w = packed;
+    for (int p = 0; p < 3; ++p) a.emb[p] = emb[p];
+    for (int l = 0; l < NLEV; ++l) {
+        const float scale = exp2f((float)l * log2_pls) * (float)base_res - 1.0f;      // gridencoder.cu:123-124
+        a.scale[l] = scale;
+        a.resolution[l] = (uint32_t)std::ceil(scale) + 1;
+        a.offset[l] = (uint32_t)offsets[l];
+        a.hashmap_size[l] = (uint32_t)(offsets[l + 1] - offsets[l]);
+    }
+    a.bound = bound; a.eye = eye; a.n_ind = n_ind; a.has_eye = has_eye; a.M = M;
+    a.ntiles = (M + TILE - 1) / TILE;
+    a.sigmas = sigmas; a.rgbs = rgbs; a.amb_aud = amb_aud; a.amb_eye = amb_eye; a.unc = unc;
+    const size_t lds = (size_t)NFRAG * (x3 ? 2 : 1) * 1024;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[x3]) {
+        if (x3) MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nerf_field_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nerf_field_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[x3] = true;
+    }
+    const int grid = std::min(a.ntiles, 256);
+    if (x3) hipLaunchKernelGGL(k_nerf_field_fused<true>, dim3(grid), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(k_nerf_field_fused<false>, dim3(grid), dim3(512), lds, s, a);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}

@@ -14,6 +14,7 @@
 // (and zero on h0), so geo_feat is never copied.
 #include "mf_nn.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -23,6 +24,12 @@
 extern "C" int mf_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B,
                                       uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
                                       int out_blc, void* stream);
+
+// mf_nerf_fused.hip: the whole field as one kernel (default); the per-layer GEMM path below stays for A/B (MF_NERF_FIELD=gemm)
+int mf_nerf_fused_pack(const float* const w[9], int n_ind, bool has_eye, bool x3, bf16_t** dev_out);
+int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound,
+                         const float* xyzs, const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M,
+                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s);
 
 namespace {
 
@@ -183,6 +190,7 @@ struct mf_nerf_field : TokenNet {
     ConvPlan *a1, *a2, *e1, *e2, *s1, *s2, *s3, *c1, *c2;
     float* emb[3] = {nullptr, nullptr, nullptr};
     float *coords = nullptr, *enc = nullptr, *d_enc_a = nullptr, *d_ind = nullptr;
+    bf16_t* fused_w = nullptr;      // weight fragments of k_nerf_field_fused, or null (MF_NERF_FIELD=gemm)
 };
 
 static const mf_tensor* nf_find(const std::map<std::string, const mf_tensor*>& sd, const std::string& k, int64_t r, int64_t c) {
@@ -265,6 +273,22 @@ extern "C" int mf_nerf_field_create(const mf_nerf_field_config* cfg, const mf_te
         if ((rc = relay("color_net.net.0.weight", 64, col_in, CI_C, col, w)) || (rc = h->linear(&h->c1, w, CI_C, 64, 1, h->CI))) return rc;
     }
     if ((rc = relay("color_net.net.1.weight", 3, 64, 64, iota(64), w)) || (rc = h->linear(&h->c2, w, 64, 3, 2, h->C1))) return rc;
+    {
+        const char* e = getenv("MF_NERF_FIELD");
+        if (!(e && !strcmp(e, "gemm"))) {
+            const char* names[9] = {"aud_ch_att_net.net.0.weight", "aud_ch_att_net.net.1.weight", "eye_att_net.net.0.weight", "eye_att_net.net.1.weight",
+                                    "sigma_net.net.0.weight", "sigma_net.net.1.weight", "sigma_net.net.2.weight", "color_net.net.0.weight",
+                                    "color_net.net.1.weight"};
+            const float* w9[9];
+            for (int i = 0; i < 9; ++i) {
+                auto it = sd.find(names[i]);
+                w9[i] = it == sd.end() ? nullptr : (const float*)it->second->data;   // shapes were checked by the relay() calls above
+                MF_REQUIRE(w9[i] || ((i == 2 || i == 3) && !eye), "nerf_field_create: tensor '%s' missing", names[i]);
+            }
+            if ((rc = mf_nerf_fused_pack(w9, nind, eye != 0, precision == MF_PREC_BF16X3, &h->fused_w))) return rc;
+            h->dev.push_back(h->fused_w);
+        }
+    }
     MF_HIP(hipDeviceSynchronize());
     *out = h.release();
     return MF_OK;
@@ -282,6 +306,9 @@ extern "C" int mf_nerf_field_forward(mf_nerf_field* h, const float* xyzs, const 
     const int M = n_samples, nb = (M + TW - 1) / TW, gb = (M + 255) / 256;
     const bool x3 = h->precision == MF_PREC_BF16X3;
     const mf_nerf_field_config& c = h->cfg;
+    if (h->fused_w)
+        return mf_nerf_fused_launch(h->fused_w, x3, h->emb, c.offsets, c.log2_per_level_scale, c.base_resolution, c.bound, xyzs, dirs, enc_a, ind_code,
+                                    c.individual_dim, eye, c.exp_eye, M, sigmas, rgbs, amb_aud, amb_eye, uncertainty, s);
     MF_HIP(hipMemcpyAsync(h->d_enc_a, enc_a, AUD * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (c.individual_dim) MF_HIP(hipMemcpyAsync(h->d_ind, ind_code, c.individual_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_nf_prep, dim3(gb), dim3(256), 0, s, xyzs, dirs, h->d_ind, c.individual_dim, c.bound, M, h->coords, h->CI->hi, h->CI->lo);
