@@ -14,6 +14,8 @@ namespace {
 
 constexpr int SEQ = 8, WIN = 16, AUD_DIM = 32;
 constexpr int MAX_ACT = 8 * 64 * 16;     // largest intermediate: 8 windows x 64 channels x 16 steps (the input for in_dim <= 64)
+constexpr int MAX_W = 64 * 64 * 3;
+constexpr size_t AUDIO_LDS = (MAX_ACT + MAX_ACT / 2 + SEQ * AUD_DIM + 64 + MAX_W) * sizeof(float);
 
 struct Layer { const float* w; const float* b; int cin, cout; };
 struct AudioArgs {
@@ -26,14 +28,22 @@ struct AudioArgs {
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.02f * v; }
 
+// the layer's weights and bias into LDS (coalesced), so the MAC loops below never wait on a global load
+__device__ void stage_weights(const Layer& L, int k, float* wbuf, float* bbuf) {
+    for (int i = threadIdx.x; i < L.cout * L.cin * k; i += blockDim.x) wbuf[i] = L.w[i];
+    for (int i = threadIdx.x; i < L.cout; i += blockDim.x) bbuf[i] = L.b[i];
+    __syncthreads();
+}
+
 // out[n][co][t] = act(b[co] + sum_{ci,k} w[co][ci][k] * in[n][ci][t*stride + k - 1]), zero padding 1
-__device__ void conv1d(const float* in, float* out, const Layer& L, int n, int tin, int stride, bool act) {
+__device__ void conv1d(const float* in, float* out, const Layer& L, int n, int tin, int stride, bool act, float* wbuf, float* bbuf) {
+    stage_weights(L, 3, wbuf, bbuf);
     const int tout = (tin + 2 - 3) / stride + 1;
     for (int idx = threadIdx.x; idx < n * L.cout * tout; idx += blockDim.x) {
         const int t = idx % tout, co = (idx / tout) % L.cout, b = idx / (tout * L.cout);
-        float acc = L.b[co];
+        float acc = bbuf[co];
         for (int ci = 0; ci < L.cin; ++ci) {
-            const float* wr = L.w + ((size_t)co * L.cin + ci) * 3;
+            const float* wr = wbuf + ((size_t)co * L.cin + ci) * 3;
             const float* xr = in + ((size_t)b * L.cin + ci) * tin;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -47,28 +57,33 @@ __device__ void conv1d(const float* in, float* out, const Layer& L, int n, int t
 }
 
 // out[n][o] = act(b[o] + sum_i w[o][i] * in[n][i])
-__device__ void linear(const float* in, float* out, const Layer& L, int n, bool act) {
+__device__ void linear(const float* in, float* out, const Layer& L, int n, bool act, float* wbuf, float* bbuf) {
+    stage_weights(L, 1, wbuf, bbuf);
     for (int idx = threadIdx.x; idx < n * L.cout; idx += blockDim.x) {
         const int o = idx % L.cout, b = idx / L.cout;
-        float acc = L.b[o];
-        for (int i = 0; i < L.cin; ++i) acc += L.w[(size_t)o * L.cin + i] * in[(size_t)b * L.cin + i];
+        float acc = bbuf[o];
+        for (int i = 0; i < L.cin; ++i) acc += wbuf[(size_t)o * L.cin + i] * in[(size_t)b * L.cin + i];
         out[idx] = act ? lrelu(acc) : acc;
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_audio_encode(const AudioArgs a, const float* __restrict__ auds, int n_win, float* enc_a) {
-    __shared__ float bufA[MAX_ACT], bufB[MAX_ACT / 2];
-    __shared__ float feat[SEQ * AUD_DIM];
+__global__ __launch_bounds__(1024) void k_audio_encode(const AudioArgs a, const float* __restrict__ auds, int n_win, float* enc_a) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* bufA = dyn;                        // MAX_ACT
+    float* bufB = bufA + MAX_ACT;             // MAX_ACT / 2
+    float* feat = bufB + MAX_ACT / 2;         // SEQ * AUD_DIM
+    float* bbuf = feat + SEQ * AUD_DIM;       // 64
+    float* wbuf = bbuf + 64;                  // MAX_W: the largest layer, 64 x 64 x 3
     // network.py:61-62: the centre 16 steps of the window (win_size 16 -> all of them)
     for (int i = threadIdx.x; i < n_win * a.in_dim * WIN; i += blockDim.x) bufA[i] = auds[i];
     __syncthreads();
-    conv1d(bufA, bufB, a.conv[0], n_win, 16, 2, true);
-    conv1d(bufB, bufA, a.conv[1], n_win, 8, 2, true);
-    conv1d(bufA, bufB, a.conv[2], n_win, 4, 2, true);
-    conv1d(bufB, bufA, a.conv[3], n_win, 2, 2, true);        // [n, 64, 1]
-    linear(bufA, bufB, a.fc[0], n_win, true);
-    linear(bufB, feat, a.fc[1], n_win, false);               // [n, 32]
+    conv1d(bufA, bufB, a.conv[0], n_win, 16, 2, true, wbuf, bbuf);
+    conv1d(bufB, bufA, a.conv[1], n_win, 8, 2, true, wbuf, bbuf);
+    conv1d(bufA, bufB, a.conv[2], n_win, 4, 2, true, wbuf, bbuf);
+    conv1d(bufB, bufA, a.conv[3], n_win, 2, 2, true, wbuf, bbuf);        // [n, 64, 1]
+    linear(bufA, bufB, a.fc[0], n_win, true, wbuf, bbuf);
+    linear(bufB, feat, a.fc[1], n_win, false, wbuf, bbuf);               // [n, 32]
     if (!a.use_att || n_win != SEQ) {
         // att == 0: encode_audio returns audio_net's output as is (network.py:230-235); callers pass one window then
         for (int i = threadIdx.x; i < AUD_DIM; i += blockDim.x) enc_a[i] = feat[i];
@@ -77,12 +92,12 @@ __global__ __launch_bounds__(256) void k_audio_encode(const AudioArgs a, const f
     // AudioAttNet: y = x.permute(0, 2, 1) -> [1, 32, 8]
     for (int i = threadIdx.x; i < SEQ * AUD_DIM; i += blockDim.x) { const int t = i % SEQ, c = i / SEQ; bufA[c * SEQ + t] = feat[t * AUD_DIM + c]; }
     __syncthreads();
-    conv1d(bufA, bufB, a.att[0], 1, SEQ, 1, true);
-    conv1d(bufB, bufA, a.att[1], 1, SEQ, 1, true);
-    conv1d(bufA, bufB, a.att[2], 1, SEQ, 1, true);
-    conv1d(bufB, bufA, a.att[3], 1, SEQ, 1, true);
-    conv1d(bufA, bufB, a.att[4], 1, SEQ, 1, true);           // [1, 1, 8]
-    linear(bufB, bufA, a.att_fc, 1, false);                  // [1, 8]
+    conv1d(bufA, bufB, a.att[0], 1, SEQ, 1, true, wbuf, bbuf);
+    conv1d(bufB, bufA, a.att[1], 1, SEQ, 1, true, wbuf, bbuf);
+    conv1d(bufA, bufB, a.att[2], 1, SEQ, 1, true, wbuf, bbuf);
+    conv1d(bufB, bufA, a.att[3], 1, SEQ, 1, true, wbuf, bbuf);
+    conv1d(bufA, bufB, a.att[4], 1, SEQ, 1, true, wbuf, bbuf);           // [1, 1, 8]
+    linear(bufB, bufA, a.att_fc, 1, false, wbuf, bbuf);                  // [1, 8]
     if (threadIdx.x == 0) {
         float m = bufA[0];
         for (int t = 1; t < SEQ; ++t) m = fmaxf(m, bufA[t]);
@@ -159,7 +174,12 @@ extern "C" int mf_audio_encoder_forward(mf_audio_encoder* h, const float* auds, 
     MF_REQUIRE(h && auds && enc_a, "audio_encoder_forward: null argument");
     MF_REQUIRE(h->a.use_att ? n_windows == SEQ : n_windows == 1,
                "audio_encoder_forward: %d windows (the attention net pools exactly 8, network.py:10; without it one window)", n_windows);
-    hipLaunchKernelGGL(k_audio_encode, dim3(1), dim3(256), 0, (hipStream_t)stream, h->a, auds, n_windows, enc_a);
+    static bool attr_done = false;
+    if (!attr_done) {
+        MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_audio_encode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AUDIO_LDS));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_audio_encode, dim3(1), dim3(1024), AUDIO_LDS, (hipStream_t)stream, h->a, auds, n_windows, enc_a);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
