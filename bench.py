@@ -537,6 +537,21 @@ def main():
                                "latent_linf_vs_oracle": par["latent_linf_vs_oracle"], "u8_max_diff": par["u8_max_diff"]}
                 del alt
                 torch.cuda.empty_cache()
+                # cross-session batching: 4 sessions x 8 frames in one step (what a node does with >= 4 sessions per GPU);
+                # the UNet's GEMMs get 4x the pixels per launch
+                if args.sessions > 0:
+                    ms_b = 4 * args.batch
+                    big = MuseTalkRunner(args.precision, ms_b, device)
+                    el3 = harness.timed_steps(big.step, 10, 2, sync_fn=torch.cuda.synchronize)
+                    rows_b = big.profile(2)
+                    cb = [r for r in rows_b if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
+                    tb, fb = sum(r["ms"] for r in cb), sum(r["flops"] for r in cb)
+                    line["multi_session"] = {"sessions_per_step": 4, "batch": ms_b, "value": round(ms_b * 10 / el3, 1), "unit": "frames/s",
+                                             "ms_per_step": round(el3 / 10 * 1e3, 3), "sessions_at_25fps": round(ms_b * 10 / el3 / 25.0, 1),
+                                             "unet_conv_blocks": {"achieved_tflops": round(fb / (tb * 1e-3) / 1e12, 1),
+                                                                  "mfma_issue_frac_of_bf16_peak": round(MFMA_PASSES[args.precision] * fb / (tb * 1e-3) / 1e12 / BF16_DENSE_PEAK_TF, 3)}}
+                    del big
+                    torch.cuda.empty_cache()
                 dl = args.dump_layers
                 args.dump_layers = dl + ".wav2lip.json" if dl else None
                 line["wav2lip"] = wav2lip_report(args, device, world, rank)

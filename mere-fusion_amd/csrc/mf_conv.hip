@@ -969,7 +969,7 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
             for (int si = 0; si < (fs ? 1 : (int)(sizeof(splits) / sizeof(splits[0]))); ++si) {
                 const int S = fs ? fs : splits[si];
                 if (S > kt_min) continue;
-                if (c.bm == 256 && Kavg / S < 1024 && !force_tile) continue;   // too few K tiles to amortise a 256-wide prologue / epilogue
+                if (c.bm == 256 && Kavg / S < 512 && !force_tile) continue;    // too few K tiles to amortise a 256-wide prologue / epilogue
                 const double wg = (double)cdiv(M, c.bm) * cdiv(N, c.bn) * p->nphase * S;
                 const double slots = 256.0 * c.resident;
                 const double rate = std::min(PW, CHIP / std::min(wg, slots));
