@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmerefusion_hip.so")
-SOURCES = ["mf_api.cpp", "mf_conv.hip", "mf_conv_halo.hip", "mf_aux.hip", "mf_wav2lip.hip", "mf_conv_api.hip", "mf_mel.hip", "mf_nn.hip", "mf_attn.hip", "mf_whisper.hip", "mf_musetalk.hip", "mf_nerf.hip", "mf_nerf_net.hip", "mf_nerf_fused.hip", "mf_nerf_audio.hip"]
+SOURCES = ["mf_api.cpp", "mf_conv.hip", "mf_conv_halo.hip", "mf_conv_halo2.hip", "mf_aux.hip", "mf_wav2lip.hip", "mf_conv_api.hip", "mf_mel.hip", "mf_nn.hip", "mf_attn.hip", "mf_whisper.hip", "mf_musetalk.hip", "mf_nerf.hip", "mf_nerf_net.hip", "mf_nerf_fused.hip", "mf_nerf_audio.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

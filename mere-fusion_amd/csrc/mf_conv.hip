@@ -794,6 +794,8 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
             }
         }
         ha.act = p->d.act;
+        const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
+        if (tw.ph) return mf_halo_w_launch(ha, tw, x3, stream);
         return mf_halo_launch(ha, mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch), x3, stream);
     }
 
@@ -990,8 +992,9 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
 void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision == MF_PREC_BF16X3 ? "true" : "false";
     if (p->halo) {
-        const HaloTile t = mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
-        snprintf(buf, cap, "k_conv3x3_halo<%d,%d,%d,%d,%s,2>", t.ph, t.bn, t.wgm, t.wgn, x3);
+        const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
+        const HaloTile t = tw.ph ? tw : mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
+        snprintf(buf, cap, "k_conv3x3_halo%s<%d,%d,%d,%d,%s,2>", tw.ph ? "_w" : "", t.ph, t.bn, t.wgm, t.wgn, x3);
     } else {
         const ConvTile t = mf_conv_pick_tile(p, batch);
         const int bk = (p->precision == MF_PREC_BF16X3 && t.bm + t.bn > 128) ? 32 : 64;

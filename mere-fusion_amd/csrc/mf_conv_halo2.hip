@@ -1,0 +1,347 @@
+// 3x3 stride-1 convolution on MFMA, second generation of the LDS halo-tile kernel (mf_conv_halo.hip): the WEIGHTS also go
+// through LDS, shared by every wave of the workgroup.
+//
+// Why: in mf_conv_halo.hip each wave streams its own (slice, tap) A fragments straight from L2.  rocprofv3 on the VAE's
+// 128 -> 128 layer at 256x256 (profiles/r01_pmc_halo_128x128_256.txt): TCC_REQ = 42.2 M x 128 B = 5.4 GB per launch, 86 % of it
+// weights (147 KB per workgroup and slice against a 23 KB halo patch) -- the kernel sits on the ~10-12 TB/s L2 -> CU ceiling
+// with the MFMA pipe 42 % busy.  Here a 16 x 16-pixel patch (8 waves) shares ONE copy of each tap's weight tile:
+// L2 traffic per FLOP drops to about a third.
+//
+// Pipeline per channel slice (CK = 32 channels in bf16x3, 64 in bf16): the halo patch is double-buffered as before; the nine
+// taps' weight tiles arrive in three rows of three taps through a 2-deep LDS ring (row r+1 lands while row r is multiplied);
+// one barrier per tap row.  Both images are filled by LDS-DMA (lane-linear), so the bank-conflict swizzle is applied to the DMA
+// source address and again on the ds_read side, exactly as in the other two conv kernels.
+#include "mf_conv.h"
+#include <cstdlib>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+constexpr int PW = 16;   // patch width = one MFMA pixel fragment
+
+// XOR term of the 16-byte slot index, a function of the halo COLUMN hx only, so that a fragment
+// address is (lane-constant per dx) + (compile-time row offset).  Conflict-free for every tap shift.
+template <int CK>
+__device__ __forceinline__ int hswz(int hx) {
+    return CK == 32 ? (((hx >> 2) & 1) << 1) : (((hx >> 1) & 3) << 1);
+}
+
+__device__ __forceinline__ float hbf2f(uint32_t h16) { return __uint_as_float(h16 << 16); }
+__device__ __forceinline__ uint32_t hf2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+__device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+}  // namespace
+
+template <int PH, int BN, int WGM, int WGN, bool X3, int NST>
+__global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const HaloArgs a) {
+    constexpr int NW = WGM * WGN;                           // waves per workgroup
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    constexpr int CK = X3 ? 32 : 64;
+    constexpr int KG = CK / 8, ROWB = CK * 2, RPC = 1024 / ROWB;
+    constexpr int NP = X3 ? 2 : 1;
+    constexpr int KK = CK / 32;                             // MFMA k-steps per slice
+    constexpr int HW = PW + 2, HROWS = (PH + 2) * HW;
+    constexpr int HCH = (HROWS + RPC - 1) / RPC;           // 1-KiB DMA chunks of the halo image
+    constexpr int H_BYTES = HCH * 1024;
+    constexpr int NHC = (HCH + NW - 1) / NW;
+    constexpr int FM = PH / WGM;                            // patch rows (= pixel fragments) per wave
+    constexpr int FN = BN / WGN / 16;                       // 16-channel fragment rows per wave
+    static_assert(FN >= 1 && FM >= 1, "wave tile must hold a fragment");
+    constexpr int STAGE = NP * H_BYTES;                     // one halo image (hi, lo); two stages
+    constexpr int WT_BYTES = BN * ROWB;                     // one tap's weight tile, one plane: [BN][CK] bf16
+    constexpr int WCH = WT_BYTES / 1024;                    // its 1-KiB DMA chunks
+    constexpr int WROW = 3 * NP * WT_BYTES;                 // one tap row (3 taps, planes) of the ring
+    constexpr int WRC = 3 * NP * WCH;                       // DMA chunks per tap row
+    constexpr int NWR = (WRC + NW - 1) / NW;
+    static_assert(WT_BYTES % 1024 == 0, "weight tile must be whole DMA chunks");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wring = smem + 2 * STAGE;                   // 2 x WROW
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // XCD-aware order, n tile fastest
+    const int nt = a.n_patches * a.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int patch = t / a.tiles_n, tn = t - patch * a.tiles_n;
+    const int b = patch / a.patches_per_img;
+    const int pr = patch - b * a.patches_per_img;
+    const int py = pr / a.patches_x, px = pr - py * a.patches_x;
+    const int y0 = py * PH, x0 = px * PW;      // patch origin (unpadded output == input coordinates)
+    const int n0 = tn * BN;
+
+    // ---- halo DMA sources ------------------------------------------------------------------------
+    // halo row hr -> input pixel (y0 - 1 + hy, x0 - 1 + hx); with the input buffer's zero ring that is
+    // padded coordinate (y0 + hy + halo - 1, ...).  Rows/cols past the buffer are clamped: they only
+    // feed output pixels that are masked below.
+    const bf16_t* hp[NHC];
+    const int64_t x_delta = X3 ? (a.x_lo - a.x_hi) : 0;
+#pragma unroll
+    for (int i = 0; i < NHC; ++i) {
+        int hr = (wave + NW * i) * RPC + lane / KG;
+        const int kg = (lane % KG) ^ hswz<CK>(hr % HW);
+        hr = hr < HROWS ? hr : HROWS - 1;
+        const int hy = hr / HW, hx = hr - hy * HW;
+        int iy = y0 + hy + a.in_halo - 1, ix = x0 + hx + a.in_halo - 1;
+        iy = iy < a.in_hp ? iy : a.in_hp - 1;
+        ix = ix < a.in_wp ? ix : a.in_wp - 1;
+        hp[i] = a.x_hi + ((int64_t)b * a.xb + ((int64_t)iy * a.in_wp + ix) * a.x_ld + kg * 8);
+    }
+    auto load_halo = [&](int slice, int stage) __attribute__((always_inline)) {
+        char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < NHC; ++i) {
+            const int c = wave + NW * i;
+            if (HCH % NW == 0 || c < HCH) {
+                const bf16_t* src = hp[i] + slice * CK;
+                hglds16(src, base + c * 1024);
+                if (X3) hglds16(src + x_delta, base + H_BYTES + c * 1024);
+            }
+        }
+    };
+
+    // ---- weights: one tile [BN][CK] per (slice, tap, plane), DMA'd by tap rows into the LDS ring ------------------------
+    const int wave_m = wave % WGM, wave_n = wave / WGM;
+    const int row0 = wave_m * FM;
+    const int cn0 = wave_n * (FN * 16);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int64_t w_delta = X3 ? (a.w_lo - a.w_hi) : 0;
+    const int64_t w_tap = (int64_t)a.Npad * CK;            // one (slice, tap) tile in the packed weights
+    // chunk c of a tap row = (tap t = c / (NP * WCH), plane, 1-KiB piece q): lane l lands in LDS row q*RPC + l/KG, slot l%KG
+    const bf16_t* wsrc[NWR];
+    int wtap[NWR];
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) {
+        const int c = wave + NW * i;
+        const int t3 = c / (NP * WCH), rem = c - t3 * (NP * WCH), pl = rem / WCH, q = rem - pl * WCH;
+        const int r = q * RPC + lane / KG;
+        const int kg = (lane % KG) ^ hswz<CK>(r);
+        int nrow = n0 + r;
+        nrow = nrow < a.Npad ? nrow : a.Npad - 1;
+        wsrc[i] = a.w_hi + (pl ? w_delta : 0) + ((int64_t)nrow * CK + kg * 8);
+        wtap[i] = t3;
+    }
+    // tap row `trow` (0..2) of slice `slice` into ring buffer `buf`
+    auto load_wrow = [&](int slice, int trow, int buf) __attribute__((always_inline)) {
+        char* base = wring + buf * WROW;
+#pragma unroll
+        for (int i = 0; i < NWR; ++i) {
+            const int c = wave + NW * i;
+            if (WRC % NW == 0 || c < WRC) hglds16(wsrc[i] + (int64_t)(slice * 9 + trow * 3 + wtap[i]) * w_tap, base + c * 1024);
+        }
+    };
+    // A fragment of (tap-in-row t3, channel block i, k-step kk, plane): rows cn0 + i*16 + fr, 16-byte slot kk*4 + fk
+    int wlane[FN][KK];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int r = cn0 + i * 16 + fr;
+            wlane[i][kk] = r * ROWB + (((kk * 4 + fk) ^ hswz<CK>(r)) << 4);
+        }
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // lane part of a pixel-fragment address, one per horizontal tap shift and k-step
+    int lane_off[3][KK];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            lane_off[dx][kk] = (row0 * HW + fr + dx) * ROWB + (((kk * 4 + fk) ^ hswz<CK>(fr + dx)) << 4);
+
+    // residual taken from the halo image (conv.py:17-18 `out += x`), once per slice that carries the lane's channels
+    auto add_residual = [&](int stage, int slice) __attribute__((always_inline)) {
+        const char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int cb = n0 + cn0 + i * 16;                  // wave-uniform
+            if (cb / CK == slice) {
+                const int kg = (cb % CK) / 8 + (fk >> 1);
+                const int hx = fr + 1;
+                const int lo8 = ((kg ^ hswz<CK>(hx)) << 4) + (fk & 1) * 8;
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    const char* p = base + ((row0 + j + 1) * HW + hx) * ROWB + lo8;
+                    uint2 rh = *reinterpret_cast<const uint2*>(p);
+                    acc[i][j][0] += hbf2f(rh.x & 0xffffu); acc[i][j][1] += hbf2f(rh.x >> 16);
+                    acc[i][j][2] += hbf2f(rh.y & 0xffffu); acc[i][j][3] += hbf2f(rh.y >> 16);
+                    if (X3) {
+                        rh = *reinterpret_cast<const uint2*>(p + H_BYTES);
+                        acc[i][j][0] += hbf2f(rh.x & 0xffffu); acc[i][j][1] += hbf2f(rh.x >> 16);
+                        acc[i][j][2] += hbf2f(rh.y & 0xffffu); acc[i][j][3] += hbf2f(rh.y >> 16);
+                    }
+                }
+            }
+        }
+    };
+    // the three taps of kernel row `dy`: pixel fragments from the halo image at row shift dy, weights from ring buffer `buf`
+    auto compute_row = [&](int stage, int dy, int buf) __attribute__((always_inline)) {
+        const char* base = smem + stage * STAGE;
+        const char* wb = wring + buf * WROW;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                bf16x8 whi[FN], wlo[FN];
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    whi[i] = *reinterpret_cast<const bf16x8*>(wb + (dx * NP) * WT_BYTES + wlane[i][kk]);
+                    if (X3) wlo[i] = *reinterpret_cast<const bf16x8*>(wb + (dx * NP + 1) * WT_BYTES + wlane[i][kk]);
+                }
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    const char* p = base + lane_off[dx][kk] + (j + dy) * HW * ROWB;
+                    const bf16x8 c_hi = *reinterpret_cast<const bf16x8*>(p);
+                    bf16x8 c_lo;
+                    if (X3) c_lo = *reinterpret_cast<const bf16x8*>(p + H_BYTES);
+                    if (X3) {
+#pragma unroll
+                        for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[i], c_hi, acc[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[i], c_lo, acc[i][j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[i], c_hi, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    load_halo(0, 0);
+    load_wrow(0, 0, 0);
+    __syncthreads();                           // drains the DMA (vmcnt) and publishes halo stage 0 + weight row 0
+    int wbuf = 0;
+    for (int slice = 0; slice < a.n_slices; ++slice) {
+        const bool more = slice + 1 < a.n_slices;
+        const int st = slice & 1;
+        if (more) load_halo(slice + 1, st ^ 1);            // flies under this slice's MFMAs
+        if (a.res_from_halo) add_residual(st, slice);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            // the next tap row (of this slice, or row 0 of the next) into the other ring buffer: everyone left it at the last barrier
+            if (dy < 2) load_wrow(slice, dy + 1, wbuf ^ 1);
+            else if (more) load_wrow(slice + 1, 0, wbuf ^ 1);
+            compute_row(st, dy, wbuf);
+            if (dy < 2 || more) __syncthreads();           // next row (and, at dy == 2, the next halo image) landed; this row is released
+            wbuf ^= 1;
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int oy = y0 + row0 + j, ox = x0 + fr;
+        if (oy >= a.H || ox >= a.W) continue;
+        const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
+        const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)ox * a.rj;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int c = n0 + cn0 + i * 16 + fk * 4;
+            if (c >= a.N) continue;
+            const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
+            float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+            if (a.r_hi) {
+                const uint2 rh = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
+                v[0] += hbf2f(rh.x & 0xffffu); v[1] += hbf2f(rh.x >> 16);
+                v[2] += hbf2f(rh.y & 0xffffu); v[3] += hbf2f(rh.y >> 16);
+                if (X3) {
+                    const uint2 rl = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
+                    v[0] += hbf2f(rl.x & 0xffffu); v[1] += hbf2f(rl.x >> 16);
+                    v[2] += hbf2f(rl.y & 0xffffu); v[3] += hbf2f(rl.y >> 16);
+                }
+            }
+            if (a.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (a.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+            }
+            uint32_t h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = hf2bf(v[e]);
+            *reinterpret_cast<uint2*>(a.y_hi + yo + c) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            if (X3) {
+                uint32_t l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) l[e] = hf2bf(v[e] - hbf2f(h[e]));
+                *reinterpret_cast<uint2*>(a.y_lo + yo + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+namespace {
+
+template <int PH, int BN, int WGM, int WGN, bool X3, int NST>
+int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
+    static bool attr_done = false;
+    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, NST>;
+    if (!attr_done) {
+        MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    constexpr int CK = X3 ? 32 : 64, RPC = 1024 / (CK * 2), NP = X3 ? 2 : 1;
+    constexpr int HCH = ((PH + 2) * (PW + 2) + RPC - 1) / RPC;
+    const size_t lds = (size_t)2 * NP * HCH * 1024 + (size_t)2 * 3 * NP * BN * CK * 2;
+    hipLaunchKernelGGL(kern, dim3(a.n_patches * a.tiles_n), dim3(WGM * WGN * 64), lds, s, a);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+template <int PH, int BN, int WGM, int WGN>
+int halo_w_launch_prec(const HaloArgs& a, bool x3, hipStream_t s) {
+    return x3 ? halo_w_launch_cfg<PH, BN, WGM, WGN, true, 2>(a, s) : halo_w_launch_cfg<PH, BN, WGM, WGN, false, 2>(a, s);
+}
+
+}  // namespace
+
+// Same contract as mf_halo_launch; `t` comes from mf_halo_w_pick_tile.
+int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t s) {
+    HaloArgs a = a0;
+    a.patches_x = (a.W + PW - 1) / PW;
+    const int patches_y = (a.H + t.ph - 1) / t.ph;
+    a.patches_per_img = a.patches_x * patches_y;
+    a.n_patches = a.batch * a.patches_per_img;
+    a.tiles_n = (a.N + t.bn - 1) / t.bn;
+#define MF_HCASE(PH, BN, WGM, WGN) \
+    if (t.ph == PH && t.bn == BN) return halo_w_launch_prec<PH, BN, WGM, WGN>(a, x3, s);
+    MF_HCASE(16, 64, 4, 2)
+    MF_HCASE(8, 64, 2, 2)
+#undef MF_HCASE
+    mf_set_error("halo conv (LDS weights): no kernel for patch %dx16, BN %d", t.ph, t.bn);
+    return MF_ERR_INVALID;
+}
+
+// The LDS-weights kernel pays off where the weight stream dominates the patch: 64-channel tiles on maps large enough to give every
+// CU a 16 x 16 (or 8 x 16) patch.  Returns ph == 0 when the first-generation kernel should be used.
+HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch) {
+    static const int mode = [] { const char* e = getenv("MF_HALO_WLDS"); return e ? atoi(e) : 0; }();   // opt-in: see profiles/r01_igemm_bandwidth_study.md
+    auto wgs = [&](int ph) { return batch * ((H + ph - 1) / ph) * ((W + PW - 1) / PW) * ((N + 63) / 64); };
+    if (!mode || N < 64) return HaloTile{0, 0, 0, 0};
+    if (mode == 2) return HaloTile{16, 64, 4, 2};          // tests: every eligible layer, whatever its size
+    if (mode == 3) return HaloTile{8, 64, 2, 2};
+    if (wgs(16) >= 256) return HaloTile{16, 64, 4, 2};
+    if (wgs(8) >= 256) return HaloTile{8, 64, 2, 2};
+    return HaloTile{0, 0, 0, 0};
+}
