@@ -363,13 +363,21 @@ class ErNeRFRunner:
         self.pose = torch.eye(4)[None]
         self.r = HipHeadRenderer(self.field, torch.from_numpy(self.bitfield).to(device), density_scale=40.0, torso=self.torso, audio=self.audio,
                                  ind_code=self.d_ind, smooth_lips=True)
-        self.last = None
+        self.last, self.trace, self.loop = None, None, os.environ.get("MF_NERF_LOOP", "device")
 
     def step(self):
-        self.last = self.r.render(self.ro, self.rd, self.auds, self.bg_coords, self.pose, self.d_eye, bg_color=1.0, want_u8=True)
+        # MF_NERF_LOOP=host keeps the reference's host-synced compaction (renderer.py:266); the default runs the round control on the device
+        if self.loop == "host":
+            self.last = self.r.render(self.ro, self.rd, self.auds, self.bg_coords, self.pose, self.d_eye, bg_color=1.0, want_u8=True)
+            self.trace = self.last["trace"]
+        else:
+            self.last = self.r.render(self.ro, self.rd, self.auds, self.bg_coords, self.pose, self.eye, bg_color=1.0, want_u8=True, loop="device",
+                                      graph=os.environ.get("MF_NO_GRAPH") is None)
 
     def samples_per_frame(self):
-        return sum(a * s for a, s in self.last["trace"])
+        if self.trace is None:        # the device loop keeps no host-side trace: count the same frame once through the host loop
+            self.trace = self.r.run_cuda(self.ro, self.rd, self.r.enc_a, self.d_ind, self.d_eye, bg_color=1.0)["trace"]
+        return sum(a * s for a, s in self.trace)
 
     def parity(self, width=48):
         from mere_fusion_amd.ernerf.field import HipNeRFField
@@ -410,7 +418,7 @@ def ernerf_report(args, device, world, rank, value=None, ms_per_step=None, run=N
                        "(march -> tri-plane field -> composite) x <= 16 steps, uint8 frame; synthetic occupancy, rays resident in HBM "
                        "(BASELINE.json configs[4])",
            "value": round(value, 1), "unit": "frames/s", "ms_per_step": round(ms_per_step, 3), "dtype": args.precision,
-           "samples_per_frame": int(smp), "march_iterations": len(run.last["trace"]),
+           "samples_per_frame": int(smp), "march_iterations": len(run.trace), "loop": run.loop,
            "field_tflops_algorithmic": round(smp * 46368 * value / max(world, 1) / 1e12, 2)}
     rep["parity"] = run.parity()
     if args.cpu_seconds > 0:

@@ -296,6 +296,23 @@ int mf_nerf_field_forward(mf_nerf_field* h, const float* xyzs, const float* dirs
                           float* uncertainty, void* stream);
 void mf_nerf_field_destroy(mf_nerf_field* h);
 
+/* ---- ER-NeRF head frame without host round trips ----------------------------------------------- */
+typedef struct mf_nerf_head mf_nerf_head;
+/* Scratch for up to max_rays rays over `field` (which must outlive the head and use the fused field kernel). */
+int mf_nerf_head_create(mf_nerf_field* field, int max_rays, mf_nerf_head** out);
+/* The inference branch of `NeRFRenderer.run_cuda` (renderer.py:231-291) for one frame, enqueued in one go: near/far,
+ * max_steps rounds of (round control -> march_rays -> field -> composite_rays_triplane -> compaction) whose counters
+ * (n_alive, n_step = max(min(N // n_alive, 8), 1), step) live on the device, then the background mix / depth
+ * normalisation of :275-280.  No host synchronisation: the call only enqueues (capturable in a hipGraph).
+ * rays_o, rays_d [N,3]; density_bitfield [cascades * grid_size^3 / 8]; enc_a [32]; ind_code [individual_dim] or NULL;
+ * bg as in mf_nerf_finish.  Outputs: image [N,3], depth [N], weights_sum [N] (optional), frame_u8 [N,3] (optional).
+ * Survivors of a round keep no particular order (rays are independent), unlike the reference's boolean mask. */
+int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const float* rays_d, int n_rays, const uint8_t* density_bitfield, int cascades,
+                        int grid_size, float min_near, float dt_gamma, int max_steps, float T_thresh, float density_scale, const float* enc_a,
+                        const float* ind_code, float eye, const float* bg_color, int bg_per_ray, float bg_const, float* image, float* depth,
+                        float* weights_sum, uint8_t* frame_u8, void* stream);
+void mf_nerf_head_destroy(mf_nerf_head* h);
+
 /* ---- ER-NeRF torso branch --------------------------------------------------------------------- */
 typedef struct mf_nerf_torso mf_nerf_torso;
 typedef struct mf_nerf_torso_config {

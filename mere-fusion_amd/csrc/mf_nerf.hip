@@ -82,12 +82,13 @@ __global__ __launch_bounds__(NT) void k_march_rays(uint32_t n_alive, uint32_t n_
                                                    const float* __restrict__ rays_d, float bound, float dt_gamma,
                                                    uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
                                                    const float* __restrict__ fars, float* xyzs, float* dirs, float* deltas,
-                                                   const float* __restrict__ noises) {
+                                                   const float* __restrict__ noises, const int* __restrict__ ctl) {
+    if (ctl) { n_alive = (uint32_t)ctl[0]; n_step = (uint32_t)ctl[1]; }     // device-controlled loop: counts live in HBM
     const uint32_t n = threadIdx.x + blockIdx.x * NT;
-    if (n >= n_alive) return;
+    if (n >= n_alive || n_step == 0) return;
     const float SQRT3 = 1.7320508075688772f;
     const int index = rays_alive[n];
-    const float noise = noises[n];
+    const float noise = noises ? noises[n] : 0.f;
     const float* ro = rays_o + (size_t)index * 3;
     const float* rd = rays_d + (size_t)index * 3;
     float* px = xyzs + (size_t)n * n_step * 3;
@@ -136,6 +137,13 @@ __global__ __launch_bounds__(NT) void k_march_rays(uint32_t n_alive, uint32_t n_
             } while (t < tt);
         }
     }
+    if (ctl) {
+        // the wrapper of the host-driven loop zero-fills the outputs (raymarching.py:383-385); here the kernel clears its own tail
+        for (; step < n_step; ++step) {
+            px[0] = px[1] = px[2] = 0.f; pd[0] = pd[1] = pd[2] = 0.f; pt[0] = pt[1] = 0.f;
+            px += 3; pd += 3; pt += 2;
+        }
+    }
 }
 
 // kernel_composite_rays_triplane, raymarching.cu:2142-2249
@@ -145,9 +153,10 @@ __global__ __launch_bounds__(NT) void k_composite_rays_triplane(uint32_t n_alive
                                                                 const float* __restrict__ ambs_aud, const float* __restrict__ ambs_eye,
                                                                 const float* __restrict__ uncertainties, float* weights_sum,
                                                                 float* depth, float* image, float* amb_aud_sum, float* amb_eye_sum,
-                                                                float* uncertainty_sum) {
+                                                                float* uncertainty_sum, const int* __restrict__ ctl) {
+    if (ctl) { n_alive = (uint32_t)ctl[0]; n_step = (uint32_t)ctl[1]; }
     const uint32_t n = threadIdx.x + blockIdx.x * NT;
-    if (n >= n_alive) return;
+    if (n >= n_alive || n_step == 0) return;
     const int index = rays_alive[n];
     const float* sg = sigmas + (size_t)n * n_step;
     const float* rg = rgbs + (size_t)n * n_step * 3;
@@ -332,6 +341,42 @@ __global__ __launch_bounds__(NT) void k_nerf_finish(float* image, float* depth, 
     depth[n] = fmaxf(depth[n] - nears[n], 0.f) / (fars[n] - nears[n]);
 }
 
+// ---- device-controlled render loop (no host sync between rounds) ---------------------------------------------------------
+// ctl: [0] n_alive, [1] n_step, [2] step, [3] M = n_alive * n_step, [4] unused, [5] survivors counted by k_loop_compact
+__global__ void k_loop_init(int* ctl, int N, int* alive, float* rays_t, const float* __restrict__ nears, float* weights_sum, float* depth,
+                            float* image, float* amb_aud_sum, float* amb_eye_sum, float* unc_sum) {
+    const int n = blockIdx.x * NT + threadIdx.x;
+    if (n == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; ctl[5] = N; }
+    if (n >= N) return;
+    alive[n] = n;                                   // renderer.py:242
+    rays_t[n] = nears[n];                           // renderer.py:243
+    weights_sum[n] = depth[n] = amb_aud_sum[n] = amb_eye_sum[n] = unc_sum[n] = 0.f;
+    image[3 * n] = image[3 * n + 1] = image[3 * n + 2] = 0.f;
+}
+// head of a round: `while step < max_steps`, `n_alive <= 0 -> break`, n_step = max(min(N // n_alive, 8), 1) (renderer.py:246-256)
+__global__ void k_loop_ctl(int* ctl, int N, int max_steps) {
+    const int n_alive = ctl[5], step = ctl[2];
+    int n_step = 0;
+    if (n_alive > 0 && step < max_steps) { n_step = N / n_alive; n_step = n_step < 8 ? n_step : 8; n_step = n_step > 1 ? n_step : 1; }
+    ctl[0] = n_step ? n_alive : 0; ctl[1] = n_step; ctl[2] = step + n_step; ctl[3] = n_step ? n_alive * n_step : 0;
+    ctl[5] = n_step ? 0 : n_alive;                  // a finished loop keeps its count; a live round recounts in k_loop_compact
+}
+// `rays_alive = rays_alive[rays_alive >= 0]` (renderer.py:266): wave-aggregated append; the order of the survivors is not kept
+// (rays are independent, so only their slot changes)
+__global__ __launch_bounds__(NT) void k_loop_compact(const int* __restrict__ in, int* out, int* ctl) {
+    const int n_alive = ctl[0];
+    const int n = blockIdx.x * NT + threadIdx.x;
+    const int v = n < n_alive ? in[n] : -1;
+    const bool keep = v >= 0;
+    const unsigned long long m = __ballot(keep);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&ctl[5], __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (keep) out[base + __popcll(m & ((1ull << lane) - 1))] = v;
+}
+
 inline unsigned blocks(uint64_t n) { return (unsigned)((n + NT - 1) / NT); }
 
 }  // namespace
@@ -356,7 +401,7 @@ extern "C" int mf_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_
                "march_rays: n_step=%u max_steps=%u cascades=%u grid=%u", n_step, max_steps, cascades, grid_size);
     if (n_alive == 0) return MF_OK;
     hipLaunchKernelGGL(k_march_rays, dim3(blocks(n_alive)), dim3(NT), 0, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, rays_o,
-                       rays_d, bound, dt_gamma, max_steps, cascades, grid_size, density_bitfield, fars, xyzs, dirs, deltas, noises);
+                       rays_d, bound, dt_gamma, max_steps, cascades, grid_size, density_bitfield, fars, xyzs, dirs, deltas, noises, (const int*)nullptr);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
@@ -371,7 +416,7 @@ extern "C" int mf_composite_rays_triplane(uint32_t n_alive, uint32_t n_step, flo
     if (n_alive == 0) return MF_OK;
     hipLaunchKernelGGL(k_composite_rays_triplane, dim3(blocks(n_alive)), dim3(NT), 0, (hipStream_t)stream, n_alive, n_step, T_thresh,
                        rays_alive, rays_t, sigmas, rgbs, deltas, ambs_aud, ambs_eye, uncertainties, weights_sum, depth, image, amb_aud_sum,
-                       amb_eye_sum, uncertainty_sum);
+                       amb_eye_sum, uncertainty_sum, (const int*)nullptr);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
@@ -433,5 +478,31 @@ extern "C" int mf_nerf_finish(float* image, float* depth, const float* weights_s
     hipLaunchKernelGGL(k_nerf_finish, dim3(blocks(n_rays)), dim3(NT), 0, (hipStream_t)stream, image, depth, weights_sum, nears, fars, bg_color,
                        bg_per_ray, bg_const, n_rays, frame_u8);
     MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+// ---- launchers of the device-controlled loop pieces (used by mf_nerf_head_render, mf_nerf_net.hip) -----------------------------
+int mf_nerf_loop_init(int* ctl, int N, int* alive, float* rays_t, const float* nears, float* weights_sum, float* depth, float* image,
+                      float* amb_aud_sum, float* amb_eye_sum, float* unc_sum, hipStream_t s) {
+    hipLaunchKernelGGL(k_loop_init, dim3(blocks(N)), dim3(NT), 0, s, ctl, N, alive, rays_t, nears, weights_sum, depth, image, amb_aud_sum, amb_eye_sum, unc_sum);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+int mf_nerf_loop_round(int* ctl, int N, int max_steps, const int* alive_in, int* alive_out, float* rays_t, const float* rays_o, const float* rays_d,
+                       float bound, float dt_gamma, uint32_t cascades, uint32_t grid_size, const uint8_t* bitfield, const float* nears, const float* fars,
+                       float* xyzs, float* dirs, float* deltas, int phase, float T_thresh, const float* sigmas, const float* rgbs, const float* amb_aud,
+                       const float* amb_eye, const float* unc, float* weights_sum, float* depth, float* image, float* amb_aud_sum, float* amb_eye_sum,
+                       float* unc_sum, hipStream_t s) {
+    if (phase == 0) {          // round head + march
+        hipLaunchKernelGGL(k_loop_ctl, dim3(1), dim3(1), 0, s, ctl, N, max_steps);
+        hipLaunchKernelGGL(k_march_rays, dim3(blocks(N)), dim3(NT), 0, s, 0u, 0u, alive_in, rays_t, rays_o, rays_d, bound, dt_gamma, (uint32_t)max_steps, cascades,
+                           grid_size, bitfield, fars, xyzs, dirs, deltas, (const float*)nullptr, (const int*)ctl);
+    } else {                   // composite + compaction
+        hipLaunchKernelGGL(k_composite_rays_triplane, dim3(blocks(N)), dim3(NT), 0, s, 0u, 0u, T_thresh, const_cast<int*>(alive_in), rays_t, sigmas, rgbs, deltas,
+                           amb_aud, amb_eye, unc, weights_sum, depth, image, amb_aud_sum, amb_eye_sum, unc_sum, (const int*)ctl);
+        hipLaunchKernelGGL(k_loop_compact, dim3(blocks(N)), dim3(NT), 0, s, alive_in, alive_out, ctl);
+    }
+    MF_HIP(hipGetLastError());
+    (void)nears;
     return MF_OK;
 }

@@ -47,6 +47,8 @@ struct FusedArgs {
     uint32_t resolution[NLEV], offset[NLEV], hashmap_size[NLEV];
     float bound, eye;
     int n_ind, has_eye, M, ntiles;
+    const int* M_dev;                // device-side sample count (sync-free render loop), or null
+    float sigma_scale;               // NeRFRenderer.density_scale (renderer.py:261)
     float *sigmas, *rgbs, *amb_aud, *amb_eye, *unc;
 };
 
@@ -110,6 +112,9 @@ __global__ __launch_bounds__(512) void k_nerf_field_fused(const FusedArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __shared__ LevelTab lt;
+    const int M = a.M_dev ? *a.M_dev : a.M;
+    const int ntiles = (M + TILE - 1) / TILE;
+    if ((int)blockIdx.x >= ntiles) return;          // also the "round already finished" case of the device-controlled loop (M == 0)
     for (int i = tid; i < NFRAG * NP * 64; i += 512)
         reinterpret_cast<u32x4*>(smem)[i] = reinterpret_cast<const u32x4*>(a.w)[i];
     if (tid < NLEV) { lt.scale[tid] = a.scale[tid]; lt.resolution[tid] = a.resolution[tid]; lt.offset[tid] = a.offset[tid]; lt.hashmap_size[tid] = a.hashmap_size[tid]; }
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(512) void k_nerf_field_fused(const FusedArgs a) {
 #define LAYER_FENCE() __builtin_amdgcn_sched_barrier(0)
 
     const float inv2b = 1.f / (2.f * a.bound);
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int s0 = tile * TILE + wave * 16 * NSF;
         // ---- inputs of this lane's two samples ------------------------------------------------------------------
         float px[NSF], py[NSF], pz[NSF], dx[NSF], dy[NSF], dz[NSF];
@@ -147,8 +152,8 @@ __global__ __launch_bounds__(512) void k_nerf_field_fused(const FusedArgs a) {
 #pragma unroll
         for (int sf = 0; sf < NSF; ++sf) {
             int m = s0 + sf * 16 + fr;
-            live[sf] = m < a.M;
-            m = live[sf] ? m : a.M - 1;
+            live[sf] = m < M;
+            m = live[sf] ? m : M - 1;
             px[sf] = (a.xyzs[3 * m] + a.bound) * inv2b; py[sf] = (a.xyzs[3 * m + 1] + a.bound) * inv2b; pz[sf] = (a.xyzs[3 * m + 2] + a.bound) * inv2b;
             dx[sf] = a.dirs[3 * m]; dy[sf] = a.dirs[3 * m + 1]; dz[sf] = a.dirs[3 * m + 2];
         }
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(512) void k_nerf_field_fused(const FusedArgs a) {
             for (int sf = 0; sf < NSF; ++sf) {
                 if (!live[sf]) continue;
                 const int m = s0 + sf * 16 + fr;
-                a.sigmas[m] = expf(s3[0][sf][0]);                                                   // network.py:300
+                a.sigmas[m] = a.sigma_scale * expf(s3[0][sf][0]);                                                   // network.py:300
 #pragma unroll
                 for (int k = 0; k < 3; ++k) a.rgbs[3 * m + k] = 1.f / (1.f + __expf(-rgb[sf][k])) * 1.002f - 0.001f;   // network.py:272
                 a.amb_aud[m] = amb[sf];
@@ -454,8 +459,9 @@ int mf_nerf_fused_pack(const float* const w[9], int n_ind, bool has_eye, bool x3
 
 int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound,
                          const float* xyzs, const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M,
-                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s) {
+                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev, float sigma_scale) {
     FusedArgs a{};
+    a.M_dev = M_dev; a.sigma_scale = sigma_scale;
     a.xyzs = xyzs; a.dirs = dirs; a.enc_a = enc_a; a.ind = ind; a.w = packed;
     for (int p = 0; p < 3; ++p) a.emb[p] = emb[p];
     for (int l = 0; l < NLEV; ++l) {

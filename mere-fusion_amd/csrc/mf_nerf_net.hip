@@ -29,7 +29,8 @@ extern "C" int mf_grid_encode_forward(const float* inputs, const float* embeddin
 int mf_nerf_fused_pack(const float* const w[9], int n_ind, bool has_eye, bool x3, bf16_t** dev_out);
 int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound,
                          const float* xyzs, const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M,
-                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s);
+                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev = nullptr,
+                         float sigma_scale = 1.f);
 
 namespace {
 
@@ -558,3 +559,90 @@ extern "C" int mf_nerf_torso_forward(mf_nerf_torso* h, const float* bg_coords, c
 }
 
 extern "C" void mf_nerf_torso_destroy(mf_nerf_torso* h) { delete h; }
+
+// =========================================================================================================================
+// Head render loop without host round trips: `run_cuda`'s inference branch (renderer.py:231-291) with the round control
+// (n_alive, n_step, step) kept in HBM.  The reference compacts `rays_alive` with a boolean mask and reads its length back on the
+// host every round; here k_loop_ctl / k_loop_compact (mf_nerf.hip) do both on the device, every launch has a fixed grid and
+// exits when its round has nothing to do, and max_steps rounds are enqueued back to back -- capturable as one hipGraph.
+// =========================================================================================================================
+extern "C" int mf_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t n_rays, float min_near, float* nears,
+                                     float* fars, void* stream);
+extern "C" int mf_nerf_finish(float* image, float* depth, const float* weights_sum, const float* nears, const float* fars, const float* bg_color,
+                              int bg_per_ray, float bg_const, uint32_t n_rays, uint8_t* frame_u8, void* stream);
+int mf_nerf_loop_init(int* ctl, int N, int* alive, float* rays_t, const float* nears, float* weights_sum, float* depth, float* image,
+                      float* amb_aud_sum, float* amb_eye_sum, float* unc_sum, hipStream_t s);
+int mf_nerf_loop_round(int* ctl, int N, int max_steps, const int* alive_in, int* alive_out, float* rays_t, const float* rays_o, const float* rays_d,
+                       float bound, float dt_gamma, uint32_t cascades, uint32_t grid_size, const uint8_t* bitfield, const float* nears, const float* fars,
+                       float* xyzs, float* dirs, float* deltas, int phase, float T_thresh, const float* sigmas, const float* rgbs, const float* amb_aud,
+                       const float* amb_eye, const float* unc, float* weights_sum, float* depth, float* image, float* amb_aud_sum, float* amb_eye_sum,
+                       float* unc_sum, hipStream_t s);
+
+struct mf_nerf_head {
+    mf_nerf_field* field = nullptr;
+    int cap = 0;
+    std::vector<void*> dev;
+    float *aabb, *nears, *fars, *rays_t, *xyzs, *dirs, *deltas, *sig, *rgb, *aa, *ae, *un, *wsum, *aasum, *aesum, *unsum;
+    int *alive[2], *ctl;
+    ~mf_nerf_head() { for (void* d : dev) (void)hipFree(d); }
+};
+
+extern "C" int mf_nerf_head_create(mf_nerf_field* field, int max_rays, mf_nerf_head** out) {
+    MF_REQUIRE(field && out && max_rays > 0, "nerf_head_create: bad argument");
+    MF_REQUIRE(field->fused_w, "nerf_head_create: needs the fused field kernel (unset MF_NERF_FIELD=gemm)");
+    MF_REQUIRE(max_rays <= field->cap_batches * TW, "nerf_head_create: %d rays exceed the field's sample capacity %d", max_rays, field->cap_batches * TW);
+    *out = nullptr;
+    std::unique_ptr<mf_nerf_head> h(new mf_nerf_head());
+    h->field = field; h->cap = max_rays;
+    auto fm = [&](float** p, size_t n) -> int { MF_HIP(hipMalloc(p, n * sizeof(float))); h->dev.push_back(*p); return MF_OK; };
+    auto im = [&](int** p, size_t n) -> int { MF_HIP(hipMalloc(p, n * sizeof(int))); h->dev.push_back(*p); return MF_OK; };
+    const size_t N = (size_t)max_rays;
+    int rc;
+    if ((rc = fm(&h->aabb, 6)) || (rc = fm(&h->nears, N)) || (rc = fm(&h->fars, N)) || (rc = fm(&h->rays_t, N)) || (rc = fm(&h->xyzs, 3 * N)) ||
+        (rc = fm(&h->dirs, 3 * N)) || (rc = fm(&h->deltas, 2 * N)) || (rc = fm(&h->sig, N)) || (rc = fm(&h->rgb, 3 * N)) || (rc = fm(&h->aa, N)) ||
+        (rc = fm(&h->ae, N)) || (rc = fm(&h->un, N)) || (rc = fm(&h->wsum, N)) || (rc = fm(&h->aasum, N)) || (rc = fm(&h->aesum, N)) ||
+        (rc = fm(&h->unsum, N)) || (rc = im(&h->alive[0], N)) || (rc = im(&h->alive[1], N)) || (rc = im(&h->ctl, 8)))
+        return rc;
+    const float b = field->cfg.bound;
+    const float aabb[6] = {-b, -b / 2, -b, b, b / 2, b};                                    // aabb_infer, renderer.py:86-89
+    MF_HIP(hipMemcpy(h->aabb, aabb, sizeof(aabb), hipMemcpyHostToDevice));
+    *out = h.release();
+    return MF_OK;
+}
+
+extern "C" int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const float* rays_d, int n_rays, const uint8_t* density_bitfield, int cascades,
+                                   int grid_size, float min_near, float dt_gamma, int max_steps, float T_thresh, float density_scale, const float* enc_a,
+                                   const float* ind_code, float eye, const float* bg_color, int bg_per_ray, float bg_const, float* image, float* depth,
+                                   float* weights_sum, uint8_t* frame_u8, void* stream) {
+    MF_REQUIRE(h && rays_o && rays_d && density_bitfield && enc_a && image && depth, "nerf_head_render: null argument");
+    MF_REQUIRE(n_rays > 0 && n_rays <= h->cap && max_steps > 0 && max_steps <= 1024, "nerf_head_render: n_rays=%d (capacity %d) max_steps=%d", n_rays, h->cap, max_steps);
+    hipStream_t s = (hipStream_t)stream;
+    mf_nerf_field* f = h->field;
+    const mf_nerf_field_config& c = f->cfg;
+    MF_REQUIRE(c.individual_dim == 0 || ind_code, "nerf_head_render: the field was built with an individual code");
+    const int N = n_rays;
+    float* ws = weights_sum ? weights_sum : h->wsum;
+    int rc;
+    if ((rc = mf_near_far_from_aabb(rays_o, rays_d, h->aabb, N, min_near, h->nears, h->fars, stream))) return rc;
+    if ((rc = mf_nerf_loop_init(h->ctl, N, h->alive[0], h->rays_t, h->nears, ws, depth, image, h->aasum, h->aesum, h->unsum, s))) return rc;
+    const bool x3 = f->precision == MF_PREC_BF16X3;
+    // at least one sample per alive ray and round, so max_steps rounds always suffice (step += n_step >= 1, renderer.py:270)
+    for (int it = 0; it < max_steps; ++it) {
+        int* a_in = h->alive[it & 1];
+        int* a_out = h->alive[(it + 1) & 1];
+        if ((rc = mf_nerf_loop_round(h->ctl, N, max_steps, a_in, a_out, h->rays_t, rays_o, rays_d, c.bound, dt_gamma, cascades, grid_size, density_bitfield,
+                                     h->nears, h->fars, h->xyzs, h->dirs, h->deltas, 0, T_thresh, nullptr, nullptr, nullptr, nullptr, nullptr, ws, depth, image,
+                                     h->aasum, h->aesum, h->unsum, s)))
+            return rc;
+        if ((rc = mf_nerf_fused_launch(f->fused_w, x3, f->emb, c.offsets, c.log2_per_level_scale, c.base_resolution, c.bound, h->xyzs, h->dirs, enc_a, ind_code,
+                                       c.individual_dim, eye, c.exp_eye, N, h->sig, h->rgb, h->aa, h->ae, h->un, s, h->ctl + 3, density_scale)))
+            return rc;
+        if ((rc = mf_nerf_loop_round(h->ctl, N, max_steps, a_in, a_out, h->rays_t, rays_o, rays_d, c.bound, dt_gamma, cascades, grid_size, density_bitfield,
+                                     h->nears, h->fars, h->xyzs, h->dirs, h->deltas, 1, T_thresh, h->sig, h->rgb, h->aa, h->ae, h->un, ws, depth, image,
+                                     h->aasum, h->aesum, h->unsum, s)))
+            return rc;
+    }
+    return mf_nerf_finish(image, depth, ws, h->nears, h->fars, bg_color, bg_per_ray, bg_const, N, frame_u8, stream);
+}
+
+extern "C" void mf_nerf_head_destroy(mf_nerf_head* h) { delete h; }

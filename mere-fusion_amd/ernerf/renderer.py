@@ -25,6 +25,7 @@ class HipHeadRenderer:
         b = self.bound
         self.aabb_infer = torch.tensor([-b, -b / 2, -b, b, b / 2, b], dtype=torch.float32, device=density_bitfield.device)   # renderer.py:86-89
         self._lib = _lib.lib()
+        self._head = None
 
     @torch.no_grad()
     def render(self, rays_o, rays_d, auds, bg_coords, poses, eye, bg_color=None, **kw):
@@ -37,7 +38,72 @@ class HipHeadRenderer:
             self.enc_a = enc_a
         if self.torso is not None:
             bg_color = self.torso.run_torso(bg_coords, poses, bg_color)["bg_color"]
+        if kw.pop("loop", "host") == "device":
+            return self.run_cuda_device(rays_o, rays_d, enc_a, self.ind_code, eye, bg_color=bg_color, **kw)
         return self.run_cuda(rays_o, rays_d, enc_a, self.ind_code, eye, bg_color=bg_color, **kw)
+
+    def __del__(self):
+        h = getattr(self, "_head", None)
+        if h:
+            self._lib.mf_nerf_head_destroy(h)
+            self._head = None
+
+    @torch.no_grad()
+    def run_cuda_device(self, rays_o, rays_d, enc_a, ind_code, eye, bg_color=None, dt_gamma=1 / 256, max_steps=16, T_thresh=1e-4, want_u8=False,
+                        graph=False):
+        """The same frame as run_cuda with the round control on the device (mf_nerf_head_render): one enqueue, no host sync between
+        rounds.  graph=True captures the enqueue once per (ray count, tensors) into a CUDA graph and replays it."""
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N, dev = rays_o.shape[0], rays_o.device
+        if getattr(self, "_head", None) is None or self._head_cap < N:
+            if getattr(self, "_head", None):
+                self._lib.mf_nerf_head_destroy(self._head)
+            self._head = C.c_void_p()
+            _lib.check(self._lib.mf_nerf_head_create(self.field._h, N, C.byref(self._head)), "mf_nerf_head_create")
+            self._head_cap, self._graphs = N, {}
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        bg = bg_color.float().contiguous() if torch.is_tensor(bg_color) else None
+        per_ray = bg is not None and bg.numel() == 3 * N
+        bgc = float(1.0 if bg_color is None else (0.0 if bg is not None else bg_color))
+        ea = enc_a.float().reshape(-1).contiguous()
+        ic = ind_code.float().reshape(-1).contiguous() if ind_code is not None else None
+        ev = float(eye.reshape(-1)[0]) if eye is not None else 0.0
+
+        def enqueue(out):
+            _lib.check(self._lib.mf_nerf_head_render(self._head, p(rays_o), p(rays_d), N, p(self.bitfield), self.cascade, self.grid_size, self.min_near,
+                                                     float(dt_gamma), int(max_steps), float(T_thresh), self.density_scale, p(ea), p(ic), ev, p(bg), int(per_ray),
+                                                     bgc, p(out["image"]), p(out["depth"]), p(out["weights_sum"]), p(out["frame_u8"]),
+                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mf_nerf_head_render")
+
+        def fresh():
+            return {"image": torch.empty(N, 3, device=dev), "depth": torch.empty(N, device=dev), "weights_sum": torch.empty(N, device=dev),
+                    "frame_u8": torch.empty(N, 3, dtype=torch.uint8, device=dev) if want_u8 else None}
+        if not graph:
+            out = fresh()
+            enqueue(out)
+            return out
+        # graph mode: static input / output buffers per (ray count, scalar arguments); inputs are copied in unless they already live there
+        key = (N, ev, bool(want_u8), bgc, None if bg is None else bg.numel(), float(dt_gamma), int(max_steps), float(T_thresh))
+        hit = self._graphs.get(key)
+        live = (rays_o, rays_d, ea, ic, bg)
+        if hit is None:
+            static = tuple(None if t is None else t.clone() for t in live)
+            rays_o, rays_d, ea, ic, bg = static
+            out = fresh()
+            enqueue(out)                                   # warm-up outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                enqueue(out)
+            hit = (g, out, static)
+            self._graphs[key] = hit
+        else:
+            for dst, src in zip(hit[2], live):
+                if dst is not None and dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+        hit[0].replay()
+        return hit[1]
 
     @torch.no_grad()
     def run_cuda(self, rays_o, rays_d, enc_a, ind_code, eye, bg_color=None, dt_gamma=1 / 256, max_steps=16, T_thresh=1e-4, perturb=False,

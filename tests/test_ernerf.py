@@ -631,3 +631,27 @@ def test_hip_torso_full_frame_properties(lib_built):
     img = r["bg_color"].cpu().numpy()
     assert np.isfinite(img).all() and img.min() >= -0.01 and img.max() <= 1.01
     assert np.abs(r["deform"].cpu().numpy()).max() < 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W", [48, 512])
+def test_hip_device_controlled_loop_matches_host_loop(lib_built, W):
+    """mf_nerf_head_render (round control on the device, no host sync) against the host-driven loop: every ray sees the same samples,
+    so the frames must agree to rounding; also through a captured CUDA graph replayed twice."""
+    from mere_fusion_amd.ernerf.field import HipNeRFField
+    from mere_fusion_amd.ernerf.renderer import HipHeadRenderer
+    sd, offsets, S, _, _, enc_a, c, e = _field_case(8, 3)
+    sd = {k: (v * 0.35 if k.startswith("sigma_net.net.2") else v) for k, v in sd.items()}
+    ro, rd = _camera_rays(W)
+    r = HipHeadRenderer(HipNeRFField(sd, max_samples=W * W), torch.from_numpy(_sphere_bitfield()).cuda(), density_scale=40.0)
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    args = (_cu(ro), _cu(rd), enc_a.cuda(), c.cuda(), e.cuda())
+    want = r.run_cuda(*args, bg_color=bg, want_u8=True)
+    got = r.run_cuda_device(*args, bg_color=bg, want_u8=True)
+    for k, tol in (("image", 1e-6), ("depth", 1e-6), ("weights_sum", 1e-6)):
+        assert (got[k] - want[k]).abs().max().item() <= tol, k
+    assert (got["frame_u8"].int() - want["frame_u8"].int()).abs().max().item() <= 1
+    g1 = {k: v.clone() for k, v in r.run_cuda_device(*args, bg_color=bg, want_u8=True, graph=True).items() if v is not None}
+    g2 = r.run_cuda_device(*args, bg_color=bg, want_u8=True, graph=True)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]) and (g1[k].float() - got[k].float()).abs().max().item() <= (1 if k == "frame_u8" else 1e-6), k
