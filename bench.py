@@ -372,7 +372,7 @@ class ErNeRFRunner:
             self.trace = self.last["trace"]
         else:
             self.last = self.r.render(self.ro, self.rd, self.auds, self.bg_coords, self.pose, self.eye, bg_color=1.0, want_u8=True, loop="device",
-                                      graph=os.environ.get("MF_NO_GRAPH") is None)
+                                      graph=os.environ.get("MF_NERF_GRAPH") == "1")   # replaying the head as a graph measured no faster: GPU bound
 
     def samples_per_frame(self):
         if self.trace is None:        # the device loop keeps no host-side trace: count the same frame once through the host loop

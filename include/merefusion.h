@@ -306,11 +306,17 @@ int mf_nerf_head_create(mf_nerf_field* field, int max_rays, mf_nerf_head** out);
  * normalisation of :275-280.  No host synchronisation: the call only enqueues (capturable in a hipGraph).
  * rays_o, rays_d [N,3]; density_bitfield [cascades * grid_size^3 / 8]; enc_a [32]; ind_code [individual_dim] or NULL;
  * bg as in mf_nerf_finish.  Outputs: image [N,3], depth [N], weights_sum [N] (optional), frame_u8 [N,3] (optional).
- * Survivors of a round keep no particular order (rays are independent), unlike the reference's boolean mask. */
+ * Survivors of a round keep no particular order (rays are independent), unlike the reference's boolean mask.
+ * bg_per_ray < 0 leaves image / depth unfinished (no background mix, depth not normalised): the caller finishes with
+ * mf_nerf_head_finish, e.g. after joining a stream on which the torso (mf_nerf_torso_forward) produced bg_color. */
 int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const float* rays_d, int n_rays, const uint8_t* density_bitfield, int cascades,
                         int grid_size, float min_near, float dt_gamma, int max_steps, float T_thresh, float density_scale, const float* enc_a,
                         const float* ind_code, float eye, const float* bg_color, int bg_per_ray, float bg_const, float* image, float* depth,
                         float* weights_sum, uint8_t* frame_u8, void* stream);
+/* renderer.py:275-280 + nerfreal.py:111 for the frame a mf_nerf_head_render(bg_per_ray < 0) left unfinished; weights_sum may be
+ * NULL when none was passed to the render call. */
+int mf_nerf_head_finish(mf_nerf_head* h, int n_rays, const float* bg_color, int bg_per_ray, float bg_const, float* image, float* depth,
+                        const float* weights_sum, uint8_t* frame_u8, void* stream);
 void mf_nerf_head_destroy(mf_nerf_head* h);
 
 /* ---- ER-NeRF torso branch --------------------------------------------------------------------- */

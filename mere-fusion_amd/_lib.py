@@ -115,6 +115,7 @@ SIGNATURES = {
     "mf_nerf_head_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mf_nerf_head_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 5),
+    "mf_nerf_head_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 5),
     "mf_nerf_head_destroy": (None, [C.c_void_p]),
     "mf_nerf_torso_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mf_nerf_torso_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 4),

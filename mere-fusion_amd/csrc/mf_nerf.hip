@@ -11,6 +11,8 @@
 // exactly as written (the CPU restatement the parity tests compare against is built the same way); divisions are the
 // correctly rounded default of hipcc.
 #include "mf_common.h"
+#include <cstdlib>
+#include <cstring>
 #include <cfloat>
 #include <cmath>
 
@@ -82,8 +84,7 @@ __global__ __launch_bounds__(NT) void k_march_rays(uint32_t n_alive, uint32_t n_
                                                    const float* __restrict__ rays_d, float bound, float dt_gamma,
                                                    uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
                                                    const float* __restrict__ fars, float* xyzs, float* dirs, float* deltas,
-                                                   const float* __restrict__ noises, const int* __restrict__ ctl) {
-    if (ctl) { n_alive = (uint32_t)ctl[0]; n_step = (uint32_t)ctl[1]; }     // device-controlled loop: counts live in HBM
+                                                   const float* __restrict__ noises) {
     const uint32_t n = threadIdx.x + blockIdx.x * NT;
     if (n >= n_alive || n_step == 0) return;
     const float SQRT3 = 1.7320508075688772f;
@@ -137,27 +138,117 @@ __global__ __launch_bounds__(NT) void k_march_rays(uint32_t n_alive, uint32_t n_
             } while (t < tt);
         }
     }
-    if (ctl) {
-        // the wrapper of the host-driven loop zero-fills the outputs (raymarching.py:383-385); here the kernel clears its own tail
-        for (; step < n_step; ++step) {
-            px[0] = px[1] = px[2] = 0.f; pd[0] = pd[1] = pd[2] = 0.f; pt[0] = pt[1] = 0.f;
-            px += 3; pd += 3; pt += 2;
+}
+
+// k_march_rays for the device-controlled loop: the same per-ray DDA (same float operations in the same order), but a lane only
+// records the (t, dt) of its samples in LDS while it marches -- on gfx9 stores share vmcnt with the occupancy loads, so writing
+// samples inside the loop puts a store round trip on every iteration of the dependent chain.  The block then writes its contiguous
+// [256 rays x n_step] slab of xyzs / dirs / deltas cooperatively (coalesced; empty slots are zeroed as raymarching.py:383-385 does).
+constexpr int LOOP_MAX_STEP = 8;                 // renderer.py:256 caps n_step at 8
+// FAST: one cascade and a power-of-two grid.  Then level == 0 for every position (both mip_from_* clamp to [0, C - 1]), so the mip bound and
+// its reciprocal leave the loop, and 0.5 * v * H is a power-of-two scaling -- exact in float as in the reference's double -- so the
+// double round trip goes too.  Same bits, about a third fewer instructions on the dependent chain.
+template <bool FAST>
+__global__ __launch_bounds__(NT) void k_loop_march(const int* __restrict__ ctl, const int* __restrict__ rays_alive, const float* __restrict__ rays_t,
+                                                   const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound, float dt_gamma,
+                                                   uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                                                   const float* __restrict__ fars, float* xyzs, float* dirs, float* deltas) {
+    const uint32_t n_alive = (uint32_t)ctl[0], n_step = (uint32_t)ctl[1];
+    const uint32_t base = blockIdx.x * NT;
+    if (base >= n_alive || n_step == 0) return;
+    __shared__ float s_t[LOOP_MAX_STEP][NT], s_dt[LOOP_MAX_STEP][NT], s_o[3][NT], s_d[3][NT];
+    __shared__ int s_cnt[NT];
+    const uint32_t n = threadIdx.x + base;
+    uint32_t step = 0;
+    if (n < n_alive) {
+        const float SQRT3 = 1.7320508075688772f;
+        const int index = rays_alive[n];
+        const float* ro = rays_o + (size_t)index * 3;
+        const float* rd = rays_d + (size_t)index * 3;
+        const float ox = ro[0], oy = ro[1], oz = ro[2];
+        const float dx = rd[0], dy = rd[1], dz = rd[2];
+        s_o[0][threadIdx.x] = ox; s_o[1][threadIdx.x] = oy; s_o[2][threadIdx.x] = oz;
+        s_d[0][threadIdx.x] = dx; s_d[1][threadIdx.x] = dy; s_d[2][threadIdx.x] = dz;
+        const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+        const float rH = 1 / (float)H;
+        const float H3 = (float)(H * H * H);
+        float t = rays_t[index];
+        const float far = fars[index];
+        const float dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / (float)H;
+        const float dt_min = fminf(dt_max, 2 * SQRT3 / (float)max_steps);
+        const float mip_bound0 = fminf(1.f, bound), mip_rbound0 = 1 / mip_bound0, halfH = 0.5f * (float)H;
+        while (t < far && step < n_step) {
+            const float x = clampf_(ox + t * dx, -bound, bound);
+            const float y = clampf_(oy + t * dy, -bound, bound);
+            const float z = clampf_(oz + t * dz, -bound, bound);
+            const float dt = clampf_(t * dt_gamma, dt_min, dt_max);
+            float mip_bound, mip_rbound;
+            int nx, ny, nz;
+            uint32_t gi;
+            if constexpr (FAST) {
+                mip_bound = mip_bound0; mip_rbound = mip_rbound0;
+                nx = (int)clampf_((x * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+                ny = (int)clampf_((y * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+                nz = (int)clampf_((z * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+                gi = morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+            } else {
+                const int la = mip_from_pos(x, y, z, (float)C), lb = mip_from_dt(dt, (float)H, (float)C);
+                const int level = la > lb ? la : lb;
+                mip_bound = fminf(scalbnf(1.f, level), bound);
+                mip_rbound = 1 / mip_bound;
+                nx = (int)clampf_((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+                ny = (int)clampf_((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+                nz = (int)clampf_((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+                gi = (uint32_t)((float)level * H3 + (float)morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+            }
+            const bool occ = grid[gi / 8] & (1 << (gi % 8));
+            if (occ) {
+                s_t[step][threadIdx.x] = t; s_dt[step][threadIdx.x] = dt;
+                t += dt;
+                step++;
+            } else {
+                const float tx = ((((float)nx + 0.5f + 0.5f * signf_(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
+                const float ty = ((((float)ny + 0.5f + 0.5f * signf_(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
+                const float tz = ((((float)nz + 0.5f + 0.5f * signf_(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+                const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+                do {
+                    t += clampf_(t * dt_gamma, dt_min, dt_max);
+                } while (t < tt);
+            }
         }
+    }
+    s_cnt[threadIdx.x] = (int)step;
+    __syncthreads();
+    const uint32_t rays_here = min((uint32_t)NT, n_alive - base);
+    const uint32_t total = rays_here * n_step;
+    const size_t slab = (size_t)base * n_step;
+    for (uint32_t i = threadIdx.x; i < total; i += NT) {
+        const uint32_t r = i / n_step, k = i - r * n_step;
+        float x = 0.f, y = 0.f, z = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, dt = 0.f, t1 = 0.f;
+        if ((int)k < s_cnt[r]) {
+            const float t = s_t[k][r];
+            dt = s_dt[k][r];
+            dx = s_d[0][r]; dy = s_d[1][r]; dz = s_d[2][r];
+            x = clampf_(s_o[0][r] + t * dx, -bound, bound);
+            y = clampf_(s_o[1][r] + t * dy, -bound, bound);
+            z = clampf_(s_o[2][r] + t * dz, -bound, bound);
+            t1 = t + dt;
+        }
+        float* px = xyzs + (slab + i) * 3;
+        float* pd = dirs + (slab + i) * 3;
+        float* pt = deltas + (slab + i) * 2;
+        px[0] = x; px[1] = y; px[2] = z;
+        pd[0] = dx; pd[1] = dy; pd[2] = dz;
+        pt[0] = dt; pt[1] = t1;
     }
 }
 
 // kernel_composite_rays_triplane, raymarching.cu:2142-2249
-__global__ __launch_bounds__(NT) void k_composite_rays_triplane(uint32_t n_alive, uint32_t n_step, float T_thresh, int* rays_alive,
-                                                                float* rays_t, const float* __restrict__ sigmas,
-                                                                const float* __restrict__ rgbs, const float* __restrict__ deltas,
-                                                                const float* __restrict__ ambs_aud, const float* __restrict__ ambs_eye,
-                                                                const float* __restrict__ uncertainties, float* weights_sum,
-                                                                float* depth, float* image, float* amb_aud_sum, float* amb_eye_sum,
-                                                                float* uncertainty_sum, const int* __restrict__ ctl) {
-    if (ctl) { n_alive = (uint32_t)ctl[0]; n_step = (uint32_t)ctl[1]; }
-    const uint32_t n = threadIdx.x + blockIdx.x * NT;
-    if (n >= n_alive || n_step == 0) return;
-    const int index = rays_alive[n];
+// one ray of the composite; returns true when the ray ended inside this round (rays_alive[n] = -1 in the reference)
+__device__ __forceinline__ bool composite_ray(uint32_t n, uint32_t n_step, float T_thresh, int index, float* rays_t, const float* __restrict__ sigmas,
+                                              const float* __restrict__ rgbs, const float* __restrict__ deltas, const float* __restrict__ ambs_aud,
+                                              const float* __restrict__ ambs_eye, const float* __restrict__ uncertainties, float* weights_sum, float* depth,
+                                              float* image, float* amb_aud_sum, float* amb_eye_sum, float* uncertainty_sum) {
     const float* sg = sigmas + (size_t)n * n_step;
     const float* rg = rgbs + (size_t)n * n_step * 3;
     const float* dl = deltas + (size_t)n * n_step * 2;
@@ -186,14 +277,28 @@ __global__ __launch_bounds__(NT) void k_composite_rays_triplane(uint32_t n_alive
         if (T < T_thresh) break;
         sg++; rg += 3; dl += 2; step++; aa++; ae++; un++;
     }
-    if (step < n_step) rays_alive[n] = -1;
-    else rays_t[index] = t;
+    if (step >= n_step) rays_t[index] = t;
     weights_sum[index] = weight_sum;
     depth[index] = d;
     image[3 * index] = r; image[3 * index + 1] = g; image[3 * index + 2] = b;
     amb_aud_sum[index] = a_aud;
     amb_eye_sum[index] = a_eye;
     uncertainty_sum[index] = u;
+    return step < n_step;
+}
+
+__global__ __launch_bounds__(NT) void k_composite_rays_triplane(uint32_t n_alive, uint32_t n_step, float T_thresh, int* rays_alive,
+                                                                float* rays_t, const float* __restrict__ sigmas,
+                                                                const float* __restrict__ rgbs, const float* __restrict__ deltas,
+                                                                const float* __restrict__ ambs_aud, const float* __restrict__ ambs_eye,
+                                                                const float* __restrict__ uncertainties, float* weights_sum,
+                                                                float* depth, float* image, float* amb_aud_sum, float* amb_eye_sum,
+                                                                float* uncertainty_sum) {
+    const uint32_t n = threadIdx.x + blockIdx.x * NT;
+    if (n >= n_alive || n_step == 0) return;
+    if (composite_ray(n, n_step, T_thresh, rays_alive[n], rays_t, sigmas, rgbs, deltas, ambs_aud, ambs_eye, uncertainties, weights_sum, depth, image,
+                      amb_aud_sum, amb_eye_sum, uncertainty_sum))
+        rays_alive[n] = -1;
 }
 
 // ---- grid encoder -----------------------------------------------------------------------------------------------------
@@ -342,39 +447,110 @@ __global__ __launch_bounds__(NT) void k_nerf_finish(float* image, float* depth, 
 }
 
 // ---- device-controlled render loop (no host sync between rounds) ---------------------------------------------------------
-// ctl: [0] n_alive, [1] n_step, [2] step, [3] M = n_alive * n_step, [4] unused, [5] survivors counted by k_loop_compact
-__global__ void k_loop_init(int* ctl, int N, int* alive, float* rays_t, const float* __restrict__ nears, float* weights_sum, float* depth,
+// ctl: [0] n_alive, [1] n_step, [2] step after this round, [3] M = n_alive * n_step, [6..7] one 64-bit counter: survivors appended so far (low
+// word) and blocks done (high word)
+// head of a round: `while step < max_steps`, `n_alive <= 0 -> break`, n_step = max(min(N // n_alive, 8), 1) (renderer.py:246-256)
+__device__ __forceinline__ void loop_next_round(int* ctl, int n_alive, int step, int N, int max_steps) {
+    int n_step = 0;
+    if (n_alive > 0 && step < max_steps) { n_step = N / n_alive; n_step = n_step < 8 ? n_step : 8; n_step = n_step > 1 ? n_step : 1; }
+    ctl[0] = n_step ? n_alive : 0; ctl[1] = n_step; ctl[2] = step + n_step; ctl[3] = n_step ? n_alive * n_step : 0;
+    ctl[6] = 0; ctl[7] = 0;
+}
+__global__ void k_loop_init(int* ctl, int N, int max_steps, int* alive, float* rays_t, const float* __restrict__ nears, float* weights_sum, float* depth,
                             float* image, float* amb_aud_sum, float* amb_eye_sum, float* unc_sum) {
     const int n = blockIdx.x * NT + threadIdx.x;
-    if (n == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; ctl[5] = N; }
+    if (n == 0) { ctl[4] = 0; ctl[5] = 0; loop_next_round(ctl, N, 0, N, max_steps); }
     if (n >= N) return;
     alive[n] = n;                                   // renderer.py:242
     rays_t[n] = nears[n];                           // renderer.py:243
     weights_sum[n] = depth[n] = amb_aud_sum[n] = amb_eye_sum[n] = unc_sum[n] = 0.f;
     image[3 * n] = image[3 * n + 1] = image[3 * n + 2] = 0.f;
 }
-// head of a round: `while step < max_steps`, `n_alive <= 0 -> break`, n_step = max(min(N // n_alive, 8), 1) (renderer.py:246-256)
-__global__ void k_loop_ctl(int* ctl, int N, int max_steps) {
-    const int n_alive = ctl[5], step = ctl[2];
-    int n_step = 0;
-    if (n_alive > 0 && step < max_steps) { n_step = N / n_alive; n_step = n_step < 8 ? n_step : 8; n_step = n_step > 1 ? n_step : 1; }
-    ctl[0] = n_step ? n_alive : 0; ctl[1] = n_step; ctl[2] = step + n_step; ctl[3] = n_step ? n_alive * n_step : 0;
-    ctl[5] = n_step ? 0 : n_alive;                  // a finished loop keeps its count; a live round recounts in k_loop_compact
-}
-// `rays_alive = rays_alive[rays_alive >= 0]` (renderer.py:266): wave-aggregated append; the order of the survivors is not kept
-// (rays are independent, so only their slot changes)
-__global__ __launch_bounds__(NT) void k_loop_compact(const int* __restrict__ in, int* out, int* ctl) {
-    const int n_alive = ctl[0];
-    const int n = blockIdx.x * NT + threadIdx.x;
-    const int v = n < n_alive ? in[n] : -1;
-    const bool keep = v >= 0;
+// tail of a round in one launch: composite (raymarching.cu:2142-2249), `rays_alive = rays_alive[rays_alive >= 0]` (renderer.py:266) as a
+// wave-aggregated append (the order of the survivors is not kept: rays are independent, only their slot changes), and -- by the last
+// block to finish -- the head of the next round.
+constexpr int CT = 1024;           // composite block: one contended 64-bit atomic per 1024 rays
+__global__ __launch_bounds__(CT) void k_loop_composite(int* ctl, int N, int max_steps, float T_thresh, const int* __restrict__ alive_in, int* alive_out,
+                                                       float* rays_t, const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                       const float* __restrict__ deltas, const float* __restrict__ ambs_aud,
+                                                       const float* __restrict__ ambs_eye, const float* __restrict__ uncertainties, float* weights_sum,
+                                                       float* depth, float* image, float* amb_aud_sum, float* amb_eye_sum, float* uncertainty_sum) {
+    const uint32_t n_alive = (uint32_t)ctl[0], n_step = (uint32_t)ctl[1];
+    const uint32_t base = blockIdx.x * CT;
+    if (n_step == 0 || base >= n_alive) return;     // ended loop: ctl stays as it is; blocks past the alive rays take no part
+    const uint32_t n = threadIdx.x + base;
+    int v = -1;
+    bool keep = false;
+    if (n < n_alive) {
+        v = alive_in[n];
+        // all of the ray's samples are fetched before the serial blend (the loop's early exits would otherwise put one load round trip
+        // per sample on the dependent chain); the blend itself is composite_ray's, operation for operation
+        float sg[LOOP_MAX_STEP], d0[LOOP_MAX_STEP], d1[LOOP_MAX_STEP], cr[LOOP_MAX_STEP], cg[LOOP_MAX_STEP], cb[LOOP_MAX_STEP], aa[LOOP_MAX_STEP],
+            ae[LOOP_MAX_STEP], un[LOOP_MAX_STEP];
+        const size_t o = (size_t)n * n_step;
+#pragma unroll
+        for (uint32_t k = 0; k < LOOP_MAX_STEP; ++k) {
+            const bool in = k < n_step;
+            const size_t q = in ? o + k : o;
+            sg[k] = sigmas[q]; d0[k] = deltas[2 * q]; d1[k] = deltas[2 * q + 1];
+            cr[k] = rgbs[3 * q]; cg[k] = rgbs[3 * q + 1]; cb[k] = rgbs[3 * q + 2];
+            aa[k] = ambs_aud[q]; ae[k] = ambs_eye[q]; un[k] = uncertainties[q];
+        }
+        float t = rays_t[v];
+        float weight_sum = weights_sum[v], d = depth[v];
+        float r = image[3 * v], g = image[3 * v + 1], b = image[3 * v + 2];
+        float a_aud = amb_aud_sum[v], a_eye = amb_eye_sum[v], u = uncertainty_sum[v];
+        bool live = true;
+#pragma unroll
+        for (uint32_t k = 0; k < LOOP_MAX_STEP; ++k) {
+            if (live && k < n_step) {
+                if (d0[k] == 0) live = false;
+                else {
+                    const float alpha = 1.0f - __expf(-sg[k] * d0[k]);
+                    const float T = 1 - weight_sum;
+                    const float weight = alpha * T;
+                    weight_sum += weight;
+                    t = d1[k];
+                    d += weight * t;
+                    r += weight * cr[k];
+                    g += weight * cg[k];
+                    b += weight * cb[k];
+                    a_aud += aa[k];
+                    a_eye += ae[k];
+                    u += weight * un[k];
+                    if (T < T_thresh) live = false;
+                }
+            }
+        }
+        keep = live;
+        if (keep) rays_t[v] = t;
+        weights_sum[v] = weight_sum;
+        depth[v] = d;
+        image[3 * v] = r; image[3 * v + 1] = g; image[3 * v + 2] = b;
+        amb_aud_sum[v] = a_aud;
+        amb_eye_sum[v] = a_eye;
+        uncertainty_sum[v] = u;
+    }
+    // one atomic per block: ctl[5] counts survivors, ctl[6] blocks; packed in one 64-bit add so the last block also learns the total
+    __shared__ int s_wave[CT / 64];
+    __shared__ unsigned long long s_old;
     const unsigned long long m = __ballot(keep);
-    if (m == 0) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&ctl[5], __popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (keep) out[base + __popcll(m & ((1ull << lane) - 1))] = v;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, mine = 0;
+#pragma unroll
+    for (int w = 0; w < CT / 64; ++w) { before += w < wave ? s_wave[w] : 0; mine += s_wave[w]; }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_old = atomicAdd(reinterpret_cast<unsigned long long*>(ctl + 6), ((unsigned long long)1 << 32) | (unsigned long long)mine);
+    }
+    __syncthreads();
+    const unsigned long long old = s_old;
+    const int slot = (int)(old & 0xffffffffu);
+    if (keep) alive_out[slot + before + __popcll(m & ((1ull << lane) - 1))] = v;
+    const int nblocks = (int)((n_alive + CT - 1) / CT);
+    if (threadIdx.x == 0 && (int)(old >> 32) == nblocks - 1) loop_next_round(ctl, slot + mine, ctl[2], N, max_steps);
 }
 
 inline unsigned blocks(uint64_t n) { return (unsigned)((n + NT - 1) / NT); }
@@ -401,7 +577,7 @@ extern "C" int mf_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_
                "march_rays: n_step=%u max_steps=%u cascades=%u grid=%u", n_step, max_steps, cascades, grid_size);
     if (n_alive == 0) return MF_OK;
     hipLaunchKernelGGL(k_march_rays, dim3(blocks(n_alive)), dim3(NT), 0, (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, rays_o,
-                       rays_d, bound, dt_gamma, max_steps, cascades, grid_size, density_bitfield, fars, xyzs, dirs, deltas, noises, (const int*)nullptr);
+                       rays_d, bound, dt_gamma, max_steps, cascades, grid_size, density_bitfield, fars, xyzs, dirs, deltas, noises);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
@@ -416,7 +592,7 @@ extern "C" int mf_composite_rays_triplane(uint32_t n_alive, uint32_t n_step, flo
     if (n_alive == 0) return MF_OK;
     hipLaunchKernelGGL(k_composite_rays_triplane, dim3(blocks(n_alive)), dim3(NT), 0, (hipStream_t)stream, n_alive, n_step, T_thresh,
                        rays_alive, rays_t, sigmas, rgbs, deltas, ambs_aud, ambs_eye, uncertainties, weights_sum, depth, image, amb_aud_sum,
-                       amb_eye_sum, uncertainty_sum, (const int*)nullptr);
+                       amb_eye_sum, uncertainty_sum);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
@@ -482,27 +658,32 @@ extern "C" int mf_nerf_finish(float* image, float* depth, const float* weights_s
 }
 
 // ---- launchers of the device-controlled loop pieces (used by mf_nerf_head_render, mf_nerf_net.hip) -----------------------------
-int mf_nerf_loop_init(int* ctl, int N, int* alive, float* rays_t, const float* nears, float* weights_sum, float* depth, float* image,
+int mf_nerf_loop_init(int* ctl, int N, int max_steps, int* alive, float* rays_t, const float* nears, float* weights_sum, float* depth, float* image,
                       float* amb_aud_sum, float* amb_eye_sum, float* unc_sum, hipStream_t s) {
-    hipLaunchKernelGGL(k_loop_init, dim3(blocks(N)), dim3(NT), 0, s, ctl, N, alive, rays_t, nears, weights_sum, depth, image, amb_aud_sum, amb_eye_sum, unc_sum);
+    hipLaunchKernelGGL(k_loop_init, dim3(blocks(N)), dim3(NT), 0, s, ctl, N, max_steps, alive, rays_t, nears, weights_sum, depth, image, amb_aud_sum, amb_eye_sum,
+                       unc_sum);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
 int mf_nerf_loop_round(int* ctl, int N, int max_steps, const int* alive_in, int* alive_out, float* rays_t, const float* rays_o, const float* rays_d,
-                       float bound, float dt_gamma, uint32_t cascades, uint32_t grid_size, const uint8_t* bitfield, const float* nears, const float* fars,
+                       float bound, float dt_gamma, uint32_t cascades, uint32_t grid_size, const uint8_t* bitfield, const float* fars,
                        float* xyzs, float* dirs, float* deltas, int phase, float T_thresh, const float* sigmas, const float* rgbs, const float* amb_aud,
                        const float* amb_eye, const float* unc, float* weights_sum, float* depth, float* image, float* amb_aud_sum, float* amb_eye_sum,
                        float* unc_sum, hipStream_t s) {
-    if (phase == 0) {          // round head + march
-        hipLaunchKernelGGL(k_loop_ctl, dim3(1), dim3(1), 0, s, ctl, N, max_steps);
-        hipLaunchKernelGGL(k_march_rays, dim3(blocks(N)), dim3(NT), 0, s, 0u, 0u, alive_in, rays_t, rays_o, rays_d, bound, dt_gamma, (uint32_t)max_steps, cascades,
-                           grid_size, bitfield, fars, xyzs, dirs, deltas, (const float*)nullptr, (const int*)ctl);
-    } else {                   // composite + compaction
-        hipLaunchKernelGGL(k_composite_rays_triplane, dim3(blocks(N)), dim3(NT), 0, s, 0u, 0u, T_thresh, const_cast<int*>(alive_in), rays_t, sigmas, rgbs, deltas,
-                           amb_aud, amb_eye, unc, weights_sum, depth, image, amb_aud_sum, amb_eye_sum, unc_sum, (const int*)ctl);
-        hipLaunchKernelGGL(k_loop_compact, dim3(blocks(N)), dim3(NT), 0, s, alive_in, alive_out, ctl);
+    if (phase == 0)            // march (the round's n_alive / n_step were set by k_loop_init or the previous round's tail)
+    {
+        const char* e = getenv("MF_NERF_MARCH");                                 // "generic" forces the reference-shaped index arithmetic (tests)
+        const bool fast = cascades == 1 && (grid_size & (grid_size - 1)) == 0 && !(e && !strcmp(e, "generic"));
+        if (fast)
+            hipLaunchKernelGGL(k_loop_march<true>, dim3(blocks(N)), dim3(NT), 0, s, (const int*)ctl, alive_in, rays_t, rays_o, rays_d, bound, dt_gamma,
+                               (uint32_t)max_steps, cascades, grid_size, bitfield, fars, xyzs, dirs, deltas);
+        else
+            hipLaunchKernelGGL(k_loop_march<false>, dim3(blocks(N)), dim3(NT), 0, s, (const int*)ctl, alive_in, rays_t, rays_o, rays_d, bound, dt_gamma,
+                               (uint32_t)max_steps, cascades, grid_size, bitfield, fars, xyzs, dirs, deltas);
     }
+    else                       // composite + compaction + head of the next round
+        hipLaunchKernelGGL(k_loop_composite, dim3((unsigned)((N + CT - 1) / CT)), dim3(CT), 0, s, ctl, N, max_steps, T_thresh, alive_in, alive_out, rays_t, sigmas, rgbs, deltas,
+                           amb_aud, amb_eye, unc, weights_sum, depth, image, amb_aud_sum, amb_eye_sum, unc_sum);
     MF_HIP(hipGetLastError());
-    (void)nears;
     return MF_OK;
 }

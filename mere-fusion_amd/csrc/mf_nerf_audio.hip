@@ -3,7 +3,8 @@
 //
 // Replaces `NeRFNetwork.encode_audio` (reference: ernerf/nerf_triplane/network.py:222-237 -> AudioNet :40-66, AudioAttNet :9-36),
 // which runs once per frame on an [8, audio_in_dim, 16] window: ~0.3 MFLOP, pure launch latency in the reference (about 25
-// kernels).  Here it is ONE workgroup, fp32, every intermediate in LDS.
+// kernels).  Here it is one launch: a workgroup per window through AudioNet, the last one to finish runs AudioAttNet; fp32, every
+// intermediate in LDS.
 #include "mf_common.h"
 #include <map>
 #include <memory>
@@ -28,16 +29,34 @@ struct AudioArgs {
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.02f * v; }
 
-// the layer's weights and bias into LDS (coalesced), so the MAC loops below never wait on a global load
-__device__ void stage_weights(const Layer& L, int k, float* wbuf, float* bbuf) {
-    for (int i = threadIdx.x; i < L.cout * L.cin * k; i += blockDim.x) wbuf[i] = L.w[i];
-    for (int i = threadIdx.x; i < L.cout; i += blockDim.x) bbuf[i] = L.b[i];
+// Weights travel global -> registers -> LDS one layer ahead: a layer's loads are issued before the previous layer's MAC loop and land
+// in LDS after it, so no layer waits on HBM / L2 latency (17 tiny layers: the latency chain was most of the kernel).
+constexpr int WREG = (MAX_W + 1023) / 1024;       // floats of the largest layer per thread
+struct Prefetch { float w[WREG]; float b; };
+
+__device__ __forceinline__ void prefetch(const Layer& L, int k, Prefetch& p) {
+    const int nw = L.cout * L.cin * k;
+#pragma unroll
+    for (int r = 0; r < WREG; ++r) {
+        const int i = threadIdx.x + r * 1024;
+        p.w[r] = i < nw ? L.w[i] : 0.f;
+    }
+    p.b = (int)threadIdx.x < L.cout ? L.b[threadIdx.x] : 0.f;
+}
+// call after the barrier that ended the previous layer's reads of wbuf / bbuf
+__device__ __forceinline__ void commit(const Layer& L, int k, const Prefetch& p, float* wbuf, float* bbuf) {
+    const int nw = L.cout * L.cin * k;
+#pragma unroll
+    for (int r = 0; r < WREG; ++r) {
+        const int i = threadIdx.x + r * 1024;
+        if (i < nw) wbuf[i] = p.w[r];
+    }
+    if ((int)threadIdx.x < L.cout) bbuf[threadIdx.x] = p.b;
     __syncthreads();
 }
 
-// out[n][co][t] = act(b[co] + sum_{ci,k} w[co][ci][k] * in[n][ci][t*stride + k - 1]), zero padding 1
-__device__ void conv1d(const float* in, float* out, const Layer& L, int n, int tin, int stride, bool act, float* wbuf, float* bbuf) {
-    stage_weights(L, 3, wbuf, bbuf);
+// out[n][co][t] = act(b[co] + sum_{ci,k} w[co][ci][k] * in[n][ci][t*stride + k - 1]), zero padding 1; weights already in wbuf / bbuf
+__device__ void conv1d(const float* in, float* out, const Layer& L, int n, int tin, int stride, bool act, const float* wbuf, const float* bbuf) {
     const int tout = (tin + 2 - 3) / stride + 1;
     for (int idx = threadIdx.x; idx < n * L.cout * tout; idx += blockDim.x) {
         const int t = idx % tout, co = (idx / tout) % L.cout, b = idx / (tout * L.cout);
@@ -57,8 +76,7 @@ __device__ void conv1d(const float* in, float* out, const Layer& L, int n, int t
 }
 
 // out[n][o] = act(b[o] + sum_i w[o][i] * in[n][i])
-__device__ void linear(const float* in, float* out, const Layer& L, int n, bool act, float* wbuf, float* bbuf) {
-    stage_weights(L, 1, wbuf, bbuf);
+__device__ void linear(const float* in, float* out, const Layer& L, int n, bool act, const float* wbuf, const float* bbuf) {
     for (int idx = threadIdx.x; idx < n * L.cout; idx += blockDim.x) {
         const int o = idx % L.cout, b = idx / L.cout;
         float acc = bbuf[o];
@@ -68,7 +86,12 @@ __device__ void linear(const float* in, float* out, const Layer& L, int n, bool 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_audio_encode(const AudioArgs a, const float* __restrict__ auds, int n_win, float* enc_a) {
+// One workgroup per window through AudioNet (the windows are independent there, and one CU's issue rate was the bound: ~10 instructions
+// per MAC); the last workgroup to finish pools the 8 feature vectors through AudioAttNet.
+__global__ __launch_bounds__(1024) void k_audio_encode(const AudioArgs a, const float* __restrict__ auds_all, int n_win_all, float* enc_a, float* feat_g,
+                                                       int* done) {
+    const float* auds = auds_all + (size_t)blockIdx.x * a.in_dim * WIN;
+    constexpr int n_win = 1;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* bufA = dyn;                        // MAX_ACT
     float* bufB = bufA + MAX_ACT;             // MAX_ACT / 2
@@ -76,27 +99,46 @@ __global__ __launch_bounds__(1024) void k_audio_encode(const AudioArgs a, const 
     float* bbuf = feat + SEQ * AUD_DIM;       // 64
     float* wbuf = bbuf + 64;                  // MAX_W: the largest layer, 64 x 64 x 3
     // network.py:61-62: the centre 16 steps of the window (win_size 16 -> all of them)
+    Prefetch pf;
+    const bool att = a.use_att && n_win_all == SEQ;
+    prefetch(a.conv[0], 3, pf);
     for (int i = threadIdx.x; i < n_win * a.in_dim * WIN; i += blockDim.x) bufA[i] = auds[i];
-    __syncthreads();
-    conv1d(bufA, bufB, a.conv[0], n_win, 16, 2, true, wbuf, bbuf);
-    conv1d(bufB, bufA, a.conv[1], n_win, 8, 2, true, wbuf, bbuf);
-    conv1d(bufA, bufB, a.conv[2], n_win, 4, 2, true, wbuf, bbuf);
-    conv1d(bufB, bufA, a.conv[3], n_win, 2, 2, true, wbuf, bbuf);        // [n, 64, 1]
-    linear(bufA, bufB, a.fc[0], n_win, true, wbuf, bbuf);
+    commit(a.conv[0], 3, pf, wbuf, bbuf);
+    prefetch(a.conv[1], 3, pf); conv1d(bufA, bufB, a.conv[0], n_win, 16, 2, true, wbuf, bbuf); commit(a.conv[1], 3, pf, wbuf, bbuf);
+    prefetch(a.conv[2], 3, pf); conv1d(bufB, bufA, a.conv[1], n_win, 8, 2, true, wbuf, bbuf); commit(a.conv[2], 3, pf, wbuf, bbuf);
+    prefetch(a.conv[3], 3, pf); conv1d(bufA, bufB, a.conv[2], n_win, 4, 2, true, wbuf, bbuf); commit(a.conv[3], 3, pf, wbuf, bbuf);
+    prefetch(a.fc[0], 1, pf); conv1d(bufB, bufA, a.conv[3], n_win, 2, 2, true, wbuf, bbuf); commit(a.fc[0], 1, pf, wbuf, bbuf);        // [n, 64, 1]
+    prefetch(a.fc[1], 1, pf); linear(bufA, bufB, a.fc[0], n_win, true, wbuf, bbuf); commit(a.fc[1], 1, pf, wbuf, bbuf);
+    if (att) prefetch(a.att[0], 3, pf);
     linear(bufB, feat, a.fc[1], n_win, false, wbuf, bbuf);               // [n, 32]
-    if (!a.use_att || n_win != SEQ) {
+    if (!att) {
         // att == 0: encode_audio returns audio_net's output as is (network.py:230-235); callers pass one window then
         for (int i = threadIdx.x; i < AUD_DIM; i += blockDim.x) enc_a[i] = feat[i];
         return;
     }
+    // hand this window's features over; the last workgroup gathers all eight
+    for (int i = threadIdx.x; i < AUD_DIM; i += blockDim.x) feat_g[blockIdx.x * AUD_DIM + i] = feat[i];
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(done, 1) == SEQ - 1;
+        if (s_last) *done = 0;
+        __threadfence();
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int i = threadIdx.x; i < SEQ * AUD_DIM; i += blockDim.x) feat[i] = __builtin_nontemporal_load(feat_g + i);
+    __syncthreads();
     // AudioAttNet: y = x.permute(0, 2, 1) -> [1, 32, 8]
     for (int i = threadIdx.x; i < SEQ * AUD_DIM; i += blockDim.x) { const int t = i % SEQ, c = i / SEQ; bufA[c * SEQ + t] = feat[t * AUD_DIM + c]; }
     __syncthreads();
-    conv1d(bufA, bufB, a.att[0], 1, SEQ, 1, true, wbuf, bbuf);
-    conv1d(bufB, bufA, a.att[1], 1, SEQ, 1, true, wbuf, bbuf);
-    conv1d(bufA, bufB, a.att[2], 1, SEQ, 1, true, wbuf, bbuf);
-    conv1d(bufB, bufA, a.att[3], 1, SEQ, 1, true, wbuf, bbuf);
-    conv1d(bufA, bufB, a.att[4], 1, SEQ, 1, true, wbuf, bbuf);           // [1, 1, 8]
+    commit(a.att[0], 3, pf, wbuf, bbuf);
+    prefetch(a.att[1], 3, pf); conv1d(bufA, bufB, a.att[0], 1, SEQ, 1, true, wbuf, bbuf); commit(a.att[1], 3, pf, wbuf, bbuf);
+    prefetch(a.att[2], 3, pf); conv1d(bufB, bufA, a.att[1], 1, SEQ, 1, true, wbuf, bbuf); commit(a.att[2], 3, pf, wbuf, bbuf);
+    prefetch(a.att[3], 3, pf); conv1d(bufA, bufB, a.att[2], 1, SEQ, 1, true, wbuf, bbuf); commit(a.att[3], 3, pf, wbuf, bbuf);
+    prefetch(a.att[4], 3, pf); conv1d(bufB, bufA, a.att[3], 1, SEQ, 1, true, wbuf, bbuf); commit(a.att[4], 3, pf, wbuf, bbuf);
+    prefetch(a.att_fc, 1, pf); conv1d(bufA, bufB, a.att[4], 1, SEQ, 1, true, wbuf, bbuf); commit(a.att_fc, 1, pf, wbuf, bbuf);           // [1, 1, 8]
     linear(bufB, bufA, a.att_fc, 1, false, wbuf, bbuf);                  // [1, 8]
     if (threadIdx.x == 0) {
         float m = bufA[0];
@@ -117,6 +159,8 @@ __global__ __launch_bounds__(1024) void k_audio_encode(const AudioArgs a, const 
 
 struct mf_audio_encoder {
     AudioArgs a{};
+    float* feat_g = nullptr;
+    int* done = nullptr;
     std::vector<float*> dev;
     ~mf_audio_encoder() { for (float* d : dev) (void)hipFree(d); }
 };
@@ -166,6 +210,10 @@ extern "C" int mf_audio_encoder_create(const mf_tensor* weights, int n_weights, 
             if ((rc = layer("audio_att_net.attentionConvNet." + std::to_string(2 * i), ac[i], ac[i + 1], 3, &h->a.att[i]))) return rc;
         if ((rc = layer("audio_att_net.attentionNet.0", SEQ, SEQ, 1, &h->a.att_fc))) return rc;
     }
+    MF_HIP(hipMalloc(&h->feat_g, (SEQ * AUD_DIM + 1) * sizeof(float)));
+    h->dev.push_back(h->feat_g);
+    h->done = reinterpret_cast<int*>(h->feat_g + SEQ * AUD_DIM);
+    MF_HIP(hipMemset(h->feat_g, 0, (SEQ * AUD_DIM + 1) * sizeof(float)));
     *out = h.release();
     return MF_OK;
 }
@@ -179,7 +227,7 @@ extern "C" int mf_audio_encoder_forward(mf_audio_encoder* h, const float* auds, 
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_audio_encode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AUDIO_LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_audio_encode, dim3(1), dim3(1024), AUDIO_LDS, (hipStream_t)stream, h->a, auds, n_windows, enc_a);
+    hipLaunchKernelGGL(k_audio_encode, dim3(n_windows), dim3(1024), AUDIO_LDS, (hipStream_t)stream, h->a, auds, n_windows, enc_a, h->feat_g, h->done);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

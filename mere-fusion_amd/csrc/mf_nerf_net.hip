@@ -512,6 +512,14 @@ extern "C" int mf_nerf_torso_create(const mf_nerf_torso_config* cfg, const mf_te
     return MF_OK;
 }
 
+namespace {
+struct FrameBias { float v[64]; };
+__global__ void k_torso_bias(FrameBias fb, float* bd, float* bt) {
+    if (threadIdx.x < 32) bd[threadIdx.x] = fb.v[threadIdx.x];
+    else bt[threadIdx.x - 32] = fb.v[threadIdx.x];
+}
+}  // namespace
+
 extern "C" int mf_nerf_torso_forward(mf_nerf_torso* h, const float* bg_coords, const float* frame_consts_host, const float* bg_color,
                                      int bg_per_ray, float bg_const, float density_thresh, int n_pixels, float* bg_out, float* torso_alpha,
                                      float* deform, void* stream) {
@@ -522,7 +530,8 @@ extern "C" int mf_nerf_torso_forward(mf_nerf_torso* h, const float* bg_coords, c
     const int N = n_pixels, nb = (N + TW - 1) / TW, gb = (N + 255) / 256;
     const int ncst = 42 + h->cfg.individual_dim;
     // per-frame biases of the two first layers: W[:, constant columns] . [freq(wrapped anchors) | individual code]
-    float bd[32], bt[32];
+    FrameBias fb;
+    float *bd = fb.v, *bt = fb.v + 32;
     for (int o = 0; o < 32; ++o) {
         double a = 0, b = 0;
         for (int i = 0; i < ncst; ++i) {
@@ -531,9 +540,7 @@ extern "C" int mf_nerf_torso_forward(mf_nerf_torso* h, const float* bg_coords, c
         }
         bd[o] = (float)a; bt[o] = (float)b;
     }
-    MF_HIP(hipMemcpyAsync(h->d1->bias, bd, sizeof(bd), hipMemcpyHostToDevice, s));
-    MF_HIP(hipMemcpyAsync(h->t1->bias, bt, sizeof(bt), hipMemcpyHostToDevice, s));
-    MF_HIP(hipStreamSynchronize(s));     // bd / bt live on this stack frame
+    hipLaunchKernelGGL(k_torso_bias, dim3(1), dim3(64), 0, s, fb, h->d1->bias, h->t1->bias);   // by value: no staging copy, no host sync
     hipLaunchKernelGGL(k_torso_prep, dim3((unsigned)(((int64_t)N * TX_C + 255) / 256)), dim3(256), 0, s, bg_coords, h->cfg.torso_shrink, N, h->xs,
                        h->TX->hi, h->TX->lo, h->TH->hi, h->TH->lo);
     MF_HIP(hipGetLastError());
@@ -570,10 +577,10 @@ extern "C" int mf_near_far_from_aabb(const float* rays_o, const float* rays_d, c
                                      float* fars, void* stream);
 extern "C" int mf_nerf_finish(float* image, float* depth, const float* weights_sum, const float* nears, const float* fars, const float* bg_color,
                               int bg_per_ray, float bg_const, uint32_t n_rays, uint8_t* frame_u8, void* stream);
-int mf_nerf_loop_init(int* ctl, int N, int* alive, float* rays_t, const float* nears, float* weights_sum, float* depth, float* image,
+int mf_nerf_loop_init(int* ctl, int N, int max_steps, int* alive, float* rays_t, const float* nears, float* weights_sum, float* depth, float* image,
                       float* amb_aud_sum, float* amb_eye_sum, float* unc_sum, hipStream_t s);
 int mf_nerf_loop_round(int* ctl, int N, int max_steps, const int* alive_in, int* alive_out, float* rays_t, const float* rays_o, const float* rays_d,
-                       float bound, float dt_gamma, uint32_t cascades, uint32_t grid_size, const uint8_t* bitfield, const float* nears, const float* fars,
+                       float bound, float dt_gamma, uint32_t cascades, uint32_t grid_size, const uint8_t* bitfield, const float* fars,
                        float* xyzs, float* dirs, float* deltas, int phase, float T_thresh, const float* sigmas, const float* rgbs, const float* amb_aud,
                        const float* amb_eye, const float* unc, float* weights_sum, float* depth, float* image, float* amb_aud_sum, float* amb_eye_sum,
                        float* unc_sum, hipStream_t s);
@@ -624,25 +631,32 @@ extern "C" int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const f
     float* ws = weights_sum ? weights_sum : h->wsum;
     int rc;
     if ((rc = mf_near_far_from_aabb(rays_o, rays_d, h->aabb, N, min_near, h->nears, h->fars, stream))) return rc;
-    if ((rc = mf_nerf_loop_init(h->ctl, N, h->alive[0], h->rays_t, h->nears, ws, depth, image, h->aasum, h->aesum, h->unsum, s))) return rc;
+    if ((rc = mf_nerf_loop_init(h->ctl, N, max_steps, h->alive[0], h->rays_t, h->nears, ws, depth, image, h->aasum, h->aesum, h->unsum, s))) return rc;
     const bool x3 = f->precision == MF_PREC_BF16X3;
     // at least one sample per alive ray and round, so max_steps rounds always suffice (step += n_step >= 1, renderer.py:270)
     for (int it = 0; it < max_steps; ++it) {
         int* a_in = h->alive[it & 1];
         int* a_out = h->alive[(it + 1) & 1];
         if ((rc = mf_nerf_loop_round(h->ctl, N, max_steps, a_in, a_out, h->rays_t, rays_o, rays_d, c.bound, dt_gamma, cascades, grid_size, density_bitfield,
-                                     h->nears, h->fars, h->xyzs, h->dirs, h->deltas, 0, T_thresh, nullptr, nullptr, nullptr, nullptr, nullptr, ws, depth, image,
+                                     h->fars, h->xyzs, h->dirs, h->deltas, 0, T_thresh, nullptr, nullptr, nullptr, nullptr, nullptr, ws, depth, image,
                                      h->aasum, h->aesum, h->unsum, s)))
             return rc;
         if ((rc = mf_nerf_fused_launch(f->fused_w, x3, f->emb, c.offsets, c.log2_per_level_scale, c.base_resolution, c.bound, h->xyzs, h->dirs, enc_a, ind_code,
                                        c.individual_dim, eye, c.exp_eye, N, h->sig, h->rgb, h->aa, h->ae, h->un, s, h->ctl + 3, density_scale)))
             return rc;
         if ((rc = mf_nerf_loop_round(h->ctl, N, max_steps, a_in, a_out, h->rays_t, rays_o, rays_d, c.bound, dt_gamma, cascades, grid_size, density_bitfield,
-                                     h->nears, h->fars, h->xyzs, h->dirs, h->deltas, 1, T_thresh, h->sig, h->rgb, h->aa, h->ae, h->un, ws, depth, image,
+                                     h->fars, h->xyzs, h->dirs, h->deltas, 1, T_thresh, h->sig, h->rgb, h->aa, h->ae, h->un, ws, depth, image,
                                      h->aasum, h->aesum, h->unsum, s)))
             return rc;
     }
+    if (bg_per_ray < 0) return MF_OK;                                                       // finished later by mf_nerf_head_finish
     return mf_nerf_finish(image, depth, ws, h->nears, h->fars, bg_color, bg_per_ray, bg_const, N, frame_u8, stream);
+}
+
+extern "C" int mf_nerf_head_finish(mf_nerf_head* h, int n_rays, const float* bg_color, int bg_per_ray, float bg_const, float* image, float* depth,
+                                   const float* weights_sum, uint8_t* frame_u8, void* stream) {
+    MF_REQUIRE(h && image && depth && n_rays > 0 && n_rays <= h->cap && bg_per_ray >= 0, "nerf_head_finish: bad argument");
+    return mf_nerf_finish(image, depth, weights_sum ? weights_sum : h->wsum, h->nears, h->fars, bg_color, bg_per_ray, bg_const, n_rays, frame_u8, stream);
 }
 
 extern "C" void mf_nerf_head_destroy(mf_nerf_head* h) { delete h; }

@@ -25,22 +25,51 @@ class HipHeadRenderer:
         b = self.bound
         self.aabb_infer = torch.tensor([-b, -b / 2, -b, b, b / 2, b], dtype=torch.float32, device=density_bitfield.device)   # renderer.py:86-89
         self._lib = _lib.lib()
-        self._head = None
+        self._head, self._side = None, None
 
     @torch.no_grad()
     def render(self, rays_o, rays_d, auds, bg_coords, poses, eye, bg_color=None, **kw):
         """One frame as `NeRFRenderer.render` -> `run_cuda` does it (renderer.py:657-677, 158-291): audio window -> enc_a (+ the lip
-        smoothing EMA of :190-194), fixed individual code 0 (:197-202), head loop, torso / background mix (:272-277)."""
-        enc_a = self.audio.encode_audio(auds) if self.audio is not None else auds
-        if enc_a is not None and self.smooth_lips:
-            if self.enc_a is not None:
-                enc_a = 0.35 * self.enc_a + (1 - 0.35) * enc_a
-            self.enc_a = enc_a
+        smoothing EMA of :190-194), fixed individual code 0 (:197-202), head loop, torso / background mix (:272-277).
+        loop="device" runs the head with device-side round control and the torso concurrently on a second stream (the head only needs
+        the torso's colours for the final mix)."""
+        def audio_part():
+            enc_a = self.audio.encode_audio(auds) if self.audio is not None else auds
+            if enc_a is not None and self.smooth_lips:
+                if self.enc_a is not None:
+                    enc_a = 0.35 * self.enc_a + (1 - 0.35) * enc_a
+                self.enc_a = enc_a
+            return enc_a
+        device_loop = kw.pop("loop", "host") == "device"
+        if device_loop and self.torso is not None:
+            cur = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(cur)
+            enc_a = audio_part()                           # enqueued first: the head's first field evaluation waits for it
+            with torch.cuda.stream(self._side):
+                bg = self.torso.run_torso(bg_coords, poses, bg_color)["bg_color"]
+            out = self.run_cuda_device(rays_o, rays_d, enc_a, self.ind_code, eye, bg_color=None, finish=False, **kw)
+            cur.wait_stream(self._side)
+            bg.record_stream(cur)
+            return self.finish_device(out, bg)
+        enc_a = audio_part()
         if self.torso is not None:
             bg_color = self.torso.run_torso(bg_coords, poses, bg_color)["bg_color"]
-        if kw.pop("loop", "host") == "device":
+        if device_loop:
             return self.run_cuda_device(rays_o, rays_d, enc_a, self.ind_code, eye, bg_color=bg_color, **kw)
         return self.run_cuda(rays_o, rays_d, enc_a, self.ind_code, eye, bg_color=bg_color, **kw)
+
+    def finish_device(self, out, bg_color):
+        """Background mix / depth normalisation / uint8 frame for a run_cuda_device(finish=False) result."""
+        N = out["image"].shape[0]
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        bg = bg_color.float().contiguous() if torch.is_tensor(bg_color) else None
+        per_ray = bg is not None and bg.numel() == 3 * N
+        bgc = float(1.0 if bg_color is None else (0.0 if bg is not None else bg_color))
+        _lib.check(self._lib.mf_nerf_head_finish(self._head, N, p(bg), int(per_ray), bgc, p(out["image"]), p(out["depth"]), p(out["weights_sum"]),
+                                                 p(out["frame_u8"]), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mf_nerf_head_finish")
+        return out
 
     def __del__(self):
         h = getattr(self, "_head", None)
@@ -50,7 +79,7 @@ class HipHeadRenderer:
 
     @torch.no_grad()
     def run_cuda_device(self, rays_o, rays_d, enc_a, ind_code, eye, bg_color=None, dt_gamma=1 / 256, max_steps=16, T_thresh=1e-4, want_u8=False,
-                        graph=False):
+                        graph=False, finish=True):
         """The same frame as run_cuda with the round control on the device (mf_nerf_head_render): one enqueue, no host sync between
         rounds.  graph=True captures the enqueue once per (ray count, tensors) into a CUDA graph and replays it."""
         rays_o = rays_o.contiguous().view(-1, 3).float()
@@ -72,7 +101,7 @@ class HipHeadRenderer:
 
         def enqueue(out):
             _lib.check(self._lib.mf_nerf_head_render(self._head, p(rays_o), p(rays_d), N, p(self.bitfield), self.cascade, self.grid_size, self.min_near,
-                                                     float(dt_gamma), int(max_steps), float(T_thresh), self.density_scale, p(ea), p(ic), ev, p(bg), int(per_ray),
+                                                     float(dt_gamma), int(max_steps), float(T_thresh), self.density_scale, p(ea), p(ic), ev, p(bg), int(per_ray) if finish else -1,
                                                      bgc, p(out["image"]), p(out["depth"]), p(out["weights_sum"]), p(out["frame_u8"]),
                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mf_nerf_head_render")
 
@@ -84,7 +113,7 @@ class HipHeadRenderer:
             enqueue(out)
             return out
         # graph mode: static input / output buffers per (ray count, scalar arguments); inputs are copied in unless they already live there
-        key = (N, ev, bool(want_u8), bgc, None if bg is None else bg.numel(), float(dt_gamma), int(max_steps), float(T_thresh))
+        key = (N, ev, bool(want_u8), bgc, bool(finish), None if bg is None else bg.numel(), float(dt_gamma), int(max_steps), float(T_thresh))
         hit = self._graphs.get(key)
         live = (rays_o, rays_d, ea, ic, bg)
         if hit is None:

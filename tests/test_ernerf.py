@@ -651,7 +651,31 @@ def test_hip_device_controlled_loop_matches_host_loop(lib_built, W):
     for k, tol in (("image", 1e-6), ("depth", 1e-6), ("weights_sum", 1e-6)):
         assert (got[k] - want[k]).abs().max().item() <= tol, k
     assert (got["frame_u8"].int() - want["frame_u8"].int()).abs().max().item() <= 1
+    os.environ["MF_NERF_MARCH"] = "generic"              # the reference-shaped index arithmetic instead of the one-cascade fast path: same bits
+    try:
+        gen = r.run_cuda_device(*args, bg_color=bg, want_u8=True)
+    finally:
+        del os.environ["MF_NERF_MARCH"]
+    assert torch.equal(gen["image"], got["image"]) and torch.equal(gen["depth"], got["depth"])
     g1 = {k: v.clone() for k, v in r.run_cuda_device(*args, bg_color=bg, want_u8=True, graph=True).items() if v is not None}
     g2 = r.run_cuda_device(*args, bg_color=bg, want_u8=True, graph=True)
     for k in g1:
         assert torch.equal(g1[k], g2[k]) and (g1[k].float() - got[k].float()).abs().max().item() <= (1 if k == "frame_u8" else 1e-6), k
+
+
+@pytest.mark.gpu
+def test_hip_full_frame_device_loop_with_torso_stream(lib_built):
+    """`render(loop="device")`: torso on a second stream, head with device-side round control, deferred finish -- the same frame as
+    the host-driven `render` (audio nets, EMA, torso mix included), three frames in a row so the stream joins are exercised."""
+    import bench
+    a = bench.ErNeRFRunner("bf16x3", 128, torch.device("cuda:0"), seed=3)
+    b = bench.ErNeRFRunner("bf16x3", 128, torch.device("cuda:0"), seed=3)
+    for i in range(3):
+        auds = torch.randn(8, 44, 16, generator=torch.Generator().manual_seed(i)).cuda()
+        want = a.r.render(a.ro, a.rd, auds, a.bg_coords, a.pose, a.d_eye, bg_color=1.0, want_u8=True)
+        got = b.r.render(b.ro, b.rd, auds, b.bg_coords, b.pose, b.eye, bg_color=1.0, want_u8=True, loop="device")
+        torch.cuda.synchronize()
+        assert (got["image"] - want["image"]).abs().max().item() <= 1e-6
+        assert (got["depth"] - want["depth"]).abs().max().item() <= 1e-6
+        assert (got["frame_u8"].int() - want["frame_u8"].int()).abs().max().item() <= 1
+        assert want["frame_u8"].float().std().item() > 5
