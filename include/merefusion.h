@@ -296,6 +296,13 @@ int mf_nerf_field_forward(mf_nerf_field* h, const float* xyzs, const float* dirs
                           float* uncertainty, void* stream);
 void mf_nerf_field_destroy(mf_nerf_field* h);
 
+/* a24, `Trainer.test_gui_with_data` utils.py:1208-1216 + nerfreal.py:111: the [h,w] render resized to the GUI's [H,W].
+ * image [h,w,3] -> out_image [H,W,3] as F.interpolate(mode='bilinear') (align_corners False, no antialias); depth [h,w] ->
+ * out_depth [H,W] as mode='nearest'; frame_u8 [H,W,3] = uint8(out_image * 255) truncating.  Any of the three outputs may
+ * be NULL (depth may be NULL when out_depth is). */
+int mf_nerf_resize_frame(const float* image, const float* depth, int h, int w, int H, int W, float* out_image, float* out_depth,
+                         uint8_t* frame_u8, void* stream);
+
 /* ---- ER-NeRF head frame without host round trips ----------------------------------------------- */
 typedef struct mf_nerf_head mf_nerf_head;
 /* Scratch for up to max_rays rays over `field` (which must outlive the head and use the fused field kernel). */

@@ -112,6 +112,7 @@ SIGNATURES = {
     "mf_nerf_field_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mf_nerf_field_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 6),
     "mf_nerf_field_destroy": (None, [C.c_void_p]),
+    "mf_nerf_resize_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mf_nerf_head_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mf_nerf_head_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 5),

@@ -446,6 +446,36 @@ __global__ __launch_bounds__(NT) void k_nerf_finish(float* image, float* depth, 
     depth[n] = fmaxf(depth[n] - nears[n], 0.f) / (fars[n] - nears[n]);
 }
 
+// a24, utils.py:1208-1216 + nerfreal.py:111: the rendered [h, w] frame resized to the GUI's [H, W] -- image bilinear with half-pixel centres
+// (F.interpolate(mode='bilinear'), align_corners=False: src = max((dst + 0.5) * in / out - 0.5, 0), weights (1 - l, l), the row blend of
+// two column blends as aten's upsample_bilinear2d forms it), depth nearest (src = min(floor(dst * in / out), in - 1)), frame =
+// uint8(image * 255).  One lane per output pixel.
+__global__ __launch_bounds__(NT) void k_nerf_resize(const float* __restrict__ image, const float* __restrict__ depth, int h, int w, int H, int W,
+                                                    float* out_image, float* out_depth, uint8_t* frame) {
+    const int i = threadIdx.x + blockIdx.x * NT;
+    if (i >= H * W) return;
+    const int oy = i / W, ox = i - oy * W;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    float fy = fmaf(sy, (float)oy + 0.5f, -0.5f), fx = fmaf(sx, (float)ox + 0.5f, -0.5f);     // fused, as aten's builds contract it
+    fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float p00 = image[((size_t)y0 * w + x0) * 3 + k], p01 = image[((size_t)y0 * w + x1) * 3 + k];
+        const float p10 = image[((size_t)y1 * w + x0) * 3 + k], p11 = image[((size_t)y1 * w + x1) * 3 + k];
+        const float v = ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11);
+        if (out_image) out_image[(size_t)i * 3 + k] = v;
+        if (frame) frame[(size_t)i * 3 + k] = (uint8_t)(v * 255.f);
+    }
+    if (out_depth) {
+        int ny = (int)floorf((float)oy * sy), nx = (int)floorf((float)ox * sx);
+        ny = ny < h - 1 ? ny : h - 1; nx = nx < w - 1 ? nx : w - 1;
+        out_depth[i] = depth[(size_t)ny * w + nx];
+    }
+}
+
 // ---- device-controlled render loop (no host sync between rounds) ---------------------------------------------------------
 // ctl: [0] n_alive, [1] n_step, [2] step after this round, [3] M = n_alive * n_step, [6..7] one 64-bit counter: survivors appended so far (low
 // word) and blocks done (high word)
@@ -653,6 +683,16 @@ extern "C" int mf_nerf_finish(float* image, float* depth, const float* weights_s
     if (n_rays == 0) return MF_OK;
     hipLaunchKernelGGL(k_nerf_finish, dim3(blocks(n_rays)), dim3(NT), 0, (hipStream_t)stream, image, depth, weights_sum, nears, fars, bg_color,
                        bg_per_ray, bg_const, n_rays, frame_u8);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+extern "C" int mf_nerf_resize_frame(const float* image, const float* depth, int h, int w, int H, int W, float* out_image, float* out_depth,
+                                    uint8_t* frame_u8, void* stream) {
+    MF_REQUIRE(image && h > 0 && w > 0 && H > 0 && W > 0 && (out_image || frame_u8 || out_depth), "nerf_resize_frame: bad argument");
+    MF_REQUIRE(!out_depth || depth, "nerf_resize_frame: out_depth without depth");
+    MF_REQUIRE((int64_t)H * W < (1ll << 31) && (int64_t)h * w < (1ll << 31), "nerf_resize_frame: frame too large");
+    hipLaunchKernelGGL(k_nerf_resize, dim3(blocks((uint64_t)H * W)), dim3(NT), 0, (hipStream_t)stream, image, depth, h, w, H, W, out_image, out_depth, frame_u8);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

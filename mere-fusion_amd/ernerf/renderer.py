@@ -60,6 +60,19 @@ class HipHeadRenderer:
             return self.run_cuda_device(rays_o, rays_d, enc_a, self.ind_code, eye, bg_color=bg_color, **kw)
         return self.run_cuda(rays_o, rays_d, enc_a, self.ind_code, eye, bg_color=bg_color, **kw)
 
+    @torch.no_grad()
+    def resize(self, out, h, w, H, W, want_u8=True):
+        """`test_gui_with_data`'s resize to the GUI size (utils.py:1208-1216): image bilinear, depth nearest, uint8 frame of nerfreal.py:111."""
+        dev = out["image"].device
+        img, dep = out["image"].contiguous(), out["depth"].contiguous()
+        assert img.numel() == 3 * h * w and dep.numel() == h * w
+        res = {"image": torch.empty(H, W, 3, device=dev), "depth": torch.empty(H, W, device=dev),
+               "frame_u8": torch.empty(H, W, 3, dtype=torch.uint8, device=dev) if want_u8 else None}
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(self._lib.mf_nerf_resize_frame(p(img), p(dep), h, w, H, W, p(res["image"]), p(res["depth"]), p(res["frame_u8"]),
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mf_nerf_resize_frame")
+        return res
+
     def finish_device(self, out, bg_color):
         """Background mix / depth normalisation / uint8 frame for a run_cuda_device(finish=False) result."""
         N = out["image"].shape[0]

@@ -57,3 +57,33 @@ def run_cuda(sd, offsets, S, rays_o, rays_d, enc_a, ind_code, eye, bitfield, bou
     dep = np.maximum(depth - nears, 0) / (fars - nears)                                       # renderer.py:279
     return {"image": img, "depth": dep.astype(np.float32), "ambient_aud": aa_sum, "ambient_eye": ae_sum, "weights_sum": weights_sum, "trace": trace,
             "frame_u8": (img * 255).astype(np.uint8)}
+
+
+def resize_frame(image, depth, H, W):
+    """`Trainer.test_gui_with_data` tail (ernerf/nerf_triplane/utils.py:1208-1216) + nerfreal.py:111 in numpy fp32: image [h, w, 3] bilinear
+    with half-pixel centres (aten upsample_bilinear2d, align_corners=False), depth [h, w] nearest (legacy floor rule), frame = uint8(image * 255).
+    Pinned: tests/test_ernerf.py checks it against torch.nn.functional.interpolate -- the very call the reference makes -- on CPU."""
+    image = np.asarray(image, np.float32)
+    depth = np.asarray(depth, np.float32)
+    h, w = depth.shape
+    f = np.float32
+
+    def src(n_out, n_in):
+        s = f(n_in) / f(n_out)
+        # aten's `scale * (dst + 0.5) - 0.5` is compiled to one fused multiply-add (CPU and CUDA builds alike): a float product is exact in
+        # double, so rounding once from double reproduces it
+        x = (np.float64(s) * (np.arange(n_out, dtype=np.float32) + f(0.5)).astype(np.float64) - 0.5).astype(np.float32)
+        x = np.maximum(x, f(0))
+        i0 = x.astype(np.int64)
+        i1 = i0 + (i0 < n_in - 1)
+        l1 = (x - i0.astype(np.float32)).astype(np.float32)
+        return i0, i1, (f(1) - l1).astype(np.float32), l1
+    y0, y1, ly0, ly1 = src(H, h)
+    x0, x1, lx0, lx1 = src(W, w)
+    lx0, lx1 = lx0[None, :, None], lx1[None, :, None]
+    top = lx0 * image[y0][:, x0] + lx1 * image[y0][:, x1]
+    bot = lx0 * image[y1][:, x0] + lx1 * image[y1][:, x1]
+    out = (ly0[:, None, None] * top + ly1[:, None, None] * bot).astype(np.float32)
+    ny = np.minimum(np.floor(np.arange(H, dtype=np.float32) * (f(h) / f(H))).astype(np.int64), h - 1)
+    nx = np.minimum(np.floor(np.arange(W, dtype=np.float32) * (f(w) / f(W))).astype(np.int64), w - 1)
+    return out, depth[ny][:, nx], (out * f(255)).astype(np.uint8)

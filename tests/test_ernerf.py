@@ -679,3 +679,38 @@ def test_hip_full_frame_device_loop_with_torso_stream(lib_built):
         assert (got["depth"] - want["depth"]).abs().max().item() <= 1e-6
         assert (got["frame_u8"].int() - want["frame_u8"].int()).abs().max().item() <= 1
         assert want["frame_u8"].float().std().item() > 5
+
+
+_RESIZE_CASES = [(24, 24, 24, 24), (24, 32, 45, 70), (64, 48, 17, 31), (1, 5, 4, 9), (50, 50, 450, 450)]
+
+
+@pytest.mark.parametrize("h,w,H,W", _RESIZE_CASES)
+def test_oracle_resize_matches_torch_interpolate(h, w, H, W):
+    """a24: the reference resizes with F.interpolate (utils.py:1208-1209); torch on CPU is that very call."""
+    import torch.nn.functional as F
+    from oracle import ernerf_render_ref as RR
+    g = np.random.default_rng(h * 1000 + W)
+    img, dep = g.random((h, w, 3), dtype=np.float32), g.random((h, w), dtype=np.float32)
+    want = F.interpolate(torch.from_numpy(img)[None].permute(0, 3, 1, 2), size=(H, W), mode="bilinear").permute(0, 2, 3, 1)[0].numpy()
+    want_d = F.interpolate(torch.from_numpy(dep)[None, None], size=(H, W), mode="nearest")[0, 0].numpy()
+    got, got_d, u8 = RR.resize_frame(img, dep, H, W)
+    assert np.abs(got - want).max() <= 2.4e-7          # 2 ulp at 1.0: the blend itself may or may not be contracted
+    assert np.array_equal(got_d, want_d)
+    assert np.array_equal(u8, (got * 255).astype(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,H,W", _RESIZE_CASES + [(512, 512, 450, 450)])
+def test_hip_resize_frame_matches_oracle(lib_built, h, w, H, W):
+    from mere_fusion_amd.ernerf.renderer import HipHeadRenderer
+    from oracle import ernerf_render_ref as RR
+    g = np.random.default_rng(h + W)
+    img, dep = g.random((h, w, 3), dtype=np.float32), g.random((h, w), dtype=np.float32)
+    r = HipHeadRenderer.__new__(HipHeadRenderer)
+    from mere_fusion_amd import _lib
+    r._lib, r._head = _lib.lib(), None
+    got = r.resize({"image": _cu(img.reshape(-1, 3)), "depth": _cu(dep.reshape(-1))}, h, w, H, W)
+    want, want_d, want_u8 = RR.resize_frame(img, dep, H, W)
+    assert np.abs(got["image"].cpu().numpy() - want).max() <= 2.4e-7
+    assert np.array_equal(got["depth"].cpu().numpy(), want_d)
+    assert np.abs(got["frame_u8"].cpu().numpy().astype(int) - want_u8.astype(int)).max() <= 1
