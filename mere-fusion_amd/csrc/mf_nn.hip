@@ -230,7 +230,34 @@ __global__ __launch_bounds__(256) void k_gn_stats(Rows X, int groups, int cpg, i
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[j][e] = 0.f; q[j][e] = 0.f; }
     if (pp < ppi) {
-        for (int t = t0 + pp; t < t1; t += ppi) {
+        // GN_UP pixels per trip with every load issued before the first add: a lane otherwise has two 16-byte loads in flight, and the
+        // big VAE maps (268 MB per tensor) streamed at 1.8 TB/s
+        auto acc = [&](int j, const uint4& vh, const uint4& vl) __attribute__((always_inline)) {
+            const uint32_t hh[4] = {vh.x, vh.y, vh.z, vh.w}, ll[4] = {vl.x, vl.y, vl.z, vl.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = nbf2f(hh[e] & 0xffffu) + nbf2f(ll[e] & 0xffffu);
+                const float v1 = nbf2f(hh[e] >> 16) + nbf2f(ll[e] >> 16);
+                s[j][2 * e] += v0; q[j][2 * e] += v0 * v0;
+                s[j][2 * e + 1] += v1; q[j][2 * e + 1] += v1 * v1;
+            }
+        };
+        constexpr int GN_UP = 4;
+        int t = t0 + pp;
+        if (c8 <= 256) {
+            for (; t + (GN_UP - 1) * ppi < t1; t += GN_UP * ppi) {
+                uint4 vh[GN_UP], vl[GN_UP];
+#pragma unroll
+                for (int u = 0; u < GN_UP; ++u) {
+                    const int64_t o = X.off(b, t + u * ppi) + k0 * 8;
+                    vh[u] = *reinterpret_cast<const uint4*>(X.hi + o);
+                    vl[u] = X.lo ? *reinterpret_cast<const uint4*>(X.lo + o) : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < GN_UP; ++u) acc(0, vh[u], vl[u]);
+            }
+        }
+        for (; t < t1; t += ppi) {
             const int64_t o = X.off(b, t);
 #pragma unroll
             for (int j = 0; j < GN_MAXCOL; ++j) {
@@ -239,14 +266,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(Rows X, int groups, int cpg, i
                 const uint4 vh = *reinterpret_cast<const uint4*>(X.hi + o + k * 8);
                 uint4 vl = make_uint4(0, 0, 0, 0);
                 if (X.lo) vl = *reinterpret_cast<const uint4*>(X.lo + o + k * 8);
-                const uint32_t hh[4] = {vh.x, vh.y, vh.z, vh.w}, ll[4] = {vl.x, vl.y, vl.z, vl.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v0 = nbf2f(hh[e] & 0xffffu) + nbf2f(ll[e] & 0xffffu);
-                    const float v1 = nbf2f(hh[e] >> 16) + nbf2f(ll[e] >> 16);
-                    s[j][2 * e] += v0; q[j][2 * e] += v0 * v0;
-                    s[j][2 * e + 1] += v1; q[j][2 * e + 1] += v1 * v1;
-                }
+                acc(j, vh, vl);
             }
         }
 #pragma unroll
@@ -279,36 +299,32 @@ __global__ void k_zero_f64(double* p, int n) {
     if (i < n) p[i] = 0.0;
 }
 
-// one thread per (token, 8 channels): y = (x - mean) * rstd * gamma + beta [, SiLU]
+// y = (x - mean) * rstd * gamma + beta [, SiLU].  A thread owns one 8-channel column and GA_U tokens (t, t + TS, ...): the column's
+// gamma / beta / (mean, rstd) are formed once, the GA_U (hi, lo) loads are all issued before the first use, and the grid is
+// (token blocks, batch) so no 64-bit division is left.  (One token per thread streamed the big VAE maps at 2.5 TB/s.)
+constexpr int GA_U = 4;
 __global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  const double* stats, double inv_n, float eps, int groups, int cpg, int C, int silu,
-                                                  int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+                                                  const double* stats, double inv_n, float eps, int groups, int cpg, int C, int silu, int TS) {
     const int c8 = C / 8;
-    const int c0 = (int)(idx % c8) * 8;
-    const int64_t r = idx / c8;
-    const int t = (int)(r % X.T), b = (int)(r / X.T);
-    const int64_t xo = X.off(b, t) + c0, yo = Y.off(b, t) + c0;
-
-    const uint4 vh = *reinterpret_cast<const uint4*>(X.hi + xo);
-    uint4 vl = make_uint4(0, 0, 0, 0);
-    if (X.lo) vl = *reinterpret_cast<const uint4*>(X.lo + xo);
-    const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
-    const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-    const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    const uint32_t hh[4] = {vh.x, vh.y, vh.z, vh.w}, ll[4] = {vl.x, vl.y, vl.z, vl.w};
-    uint32_t oh[4], ol[4];
-    int g_prev = -1;
-    float2 st2 = make_float2(0.f, 1.f);
+    const int b = blockIdx.y;
+    // 256 threads = (256 / cols) token lanes x cols columns, cols = min(c8, 256); wider tensors loop over column blocks
+    const int cols = c8 < 256 ? c8 : 256;
+    const int tl = threadIdx.x / cols, kk = threadIdx.x - tl * cols;
+    const int tpb = 256 / cols;                               // token lanes per block
+    const int tbase = blockIdx.x * tpb * GA_U + tl;           // tokens tbase + u * tpb
+    if (tl >= tpb) return;
+    for (int k = kk; k < c8; k += 256) {
+        const int c0 = k * 8;
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
+        float sc[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float mu[8], rs[8];
+        int g_prev = -1;
+        float2 st2 = make_float2(0.f, 1.f);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float out2[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c = c0 + 2 * e + k;
-            const int g = c / cpg;
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c0 + e) / cpg;
             if (g != g_prev) {
                 // finalise (sum, sum of squares) -> (mean, rstd): a handful of fp64 ops per thread and group
                 const double2 sq = *reinterpret_cast<const double2*>(stats + 2 * (b * groups + g));
@@ -317,17 +333,46 @@ __global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* _
                 st2 = make_float2((float)mean, rsqrtf((float)var + eps));
                 g_prev = g;
             }
-            const float x = nbf2f(k ? hh[e] >> 16 : hh[e] & 0xffffu) + nbf2f(k ? ll[e] >> 16 : ll[e] & 0xffffu);
-            float v = (x - st2.x) * st2.y * gm[2 * e + k] + bt[2 * e + k];
-            if (silu) v = v / (1.f + __expf(-v));
-            out2[k] = v;
+            mu[e] = st2.x; rs[e] = st2.y;
         }
-        const uint32_t h0 = nf2bf(out2[0]), h1 = nf2bf(out2[1]);
-        oh[e] = h0 | (h1 << 16);
-        ol[e] = nf2bf(out2[0] - nbf2f(h0)) | (nf2bf(out2[1] - nbf2f(h1)) << 16);
+        uint4 vh[GA_U], vl[GA_U];
+        int64_t yo[GA_U];
+        bool ok[GA_U];
+#pragma unroll
+        for (int u = 0; u < GA_U; ++u) {
+            const int t = tbase + u * tpb;
+            ok[u] = t < X.T;
+            const int tt = ok[u] ? t : X.T - 1;
+            const int64_t xo = X.off(b, tt) + c0;
+            yo[u] = Y.off(b, tt) + c0;
+            vh[u] = *reinterpret_cast<const uint4*>(X.hi + xo);
+            vl[u] = X.lo ? *reinterpret_cast<const uint4*>(X.lo + xo) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < GA_U; ++u) {
+            const uint32_t hh[4] = {vh[u].x, vh[u].y, vh[u].z, vh[u].w}, ll[4] = {vl[u].x, vl[u].y, vl[u].z, vl[u].w};
+            uint32_t oh[4], ol[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float out2[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float x = nbf2f(q ? hh[e] >> 16 : hh[e] & 0xffffu) + nbf2f(q ? ll[e] >> 16 : ll[e] & 0xffffu);
+                    float v = (x - mu[2 * e + q]) * rs[2 * e + q] * sc[2 * e + q] + sh[2 * e + q];
+                    if (silu) v = v / (1.f + __expf(-v));
+                    out2[q] = v;
+                }
+                const uint32_t h0 = nf2bf(out2[0]), h1 = nf2bf(out2[1]);
+                oh[e] = h0 | (h1 << 16);
+                ol[e] = nf2bf(out2[0] - nbf2f(h0)) | (nf2bf(out2[1] - nbf2f(h1)) << 16);
+            }
+            if (ok[u]) {
+                *reinterpret_cast<uint4*>(const_cast<bf16_t*>(Y.hi) + yo[u]) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+                if (Y.lo) *reinterpret_cast<uint4*>(const_cast<bf16_t*>(Y.lo) + yo[u]) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+            }
+        }
     }
-    *reinterpret_cast<uint4*>(const_cast<bf16_t*>(Y.hi) + yo) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
-    if (Y.lo) *reinterpret_cast<uint4*>(const_cast<bf16_t*>(Y.lo) + yo) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+    (void)TS;
 }
 
 __global__ __launch_bounds__(256) void k_geglu(Rows X, Rows Y, int C, int64_t total) {
@@ -431,9 +476,11 @@ int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const f
     int P = std::max(ppi, std::min(64 * ppi, (xr.T * batch + 1023) / 1024));
     hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, cpg, x.C, P, stats);
     MF_HIP(hipGetLastError());
-    const int64_t total = (int64_t)batch * xr.T * (x.C / 8);
-    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xr, yr, gamma, beta, stats,
-                       1.0 / ((double)xr.T * cpg), eps, groups, cpg, x.C, silu ? 1 : 0, total);
+    {
+        const int tpb = 256 / cols;
+        hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((xr.T + tpb * GA_U - 1) / (tpb * GA_U)), batch), dim3(256), 0, s, xr, yr, gamma, beta, stats,
+                           1.0 / ((double)xr.T * cpg), eps, groups, cpg, x.C, silu ? 1 : 0, 0);
+    }
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

@@ -14,5 +14,9 @@ rm -rf /tmp/prof_w2l
 rocprofv3 --kernel-trace --stats -d /tmp/prof_w2l -o w2l -- python $R/bench.py --workload wav2lip --steps 30 --warmup 5 --extras 0 --cpu-seconds 0 > /tmp/prof_w2l.log 2>&1
 DB=$(find /tmp/prof_w2l -name "*.db" | head -1)
 python $R/tools/rocprof_summary.py $DB > $R/gpurun_out/kernel_stats_wav2lip.md 2>&1
+rm -rf /tmp/prof_nf
+rocprofv3 --kernel-trace --stats -d /tmp/prof_nf -o nf -- python $R/bench.py --workload ernerf --steps 30 --warmup 3 --extras 0 --cpu-seconds 0 > /tmp/prof_nf.log 2>&1
+DB=$(find /tmp/prof_nf -name "*.db" | head -1)
+python $R/tools/rocprof_summary.py $DB > $R/gpurun_out/kernel_stats_ernerf.md 2>&1
 cd $R
 cat gpurun_out/gpu_tests.txt; cut -c1-1500 gpurun_out/bench_line.json; head -20 gpurun_out/kernel_stats_musetalk.md
