@@ -302,7 +302,7 @@ __global__ void k_zero_f64(double* p, int n) {
 // y = (x - mean) * rstd * gamma + beta [, SiLU].  A thread owns one 8-channel column and GA_U tokens (t, t + TS, ...): the column's
 // gamma / beta / (mean, rstd) are formed once, the GA_U (hi, lo) loads are all issued before the first use, and the grid is
 // (token blocks, batch) so no 64-bit division is left.  (One token per thread streamed the big VAE maps at 2.5 TB/s.)
-constexpr int GA_U = 4;
+template <int GA_U>
 __global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const double* stats, double inv_n, float eps, int groups, int cpg, int C, int silu, int TS) {
     const int c8 = C / 8;
@@ -477,9 +477,15 @@ int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const f
     hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, cpg, x.C, P, stats);
     MF_HIP(hipGetLastError());
     {
+        // four tokens per thread once the tensor is big enough to fill the chip that way; small maps keep one token per thread
         const int tpb = 256 / cols;
-        hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((xr.T + tpb * GA_U - 1) / (tpb * GA_U)), batch), dim3(256), 0, s, xr, yr, gamma, beta, stats,
-                           1.0 / ((double)xr.T * cpg), eps, groups, cpg, x.C, silu ? 1 : 0, 0);
+        const bool big = (int64_t)batch * xr.T * (x.C / 8) >= (int64_t)1 << 20;
+        const int U = big ? 4 : 1;
+        const dim3 grid((unsigned)((xr.T + tpb * U - 1) / (tpb * U)), batch);
+        if (big)
+            hipLaunchKernelGGL(k_gn_apply<4>, grid, dim3(256), 0, s, xr, yr, gamma, beta, stats, 1.0 / ((double)xr.T * cpg), eps, groups, cpg, x.C, silu ? 1 : 0, 0);
+        else
+            hipLaunchKernelGGL(k_gn_apply<1>, grid, dim3(256), 0, s, xr, yr, gamma, beta, stats, 1.0 / ((double)xr.T * cpg), eps, groups, cpg, x.C, silu ? 1 : 0, 0);
     }
     MF_HIP(hipGetLastError());
     return MF_OK;
