@@ -63,6 +63,7 @@ struct ConvArgs {
     int64_t zx_b, zx_h, zw, zy_b, zy_h;
     float* ws;                // split-K fp32 partials [split][B][Ho][Wo][N], or null
     int64_t ws_split, wsb; int wsi, wsj;
+    int* tile_cnt;            // fused split-K combine: arrivals per (phase, tile); the last workgroup reduces and resets it (null: k_splitk_epilogue)
     ConvPhase ph[MF_MAX_PHASE];
 };
 
@@ -109,6 +110,8 @@ struct ConvPlan {
     hipEvent_t prof_mid = nullptr;   // measurement only: recorded between the MFMA kernel and its split-K combine
     float* ws = nullptr;  // split-K workspace, grown on the first (eager) launch that needs it
     int64_t ws_cap = 0;
+    int* tile_cnt = nullptr;  // arrival counters of the fused split-K combine (zeroed once; self-resetting)
+    int tile_cnt_cap = 0;
     // host-side phase description, independent of the buffers the layer is later bound to
     struct Tap {                              // input displacement in pixels relative to anchor
         int dy, dx;

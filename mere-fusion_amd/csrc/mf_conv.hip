@@ -306,8 +306,45 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
                 *reinterpret_cast<float4*>(wo + c) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             }
         }
-        if (dbg && threadIdx.x == 0) dbg[3] = __builtin_amdgcn_s_memtime();
-        return;
+        if (!a.tile_cnt) {
+            if (dbg && threadIdx.x == 0) dbg[3] = __builtin_amdgcn_s_memtime();
+            return;
+        }
+        // Fused combine (small tiles): the last workgroup of a tile to arrive sums the partials -- its own included, in split order, so
+        // the result does not depend on arrival order -- back into its accumulator registers and runs the ordinary epilogue below.
+        // Saves the k_splitk_epilogue launch and its pass over the output.
+        __threadfence();
+        __syncthreads();
+        int* s_flag = reinterpret_cast<int*>(smem);          // the ring is drained: its first word is free
+        if (threadIdx.x == 0) {
+            int* cnt = a.tile_cnt + (int)blockIdx.z * nt + t;
+            const int last = atomicAdd(cnt, 1) == (int)gridDim.y - 1;
+            if (last) *cnt = 0;
+            *s_flag = last;
+        }
+        __syncthreads();
+        if (!*s_flag) return;
+        __threadfence();
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = m0 + pm0 + j * 16 + fr;
+            if (m >= a.M) continue;
+            const int b = m / a.HqWq;
+            const int rem = m - b * a.HqWq;
+            const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+            const float* wo = a.ws + (int64_t)b * a.wsb + (int64_t)qi * a.wsi + (int64_t)qj * a.wsj + ph.ws_off;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int c = n0 + cn0 + i * 16 + fk * 4;
+                if (c >= a.N) continue;
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < (int)gridDim.y; ++k) {
+                    const float4 v = *reinterpret_cast<const float4*>(wo + (int64_t)k * a.ws_split + c);
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                }
+                acc[i][j][0] = sum.x; acc[i][j][1] = sum.y; acc[i][j][2] = sum.z; acc[i][j][3] = sum.w;
+            }
+        }
     }
     // Bias quads of this lane, fetched once and with clamped (never branched-around) addresses; the activation is a
     // compile-time parameter of the body below.  Both keep the per-fragment code straight-line, so the residual loads of a
@@ -733,6 +770,8 @@ void mf_conv_plan_destroy(ConvPlan* p) {
     if (p->bias) (void)hipFree(p->bias);
     if (p->goff) (void)hipFree(p->goff);
     if (p->ws) (void)hipFree(p->ws);
+    if (p->tile_cnt) (void)hipFree(p->tile_cnt);
+    p->tile_cnt = nullptr; p->tile_cnt_cap = 0;
     p->w_hi = p->w_lo = nullptr; p->bias = nullptr; p->goff = nullptr; p->ws = nullptr; p->ws_cap = 0;
 }
 
@@ -842,6 +881,7 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
             a.dbg = (int64_t)a.tiles_m * a.tiles_n * tc.nsplit * p->nphase <= 65536 ? dbg_buf : nullptr;
         }
     }
+    bool fused = false;
     if (tc.nsplit > 1) {
         // fp32 partial tiles [split][B][Ho][Wo][N]; combined by k_splitk_epilogue below
         const int64_t per_split = (int64_t)batch * p->out_h * p->out_w * a.N;
@@ -855,6 +895,21 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         a.ws = p->ws; a.ws_split = per_split;
         a.wsb = (int64_t)p->out_h * p->out_w * a.N;
         a.wsi = p->out_step * p->out_w * a.N; a.wsj = p->out_step * a.N;
+        // MF_SPLITK_FUSE=1: combine inside the conv kernel (the last workgroup of a tile re-reads the nsplit partial tiles).  Measured
+        // SLOWER than the separate chip-wide pass (Wav2Lip 14.2 k -> 11.2 k frames/s, MuseTalk 322 -> 316: one workgroup re-reading
+        // nsplit tiles after two fences and an atomic is a longer tail than a 5 us launch spread over every CU), so it stays opt-in.
+        static const int fuse_mode = [] { const char* e = getenv("MF_SPLITK_FUSE"); return e ? atoi(e) : 0; }();
+        fused = fuse_mode > 0 && (int64_t)tc.bm * tc.bn * 4 * tc.nsplit <= 160 * 1024;
+        if (fused) {
+            const int need_cnt = a.tiles_m * a.tiles_n * std::max(1, p->nphase);
+            if (need_cnt > p->tile_cnt_cap) {
+                if (p->tile_cnt) { MF_HIP(hipStreamSynchronize(stream)); MF_HIP(hipFree(p->tile_cnt)); p->tile_cnt = nullptr; p->tile_cnt_cap = 0; }
+                MF_HIP(hipMalloc(&p->tile_cnt, need_cnt * sizeof(int)));
+                MF_HIP(hipMemset(p->tile_cnt, 0, need_cnt * sizeof(int)));
+                p->tile_cnt_cap = need_cnt;
+            }
+            a.tile_cnt = p->tile_cnt;
+        }
     }
     int rc = MF_ERR_INVALID;
 #define MF_CASE(BM, BN, WGM, WGN)                                                          \
@@ -893,8 +948,8 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
                     nwg, tc.bm, tc.bn, tc.nsplit, hi - lo, med(d[0]), mx(d[0]), med(d[1]), mx(d[1]), med(d[2]), mx(d[2]), med(start), mx(start), med(end));
         }
     }
-    if (tc.nsplit > 1) {
-        if (p->prof_mid) MF_HIP(hipEventRecord(p->prof_mid, stream));
+    if (tc.nsplit > 1 && p->prof_mid) MF_HIP(hipEventRecord(p->prof_mid, stream));   // (fused combine: the second row of the launch table reads ~0)
+    if (tc.nsplit > 1 && !fused) {
         ConvArgs e = a;   // unit-grid strides for the combine pass
         e.yi = ob.Wp() * ob.C; e.yj = ob.C;
         const int64_t total = (int64_t)batch * p->out_h * p->out_w * ((a.act == 5 ? a.N / 2 : a.N) / 4);
