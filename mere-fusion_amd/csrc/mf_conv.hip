@@ -835,7 +835,7 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         ha.act = p->d.act;
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
         if (tw.ph) return mf_halo_w_launch(ha, tw, x3, stream);
-        return mf_halo_launch(ha, mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch), x3, stream);
+        return mf_halo_launch(ha, mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin), x3, stream);
     }
 
     ConvArgs a{};
@@ -1048,7 +1048,7 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision == MF_PREC_BF16X3 ? "true" : "false";
     if (p->halo) {
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
-        const HaloTile t = tw.ph ? tw : mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
+        const HaloTile t = tw.ph ? tw : mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         snprintf(buf, cap, "k_conv3x3_halo%s<%d,%d,%d,%d,%s,2>", tw.ph ? "_w" : "", t.ph, t.bn, t.wgm, t.wgn, x3);
     } else {
         const ConvTile t = mf_conv_pick_tile(p, batch);

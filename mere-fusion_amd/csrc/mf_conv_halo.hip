@@ -18,6 +18,7 @@
 // Same operand roles and epilogue as mf_conv.hip: weights = MFMA A (rows = channels), pixels = B,
 // one lane owns 4 consecutive channels of one pixel.
 #include "mf_conv.h"
+#include <cstdio>
 #include <cstdlib>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -49,7 +50,7 @@ __device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
 }  // namespace
 
 template <int PH, int BN, int WGM, int WGN, bool X3, int NST>
-__global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN == 4 ? 2 : 1) void k_conv3x3_halo(const HaloArgs a) {
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4 && (PH / WGM) * (BN / WGN / 16) <= 8) ? 2 : 1) void k_conv3x3_halo(const HaloArgs a) {
     constexpr int NW = WGM * WGN;                           // waves per workgroup
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int CK = X3 ? 32 : 64;
@@ -325,13 +326,21 @@ int halo_launch_prec(const HaloArgs& a, bool x3, hipStream_t s) {
 
 // Patch selection: 8x16 pixels x 64 (or 32) channels; maps too small to give every CU a workgroup fall
 // back to 4-row patches and then to 32-channel tiles (4x the workgroups, 1/4 of the MFMAs each).
-HaloTile mf_halo_pick_tile(int H, int W, int N, int batch) {
+HaloTile mf_halo_pick_tile(int H, int W, int N, int batch, int cin) {
     auto wgs = [&](int ph, int bn) { return batch * ((H + ph - 1) / ph) * ((W + PW - 1) / PW) * ((N + bn - 1) / bn); };
     if (N <= 32) return wgs(8, 32) >= 256 ? HaloTile{8, 32, 2, 2} : HaloTile{4, 32, 2, 2};
     // 16 x 16 patch, 8 waves (the weight stream shared by twice the pixels): measured 4 % SLOWER than the 8-row patch on
     // the VAE's 128 / 256-channel layers and on Wav2Lip's 96^2 layers, so it stays opt-in (MF_HALO_PH16=1)
     static const int big = [] { const char* e = getenv("MF_HALO_PH16"); return e ? atoi(e) : 0; }();
     if (big && wgs(16, 64) >= 512) return HaloTile{16, 64, 4, 2};
+    // Fat wave tiles, 2 x 2 waves (MF_HALO_TILE=8x128 | 16x64 | 16x128, A/B only): a wave's weight fragment (L1 -> VGPR) and pixel fragment
+    // (LDS -> VGPR) each feed more MFMAs -- per CU and clock the 8x64 tile moves 85 B from LDS and 43 B through L1, 16x128 (wave = 128
+    // pixels x 64 channels, one wave per SIMD) 43 and 21.  Alone the VAE's 256-channel layers gain 6-8 % with 16x128 and the 128-channel
+    // ones 3 % with 8x128, but inside the decoder (residual epilogues, GroupNorm neighbours) the step time does not move, so the default
+    // stays 8x64: neither L1 nor LDS bandwidth is what holds this kernel at ~45 % MFMA issue.
+    static const int fat = [] { const char* e = getenv("MF_HALO_TILE"); int a = 0, b = 0; return e && sscanf(e, "%dx%d", &a, &b) == 2 ? a * 1000 + b : 0; }();
+    if (fat && N >= fat % 1000 && wgs(fat / 1000, fat % 1000) >= 256) return HaloTile{fat / 1000, fat % 1000, 2, 2};
+    (void)cin;
     if (wgs(8, 64) >= 256) return HaloTile{8, 64, 2, 2};
     if (wgs(4, 64) >= 256) return HaloTile{4, 64, 2, 2};
     return HaloTile{4, 32, 2, 2};
@@ -345,7 +354,10 @@ int mf_halo_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t s
     a.n_patches = a.batch * a.patches_per_img;
     a.tiles_n = (a.N + t.bn - 1) / t.bn;
 #define MF_HCASE(PH, BN, WGM, WGN) \
-    if (t.ph == PH && t.bn == BN) return halo_launch_prec<PH, BN, WGM, WGN>(a, x3, s);
+    if (t.ph == PH && t.bn == BN && t.wgm == WGM) return halo_launch_prec<PH, BN, WGM, WGN>(a, x3, s);
+    MF_HCASE(16, 128, 2, 2)
+    MF_HCASE(16, 64, 2, 2)
+    MF_HCASE(8, 128, 2, 2)
     MF_HCASE(16, 64, 4, 2)
     MF_HCASE(8, 64, 2, 2)
     MF_HCASE(4, 64, 2, 2)
