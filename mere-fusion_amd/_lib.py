@@ -139,7 +139,8 @@ def lib():
         # torch first: its wheel carries its own HIP / HSA runtime, and device buffers are torch's.  Loading this library
         # before torch would bring a second runtime (/opt/rocm) into the process, which then sees no device.
         import torch  # noqa: F401
-        l = C.CDLL(LIB_PATH)
+        # MF_LIB_PATH: an alternative build of the same library (kernel ablation studies, tools/halo_ablate.sh)
+        l = C.CDLL(os.environ.get("MF_LIB_PATH") or LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype = res

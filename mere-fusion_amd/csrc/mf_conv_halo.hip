@@ -24,6 +24,15 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// Ablation builds (tools/halo_ablate.sh; wrong results, timing only): bit 0 = no epilogue stores / residual reads, bit 1 = weights loaded
+// once instead of streamed, bit 2 = no per-slice halo DMA, bit 3 = pixel fragments read from LDS once per slice.
+#ifndef MF_HALO_ABLATE
+#define MF_HALO_ABLATE 0
+#endif
+#ifndef MF_HALO_RING9
+#define MF_HALO_RING9 0
+#endif
+
 namespace {
 
 constexpr int PW = 16;   // patch width = one MFMA pixel fragment
@@ -132,13 +141,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4 && (PH / WGM) * (BN
 
     // Rolling 3-deep ring over the flattened (slice, tap) sequence: the fragment for step s+2 is
     // requested while step s computes, so only 3 taps' weights are ever live (24 VGPRs in bf16x3).
-    constexpr int RING = FN == 1 ? 9 : 3;   // FN == 1: in-place refill one whole slice ahead
+    constexpr int RING = (FN <= 2 && MF_HALO_RING9) ? 9 : (FN == 1 ? 9 : 3);   // 9: in-place refill one whole slice ahead
     constexpr int DIST = RING - 1;
     bf16x8 wr[RING][FN][KK][NP];
     auto load_step = [&](int ring, int step) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
             const bf16_t* src = wsrc[i] + (int64_t)step * w_tap;
+            if ((MF_HALO_ABLATE & 2) && step >= RING) continue;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 wr[ring][i][kk][0] = *reinterpret_cast<const bf16x8*>(src + kk * 32);
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4 && (PH / WGM) * (BN
                 const int step2 = slice * 9 + tap + DIST;
                 load_step((tap + DIST) % RING, step2 < n_steps ? step2 : n_steps - 1);
             }
-            if (idx + 1 < NF) rd(idx + 1, n_hi, n_lo);
+            if (idx + 1 < NF && !((MF_HALO_ABLATE & 8) && idx > 0)) rd(idx + 1, n_hi, n_lo);
             // pin the prefetch ABOVE this fragment's MFMAs (hipcc otherwise sinks it to its first use
             // and every MFMA group eats a full LDS round trip)
             __builtin_amdgcn_sched_barrier(0);
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4 && (PH / WGM) * (BN
         const bool more = slice + 1 < a.n_slices;
         if (NST == 2) {
             const int st = slice & 1;
-            if (more) load_halo(slice + 1, st ^ 1);   // flies under this slice's MFMAs
+            if (more && !(MF_HALO_ABLATE & 4)) load_halo(slice + 1, st ^ 1);   // flies under this slice's MFMAs
             compute(st, slice);
             if (more) __syncthreads();         // next halo landed; everyone is done with this one
         } else {
@@ -251,6 +261,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4 && (PH / WGM) * (BN
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
+    if (MF_HALO_ABLATE & 1) {
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keep == 1234.5f) a.y_hi[0] = 1;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
         const int oy = y0 + row0 + j, ox = x0 + fr;
