@@ -714,3 +714,31 @@ def test_hip_resize_frame_matches_oracle(lib_built, h, w, H, W):
     assert np.abs(got["image"].cpu().numpy() - want).max() <= 2.4e-7
     assert np.array_equal(got["depth"].cpu().numpy(), want_d)
     assert np.abs(got["frame_u8"].cpu().numpy().astype(int) - want_u8.astype(int)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_hip_device_loop_edge_cases(lib_built):
+    """Ragged ray counts (not a multiple of the 256 / 1024-lane blocks), rays that all miss the box (near = far = FLT_MAX -> background only),
+    a single round (max_steps = 1), and a second frame on the same handle with fewer rays (stale control block / alive lists)."""
+    from mere_fusion_amd.ernerf.field import HipNeRFField
+    from mere_fusion_amd.ernerf.renderer import HipHeadRenderer
+    sd, offsets, S, _, _, enc_a, c, e = _field_case(8, 3)
+    sd = {k: (v * 0.35 if k.startswith("sigma_net.net.2") else v) for k, v in sd.items()}
+    r = HipHeadRenderer(HipNeRFField(sd, max_samples=4096), torch.from_numpy(_sphere_bitfield()).cuda(), density_scale=40.0)
+    bg = torch.tensor([0.2, 0.4, 0.6], device="cuda")
+    ro, rd = _camera_rays(48)
+    for n in (1, 255, 257, 1025, 2304, 1000):
+        args = (_cu(ro[:n]), _cu(rd[:n]), enc_a.cuda(), c.cuda(), e.cuda())
+        want = r.run_cuda(*args, bg_color=bg)
+        got = r.run_cuda_device(*args, bg_color=bg)
+        assert (got["image"] - want["image"]).abs().max().item() <= 1e-6, n
+        assert (got["depth"] - want["depth"]).abs().max().item() <= 1e-6, n
+    # every ray points away from the volume: nothing is sampled, the frame is the background
+    away = rd.copy(); away[:, 2] = np.abs(away[:, 2]) + 1.0
+    far_o = ro.copy(); far_o[:, 2] = 10.0
+    got = r.run_cuda_device(_cu(far_o), _cu(away), enc_a.cuda(), c.cuda(), e.cuda(), bg_color=bg)
+    assert torch.allclose(got["image"], bg.expand_as(got["image"]), atol=1e-7) and float(got["weights_sum"].abs().max()) == 0.0
+    # one round only
+    args = (_cu(ro), _cu(rd), enc_a.cuda(), c.cuda(), e.cuda())
+    a1, b1 = r.run_cuda(*args, bg_color=bg, max_steps=1), r.run_cuda_device(*args, bg_color=bg, max_steps=1)
+    assert (a1["image"] - b1["image"]).abs().max().item() <= 1e-6
