@@ -532,6 +532,7 @@ int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3
 }
 
 int cdiv(int a, int b) { return (a + b - 1) / b; }
+bool mf_k_tap_major() { static const bool v = [] { const char* e = getenv("MF_K_ORDER"); return e && !strcmp(e, "tap"); }(); return v; }
 
 }  // namespace
 
@@ -702,7 +703,14 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
         p->bound_in_ld = p->bound_in_wp = -1;
         return MF_OK;
     }
-    // ---- pack: per phase [K/64][Npad][64], K groups tap-major ---------------------------------------
+    // ---- pack: per phase [K/64][Npad][64] ---------------------------------------------------------------
+    // K order.  Tap-major (all channels of tap 0, then tap 1, ...) re-reads every input pixel once per tap with C/32 K-tiles in
+    // between: by then the lines have left L2 (64 workgroups per XCD x 0.5 MB), so a 3x3 layer pulled its input ~9x from HBM / MALL
+    // (PMC: 510-627 MB per launch against 153 MB of tensors on the VAE's 512-channel layers).  Channel-slice-major (for each 64-channel
+    // slice: its taps back to back) keeps the taps' overlapping rows within nine consecutive K-tiles -- about 50 KB per workgroup.
+    // MF_K_ORDER=tap restores the old order (A/B).
+    const bool k_tap_major = mf_k_tap_major();
+    auto kgroup = [&](int ntaps, int ti, int cg) { return (!k_tap_major && cpg % 8 == 0) ? ((cg / 8) * ntaps + ti) * 8 + cg % 8 : ti * cpg + cg; };
     int64_t total = 0;
     int goff_total = 0;
     for (int ph = 0; ph < p->nphase; ++ph) {
@@ -742,7 +750,7 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
                         w += d.transposed ? weight[(((int64_t)c * d.cout + n) * k + kk.first) * k + kk.second]
                                           : weight[(((int64_t)n * d.cin + c) * d.kh + kk.first) * d.kw + kk.second];
                     const float wf = (float)(w * (double)scale[n]);
-                    const int g = (int)ti * cpg + c / 8;
+                    const int g = kgroup((int)taps.size(), (int)ti, c / 8);
                     const int64_t idx = p->ph[ph].w_off + ((int64_t)(g / KG) * p->Npad + n) * BK + (g % KG) * 8 + c % 8;
                     const bf16_t h = mf_f2bf(wf);
                     hi[idx] = h;
@@ -789,7 +797,11 @@ int mf_conv_bind(ConvPlan* p, const ActBuf& in) {
         const int real = (int)taps.size() * cpg;
         for (int g = 0; g < p->ph[ph].ngroups; ++g) {
             const int gg = g < real ? g : 0;   // padding groups re-read group 0 against zero weights
-            const int ti = gg / cpg, cg = gg % cpg;
+            int ti = gg / cpg, cg = gg % cpg;
+            if (!mf_k_tap_major() && cpg % 8 == 0) {           // inverse of kgroup() in mf_conv_plan_create
+                const int nt = (int)taps.size(), s8 = gg / (nt * 8), rem = gg % (nt * 8);
+                ti = rem / 8; cg = s8 * 8 + rem % 8;
+            }
             goff[p->ph[ph].goff_begin + g] =
                 ((taps[ti].dy + in.halo) * in.Wp() + (taps[ti].dx + in.halo)) * in.C + cg * 8;
         }
