@@ -105,6 +105,8 @@ struct ConvPlan {
     float* bias = nullptr;
     int* goff = nullptr;
     bool halo = false;    // 3x3 s1 p1 on a >= 16x16 map: LDS halo-tile kernel, weights packed [slice][tap][Npad][CK]
+    ConvPlan* alt = nullptr;  // wide halo layers (> 256 channels) only run on the LDS-weights kernel's fat tiles, which need a few hundred
+                              // workgroups: this implicit-GEMM twin (own weight pack) takes the launches whose batch is too small
     int n_slices = 0;
     int groups_cap = 1;   // grouped GEMM shells: packed operands the weight buffers hold
     hipEvent_t prof_mid = nullptr;   // measurement only: recorded between the MFMA kernel and its split-K combine

@@ -532,6 +532,7 @@ int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3
 }
 
 int cdiv(int a, int b) { return (a + b - 1) / b; }
+bool g_no_halo_wide = false;   // set while mf_conv_plan_create builds the implicit-GEMM twin of a wide halo plan
 bool mf_k_tap_major() { static const bool v = [] { const char* e = getenv("MF_K_ORDER"); return e && !strcmp(e, "tap"); }(); return v; }
 
 }  // namespace
@@ -669,14 +670,21 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     const int HCK = precision == MF_PREC_BF16X3 ? 32 : 64;   // channel slice of the halo kernel
     const int BK = 64, KG = BK / 8;                            // packed K tile of the implicit-GEMM kernel
     p->BK = BK;
+    // up to 256 channels: the register-weights halo kernel (mf_conv_halo.hip) or the LDS-weights one (mf_conv_halo2.hip);
+    // wider (<= 1024, cout a multiple of 128, maps >= 64 x 64): only the LDS-weights kernel's fat tiles, with an implicit-GEMM twin
+    // (p->alt) for launches too small to fill the chip with 16 x 16-pixel patches.  MF_HALO_WIDE=0 keeps wide layers on implicit GEMM.
+    static const bool halo_wide = [] { const char* e = getenv("MF_HALO_WIDE"); return !e || atoi(e) != 0; }();
+    const bool narrow = d.cin <= 256 && d.cout <= 256;
+    const bool wide_ok = halo_wide && !g_no_halo_wide && d.cin <= 1024 && d.cout <= 1024 && d.cout % 128 == 0 && d.in_h * d.in_w >= 64 * 64 && d.cin % 32 == 0;
     p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
               d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16 && d.residual != 2 && d.act <= 2 && !d.upsample &&
-              d.cin <= 256 && d.cout <= 256 && d.cout % 4 == 0;   // wide layers: weights must be shared through LDS
+              (narrow || wide_ok) && d.cout % 4 == 0;
     {
         // MF_HALO_MAXC=n: halo kernel only up to n input channels (A/B against the 8-wave implicit-GEMM tiles)
         static const int maxc = [] { const char* e = getenv("MF_HALO_MAXC"); return e ? atoi(e) : 256; }();
-        if (d.cin > maxc) p->halo = false;
+        if (d.cin > maxc && narrow) p->halo = false;
     }
+    const bool want_alt = p->halo && !narrow;
     if (p->halo) {
         // ---- pack for the halo-tile kernel: [slice][tap][Npad][CK], channels past cin are zero --------
         p->n_slices = cdiv(d.cin, HCK);
@@ -701,6 +709,13 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
         MF_HIP(hipMalloc(&p->bias, p->Npad * sizeof(float)));
         MF_HIP(hipMemcpy(p->bias, fbias.data(), p->Npad * sizeof(float), hipMemcpyHostToDevice));
         p->bound_in_ld = p->bound_in_wp = -1;
+        if (want_alt) {
+            p->alt = new ConvPlan();
+            g_no_halo_wide = true;
+            const int rc = mf_conv_plan_create(p->alt, d, weight, bias, bn_gamma, bn_beta, bn_mean, bn_var, precision);
+            g_no_halo_wide = false;
+            if (rc) return rc;
+        }
         return MF_OK;
     }
     // ---- pack: per phase [K/64][Npad][64] ---------------------------------------------------------------
@@ -773,6 +788,7 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
 
 void mf_conv_plan_destroy(ConvPlan* p) {
     if (!p) return;
+    if (p->alt) { mf_conv_plan_destroy(p->alt); delete p->alt; p->alt = nullptr; }
     if (p->w_hi) (void)hipFree(p->w_hi);
     if (p->w_lo) (void)hipFree(p->w_lo);
     if (p->bias) (void)hipFree(p->bias);
@@ -789,7 +805,10 @@ int mf_conv_bind(ConvPlan* p, const ActBuf& in) {
                p->d.in_h, p->d.in_w, in.H, in.W);
     MF_REQUIRE(in.C % 8 == 0 && in.C >= p->cin_pad, "conv: input buffer has %d channels, need >= %d (multiple of 8)", in.C, p->cin_pad);
     if (p->bound_in_ld == in.C && p->bound_in_wp == in.Wp()) return MF_OK;
-    if (p->halo) { p->bound_in_ld = in.C; p->bound_in_wp = in.Wp(); return MF_OK; }
+    if (p->halo) {
+        p->bound_in_ld = in.C; p->bound_in_wp = in.Wp();
+        return p->alt ? mf_conv_bind(p->alt, in) : MF_OK;
+    }
     const int cpg = p->cin_pad / 8;
     std::vector<int> goff(p->goff_total, 0);
     for (int ph = 0; ph < p->nphase; ++ph) {
@@ -847,6 +866,12 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         ha.act = p->d.act;
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
         if (tw.ph) return mf_halo_w_launch(ha, tw, x3, stream);
+        if (p->alt) {                          // wide layer, too few patches for the fat tiles at this batch: implicit GEMM
+            p->alt->prof_mid = p->prof_mid;
+            const int rc = mf_conv_launch(p->alt, in, out, res, batch, stream);
+            p->alt->prof_mid = nullptr;
+            return rc;
+        }
         return mf_halo_launch(ha, mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin), x3, stream);
     }
 
@@ -1060,6 +1085,7 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision == MF_PREC_BF16X3 ? "true" : "false";
     if (p->halo) {
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
+        if (!tw.ph && p->alt) { mf_conv_kernel_name(p->alt, batch, buf, cap); return; }
         const HaloTile t = tw.ph ? tw : mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         snprintf(buf, cap, "k_conv3x3_halo%s<%d,%d,%d,%d,%s,2>", tw.ph ? "_w" : "", t.ph, t.bn, t.wgm, t.wgn, x3);
     } else {

@@ -42,7 +42,8 @@ __device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
 
 }  // namespace
 
-template <int PH, int BN, int WGM, int WGN, bool X3, int NST>
+// TR = taps per ring slot: 3 (one kernel row, a barrier per row) or 1 (a barrier per tap: the wide tiles, whose 3-tap slot would not fit)
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR>
 __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const HaloArgs a) {
     constexpr int NW = WGM * WGN;                           // waves per workgroup
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -60,8 +61,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
     constexpr int STAGE = NP * H_BYTES;                     // one halo image (hi, lo); two stages
     constexpr int WT_BYTES = BN * ROWB;                     // one tap's weight tile, one plane: [BN][CK] bf16
     constexpr int WCH = WT_BYTES / 1024;                    // its 1-KiB DMA chunks
-    constexpr int WROW = 3 * NP * WT_BYTES;                 // one tap row (3 taps, planes) of the ring
-    constexpr int WRC = 3 * NP * WCH;                       // DMA chunks per tap row
+    static_assert(TR == 1 || TR == 3, "ring slot = one tap or one kernel row");
+    constexpr int WROW = TR * NP * WT_BYTES;                // one ring slot (TR taps, planes)
+    constexpr int WRC = TR * NP * WCH;                      // DMA chunks per slot
     constexpr int NWR = (WRC + NW - 1) / NW;
     static_assert(WT_BYTES % 1024 == 0, "weight tile must be whole DMA chunks");
 
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
 #pragma unroll
         for (int i = 0; i < NWR; ++i) {
             const int c = wave + NW * i;
-            if (WRC % NW == 0 || c < WRC) hglds16(wsrc[i] + (int64_t)(slice * 9 + trow * 3 + wtap[i]) * w_tap, base + c * 1024);
+            if (WRC % NW == 0 || c < WRC) hglds16(wsrc[i] + (int64_t)(slice * 9 + trow * TR + wtap[i]) * w_tap, base + c * 1024);
         }
     };
     // A fragment of (tap-in-row t3, channel block i, k-step kk, plane): rows cn0 + i*16 + fr, 16-byte slot kk*4 + fk
@@ -192,19 +194,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
             }
         }
     };
-    // the three taps of kernel row `dy`: pixel fragments from the halo image at row shift dy, weights from ring buffer `buf`
-    auto compute_row = [&](int stage, int dy, int buf) __attribute__((always_inline)) {
+    // the TR taps of ring slot `step` (taps step*TR ...): pixel fragments from the halo image at the tap's shift, weights from ring buffer `buf`
+    auto compute_row = [&](int stage, int step, int buf) __attribute__((always_inline)) {
         const char* base = smem + stage * STAGE;
         const char* wb = wring + buf * WROW;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
+        for (int t3 = 0; t3 < TR; ++t3) {
+            const int tap = step * TR + t3, dy = tap / 3, dx = tap % 3;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 bf16x8 whi[FN], wlo[FN];
 #pragma unroll
                 for (int i = 0; i < FN; ++i) {
-                    whi[i] = *reinterpret_cast<const bf16x8*>(wb + (dx * NP) * WT_BYTES + wlane[i][kk]);
-                    if (X3) wlo[i] = *reinterpret_cast<const bf16x8*>(wb + (dx * NP + 1) * WT_BYTES + wlane[i][kk]);
+                    whi[i] = *reinterpret_cast<const bf16x8*>(wb + (t3 * NP) * WT_BYTES + wlane[i][kk]);
+                    if (X3) wlo[i] = *reinterpret_cast<const bf16x8*>(wb + (t3 * NP + 1) * WT_BYTES + wlane[i][kk]);
                 }
 #pragma unroll
                 for (int j = 0; j < FM; ++j) {
@@ -234,13 +237,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
         const int st = slice & 1;
         if (more) load_halo(slice + 1, st ^ 1);            // flies under this slice's MFMAs
         if (a.res_from_halo) add_residual(st, slice);
+        constexpr int NSTEP = 9 / TR;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            // the next tap row (of this slice, or row 0 of the next) into the other ring buffer: everyone left it at the last barrier
-            if (dy < 2) load_wrow(slice, dy + 1, wbuf ^ 1);
+        for (int step = 0; step < NSTEP; ++step) {
+            // the next slot (of this slice, or slot 0 of the next) into the other ring buffer: everyone left it at the last barrier
+            if (step < NSTEP - 1) load_wrow(slice, step + 1, wbuf ^ 1);
             else if (more) load_wrow(slice + 1, 0, wbuf ^ 1);
-            compute_row(st, dy, wbuf);
-            if (dy < 2 || more) __syncthreads();           // next row (and, at dy == 2, the next halo image) landed; this row is released
+            compute_row(st, step, wbuf);
+            if (step < NSTEP - 1 || more) __syncthreads();   // next slot (and, at the last step, the next halo image) landed; this one is released
             wbuf ^= 1;
         }
     }
@@ -292,10 +296,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int PH, int BN, int WGM, int WGN, bool X3, int NST>
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR>
 int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, NST>;
+    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -303,15 +307,15 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     }
     constexpr int CK = X3 ? 32 : 64, RPC = 1024 / (CK * 2), NP = X3 ? 2 : 1;
     constexpr int HCH = ((PH + 2) * (PW + 2) + RPC - 1) / RPC;
-    const size_t lds = (size_t)2 * NP * HCH * 1024 + (size_t)2 * 3 * NP * BN * CK * 2;
+    const size_t lds = (size_t)2 * NP * HCH * 1024 + (size_t)2 * TR * NP * BN * CK * 2;
     hipLaunchKernelGGL(kern, dim3(a.n_patches * a.tiles_n), dim3(WGM * WGN * 64), lds, s, a);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
 
-template <int PH, int BN, int WGM, int WGN>
+template <int PH, int BN, int WGM, int WGN, int TR>
 int halo_w_launch_prec(const HaloArgs& a, bool x3, hipStream_t s) {
-    return x3 ? halo_w_launch_cfg<PH, BN, WGM, WGN, true, 2>(a, s) : halo_w_launch_cfg<PH, BN, WGM, WGN, false, 2>(a, s);
+    return x3 ? halo_w_launch_cfg<PH, BN, WGM, WGN, true, TR>(a, s) : halo_w_launch_cfg<PH, BN, WGM, WGN, false, TR>(a, s);
 }
 
 }  // namespace
@@ -324,10 +328,12 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
     a.patches_per_img = a.patches_x * patches_y;
     a.n_patches = a.batch * a.patches_per_img;
     a.tiles_n = (a.N + t.bn - 1) / t.bn;
-#define MF_HCASE(PH, BN, WGM, WGN) \
-    if (t.ph == PH && t.bn == BN) return halo_w_launch_prec<PH, BN, WGM, WGN>(a, x3, s);
-    MF_HCASE(16, 64, 4, 2)
-    MF_HCASE(8, 64, 2, 2)
+#define MF_HCASE(PH, BN, WGM, WGN, TR) \
+    if (t.ph == PH && t.bn == BN) return halo_w_launch_prec<PH, BN, WGM, WGN, TR>(a, x3, s);
+    MF_HCASE(16, 256, 2, 4, 1)     // wave tile 128 pixels x 64 channels (FM 8, FN 4): the implicit-GEMM 256x256 wave tile with the input read once
+    MF_HCASE(16, 128, 2, 4, 1)     // 128 pixels x 32 channels
+    MF_HCASE(16, 64, 4, 2, 3)
+    MF_HCASE(8, 64, 2, 2, 3)
 #undef MF_HCASE
     mf_set_error("halo conv (LDS weights): no kernel for patch %dx16, BN %d", t.ph, t.bn);
     return MF_ERR_INVALID;
@@ -336,12 +342,19 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
 // The LDS-weights kernel pays off where the weight stream dominates the patch: 64-channel tiles on maps large enough to give every
 // CU a 16 x 16 (or 8 x 16) patch.  Returns ph == 0 when the first-generation kernel should be used.
 HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch) {
-    static const int mode = [] { const char* e = getenv("MF_HALO_WLDS"); return e ? atoi(e) : 0; }();   // opt-in: see profiles/r01_igemm_bandwidth_study.md
-    auto wgs = [&](int ph) { return batch * ((H + ph - 1) / ph) * ((W + PW - 1) / PW) * ((N + 63) / 64); };
+    // default (unset): the fat tiles wherever they fill the chip; 0: never; 1: also the 64-channel tiles (measured no faster than the
+    // register-weights kernel); 2 / 3 / 5: force 16x64 / 8x64 / the fat tiles whatever the size (tests)
+    static const int mode = [] { const char* e = getenv("MF_HALO_WLDS"); return e ? atoi(e) : -1; }();
+    auto wgs = [&](int ph, int bn) { return batch * ((H + ph - 1) / ph) * ((W + PW - 1) / PW) * ((N + bn - 1) / bn); };
     if (!mode || N < 64) return HaloTile{0, 0, 0, 0};
-    if (mode == 2) return HaloTile{16, 64, 4, 2};          // tests: every eligible layer, whatever its size
+    if (mode == 2) return HaloTile{16, 64, 4, 2};
     if (mode == 3) return HaloTile{8, 64, 2, 2};
-    if (wgs(16) >= 256) return HaloTile{16, 64, 4, 2};
-    if (wgs(8) >= 256) return HaloTile{8, 64, 2, 2};
+    // fat wave tiles: 16 x 16 pixels x 256 / 128 channels, 2 x 4 waves of 128 pixels x 64 / 32 channels, a ring slot per tap
+    if (N % 256 == 0 && (mode == 5 || wgs(16, 256) >= 256)) return HaloTile{16, 256, 2, 4};
+    if (N % 128 == 0 && (mode == 5 || wgs(16, 128) >= 256)) return HaloTile{16, 128, 2, 4};
+    if (mode == 1) {
+        if (wgs(16, 64) >= 256) return HaloTile{16, 64, 4, 2};
+        if (wgs(8, 64) >= 256) return HaloTile{8, 64, 2, 2};
+    }
     return HaloTile{0, 0, 0, 0};
 }

@@ -26,6 +26,7 @@ ap.add_argument("--transposed", type=int, default=0)
 ap.add_argument("--outpad", type=int, default=0)
 ap.add_argument("--precision", default="bf16x3")
 ap.add_argument("--iters", type=int, default=50)
+ap.add_argument("--check", type=int, default=0, help="1: compare with torch fp32 conv2d (+ReLU, residual) on the GPU")
 a = ap.parse_args()
 
 l = _lib.lib()
@@ -47,6 +48,12 @@ y = torch.empty(a.batch, a.cout, oh.value, ow.value, device="cuda")
 for _ in range(3):
     _lib.check(l.mf_conv2d_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), a.batch, None))
 torch.cuda.synchronize()
+if a.check and not a.transposed:
+    ref = torch.nn.functional.conv2d(x.double(), w.cuda().double(), b.cuda().double(), stride=a.stride, padding=a.pad)
+    if a.residual:
+        ref = ref + x.double()
+    ref = torch.relu(ref).float()
+    print(f"   check vs torch fp64 conv: L-inf {float((y - ref).abs().max()):.3e}, rel {float((y - ref).abs().max() / ref.abs().max()):.3e}")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(a.iters):
