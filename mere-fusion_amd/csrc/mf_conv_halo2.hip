@@ -350,8 +350,10 @@ HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch) {
     if (mode == 2) return HaloTile{16, 64, 4, 2};
     if (mode == 3) return HaloTile{8, 64, 2, 2};
     // fat wave tiles: 16 x 16 pixels x 256 / 128 channels, 2 x 4 waves of 128 pixels x 64 / 32 channels, a ring slot per tap
-    if (N % 256 == 0 && (mode == 5 || wgs(16, 256) >= 256)) return HaloTile{16, 256, 2, 4};
-    if (N % 128 == 0 && (mode == 5 || wgs(16, 128) >= 256)) return HaloTile{16, 128, 2, 4};
+    // (maps of at least 64 x 64: on Wav2Lip's 24^2 / 48^2 layers at batch 128 they measured 2 % slower than the register-weights kernel)
+    const bool big_map = H * W >= 64 * 64;
+    if (N % 256 == 0 && (mode == 5 || (big_map && wgs(16, 256) >= 256))) return HaloTile{16, 256, 2, 4};
+    if (N % 128 == 0 && (mode == 5 || (big_map && wgs(16, 128) >= 256))) return HaloTile{16, 128, 2, 4};
     if (mode == 1) {
         if (wgs(16, 64) >= 256) return HaloTile{16, 64, 4, 2};
         if (wgs(8, 64) >= 256) return HaloTile{8, 64, 2, 2};
