@@ -87,7 +87,7 @@ struct HaloTile { int ph, bn, wgm, wgn; };
 HaloTile mf_halo_pick_tile(int H, int W, int N, int batch, int cin = 0);
 int mf_halo_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s);
 // second generation (mf_conv_halo2.hip): weights shared through an LDS ring; pick_tile returns ph == 0 to decline
-HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch);
+HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch, int cin = 0);
 int mf_halo_w_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s);
 
 struct ConvPlan {

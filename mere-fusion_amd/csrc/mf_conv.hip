@@ -674,8 +674,10 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     // wider (<= 1024, cout a multiple of 128, maps >= 64 x 64): only the LDS-weights kernel's fat tiles, with an implicit-GEMM twin
     // (p->alt) for launches too small to fill the chip with 16 x 16-pixel patches.  MF_HALO_WIDE=0 keeps wide layers on implicit GEMM.
     static const bool halo_wide = [] { const char* e = getenv("MF_HALO_WIDE"); return !e || atoi(e) != 0; }();
+    static const int halo_wide_minpx = [] { const char* e = getenv("MF_HALO_WIDE_MINPX"); return e ? atoi(e) : 64 * 64; }();
     const bool narrow = d.cin <= 256 && d.cout <= 256;
-    const bool wide_ok = halo_wide && !g_no_halo_wide && d.cin <= 1024 && d.cout <= 1024 && d.cout % 128 == 0 && d.in_h * d.in_w >= 64 * 64 && d.cin % 32 == 0;
+    const bool wide_ok = halo_wide && !g_no_halo_wide && d.cin <= 1024 && d.cout <= 1024 && d.cout % 128 == 0 && d.cin % 32 == 0 &&
+                         (d.in_h * d.in_w >= halo_wide_minpx || (d.cout % 256 == 0 && d.cin >= 512));   // small maps: only the 256-channel tile pays
     p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
               d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16 && d.residual != 2 && d.act <= 2 && !d.upsample &&
               (narrow || wide_ok) && d.cout % 4 == 0;
@@ -864,7 +866,7 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
             }
         }
         ha.act = p->d.act;
-        const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
+        const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         if (tw.ph) return mf_halo_w_launch(ha, tw, x3, stream);
         if (p->alt) {                          // wide layer, too few patches for the fat tiles at this batch: implicit GEMM
             p->alt->prof_mid = p->prof_mid;
@@ -1084,7 +1086,7 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
 void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision == MF_PREC_BF16X3 ? "true" : "false";
     if (p->halo) {
-        const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch);
+        const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         if (!tw.ph && p->alt) { mf_conv_kernel_name(p->alt, batch, buf, cap); return; }
         const HaloTile t = tw.ph ? tw : mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         snprintf(buf, cap, "k_conv3x3_halo%s<%d,%d,%d,%d,%s,2>", tw.ph ? "_w" : "", t.ph, t.bn, t.wgm, t.wgn, x3);

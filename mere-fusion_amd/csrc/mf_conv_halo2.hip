@@ -341,7 +341,7 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
 
 // The LDS-weights kernel pays off where the weight stream dominates the patch: 64-channel tiles on maps large enough to give every
 // CU a 16 x 16 (or 8 x 16) patch.  Returns ph == 0 when the first-generation kernel should be used.
-HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch) {
+HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch, int cin) {
     // default (unset): the fat tiles wherever they fill the chip; 0: never; 1: also the 64-channel tiles (measured no faster than the
     // register-weights kernel); 2 / 3 / 5: force 16x64 / 8x64 / the fat tiles whatever the size (tests)
     static const int mode = [] { const char* e = getenv("MF_HALO_WLDS"); return e ? atoi(e) : -1; }();
@@ -351,8 +351,10 @@ HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch) {
     if (mode == 3) return HaloTile{8, 64, 2, 2};
     // fat wave tiles: 16 x 16 pixels x 256 / 128 channels, 2 x 4 waves of 128 pixels x 64 / 32 channels, a ring slot per tap
     // (maps of at least 64 x 64: on Wav2Lip's 24^2 / 48^2 layers at batch 128 they measured 2 % slower than the register-weights kernel)
+    // 512+ -> 256k-channel layers gain on small maps too once there are 256 patches x channel tiles (512 -> 512 @32^2: 464 -> 521 TF at
+    // batch 64, 459 -> 498 at 32; 374 -> 298 at 16, hence the workgroup floor)
     const bool big_map = H * W >= 64 * 64;
-    if (N % 256 == 0 && (mode == 5 || (big_map && wgs(16, 256) >= 256))) return HaloTile{16, 256, 2, 4};
+    if (N % 256 == 0 && (mode == 5 || ((big_map || cin >= 512) && wgs(16, 256) >= 256))) return HaloTile{16, 256, 2, 4};
     if (N % 128 == 0 && (mode == 5 || (big_map && wgs(16, 128) >= 256))) return HaloTile{16, 128, 2, 4};
     if (mode == 1) {
         if (wgs(16, 64) >= 256) return HaloTile{16, 64, 4, 2};
