@@ -329,9 +329,10 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
     a.n_patches = a.batch * a.patches_per_img;
     a.tiles_n = (a.N + t.bn - 1) / t.bn;
 #define MF_HCASE(PH, BN, WGM, WGN, TR) \
-    if (t.ph == PH && t.bn == BN) return halo_w_launch_prec<PH, BN, WGM, WGN, TR>(a, x3, s);
+    if (t.ph == PH && t.bn == BN && t.wgm == WGM) return halo_w_launch_prec<PH, BN, WGM, WGN, TR>(a, x3, s);
     MF_HCASE(16, 256, 2, 4, 1)     // wave tile 128 pixels x 64 channels (FM 8, FN 4): the implicit-GEMM 256x256 wave tile with the input read once
     MF_HCASE(16, 128, 2, 4, 1)     // 128 pixels x 32 channels
+    MF_HCASE(16, 128, 4, 2, 1)     // 64 pixels x 64 channels (A/B: MF_HALO_W128=42)
     MF_HCASE(16, 64, 4, 2, 3)
     MF_HCASE(8, 64, 2, 2, 3)
 #undef MF_HCASE
@@ -355,7 +356,8 @@ HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch, int cin) {
     // batch 64, 459 -> 498 at 32; 374 -> 298 at 16, hence the workgroup floor)
     const bool big_map = H * W >= 64 * 64;
     if (N % 256 == 0 && (mode == 5 || ((big_map || cin >= 512) && wgs(16, 256) >= 256))) return HaloTile{16, 256, 2, 4};
-    if (N % 128 == 0 && (mode == 5 || (big_map && wgs(16, 128) >= 256))) return HaloTile{16, 128, 2, 4};
+    static const bool w128_42 = [] { const char* e = getenv("MF_HALO_W128"); return !e || atoi(e) == 42; }();   // 4 x 2 waves (64 px x 64 ch each) measured 0-4 % ahead of 2 x 4 (128 px x 32 ch)
+    if (N % 128 == 0 && (mode == 5 || (big_map && wgs(16, 128) >= 256))) return w128_42 ? HaloTile{16, 128, 4, 2} : HaloTile{16, 128, 2, 4};
     if (mode == 1) {
         if (wgs(16, 64) >= 256) return HaloTile{16, 64, 4, 2};
         if (wgs(8, 64) >= 256) return HaloTile{8, 64, 2, 2};
