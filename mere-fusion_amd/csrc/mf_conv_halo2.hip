@@ -17,6 +17,11 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// timing-only ablation builds (tools/halo_ablate.sh): bit 0 = no epilogue stores / residual reads, bit 4 = no residual reads only
+#ifndef MF_HALO_ABLATE
+#define MF_HALO_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int PW = 16;   // patch width = one MFMA pixel fragment
@@ -250,6 +255,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
+    if (MF_HALO_ABLATE & 1) {
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keep == 1234.5f) a.y_hi[0] = 1;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
         const int oy = y0 + row0 + j, ox = x0 + fr;
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
             if (c >= a.N) continue;
             const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
             float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-            if (a.r_hi) {
+            if (a.r_hi && !(MF_HALO_ABLATE & 16)) {
                 const uint2 rh = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
                 v[0] += hbf2f(rh.x & 0xffffu); v[1] += hbf2f(rh.x >> 16);
                 v[2] += hbf2f(rh.y & 0xffffu); v[3] += hbf2f(rh.y >> 16);
