@@ -197,7 +197,7 @@ def pmc_traffic(kernel, workload, precision, batch_args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    want = "void" + kernel.replace(" ", "")[:-1] + ","          # "voidk_conv_igemm<256,256,2,4,true,32," + ring-depth parameter
+    want = "void" + kernel.replace(" ", "")[:-1]                # "voidk_conv_igemm<256,256,2,4,true,32" (+ ",<ring depth>>" or ">")
     vals = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="mf_pmc_")
@@ -210,7 +210,8 @@ def pmc_traffic(kernel, workload, precision, batch_args):
             tot, n = 0.0, 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r.get("Counter_Name") == ctr and r.get("Kernel_Name", "").replace(" ", "").startswith(want):
+                    kn = r.get("Kernel_Name", "").replace(" ", "")
+                    if r.get("Counter_Name") == ctr and kn.startswith(want) and kn[len(want):len(want) + 1] in (",", ">"):
                         tot += float(r["Counter_Value"]); n += 1
             if n == 0:
                 return None, f"no {ctr} rows for {kernel}"

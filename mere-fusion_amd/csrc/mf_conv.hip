@@ -1089,7 +1089,8 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         if (!tw.ph && p->alt) { mf_conv_kernel_name(p->alt, batch, buf, cap); return; }
         const HaloTile t = tw.ph ? tw : mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
-        snprintf(buf, cap, "k_conv3x3_halo%s<%d,%d,%d,%d,%s,2>", tw.ph ? "_w" : "", t.ph, t.bn, t.wgm, t.wgn, x3);
+        // last template argument: halo stages (register-weights kernel) / taps per weight-ring slot (LDS-weights kernel)
+        snprintf(buf, cap, "k_conv3x3_halo%s<%d,%d,%d,%d,%s,%d>", tw.ph ? "_w" : "", t.ph, t.bn, t.wgm, t.wgn, x3, tw.ph ? (t.bn >= 128 ? 1 : 3) : 2);
     } else {
         const ConvTile t = mf_conv_pick_tile(p, batch);
         const int bk = (p->precision == MF_PREC_BF16X3 && t.bm + t.bn > 128) ? 32 : 64;
