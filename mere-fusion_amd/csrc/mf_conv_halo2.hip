@@ -214,12 +214,29 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
                     whi[i] = *reinterpret_cast<const bf16x8*>(wb + (t3 * NP) * WT_BYTES + wlane[i][kk]);
                     if (X3) wlo[i] = *reinterpret_cast<const bf16x8*>(wb + (t3 * NP + 1) * WT_BYTES + wlane[i][kk]);
                 }
+                // pixel fragments one ahead of the MFMAs that use them (pinned above them: hipcc otherwise sinks the read to its first use) --
+                // only where registers allow: the 128 x 64 wave tile already sits at 256 VGPRs and would spill
+                constexpr bool PF = FN * FM <= 16;
+                bf16x8 n_hi, n_lo, c_hi, c_lo;
+                if (PF) {
+                    const char* p0 = base + lane_off[dx][kk] + dy * HW * ROWB;
+                    c_hi = *reinterpret_cast<const bf16x8*>(p0);
+                    if (X3) c_lo = *reinterpret_cast<const bf16x8*>(p0 + H_BYTES);
+                }
 #pragma unroll
                 for (int j = 0; j < FM; ++j) {
-                    const char* p = base + lane_off[dx][kk] + (j + dy) * HW * ROWB;
-                    const bf16x8 c_hi = *reinterpret_cast<const bf16x8*>(p);
-                    bf16x8 c_lo;
-                    if (X3) c_lo = *reinterpret_cast<const bf16x8*>(p + H_BYTES);
+                    if (PF) {
+                        if (j + 1 < FM) {
+                            const char* p = base + lane_off[dx][kk] + (j + 1 + dy) * HW * ROWB;
+                            n_hi = *reinterpret_cast<const bf16x8*>(p);
+                            if (X3) n_lo = *reinterpret_cast<const bf16x8*>(p + H_BYTES);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        const char* p = base + lane_off[dx][kk] + (j + dy) * HW * ROWB;
+                        c_hi = *reinterpret_cast<const bf16x8*>(p);
+                        if (X3) c_lo = *reinterpret_cast<const bf16x8*>(p + H_BYTES);
+                    }
                     if (X3) {
 #pragma unroll
                         for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[i], c_hi, acc[i][j], 0, 0, 0);
@@ -228,6 +245,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
                     }
 #pragma unroll
                     for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[i], c_hi, acc[i][j], 0, 0, 0);
+                    if (PF) { c_hi = n_hi; c_lo = n_lo; }
                 }
             }
         }
