@@ -88,7 +88,7 @@ HaloTile mf_halo_pick_tile(int H, int W, int N, int batch, int cin = 0);
 int mf_halo_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s);
 // second generation (mf_conv_halo2.hip): weights shared through an LDS ring; pick_tile returns ph == 0 to decline
 HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch, int cin = 0);
-int mf_halo_w_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s);
+int mf_halo_w_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s, int phase = -1);   // phase 0..3: one phase of upsample + 3x3
 
 struct ConvPlan {
     mf_conv2d_desc d{};
@@ -105,6 +105,8 @@ struct ConvPlan {
     float* bias = nullptr;
     int* goff = nullptr;
     bool halo = false;    // 3x3 s1 p1 on a >= 16x16 map: LDS halo-tile kernel, weights packed [slice][tap][Npad][CK]
+    bf16_t* up_hi = nullptr;  // nearest-2x-upsample + 3x3 layers that qualify for the fat halo tiles: [phase][slice][4 taps][Npad][CK], pre-summed taps
+    bf16_t* up_lo = nullptr;
     ConvPlan* alt = nullptr;  // wide halo layers (> 256 channels) only run on the LDS-weights kernel's fat tiles, which need a few hundred
                               // workgroups: this implicit-GEMM twin (own weight pack) takes the launches whose batch is too small
     int n_slices = 0;

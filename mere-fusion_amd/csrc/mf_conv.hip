@@ -785,6 +785,37 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     MF_HIP(hipMemcpy(p->bias, fbias.data(), p->Npad * sizeof(float), hipMemcpyHostToDevice));
     MF_HIP(hipMalloc(&p->goff, goff_total * sizeof(int)));
     p->bound_in_ld = p->bound_in_wp = -1;
+    // nearest-2x upsample + 3x3 with wide channels (the VAE's upsamplers): a second pack for the LDS-weights halo kernel's fat tiles, one
+    // 2 x 2-tap phase per launch (mf_conv_launch picks it when the input grid gives >= 256 workgroups).  Opt-in (MF_HALO_UP=1): correct
+    // (checked against torch on five shapes) but only 1-5 % ahead of the 4-phase implicit GEMM per layer and nothing in the net -- a halo image
+    // amortised over 4 taps instead of 9, four launches.
+    static const bool halo_up = [] { const char* e = getenv("MF_HALO_UP"); return e && atoi(e) != 0; }();
+    if (halo_up && d.upsample && p->nphase == 4 && d.cout % 128 == 0 && d.cin % 32 == 0 && d.cin <= 1024 && d.cout <= 1024 && d.act <= 2 &&
+        !d.residual && d.in_h >= 16 && d.in_w >= 16) {
+        p->n_slices = cdiv(d.cin, HCK);
+        const int64_t per_phase = (int64_t)p->n_slices * 4 * p->Npad * HCK, tot = 4 * per_phase;
+        std::vector<bf16_t> uh(tot, 0), ul(tot, 0);
+        for (int ph = 0; ph < 4; ++ph)
+            for (int ti = 0; ti < 4; ++ti) {
+                const auto& tp = p->phase_taps[ph][ti];      // dy = py + ty - 1, dx = px + tx - 1 with ti = 2 * ty + tx: the kernel's tap order
+                for (int n = 0; n < d.cout; ++n)
+                    for (int c = 0; c < d.cin; ++c) {
+                        double w = 0.0;
+                        for (const auto& kk : tp.src) w += weight[(((int64_t)n * d.cin + c) * 3 + kk.first) * 3 + kk.second];
+                        const float wf = (float)(w * (double)scale[n]);
+                        const int64_t idx = ph * per_phase + (((int64_t)(c / HCK) * 4 + ti) * p->Npad + n) * HCK + c % HCK;
+                        const bf16_t h = mf_f2bf(wf);
+                        uh[idx] = h;
+                        ul[idx] = mf_f2bf(wf - mf_bf2f(h));
+                    }
+            }
+        MF_HIP(hipMalloc(&p->up_hi, tot * sizeof(bf16_t)));
+        MF_HIP(hipMemcpy(p->up_hi, uh.data(), tot * sizeof(bf16_t), hipMemcpyHostToDevice));
+        if (precision == MF_PREC_BF16X3) {
+            MF_HIP(hipMalloc(&p->up_lo, tot * sizeof(bf16_t)));
+            MF_HIP(hipMemcpy(p->up_lo, ul.data(), tot * sizeof(bf16_t), hipMemcpyHostToDevice));
+        }
+    }
     return MF_OK;
 }
 
@@ -797,6 +828,9 @@ void mf_conv_plan_destroy(ConvPlan* p) {
     if (p->goff) (void)hipFree(p->goff);
     if (p->ws) (void)hipFree(p->ws);
     if (p->tile_cnt) (void)hipFree(p->tile_cnt);
+    if (p->up_hi) (void)hipFree(p->up_hi);
+    if (p->up_lo) (void)hipFree(p->up_lo);
+    p->up_hi = p->up_lo = nullptr;
     p->tile_cnt = nullptr; p->tile_cnt_cap = 0;
     p->w_hi = p->w_lo = nullptr; p->bias = nullptr; p->goff = nullptr; p->ws = nullptr; p->ws_cap = 0;
 }
@@ -875,6 +909,31 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
             return rc;
         }
         return mf_halo_launch(ha, mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin), x3, stream);
+    }
+
+    if (p->up_hi) {
+        // upsample + 3x3 on the fat halo tiles: four launches, phase (py, px) writes output pixels (2i + py, 2j + px)
+        const HaloTile tw = mf_halo_w_pick_tile(p->d.in_h, p->d.in_w, p->d.cout, batch, p->d.cin);
+        if (tw.ph == 16 && (tw.bn == 256 || (tw.bn == 128 && tw.wgm == 4))) {
+            MF_REQUIRE(ib.halo >= 1 && !res.buf, "conv: upsample halo path needs an input halo and no residual");
+            HaloArgs ha{};
+            ha.x_hi = ib.hi + in.coff; ha.x_lo = x3 ? ib.lo + in.coff : nullptr;
+            ha.bias = p->bias;
+            ha.batch = batch; ha.H = p->d.in_h; ha.W = p->d.in_w; ha.N = p->d.cout; ha.Npad = p->Npad; ha.n_slices = p->n_slices;
+            ha.in_halo = ib.halo; ha.in_hp = ib.Hp(); ha.in_wp = ib.Wp(); ha.x_ld = ib.C; ha.xb = ib.per_batch();
+            ha.yb = ob.per_batch(); ha.yi = 2 * ob.Wp() * ob.C; ha.yj = 2 * ob.C;
+            ha.act = p->d.act;
+            const int HCKl = x3 ? 32 : 64;
+            const int64_t per_phase = (int64_t)p->n_slices * 4 * p->Npad * HCKl;
+            for (int ph = 0; ph < 4; ++ph) {
+                const int64_t yb0 = ((int64_t)(ob.halo + (ph >> 1)) * ob.Wp() + ob.halo + (ph & 1)) * ob.C + out.coff;
+                ha.y_hi = ob.hi + yb0; ha.y_lo = x3 ? ob.lo + yb0 : nullptr;
+                ha.w_hi = p->up_hi + ph * per_phase; ha.w_lo = x3 ? p->up_lo + ph * per_phase : nullptr;
+                const int rc = mf_halo_w_launch(ha, tw, x3, stream, ph);
+                if (rc) return rc;
+            }
+            return MF_OK;
+        }
     }
 
     ConvArgs a{};
@@ -1091,6 +1150,10 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
         const HaloTile t = tw.ph ? tw : mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         // last template argument: halo stages (register-weights kernel) / taps per weight-ring slot (LDS-weights kernel)
         snprintf(buf, cap, "k_conv3x3_halo%s<%d,%d,%d,%d,%s,%d>", tw.ph ? "_w" : "", t.ph, t.bn, t.wgm, t.wgn, x3, tw.ph ? (t.bn >= 128 ? 1 : 3) : 2);
+    } else if (p->up_hi && [&] { const HaloTile tw = mf_halo_w_pick_tile(p->d.in_h, p->d.in_w, p->d.cout, batch, p->d.cin);
+                                 return tw.ph == 16 && (tw.bn == 256 || (tw.bn == 128 && tw.wgm == 4)); }()) {
+        const HaloTile tw = mf_halo_w_pick_tile(p->d.in_h, p->d.in_w, p->d.cout, batch, p->d.cin);
+        snprintf(buf, cap, "4 x k_conv3x3_halo_w<%d,%d,%d,%d,%s,1,phase>", tw.ph, tw.bn, tw.wgm, tw.wgn, x3);
     } else {
         const ConvTile t = mf_conv_pick_tile(p, batch);
         const int bk = (p->precision == MF_PREC_BF16X3 && t.bm + t.bn > 128) ? 32 : 64;

@@ -48,7 +48,10 @@ __device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
 }  // namespace
 
 // TR = taps per ring slot: 3 (one kernel row, a barrier per row) or 1 (a barrier per tap: the wide tiles, whose 3-tap slot would not fit)
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR>
+// PHASE = -1: the 3x3 convolution (9 taps).  PHASE = 2 * py + px in 0..3: one phase of `nearest 2x upsample -> 3x3 conv` (mf_conv.hip): a 2 x 2
+// convolution on the INPUT grid whose taps sit at halo rows py..py+1, columns px..px+1, writing output pixels (2i + py, 2j + px) -- the
+// launcher passes doubled output strides and the phase's weight block.
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1>
 __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const HaloArgs a) {
     constexpr int NW = WGM * WGN;                           // waves per workgroup
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -67,6 +70,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
     constexpr int WT_BYTES = BN * ROWB;                     // one tap's weight tile, one plane: [BN][CK] bf16
     constexpr int WCH = WT_BYTES / 1024;                    // its 1-KiB DMA chunks
     static_assert(TR == 1 || TR == 3, "ring slot = one tap or one kernel row");
+    constexpr int NT = PHASE < 0 ? 9 : 4;                   // taps per channel slice
+    static_assert(PHASE < 0 || TR == 1, "upsample phases use the one-tap ring");
     constexpr int WROW = TR * NP * WT_BYTES;                // one ring slot (TR taps, planes)
     constexpr int WRC = TR * NP * WCH;                      // DMA chunks per slot
     constexpr int NWR = (WRC + NW - 1) / NW;
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
 #pragma unroll
         for (int i = 0; i < NWR; ++i) {
             const int c = wave + NW * i;
-            if (WRC % NW == 0 || c < WRC) hglds16(wsrc[i] + (int64_t)(slice * 9 + trow * TR + wtap[i]) * w_tap, base + c * 1024);
+            if (WRC % NW == 0 || c < WRC) hglds16(wsrc[i] + (int64_t)(slice * NT + trow * TR + wtap[i]) * w_tap, base + c * 1024);
         }
     };
     // A fragment of (tap-in-row t3, channel block i, k-step kk, plane): rows cn0 + i*16 + fr, 16-byte slot kk*4 + fk
@@ -205,7 +210,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
         const char* wb = wring + buf * WROW;
 #pragma unroll
         for (int t3 = 0; t3 < TR; ++t3) {
-            const int tap = step * TR + t3, dy = tap / 3, dx = tap % 3;
+            const int tap = step * TR + t3;
+            const int dy = PHASE < 0 ? tap / 3 : (PHASE >> 1) + (tap >> 1), dx = PHASE < 0 ? tap % 3 : (PHASE & 1) + (tap & 1);
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 bf16x8 whi[FN], wlo[FN];
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
         const int st = slice & 1;
         if (more) load_halo(slice + 1, st ^ 1);            // flies under this slice's MFMAs
         if (a.res_from_halo) add_residual(st, slice);
-        constexpr int NSTEP = 9 / TR;
+        constexpr int NSTEP = NT / TR;
 #pragma unroll
         for (int step = 0; step < NSTEP; ++step) {
             // the next slot (of this slice, or slot 0 of the next) into the other ring buffer: everyone left it at the last barrier
@@ -328,10 +334,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR>
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1>
 int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR>;
+    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -345,15 +351,25 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     return MF_OK;
 }
 
-template <int PH, int BN, int WGM, int WGN, int TR>
+template <int PH, int BN, int WGM, int WGN, int TR, int PHASE = -1>
 int halo_w_launch_prec(const HaloArgs& a, bool x3, hipStream_t s) {
-    return x3 ? halo_w_launch_cfg<PH, BN, WGM, WGN, true, TR>(a, s) : halo_w_launch_cfg<PH, BN, WGM, WGN, false, TR>(a, s);
+    return x3 ? halo_w_launch_cfg<PH, BN, WGM, WGN, true, TR, PHASE>(a, s) : halo_w_launch_cfg<PH, BN, WGM, WGN, false, TR, PHASE>(a, s);
+}
+template <int PH, int BN, int WGM, int WGN>
+int halo_w_launch_phase(const HaloArgs& a, bool x3, int phase, hipStream_t s) {
+    switch (phase) {
+        case 0: return halo_w_launch_prec<PH, BN, WGM, WGN, 1, 0>(a, x3, s);
+        case 1: return halo_w_launch_prec<PH, BN, WGM, WGN, 1, 1>(a, x3, s);
+        case 2: return halo_w_launch_prec<PH, BN, WGM, WGN, 1, 2>(a, x3, s);
+        case 3: return halo_w_launch_prec<PH, BN, WGM, WGN, 1, 3>(a, x3, s);
+        default: return halo_w_launch_prec<PH, BN, WGM, WGN, 1, -1>(a, x3, s);
+    }
 }
 
 }  // namespace
 
 // Same contract as mf_halo_launch; `t` comes from mf_halo_w_pick_tile.
-int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t s) {
+int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t s, int phase) {
     HaloArgs a = a0;
     a.patches_x = (a.W + PW - 1) / PW;
     const int patches_y = (a.H + t.ph - 1) / t.ph;
@@ -362,9 +378,11 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
     a.tiles_n = (a.N + t.bn - 1) / t.bn;
 #define MF_HCASE(PH, BN, WGM, WGN, TR) \
     if (t.ph == PH && t.bn == BN && t.wgm == WGM) return halo_w_launch_prec<PH, BN, WGM, WGN, TR>(a, x3, s);
-    MF_HCASE(16, 256, 2, 4, 1)     // wave tile 128 pixels x 64 channels (FM 8, FN 4): the implicit-GEMM 256x256 wave tile with the input read once
-    MF_HCASE(16, 128, 2, 4, 1)     // 128 pixels x 32 channels
-    MF_HCASE(16, 128, 4, 2, 1)     // 64 pixels x 64 channels (A/B: MF_HALO_W128=42)
+    // the fat tiles, also as upsample phases (phase >= 0)
+    if (t.ph == 16 && t.bn == 256 && t.wgm == 2) return halo_w_launch_phase<16, 256, 2, 4>(a, x3, phase, s);   // wave tile 128 px x 64 ch (FM 8, FN 4)
+    if (t.ph == 16 && t.bn == 128 && t.wgm == 4) return halo_w_launch_phase<16, 128, 4, 2>(a, x3, phase, s);   // 64 px x 64 ch
+    if (phase >= 0) { mf_set_error("halo conv (LDS weights): upsample phases need a fat tile"); return MF_ERR_INVALID; }
+    MF_HCASE(16, 128, 2, 4, 1)     // 128 pixels x 32 channels (A/B: MF_HALO_W128=24)
     MF_HCASE(16, 64, 4, 2, 3)
     MF_HCASE(8, 64, 2, 2, 3)
 #undef MF_HCASE

@@ -26,6 +26,7 @@ ap.add_argument("--transposed", type=int, default=0)
 ap.add_argument("--outpad", type=int, default=0)
 ap.add_argument("--precision", default="bf16x3")
 ap.add_argument("--iters", type=int, default=50)
+ap.add_argument("--upsample", type=int, default=0, help="1: nearest 2x upsample in front of the conv")
 ap.add_argument("--check", type=int, default=0, help="1: compare with torch fp32 conv2d (+ReLU, residual) on the GPU")
 a = ap.parse_args()
 
@@ -37,7 +38,7 @@ w = torch.from_numpy((rng.standard_normal(shape) * np.sqrt(2.0 / (a.cin * a.k * 
 b = torch.zeros(a.cout)
 d = _lib.MfConv2dDesc(cin=a.cin, cout=a.cout, kh=a.k, kw=a.k, stride_h=a.stride, stride_w=a.stride, pad_h=a.pad,
                       pad_w=a.pad, transposed=a.transposed, output_padding=a.outpad, residual=a.residual, act=1,
-                      in_h=a.hw, in_w=a.hw)
+                      in_h=a.hw, in_w=a.hw, upsample=a.upsample)
 h = C.c_void_p()
 _lib.check(l.mf_conv2d_create(C.byref(d), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), None, None, None, None,
                               _lib.PRECISIONS[a.precision], C.byref(h)))
@@ -49,7 +50,8 @@ for _ in range(3):
     _lib.check(l.mf_conv2d_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), a.batch, None))
 torch.cuda.synchronize()
 if a.check and not a.transposed:
-    ref = torch.nn.functional.conv2d(x.double(), w.cuda().double(), b.cuda().double(), stride=a.stride, padding=a.pad)
+    xin = torch.nn.functional.interpolate(x.double(), scale_factor=2.0, mode="nearest") if a.upsample else x.double()
+    ref = torch.nn.functional.conv2d(xin, w.cuda().double(), b.cuda().double(), stride=a.stride, padding=a.pad)
     if a.residual:
         ref = ref + x.double()
     ref = torch.relu(ref).float()
@@ -62,7 +64,7 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 taps = a.k * a.k
-sites = a.hw * a.hw if a.transposed else oh.value * ow.value
+sites = a.hw * a.hw if a.transposed else oh.value * ow.value   # (upsample: counted at the output resolution, 9 taps)
 gf = 2.0 * a.batch * sites * a.cin * a.cout * taps / 1e9
 t = C.c_float()
 _lib.check(l.mf_conv2d_time(h, a.batch, a.iters, C.byref(t), None))
