@@ -1,0 +1,57 @@
+"""GPU parity of the wide 3x3 convolutions (the MuseTalk VAE decoder's shapes) through the C ABI's single-layer entry point
+(mf_conv2d_*): the LDS-weights halo kernel's fat tiles (mf_conv_halo2.hip: 16 x 16 pixels x 256 / 128 channels, picked once a layer has
+>= 256 workgroups on a >= 64 x 64 map), their implicit-GEMM twin for small batches, and the 4-phase upsample + 3x3, against a float64
+torch convolution of the same inputs.  Tolerance: 1e-3 of the output range for bf16x3 (observed ~7e-6), 3e-2 for bf16."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# (cin, cout, H, W, batch, residual `out += x`, upsample); sizes chosen so that both the fat tiles (first rows) and the fallback paths run,
+# with maps that are not multiples of the 16 x 16 patch
+CASES = [(128, 128, 96, 100, 8, 1, 0), (256, 256, 70, 90, 8, 0, 0), (512, 512, 64, 64, 8, 0, 0), (256, 128, 72, 88, 10, 0, 0),
+         (512, 256, 64, 64, 2, 0, 0), (384, 128, 33, 47, 3, 0, 0), (512, 512, 32, 32, 2, 0, 1), (256, 256, 40, 24, 3, 0, 1)]
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B,res,up", CASES)
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_wide_conv3x3_matches_fp64(lib_built, cin, cout, H, W, B, res, up, precision):
+    from mere_fusion_amd import _lib
+    if precision == "bf16" and B > 4:
+        pytest.skip("bf16 mode: the small cases cover it")
+    l = _lib.lib()
+    _lib.init_device(0)
+    g = torch.Generator().manual_seed(cin * 7 + H)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    d = _lib.MfConv2dDesc(cin=cin, cout=cout, kh=3, kw=3, stride_h=1, stride_w=1, pad_h=1, pad_w=1, transposed=0, output_padding=0,
+                          residual=res, act=1, in_h=H, in_w=W, upsample=up)
+    h = C.c_void_p()
+    _lib.check(l.mf_conv2d_create(C.byref(d), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), None, None, None, None,
+                                  _lib.PRECISIONS[precision], C.byref(h)))
+    try:
+        oh, ow = C.c_int(), C.c_int()
+        l.mf_conv2d_out_shape(h, C.byref(oh), C.byref(ow))
+        assert (oh.value, ow.value) == ((2 * H, 2 * W) if up else (H, W))
+        x = torch.randn(B, cin, H, W, generator=g).cuda()
+        y = torch.empty(B, cout, oh.value, ow.value, device="cuda")
+        _lib.check(l.mf_conv2d_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), B, None))
+        torch.cuda.synchronize()
+        xin = torch.nn.functional.interpolate(x.double(), scale_factor=2.0, mode="nearest") if up else x.double()
+        ref = torch.nn.functional.conv2d(xin, w.cuda().double(), b.cuda().double(), padding=1)
+        if res:
+            ref = ref + x.double()
+        ref = torch.relu(ref).float()
+        err = float((y - ref).abs().max() / ref.abs().max())
+        assert err <= (1e-3 if precision == "bf16x3" else 3e-2), err
+        # a second launch at a smaller batch takes the other path of a wide plan (twin implicit GEMM) and must agree too
+        nb = max(1, B // 4)
+        y2 = torch.empty(nb, cout, oh.value, ow.value, device="cuda")
+        _lib.check(l.mf_conv2d_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y2.data_ptr()), nb, None))
+        torch.cuda.synchronize()
+        err2 = float((y2 - ref[:nb]).abs().max() / ref.abs().max())
+        assert err2 <= (1e-3 if precision == "bf16x3" else 3e-2), err2
+    finally:
+        l.mf_conv2d_destroy(h)
