@@ -51,8 +51,10 @@ __device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
 // PHASE = -1: the 3x3 convolution (9 taps).  PHASE = 2 * py + px in 0..3: one phase of `nearest 2x upsample -> 3x3 conv` (mf_conv.hip): a 2 x 2
 // convolution on the INPUT grid whose taps sit at halo rows py..py+1, columns px..px+1, writing output pixels (2i + py, 2j + px) -- the
 // launcher passes doubled output strides and the phase's weight block.
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1>
-__global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const HaloArgs a) {
+// HS = halo images in LDS: 2 (the next slice's image lands under this slice's MFMAs) or 1 (half the LDS: two 4-wave workgroups per CU, each
+// other's DMA waits and epilogues hidden by the neighbour's MFMAs)
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2>
+__global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_halo_w(const HaloArgs a) {
     constexpr int NW = WGM * WGN;                           // waves per workgroup
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int CK = X3 ? 32 : 64;
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
     static_assert(WT_BYTES % 1024 == 0, "weight tile must be whole DMA chunks");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const wring = smem + 2 * STAGE;                   // 2 x WROW
+    static_assert(HS == 1 || HS == 2, "halo stages");
+    char* const wring = smem + HS * STAGE;                  // 2 x WROW
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -263,8 +266,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
     int wbuf = 0;
     for (int slice = 0; slice < a.n_slices; ++slice) {
         const bool more = slice + 1 < a.n_slices;
-        const int st = slice & 1;
-        if (more) load_halo(slice + 1, st ^ 1);            // flies under this slice's MFMAs
+        const int st = HS == 2 ? (slice & 1) : 0;
+        if (HS == 2 && more) load_halo(slice + 1, st ^ 1); // flies under this slice's MFMAs
         if (a.res_from_halo) add_residual(st, slice);
         constexpr int NSTEP = NT / TR;
 #pragma unroll
@@ -274,6 +277,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
             else if (more) load_wrow(slice + 1, 0, wbuf ^ 1);
             compute_row(st, step, wbuf);
             if (step < NSTEP - 1 || more) __syncthreads();   // next slot (and, at the last step, the next halo image) landed; this one is released
+            if (HS == 1 && step == NSTEP - 1 && more) {      // single image: reload it now that every wave is done with it
+                load_halo(slice + 1, 0);
+                __syncthreads();
+            }
             wbuf ^= 1;
         }
     }
@@ -334,10 +341,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 1) void k_conv3x3_halo_w(const Halo
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1>
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2>
 int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE>;
+    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE, HS>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -345,7 +352,7 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     }
     constexpr int CK = X3 ? 32 : 64, RPC = 1024 / (CK * 2), NP = X3 ? 2 : 1;
     constexpr int HCH = ((PH + 2) * (PW + 2) + RPC - 1) / RPC;
-    const size_t lds = (size_t)2 * NP * HCH * 1024 + (size_t)2 * TR * NP * BN * CK * 2;
+    const size_t lds = (size_t)HS * NP * HCH * 1024 + (size_t)2 * TR * NP * BN * CK * 2;
     hipLaunchKernelGGL(kern, dim3(a.n_patches * a.tiles_n), dim3(WGM * WGN * 64), lds, s, a);
     MF_HIP(hipGetLastError());
     return MF_OK;
@@ -382,6 +389,9 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
     if (t.ph == 16 && t.bn == 256 && t.wgm == 2) return halo_w_launch_phase<16, 256, 2, 4>(a, x3, phase, s);   // wave tile 128 px x 64 ch (FM 8, FN 4)
     if (t.ph == 16 && t.bn == 128 && t.wgm == 4) return halo_w_launch_phase<16, 128, 4, 2>(a, x3, phase, s);   // 64 px x 64 ch
     if (phase >= 0) { mf_set_error("halo conv (LDS weights): upsample phases need a fat tile"); return MF_ERR_INVALID; }
+    // two 4-wave workgroups per CU (single halo image): wave tile 128 px x 64 ch like the 256-channel tile
+    if (t.ph == 16 && t.bn == 128 && t.wgm == 2 && t.wgn == 2)
+        return x3 ? halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 1>(a, s) : halo_w_launch_cfg<16, 128, 2, 2, false, 1, -1, 1>(a, s);
     MF_HCASE(16, 128, 2, 4, 1)     // 128 pixels x 32 channels (A/B: MF_HALO_W128=24)
     MF_HCASE(16, 64, 4, 2, 3)
     MF_HCASE(8, 64, 2, 2, 3)
@@ -405,8 +415,14 @@ HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch, int cin) {
     // 512+ -> 256k-channel layers gain on small maps too once there are 256 patches x channel tiles (512 -> 512 @32^2: 464 -> 521 TF at
     // batch 64, 459 -> 498 at 32; 374 -> 298 at 16, hence the workgroup floor)
     const bool big_map = H * W >= 64 * 64;
-    if (N % 256 == 0 && (mode == 5 || ((big_map || cin >= 512) && wgs(16, 256) >= 256))) return HaloTile{16, 256, 2, 4};
-    static const bool w128_42 = [] { const char* e = getenv("MF_HALO_W128"); return !e || atoi(e) == 42; }();   // 4 x 2 waves (64 px x 64 ch each) measured 0-4 % ahead of 2 x 4 (128 px x 32 ch)
+    static const bool no256 = [] { const char* e = getenv("MF_HALO_W256"); return e && atoi(e) == 0; }();   // A/B: every wide layer on the 128-channel tile
+    if (!no256 && N % 256 == 0 && (mode == 5 || ((big_map || cin >= 512) && wgs(16, 256) >= 256))) return HaloTile{16, 256, 2, 4};
+    // 128-channel tile: two 4-wave workgroups per CU on one halo image each (wave 128 px x 64 ch) wherever that still gives every CU its
+    // pair -- each other's DMA waits and epilogues are hidden: 128 -> 128 @256^2 401 -> 373 us, VAE 128-channel convs 2.83 -> 2.62 ms;
+    // MF_HALO_W128=42 / 24 select the 8-wave arrangements
+    static const int w128 = [] { const char* e = getenv("MF_HALO_W128"); return e ? atoi(e) : 22; }();
+    if (w128 == 22 && N % 128 == 0 && (mode == 5 || (big_map && wgs(16, 128) >= 512))) return HaloTile{16, 128, 2, 2};
+    const bool w128_42 = w128 != 24;   // 4 x 2 waves (64 px x 64 ch each) measured 0-4 % ahead of 2 x 4 (128 px x 32 ch)
     if (N % 128 == 0 && (mode == 5 || (big_map && wgs(16, 128) >= 256))) return w128_42 ? HaloTile{16, 128, 4, 2} : HaloTile{16, 128, 2, 4};
     if (mode == 1) {
         if (wgs(16, 64) >= 256) return HaloTile{16, 64, 4, 2};
