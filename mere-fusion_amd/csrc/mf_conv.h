@@ -82,6 +82,8 @@ struct HaloArgs {
     int act;
     int res_from_halo;                          // residual == the layer input: taken from the LDS halo image
     int patches_x, patches_per_img, n_patches, tiles_n;   // filled by mf_halo_launch
+    // LDS-weights kernel only: channel slices split over blockIdx.y, fp32 partial tiles [split][B][H][W][N] combined by k_splitk_epilogue
+    float* ws; int64_t ws_split; int nsplit;
 };
 struct HaloTile { int ph, bn, wgm, wgn; };
 HaloTile mf_halo_pick_tile(int H, int W, int N, int batch, int cin = 0);

@@ -902,6 +902,44 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         ha.act = p->d.act;
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         if (tw.ph) return mf_halo_w_launch(ha, tw, x3, stream);
+        // Wide layer on a map too small to give every CU a 16 x 16 patch (the VAE's 512-channel 32 x 32 levels at batch 8: 64 patches x
+        // channel tiles): the 256-channel tile with the channel slices split over blockIdx.y, fp32 partials combined by
+        // k_splitk_epilogue -- the same two-pass scheme as the implicit GEMM's split-K, with half its L2 -> LDS bytes.  MF_HALO_SPLIT=0: off.
+        static const bool halo_split = [] { const char* e = getenv("MF_HALO_SPLIT"); return !e || atoi(e) != 0; }();
+        if (halo_split && p->alt && p->d.cout % 256 == 0 && p->d.cin >= 512) {
+            const int base = batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * (p->d.cout / 256);
+            int ns = 0;
+            for (int cand : {2, 4, 8})
+                if (!ns && base * cand >= 256 && p->n_slices / cand >= 2) ns = cand;
+            if (ns && base >= 64) {      // (at 32 patches x tiles the split measured +5 % / -2 % on two shapes: not worth the second pass)
+                const int64_t per_split = (int64_t)batch * p->out_h * p->out_w * p->d.cout;
+                const int64_t need = per_split * ns;
+                if (need > p->ws_cap) {
+                    // only reached on an eager (un-captured) launch: the first forward at a batch size runs eagerly
+                    if (p->ws) { MF_HIP(hipStreamSynchronize(stream)); MF_HIP(hipFree(p->ws)); p->ws = nullptr; p->ws_cap = 0; }
+                    MF_HIP(hipMalloc(&p->ws, need * sizeof(float)));
+                    p->ws_cap = need;
+                }
+                HaloArgs hs = ha;
+                hs.ws = p->ws; hs.ws_split = per_split; hs.nsplit = ns;
+                hs.res_from_halo = 0;
+                int rc = mf_halo_w_launch(hs, HaloTile{16, 256, 2, 4}, x3, stream);
+                if (rc) return rc;
+                ConvArgs e{};
+                e.ws = p->ws; e.ws_split = per_split; e.bias = p->bias; e.N = p->d.cout; e.act = p->d.act;
+                e.y_hi = ha.y_hi; e.y_lo = ha.y_lo; e.yb = ha.yb; e.yi = ha.yi; e.yj = ha.yj;
+                if (res.buf) {
+                    const ActBuf& rb = *res.buf;
+                    const int64_t rb0 = ((int64_t)rb.halo * rb.Wp() + rb.halo) * rb.C + res.coff;
+                    e.r_hi = rb.hi + rb0; e.r_lo = x3 ? rb.lo + rb0 : nullptr;
+                    e.rb = rb.per_batch(); e.ri = rb.Wp() * rb.C; e.rj = rb.C;
+                }
+                const int64_t total = (int64_t)batch * p->out_h * p->out_w * (p->d.cout / 4);
+                hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e, ns, p->out_h, p->out_w, total);
+                MF_HIP(hipGetLastError());
+                return MF_OK;
+            }
+        }
         if (p->alt) {                          // wide layer, too few patches for the fat tiles at this batch: implicit GEMM
             p->alt->prof_mid = p->prof_mid;
             const int rc = mf_conv_launch(p->alt, in, out, res, batch, stream);

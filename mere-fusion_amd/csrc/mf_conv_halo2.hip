@@ -260,13 +260,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         }
     };
 
-    load_halo(0, 0);
-    load_wrow(0, 0, 0);
+    // channel slices of this workgroup: all of them, or the blockIdx.y-th share when the layer is split for lack of patches
+    const int s_begin = a.nsplit > 1 ? (int)((int64_t)a.n_slices * blockIdx.y / a.nsplit) : 0;
+    const int s_end = a.nsplit > 1 ? (int)((int64_t)a.n_slices * (blockIdx.y + 1) / a.nsplit) : a.n_slices;
+    load_halo(s_begin, 0);
+    load_wrow(s_begin, 0, 0);
     __syncthreads();                           // drains the DMA (vmcnt) and publishes halo stage 0 + weight row 0
     int wbuf = 0;
-    for (int slice = 0; slice < a.n_slices; ++slice) {
-        const bool more = slice + 1 < a.n_slices;
-        const int st = HS == 2 ? (slice & 1) : 0;
+    for (int slice = s_begin; slice < s_end; ++slice) {
+        const bool more = slice + 1 < s_end;
+        const int st = HS == 2 ? ((slice - s_begin) & 1) : 0;
         if (HS == 2 && more) load_halo(slice + 1, st ^ 1); // flies under this slice's MFMAs
         if (a.res_from_halo) add_residual(st, slice);
         constexpr int NSTEP = NT / TR;
@@ -293,6 +296,23 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
 #pragma unroll
             for (int j = 0; j < FM; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (keep == 1234.5f) a.y_hi[0] = 1;
+        return;
+    }
+    if (a.ws) {
+        // split over channel slices: fp32 partial tile [split][B][H][W][N]; bias, residual, activation and the (hi, lo) store happen in
+        // k_splitk_epilogue (mf_conv.hip)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int oy = y0 + row0 + j, ox = x0 + fr;
+            if (oy >= a.H || ox >= a.W) continue;
+            float* wo = a.ws + (int64_t)blockIdx.y * a.ws_split + (((int64_t)b * a.H + oy) * a.W + ox) * a.N;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int c = n0 + cn0 + i * 16 + fk * 4;
+                if (c >= a.N) continue;
+                *reinterpret_cast<float4*>(wo + c) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
         return;
     }
 #pragma unroll
@@ -353,7 +373,7 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     constexpr int CK = X3 ? 32 : 64, RPC = 1024 / (CK * 2), NP = X3 ? 2 : 1;
     constexpr int HCH = ((PH + 2) * (PW + 2) + RPC - 1) / RPC;
     const size_t lds = (size_t)HS * NP * HCH * 1024 + (size_t)2 * TR * NP * BN * CK * 2;
-    hipLaunchKernelGGL(kern, dim3(a.n_patches * a.tiles_n), dim3(WGM * WGN * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.n_patches * a.tiles_n, a.nsplit > 1 ? a.nsplit : 1), dim3(WGM * WGN * 64), lds, s, a);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
