@@ -866,6 +866,17 @@ int mf_conv_bind(ConvPlan* p, const ActBuf& in) {
     return MF_OK;
 }
 
+// Channel-slice split of the fat 256-channel halo tile for a wide layer whose map gives too few patches at this batch (0 = no split).
+static int mf_halo_split_count(const ConvPlan* p, int batch) {
+    static const bool halo_split = [] { const char* e = getenv("MF_HALO_SPLIT"); return !e || atoi(e) != 0; }();
+    if (!halo_split || !p->halo || !p->alt || p->d.cout % 256 || p->d.cin < 512) return 0;
+    const int base = batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * (p->d.cout / 256);
+    if (base < 64) return 0;          // (at 32 patches x tiles the split measured +5 % / -2 % on two shapes: not worth the second pass)
+    for (int cand : {2, 4, 8})
+        if (base * cand >= 256 && p->n_slices / cand >= 2) return cand;
+    return 0;
+}
+
 int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
                    int batch, hipStream_t stream) {
     const ActBuf& ib = *in.buf;
@@ -905,13 +916,9 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         // Wide layer on a map too small to give every CU a 16 x 16 patch (the VAE's 512-channel 32 x 32 levels at batch 8: 64 patches x
         // channel tiles): the 256-channel tile with the channel slices split over blockIdx.y, fp32 partials combined by
         // k_splitk_epilogue -- the same two-pass scheme as the implicit GEMM's split-K, with half its L2 -> LDS bytes.  MF_HALO_SPLIT=0: off.
-        static const bool halo_split = [] { const char* e = getenv("MF_HALO_SPLIT"); return !e || atoi(e) != 0; }();
-        if (halo_split && p->alt && p->d.cout % 256 == 0 && p->d.cin >= 512) {
-            const int base = batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * (p->d.cout / 256);
-            int ns = 0;
-            for (int cand : {2, 4, 8})
-                if (!ns && base * cand >= 256 && p->n_slices / cand >= 2) ns = cand;
-            if (ns && base >= 64) {      // (at 32 patches x tiles the split measured +5 % / -2 % on two shapes: not worth the second pass)
+        {
+            const int ns = mf_halo_split_count(p, batch);
+            if (ns) {
                 const int64_t per_split = (int64_t)batch * p->out_h * p->out_w * p->d.cout;
                 const int64_t need = per_split * ns;
                 if (need > p->ws_cap) {
@@ -1184,6 +1191,10 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision == MF_PREC_BF16X3 ? "true" : "false";
     if (p->halo) {
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
+        if (!tw.ph && mf_halo_split_count(p, batch)) {
+            snprintf(buf, cap, "k_conv3x3_halo_w<16,256,2,4,%s,1> split %d", x3, mf_halo_split_count(p, batch));
+            return;
+        }
         if (!tw.ph && p->alt) { mf_conv_kernel_name(p->alt, batch, buf, cap); return; }
         const HaloTile t = tw.ph ? tw : mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         // last template argument: halo stages (register-weights kernel) / taps per weight-ring slot (LDS-weights kernel)
