@@ -434,7 +434,8 @@ HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch, int cin) {
     // (maps of at least 64 x 64: on Wav2Lip's 24^2 / 48^2 layers at batch 128 they measured 2 % slower than the register-weights kernel)
     // 512+ -> 256k-channel layers gain on small maps too once there are 256 patches x channel tiles (512 -> 512 @32^2: 464 -> 521 TF at
     // batch 64, 459 -> 498 at 32; 374 -> 298 at 16, hence the workgroup floor)
-    const bool big_map = H * W >= 64 * 64;
+    static const int big_px = [] { const char* e = getenv("MF_HALO_BIGMAP"); return e ? atoi(e) : 64 * 64; }();   // A/B: map-size floor of the fat tiles
+    const bool big_map = H * W >= big_px;
     static const bool no256 = [] { const char* e = getenv("MF_HALO_W256"); return e && atoi(e) == 0; }();   // A/B: every wide layer on the 128-channel tile
     if (!no256 && N % 256 == 0 && (mode == 5 || ((big_map || cin >= 512) && wgs(16, 256) >= 256))) return HaloTile{16, 256, 2, 4};
     // 128-channel tile: two 4-wave workgroups per CU on one halo image each (wave 128 px x 64 ch) wherever that still gives every CU its
