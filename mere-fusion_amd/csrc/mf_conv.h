@@ -84,13 +84,20 @@ struct HaloArgs {
     int patches_x, patches_per_img, n_patches, tiles_n;   // filled by mf_halo_launch
     // LDS-weights kernel only: channel slices split over blockIdx.y, fp32 partial tiles [split][B][H][W][N] combined by k_splitk_epilogue
     float* ws; int64_t ws_split; int nsplit;
+    // LDS-weights kernel only: GroupNorm + SiLU of the INPUT applied to the halo image in LDS, v = silu(x * gn_scale[b][c] + gn_shift[b][c]); null = none
+    const float* gn_scale; const float* gn_shift; int gn_C;
 };
 struct HaloTile { int ph, bn, wgm, wgn; };
 HaloTile mf_halo_pick_tile(int H, int W, int N, int batch, int cin = 0);
 int mf_halo_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s);
 // second generation (mf_conv_halo2.hip): weights shared through an LDS ring; pick_tile returns ph == 0 to decline
 HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch, int cin = 0);
-int mf_halo_w_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s, int phase = -1);   // phase 0..3: one phase of upsample + 3x3
+int mf_halo_w_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s, int phase = -1);
+// mf_conv_launch with GroupNorm + SiLU of the input folded in (scale / shift [batch][cin] from mf_groupnorm_affine); only valid when
+// mf_conv_can_fuse_gn(p, batch) (a plain 3x3 layer that runs on the LDS-weights halo kernel's fat tiles at this batch)
+bool mf_conv_can_fuse_gn(const struct ConvPlan* p, int batch);
+int mf_conv_launch_gn(struct ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, const float* gn_scale,
+                      const float* gn_shift, hipStream_t stream);   // phase 0..3: one phase of upsample + 3x3
 
 struct ConvPlan {
     mf_conv2d_desc d{};

@@ -877,6 +877,25 @@ static int mf_halo_split_count(const ConvPlan* p, int batch) {
     return 0;
 }
 
+namespace { thread_local const float* g_gn_scale = nullptr; thread_local const float* g_gn_shift = nullptr; }
+
+bool mf_conv_can_fuse_gn(const ConvPlan* p, int batch) {
+    static const bool on = [] { const char* e = getenv("MF_GN_FUSE"); return e && atoi(e) != 0; }();
+    if (!on || !p->halo || p->up_hi) return false;
+    const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
+    return tw.ph == 16 && (tw.bn == 256 || tw.bn == 128) && !(tw.bn == 128 && tw.wgm == 2 && tw.wgn == 4);
+}
+
+int mf_conv_launch_gn(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, const float* gn_scale, const float* gn_shift,
+                      hipStream_t stream) {
+    MF_REQUIRE(mf_conv_can_fuse_gn(p, batch) && gn_scale && gn_shift, "conv: GroupNorm fusion not available for this layer / batch");
+    MF_REQUIRE(!(res.buf == in.buf && res.coff == in.coff), "conv: GroupNorm fusion with the input as residual is not supported");
+    g_gn_scale = gn_scale; g_gn_shift = gn_shift;
+    const int rc = mf_conv_launch(p, in, out, res, batch, stream);
+    g_gn_scale = g_gn_shift = nullptr;
+    return rc;
+}
+
 int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
                    int batch, hipStream_t stream) {
     const ActBuf& ib = *in.buf;
@@ -912,7 +931,9 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         }
         ha.act = p->d.act;
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
+        ha.gn_scale = g_gn_scale; ha.gn_shift = g_gn_shift; ha.gn_C = p->d.cin;
         if (tw.ph) return mf_halo_w_launch(ha, tw, x3, stream);
+        MF_REQUIRE(!g_gn_scale, "conv: GroupNorm fusion requested but the fat halo tile was not picked");
         // Wide layer on a map too small to give every CU a 16 x 16 patch (the VAE's 512-channel 32 x 32 levels at batch 8: 64 patches x
         // channel tiles): the 256-channel tile with the channel slices split over blockIdx.y, fp32 partials combined by
         // k_splitk_epilogue -- the same two-pass scheme as the implicit GEMM's split-K, with half its L2 -> LDS bytes.  MF_HALO_SPLIT=0: off.

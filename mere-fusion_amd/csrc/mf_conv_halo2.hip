@@ -53,7 +53,8 @@ __device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
 // launcher passes doubled output strides and the phase's weight block.
 // HS = halo images in LDS: 2 (the next slice's image lands under this slice's MFMAs) or 1 (half the LDS: two 4-wave workgroups per CU, each
 // other's DMA waits and epilogues hidden by the neighbour's MFMAs)
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2>
+// GN: GroupNorm + SiLU of the input folded in (a separate instantiation: its extra live registers must not touch the plain kernel)
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false>
 __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_halo_w(const HaloArgs a) {
     constexpr int NW = WGM * WGN;                           // waves per workgroup
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -260,6 +261,41 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         }
     };
 
+    // GroupNorm + SiLU of the input, folded in: once a halo image has landed, every 16-byte slot of it (8 channels of one pixel, hi and lo
+    // planes) is rewritten in place as silu(x * scale[b][c] + shift[b][c]).  Pixels outside the image stay zero: the convolution pads the
+    // NORMALISED tensor.  ~3 slots per thread and slice, against ~27 k MFMA cycles per slice.
+    auto gn_transform = [&](int slice, int stage) __attribute__((always_inline)) {
+        char* base = smem + stage * STAGE;
+        for (int q = tid; q < HROWS * KG; q += NW * 64) {
+            const int r = q / KG, slot = q - r * KG;
+            const int hy = r / HW, hx = r - hy * HW;
+            const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+            if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.W) continue;
+            const int kg = slot ^ hswz<CK>(hx);                                  // logical channel group held by this slot
+            const int c0 = slice * CK + kg * 8;
+            if (c0 >= a.gn_C) continue;
+            const float* sc = a.gn_scale + (int64_t)b * a.gn_C + c0;
+            const float* sh = a.gn_shift + (int64_t)b * a.gn_C + c0;
+            const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
+            const float4 t0 = *reinterpret_cast<const float4*>(sh), t1 = *reinterpret_cast<const float4*>(sh + 4);
+            const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, shv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            char* ph = base + r * ROWB + (slot << 4);
+            uint4 vh = *reinterpret_cast<uint4*>(ph);
+            uint4 vl = X3 ? *reinterpret_cast<uint4*>(ph + H_BYTES) : make_uint4(0, 0, 0, 0);
+            uint32_t hh[4] = {vh.x, vh.y, vh.z, vh.w}, ll[4] = {vl.x, vl.y, vl.z, vl.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v0 = hbf2f(hh[e] & 0xffffu) + hbf2f(ll[e] & 0xffffu), v1 = hbf2f(hh[e] >> 16) + hbf2f(ll[e] >> 16);
+                v0 = v0 * scv[2 * e] + shv[2 * e]; v1 = v1 * scv[2 * e + 1] + shv[2 * e + 1];
+                v0 = v0 / (1.f + __expf(-v0)); v1 = v1 / (1.f + __expf(-v1));
+                const uint32_t h0 = hf2bf(v0), h1 = hf2bf(v1);
+                hh[e] = h0 | (h1 << 16);
+                ll[e] = hf2bf(v0 - hbf2f(h0)) | (hf2bf(v1 - hbf2f(h1)) << 16);
+            }
+            *reinterpret_cast<uint4*>(ph) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+            if (X3) *reinterpret_cast<uint4*>(ph + H_BYTES) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+        }
+    };
     // channel slices of this workgroup: all of them, or the blockIdx.y-th share when the layer is split for lack of patches
     const int s_begin = a.nsplit > 1 ? (int)((int64_t)a.n_slices * blockIdx.y / a.nsplit) : 0;
     const int s_end = a.nsplit > 1 ? (int)((int64_t)a.n_slices * (blockIdx.y + 1) / a.nsplit) : a.n_slices;
@@ -271,6 +307,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         const bool more = slice + 1 < s_end;
         const int st = HS == 2 ? ((slice - s_begin) & 1) : 0;
         if (HS == 2 && more) load_halo(slice + 1, st ^ 1); // flies under this slice's MFMAs
+        if (GN) {
+            gn_transform(slice, st);
+            __syncthreads();
+        }
         if (a.res_from_halo) add_residual(st, slice);
         constexpr int NSTEP = NT / TR;
 #pragma unroll
@@ -361,10 +401,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2>
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false>
 int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE, HS>;
+    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE, HS, GN>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -405,6 +445,18 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
     a.tiles_n = (a.N + t.bn - 1) / t.bn;
 #define MF_HCASE(PH, BN, WGM, WGN, TR) \
     if (t.ph == PH && t.bn == BN && t.wgm == WGM) return halo_w_launch_prec<PH, BN, WGM, WGN, TR>(a, x3, s);
+    if (a.gn_scale) {
+        // GroupNorm folded in: the three fat tiles, plain 3x3 only
+        if (phase >= 0 || a.nsplit > 1) { mf_set_error("halo conv (LDS weights): GroupNorm fusion is for plain, unsplit 3x3 layers"); return MF_ERR_INVALID; }
+        if (t.ph == 16 && t.bn == 256 && t.wgm == 2)
+            return x3 ? halo_w_launch_cfg<16, 256, 2, 4, true, 1, -1, 2, true>(a, s) : halo_w_launch_cfg<16, 256, 2, 4, false, 1, -1, 2, true>(a, s);
+        if (t.ph == 16 && t.bn == 128 && t.wgm == 2 && t.wgn == 2)
+            return x3 ? halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 1, true>(a, s) : halo_w_launch_cfg<16, 128, 2, 2, false, 1, -1, 1, true>(a, s);
+        if (t.ph == 16 && t.bn == 128 && t.wgm == 4)
+            return x3 ? halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, true>(a, s) : halo_w_launch_cfg<16, 128, 4, 2, false, 1, -1, 2, true>(a, s);
+        mf_set_error("halo conv (LDS weights): GroupNorm fusion needs a fat tile");
+        return MF_ERR_INVALID;
+    }
     // the fat tiles, also as upsample phases (phase >= 0)
     if (t.ph == 16 && t.bn == 256 && t.wgm == 2) return halo_w_launch_phase<16, 256, 2, 4>(a, x3, phase, s);   // wave tile 128 px x 64 ch (FM 8, FN 4)
     if (t.ph == 16 && t.bn == 128 && t.wgm == 4) return halo_w_launch_phase<16, 128, 4, 2>(a, x3, phase, s);   // 64 px x 64 ch

@@ -103,7 +103,8 @@ struct Net {
     // Conv2d / Linear `name` (k x k, stride, pad), optional SiLU etc., optional residual view, optional
     // nearest-2x upsample in front, optional per-channel constant added to the bias, optional input scale.
     int conv(const std::string& name, ActView in, ActView out, int cin, int cout, int k, int stride, int pad, int act,
-             ActView res, int upsample = 0, const std::vector<float>* extra_bias = nullptr, float w_scale = 1.f, bool bias = true) {
+             ActView res, int upsample = 0, const std::vector<float>* extra_bias = nullptr, float w_scale = 1.f, bool bias = true,
+             ConvPlan** plan_out = nullptr) {
         const float* w = T(name + ".weight", (int64_t)cin * cout * k * k);
         const float* b = bias ? T(name + ".bias", cout) : nullptr;
         if (!w || (bias && !b)) return MF_ERR_INVALID;
@@ -138,9 +139,51 @@ struct Net {
         int rc = mf_conv_plan_create(p, d, w, bb.data(), nullptr, nullptr, nullptr, nullptr, precision);
         if (rc) return rc;
         if ((rc = mf_conv_bind(p, *in.buf))) return rc;
+        if (plan_out) { *plan_out = p; return MF_OK; }     // the caller pushes its own op around this plan (gn_conv)
         char kn[96];
         mf_conv_kernel_name(p, cap, kn, sizeof(kn));
         push(name, kn, mf_conv_flops(p, 1), [p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
+        return MF_OK;
+    }
+    // GroupNorm(+SiLU) `gname` of x followed by the 3x3 conv `cname`.  Where the conv runs on the LDS-weights halo kernel's fat tiles at the
+    // launch's batch (mf_conv_can_fuse_gn) the normalisation is applied to the conv's halo image in LDS -- statistics + a [B][C] affine, no
+    // apply pass, `t` untouched; otherwise GroupNorm writes `t` and the conv reads it, as two launches in one op.  Opt-in (MF_GN_FUSE=1): frames
+    // agree to 1 uint8 level, per-op time of (GroupNorm + conv) drops 3-5 %, but the replayed step does not move (23.9 -> 23.6 ms in one run,
+    // 339 -> 336 frames/s in another): the in-LDS transform costs the conv about what the apply pass cost the memory system.
+    int gn_conv(const std::string& gname, const std::string& cname, ActView x, ActBuf* t, ActView out, int cin, int cout, int groups, float eps,
+                ActView res, const std::vector<float>* extra_bias = nullptr) {
+        const ActView tv{t, 0, cin};
+        const bool same_geom = x.coff == 0 && x.buf->C == t->C && x.buf->halo == t->halo && x.buf->H == t->H && x.buf->W == t->W && x.C == cin;
+        static const bool on = [] { const char* e = getenv("MF_GN_FUSE"); return e && atoi(e) != 0; }();
+        if (!on || !same_geom) {
+            int rc = gn(gname, x, tv, groups, eps, true);
+            return rc ? rc : conv(cname, tv, out, cin, cout, 3, 1, 1, 0, res, 0, extra_bias);
+        }
+        const float* g = T(gname + ".weight", cin);
+        const float* b = T(gname + ".bias", cin);
+        if (!g || !b) return MF_ERR_INVALID;
+        float* dg = upload(g, cin);
+        float* db = upload(b, cin);
+        if (!dg || !db) return MF_ERR_HIP;
+        if (gn_count >= GN_MAX_OPS) { err = "more GroupNorm layers than GN_MAX_OPS"; return MF_ERR_INVALID; }
+        double* st = gn_stats + (size_t)(gn_count++) * gn_slice;
+        float* aff = nullptr;
+        if (hipMalloc(&aff, (size_t)2 * cap * cin * sizeof(float)) != hipSuccess) { err = "hipMalloc failed for a GroupNorm affine"; return MF_ERR_HIP; }
+        dev.push_back(aff);
+        float *scale = aff, *shift = aff + (size_t)cap * cin;
+        ConvPlan* p = nullptr;
+        int rc = conv(cname, tv, out, cin, cout, 3, 1, 1, 0, res, 0, extra_bias, 1.f, true, &p);
+        if (rc) return rc;
+        char kn[96];
+        mf_conv_kernel_name(p, cap, kn, sizeof(kn));
+        push(cname + " (+" + gname.substr(gname.rfind('.') + 1) + ")", std::string("gn+") + kn, mf_conv_flops(p, 1), [=](int B, hipStream_t s) {
+            if (mf_conv_can_fuse_gn(p, B)) {
+                const int r1 = mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s);
+                return r1 ? r1 : mf_conv_launch_gn(p, x, out, res, B, scale, shift, s);
+            }
+            const int r1 = mf_groupnorm(x, tv, dg, db, groups, eps, true, st, B, s);
+            return r1 ? r1 : mf_conv_launch(p, tv, out, res, B, s);
+        });
         return MF_OK;
     }
     int gn(const std::string& name, ActView in, ActView out, int groups, float eps, bool silu) {
@@ -236,7 +279,6 @@ struct Net {
         ActBuf *t1 = tmp("rn.t1", cin, H, W, 1), *c1 = tmp("rn.c1", cout, H, W, 1), *t2 = tmp("rn.t2", cout, H, W, 1);
         if (!t1 || !c1 || !t2) return MF_ERR_HIP;
         int rc;
-        if ((rc = gn(p + ".norm1", x, ActView{t1, 0, cin}, groups, eps, true))) return rc;
         std::vector<float> tb;
         if (temb_act && has(p + ".time_emb_proj.weight")) {
             const int td = (int)temb_act->size();
@@ -250,8 +292,7 @@ struct Net {
                 tb[o] = (float)a;
             }
         }
-        if ((rc = conv(p + ".conv1", ActView{t1, 0, cin}, ActView{c1, 0, cout}, cin, cout, 3, 1, 1, 0, ActView{}, 0, tb.empty() ? nullptr : &tb))) return rc;
-        if ((rc = gn(p + ".norm2", ActView{c1, 0, cout}, ActView{t2, 0, cout}, groups, eps, true))) return rc;
+        if ((rc = gn_conv(p + ".norm1", p + ".conv1", x, t1, ActView{c1, 0, cout}, cin, cout, groups, eps, ActView{}, tb.empty() ? nullptr : &tb))) return rc;
         ActView res = x;
         if (has(p + ".conv_shortcut.weight")) {
             ActBuf* sc = tmp("rn.sc", cout, H, W, 1);
@@ -262,7 +303,7 @@ struct Net {
             err = p + ": cin != cout but no conv_shortcut in the state dict";
             return MF_ERR_INVALID;
         }
-        return conv(p + ".conv2", ActView{t2, 0, cout}, y, cout, cout, 3, 1, 1, 0, res);
+        return gn_conv(p + ".norm2", p + ".conv2", ActView{c1, 0, cout}, t2, y, cout, cout, groups, eps, res);
     }
 
     // diffusers Transformer2DModel (conv projections) with one BasicTransformerBlock; ctx = audio tokens

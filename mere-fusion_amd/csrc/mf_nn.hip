@@ -464,6 +464,41 @@ int mf_zero_f64(double* p, int n, hipStream_t s) {
     return MF_OK;
 }
 
+namespace {
+// scale[b][c] = rstd * gamma[c], shift[b][c] = beta[c] - mean * rstd * gamma[c] from the (sum, sum of squares) of k_gn_stats
+__global__ void k_gn_affine(const double* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, double inv_n, float eps,
+                            int groups, int cpg, int C, int total, float* scale, float* shift) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / C, c = i - b * C, g = c / cpg;
+    const double2 sq = *reinterpret_cast<const double2*>(stats + 2 * (b * groups + g));
+    const double mean = sq.x * inv_n;
+    const double var = fmax(sq.y * inv_n - mean * mean, 0.0);
+    const float rstd = rsqrtf((float)var + eps);
+    const float sc = rstd * gamma[c];
+    scale[i] = sc;
+    shift[i] = beta[c] - (float)mean * sc;
+}
+}  // namespace
+
+// GroupNorm folded into the consumer conv (mf_conv_halo2.hip): statistics as in mf_groupnorm, then the per-(sample, channel) affine the
+// conv applies (with SiLU) to its halo image in LDS.  scale / shift: [batch][C] fp32 device arrays.
+int mf_groupnorm_affine(const ActView& x, const float* gamma, const float* beta, int groups, float eps, double* stats, float* scale, float* shift,
+                        int batch, hipStream_t s) {
+    MF_REQUIRE(x.C % groups == 0 && x.C % 8 == 0 && x.coff % 8 == 0, "groupnorm: C=%d groups=%d", x.C, groups);
+    const Rows xr = rows_of(x);
+    const int cpg = x.C / groups;
+    MF_REQUIRE(groups <= 64 && x.C <= 8 * 256 * GN_MAXCOL, "groupnorm: groups=%d / C=%d beyond the kernel's limits", groups, x.C);
+    const int cols = std::min(256, x.C / 8), ppi = 256 / cols;
+    int P = std::max(ppi, std::min(64 * ppi, (xr.T * batch + 1023) / 1024));
+    hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, cpg, x.C, P, stats);
+    const int total = batch * x.C;
+    hipLaunchKernelGGL(k_gn_affine, dim3((total + 255) / 256), dim3(256), 0, s, stats, gamma, beta, 1.0 / ((double)xr.T * cpg), eps, groups, cpg, x.C, total,
+                       scale, shift);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
 int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, int groups, float eps,
                  bool silu, double* stats, int batch, hipStream_t s) {
     MF_REQUIRE(x.C == y.C && x.C % groups == 0 && x.C % 8 == 0 && x.coff % 8 == 0 && y.coff % 8 == 0, "groupnorm: C=%d groups=%d", x.C, groups);
