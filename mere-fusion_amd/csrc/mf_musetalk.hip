@@ -174,6 +174,14 @@ struct Net {
         ConvPlan* p = nullptr;
         int rc = conv(cname, tv, out, cin, cout, 3, 1, 1, 0, res, 0, extra_bias, 1.f, true, &p);
         if (rc) return rc;
+        if (!mf_conv_can_fuse_gn(p, cap)) {
+            // never fusable at this handle's capacity: keep GroupNorm and conv as two ops (per-op profiles stay comparable)
+            push(gname, "k_gn_stats+k_gn_apply", 0.0, [=](int B, hipStream_t s) { return mf_groupnorm(x, tv, dg, db, groups, eps, true, st, B, s); });
+            char kn0[96];
+            mf_conv_kernel_name(p, cap, kn0, sizeof(kn0));
+            push(cname, kn0, mf_conv_flops(p, 1), [=](int B, hipStream_t s) { return mf_conv_launch(p, tv, out, res, B, s); });
+            return MF_OK;
+        }
         char kn[96];
         mf_conv_kernel_name(p, cap, kn, sizeof(kn));
         push(cname + " (+" + gname.substr(gname.rfind('.') + 1) + ")", std::string("gn+") + kn, mf_conv_flops(p, 1), [=](int B, hipStream_t s) {
