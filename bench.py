@@ -83,19 +83,13 @@ class MuseTalkRunner:
     def __init__(self, precision, batch, device, seed=0):
         from mere_fusion_amd.musetalk.models.unet import UNet
         from mere_fusion_amd.musetalk.models.vae import VAE
-        from oracle.musetalk_ref import MUSETALK_V1      # the config table only (no oracle arithmetic)
+        from mere_fusion_amd.musetalk.config import MUSETALK_V1, unet_config_json, vae_config_json
         self.cfg = MUSETALK_V1
-        u = self.cfg["unet"]
-        ucfg = dict(in_channels=u["in_channels"], out_channels=u["out_channels"], block_out_channels=list(u["block_out_channels"]),
-                    layers_per_block=u["layers_per_block"], cross_attention_dim=u["cross_attention_dim"],
-                    attention_head_dim=u["attention_heads"], norm_num_groups=u["norm_num_groups"], down_attn=u["down_attn"],
-                    up_attn=u["up_attn"], sample_size=32)
         self.usd = W.make_musetalk_unet_state_dict(self.cfg, 0)
         self.vsd = W.make_musetalk_vae_state_dict(self.cfg, 0)
         with torch.cuda.device(device):
-            self.unet = UNet(ucfg, self.usd, precision=precision, max_batch=batch)
-            vc = dict(self.cfg["vae"]); vc["block_out_channels"] = list(vc["block_out_channels"])
-            self.vae = VAE(config=vc, state_dict=self.vsd, precision=precision, max_batch=batch)
+            self.unet = UNet(unet_config_json(self.cfg["unet"]), self.usd, precision=precision, max_batch=batch)
+            self.vae = VAE(config=vae_config_json(self.cfg["vae"]), state_dict=self.vsd, precision=precision, max_batch=batch)
         lat, aud = W.make_musetalk_inputs(batch, seed)
         self.lat_cpu, self.aud_cpu = lat, aud
         self.lat, self.aud = lat.to(device), aud.to(device)
@@ -105,6 +99,17 @@ class MuseTalkRunner:
     def step(self):
         pred = self.unet.model(self.lat, self.t0, encoder_hidden_states=self.unet.pe(self.aud)).sample
         return self.vae.decode_latents_device(pred)
+
+    def step_d2h(self):
+        """The reference's own "actual avg infer fps" bracket (musereal.py:99-115) ends after `vae.decode_latents`, whose last line copies the
+        uint8 frames to the host (vae.py:105): the same step with that D2H + sync inside."""
+        pred = self.unet.model(self.lat, self.t0, encoder_hidden_states=self.unet.pe(self.aud)).sample
+        return self.vae.decode_latents(pred)
+
+    def gflop_per_frame(self):
+        from mere_fusion_amd.musetalk.config import algorithmic_flops_per_frame
+        fu, fv = algorithmic_flops_per_frame(self.unet, self.vae)
+        return (fu + fv) / 1e9
 
     def profile(self, iters):
         l = _lib.lib()
@@ -141,10 +146,9 @@ class MuseTalkRunner:
             el = time.perf_counter() - t0
             if el >= seconds and n >= 2:
                 break
-        m = R.count_macs(self.cfg)
         return {"value": round(n / el, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                 "sample": f"{n} single-frame steps of the fp32 oracle (oracle/musetalk_ref.py: UNet + VAE decode), {el:.1f} s",
-                "gflops": round(n * 2 * (m["unet"] + m["vae"]) / 1e9 / el, 1)}
+                "gflops": round(n * self.gflop_per_frame() / el, 1)}
 
 
 class MultiSession:
@@ -319,6 +323,26 @@ def wav2lip_report(args, device, world, rank, value=None, ms_per_step=None, run=
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.w2l_batch, min(args.cpu_seconds, 8.0), args.cpu_threads)
     return out
+
+
+def whisper_report(args, device):
+    """H3 for the same batch: MuseASR.run_step's audio2feat on the B = 8 window ((2B + l + r) * 320 = 11520 samples -> feat (36, 5, 384),
+    museasr.py:22-27) -- the reference pads every window to 30 s and runs the whole 1500-token encoder (transcribe.py:108)."""
+    from mere_fusion_amd.musetalk.whisper.audio2feature import Audio2Feature
+    a2f = Audio2Feature(state_dict=W.make_whisper_encoder_state_dict(0), n_head=6, precision=args.precision, device=device)
+    n = (2 * args.batch + 20) * 320
+    wav = torch.from_numpy(W.make_speech_like_wav(n, 0)).to(device)
+    rep = {"samples": n, "unit": "ms per run_step window"}
+    modes = [("exact_30s_context", {})]
+    if hasattr(a2f, "set_mode"):
+        modes = [(m, {"mode": m}) for m in a2f.MODES]
+    for name, kw in modes:
+        if kw:
+            a2f.set_mode(**kw)
+        f = lambda: a2f.audio2feat_device(wav)
+        el = harness.timed_steps(f, 20, 3, sync_fn=torch.cuda.synchronize)
+        rep[name] = round(el / 20 * 1e3, 3)
+    return rep
 
 
 class ErNeRFRunner:
@@ -498,9 +522,7 @@ def main():
         elapsed = harness.timed_steps(run.step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=device)
         value = harness.aggregate_value(args.batch, args.steps, elapsed, world)
         if rank == 0:
-            from oracle.musetalk_ref import count_macs
-            m = count_macs(run.cfg)
-            gf_frame = 2 * (m["unet"] + m["vae"]) / 1e9
+            gf_frame = run.gflop_per_frame()      # summed over the handles' own op lists (tests/test_musetalk_full.py holds it to SURVEY Appendix C)
             line = {"metric": "lip-sync frames/sec @256x256", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
                     "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
@@ -508,7 +530,6 @@ def main():
                                            "Whisper chunks per GPU, inputs resident in HBM (BASELINE.json configs[2]); assumed MuseTalk-v1 / "
                                            "sd-vae-ft-mse architecture, seeded random-init weights",
                                "batch_per_gpu": args.batch, "sessions_at_25fps": round(value / 25.0, 1),
-                               "sessions_at_25fps_per_8gpu_node_if_linear": round(8 * value / world / 25.0, 1),
                                "algorithmic_gflop_per_frame": round(gf_frame, 1),
                                "parallelism": f"{world} independent replicas, sessions sharded by GPU, no collective"},
                     "net_tflops": round(value / world * gf_frame / 1e3, 1)}
@@ -529,6 +550,13 @@ def main():
                 line["unet_conv_blocks"] = {"achieved_tflops": round(f / (t * 1e-3) / 1e12, 1), "ms": round(t, 3),
                                             "mfma_issue_frac_of_bf16_peak": round(MFMA_PASSES[args.precision] * f / (t * 1e-3) / 1e12 / BF16_DENSE_PEAK_TF, 3)}
             line["parity"] = run.parity()
+            # the same step bracketed as the reference brackets it (musereal.py:99-115): uint8 frames copied to the host inside the timed region
+            el_h = harness.timed_steps(run.step_d2h, max(args.steps // 2, 1), 2, sync_fn=torch.cuda.synchronize)
+            line["with_d2h"] = {"value": round(args.batch * max(args.steps // 2, 1) / el_h, 1), "unit": "frames/s",
+                                "ms_per_step": round(el_h / max(args.steps // 2, 1) * 1e3, 3),
+                                "note": "step + vae.py:105's `.cpu().numpy()` of the uint8 frames (pageable host memory, one sync per step)"}
+            if extras:
+                line["whisper"] = whisper_report(args, device)
             if args.dump_layers:
                 with open(args.dump_layers, "w") as f_:
                     json.dump({"musetalk_rows": rows, "by_kernel": by}, f_, indent=1)

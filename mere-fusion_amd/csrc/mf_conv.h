@@ -125,6 +125,10 @@ struct ConvPlan {
     int64_t ws_cap = 0;
     int* tile_cnt = nullptr;  // arrival counters of the fused split-K combine (zeroed once; self-resetting)
     int tile_cnt_cap = 0;
+    // Outgrown workspaces / counters.  A hipGraph captured at one batch size keeps the pointer it was captured with; the split count comes
+    // from a batch-dependent cost model, so a SMALLER batch can need a LARGER workspace later.  Outgrown buffers are therefore never freed
+    // while the plan lives (a replayed graph may still write them): they are parked here until mf_conv_plan_destroy.
+    std::vector<void*> retired;
     // host-side phase description, independent of the buffers the layer is later bound to
     struct Tap {                              // input displacement in pixels relative to anchor
         int dy, dx;

@@ -830,6 +830,8 @@ void mf_conv_plan_destroy(ConvPlan* p) {
     if (p->tile_cnt) (void)hipFree(p->tile_cnt);
     if (p->up_hi) (void)hipFree(p->up_hi);
     if (p->up_lo) (void)hipFree(p->up_lo);
+    for (void* r : p->retired) (void)hipFree(r);
+    p->retired.clear();
     p->up_hi = p->up_lo = nullptr;
     p->tile_cnt = nullptr; p->tile_cnt_cap = 0;
     p->w_hi = p->w_lo = nullptr; p->bias = nullptr; p->goff = nullptr; p->ws = nullptr; p->ws_cap = 0;
@@ -943,8 +945,9 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
                 const int64_t per_split = (int64_t)batch * p->out_h * p->out_w * p->d.cout;
                 const int64_t need = per_split * ns;
                 if (need > p->ws_cap) {
-                    // only reached on an eager (un-captured) launch: the first forward at a batch size runs eagerly
-                    if (p->ws) { MF_HIP(hipStreamSynchronize(stream)); MF_HIP(hipFree(p->ws)); p->ws = nullptr; p->ws_cap = 0; }
+                    // only reached on an eager (un-captured) launch: the first forward at a batch size runs eagerly.  The outgrown
+                    // buffer is retired, not freed: graphs captured at other batch sizes still hold its address.
+                    if (p->ws) { p->retired.push_back(p->ws); p->ws = nullptr; p->ws_cap = 0; }
                     MF_HIP(hipMalloc(&p->ws, need * sizeof(float)));
                     p->ws_cap = need;
                 }
@@ -1051,8 +1054,9 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         const int64_t per_split = (int64_t)batch * p->out_h * p->out_w * a.N;
         const int64_t need = per_split * tc.nsplit;
         if (need > p->ws_cap) {
-            // only reached on an eager (un-captured) launch: the first forward at a batch size runs eagerly
-            if (p->ws) { MF_HIP(hipStreamSynchronize(stream)); MF_HIP(hipFree(p->ws)); p->ws = nullptr; p->ws_cap = 0; }
+            // only reached on an eager (un-captured) launch: the first forward at a batch size runs eagerly.  The outgrown buffer is
+            // retired, not freed: graphs captured at other batch sizes still hold its address (ConvPlan::retired).
+            if (p->ws) { p->retired.push_back(p->ws); p->ws = nullptr; p->ws_cap = 0; }
             MF_HIP(hipMalloc(&p->ws, need * sizeof(float)));
             p->ws_cap = need;
         }
@@ -1067,7 +1071,7 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         if (fused) {
             const int need_cnt = a.tiles_m * a.tiles_n * std::max(1, p->nphase);
             if (need_cnt > p->tile_cnt_cap) {
-                if (p->tile_cnt) { MF_HIP(hipStreamSynchronize(stream)); MF_HIP(hipFree(p->tile_cnt)); p->tile_cnt = nullptr; p->tile_cnt_cap = 0; }
+                if (p->tile_cnt) { p->retired.push_back(p->tile_cnt); p->tile_cnt = nullptr; p->tile_cnt_cap = 0; }
                 MF_HIP(hipMalloc(&p->tile_cnt, need_cnt * sizeof(int)));
                 MF_HIP(hipMemset(p->tile_cnt, 0, need_cnt * sizeof(int)));
                 p->tile_cnt_cap = need_cnt;

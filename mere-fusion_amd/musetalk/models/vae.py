@@ -17,6 +17,24 @@ SD_VAE_FT_MSE = dict(latent_channels=4, out_channels=3, block_out_channels=[128,
                      norm_num_groups=32, scaling_factor=0.18215, sample_size=32)
 
 
+# diffusers renamed the VAE attention block's parameters (AttentionBlock -> Attention); `AutoencoderKL.from_pretrained` -- what the reference
+# calls (vae.py:24) -- converts old checkpoints on load, and the published sd-vae-ft-mse file carries the OLD names.
+_LEGACY_ATTN_KEYS = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def remap_legacy_attention_keys(state_dict):
+    """`...attentions.N.{query,key,value,proj_attn}.{weight,bias}` -> `...attentions.N.{to_q,to_k,to_v,to_out.0}.{weight,bias}`;
+    new-style keys pass through untouched.  Old checkpoints may store the projections as 1x1 convolutions [C, C, 1, 1]: same element
+    order as the Linear [C, C] the C loader expects."""
+    out = {}
+    for k, v in state_dict.items():
+        parts = k.split(".")
+        if len(parts) >= 3 and "attentions" in parts and parts[-2] in _LEGACY_ATTN_KEYS:
+            k = ".".join(parts[:-2] + [_LEGACY_ATTN_KEYS[parts[-2]], parts[-1]])
+        out[k] = v
+    return out
+
+
 def vae_config_struct(cfg):
     boc = list(cfg["block_out_channels"])
     c = _lib.MfVaeConfig()
@@ -61,7 +79,7 @@ class VAE:
         self._resized_img = resized_img
         _lib.init_device(torch.cuda.current_device())
         self._cfg = vae_config_struct(config)
-        arr, keep = _lib.tensor_array(state_dict)
+        arr, keep = _lib.tensor_array(remap_legacy_attention_keys(state_dict))
         h = C.c_void_p()
         _lib.check(_lib.lib().mf_vae_create(C.byref(self._cfg), arr, len(keep), _lib.PRECISIONS[precision], int(max_batch), C.byref(h)),
                    "vae_create")

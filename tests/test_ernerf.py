@@ -476,10 +476,16 @@ def test_hip_render_loop_matches_oracle(lib_built, ref, W):
     want = RR.run_cuda(sd, offsets, S, ro, rd, enc_a, c, e, bitfield, bg_color=np.array([0.1, 0.2, 0.3], np.float32), density_scale=40.0)
     assert [t[1] for t in got["trace"]] == [t[1] for t in want["trace"]]
     assert all(abs(a[0] - b[0]) <= max(2, 0.002 * b[0]) for a, b in zip(got["trace"], want["trace"]))   # T_thresh ties may move a ray
+    # gate on the MAX over all rays.  A ray may stop one sample earlier / later than in the oracle when its transmittance sits within float
+    # noise of T_thresh (raymarching.cu:2236): such rays are identified by their weight sums (the skipped sample carries w < T_thresh = 1e-4,
+    # float noise is ~1e-6), COUNTED, and still held to the same bound -- the sample they gain or lose is worth < 1e-4 of colour.
     err = np.abs(img - want["image"]).max(1)
-    assert np.quantile(err, 0.995) <= 1e-3 and err.max() <= 2e-2, (np.quantile(err, 0.995), err.max())
+    ties = np.abs(w - want["weights_sum"]) > 2e-5
+    print(f"render {W}x{W}: image L-inf max {err.max():.3e}, T_thresh tie rays {int(ties.sum())} of {err.size}")
+    assert ties.mean() <= 2e-3, int(ties.sum())
+    assert err.max() <= 1e-3, (err.max(), int(ties.sum()))
     derr = np.abs(got["depth"].cpu().numpy() - want["depth"])
-    assert np.quantile(derr, 0.995) <= 1e-3
+    assert derr.max() <= 1e-3, derr.max()
 
 
 # ---- goldens produced by the REFERENCE's own Python (tests/golden/make_ernerf_golden.py) -------------------------------------------
@@ -546,8 +552,10 @@ def test_hip_field_and_render_match_reference_golden(lib_built, nerf_golden):
     got = r.run_cuda(_cu(ro), _cu(rd), cu("enc_audio"), torch.from_numpy(g["render_ind_code"])[None].cuda(), cu("field_e"),
                      bg_color=torch.tensor([0.1, 0.2, 0.3], device="cuda"))
     err = np.abs(got["image"].cpu().numpy() - g["render_image"]).max(1)
-    assert np.quantile(err, 0.99) <= 1e-3 and err.max() <= 2e-2, (np.quantile(err, 0.99), err.max())
-    assert np.quantile(np.abs(got["depth"].cpu().numpy() - g["render_depth"]), 0.99) <= 1e-3
+    derr = np.abs(got["depth"].cpu().numpy() - g["render_depth"])
+    print(f"render vs the reference's run_cuda golden: image L-inf max {err.max():.3e}, depth max {derr.max():.3e}")
+    assert err.max() <= 1e-3, err.max()                      # max over every ray of the reference's frame, no percentile
+    assert derr.max() <= 1e-3, derr.max()
 
 
 # ---- a23: audio feature nets --------------------------------------------------------------------------------------------------

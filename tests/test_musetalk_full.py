@@ -1,0 +1,130 @@
+"""BASELINE.json configs[2] at FULL size under `-m gpu`: the MuseTalk-v1 UNet (850 M weights, 367 ops, fused attention dh 40 / 80 / 160,
+split-K, halo_w twins) and the sd-vae-ft-mse decoder at batch 8 against oracle/musetalk_ref.py, through the drop-in objects -> C ABI.
+
+Parity bar (BASELINE.json north_star): fp32 L-inf <= 1e-3 on the predicted latents; uint8 frames within one grey level of the oracle's
+(round-half-even ties of `(x * 255).round()`, vae.py:106) with the differing fraction stated and bounded.
+PARITY UNPINNED at the diffusers boundary (oracle header); the oracle needs ~1 min of host time for the batch-8 step."""
+import numpy as np
+import pytest
+import torch
+
+from mere_fusion_amd import weights as W
+from mere_fusion_amd.musetalk.config import MUSETALK_V1, unet_config_json, vae_config_json
+
+pytestmark = pytest.mark.gpu
+
+B = 8
+TOL_LATENT = 1e-3          # north_star bound
+TOL_IMAGE = 4e-3           # decoder output before the clamp, values in about [-4, 4]: 1e-3 relative
+
+
+@pytest.fixture(scope="module")
+def full_sd():
+    return W.make_musetalk_unet_state_dict(MUSETALK_V1, 0), W.make_musetalk_vae_state_dict(MUSETALK_V1, 0)
+
+
+@pytest.fixture(scope="module")
+def hip_full(lib_built, full_sd):
+    from mere_fusion_amd.musetalk.models.unet import UNet
+    from mere_fusion_amd.musetalk.models.vae import VAE
+    usd, vsd = full_sd
+    unet = UNet(unet_config_json(MUSETALK_V1["unet"]), usd, max_batch=B)
+    vae = VAE(config=vae_config_json(MUSETALK_V1["vae"]), state_dict=vsd, max_batch=B)
+    return unet, vae
+
+
+@pytest.fixture(scope="module")
+def oracle_full(full_sd):
+    """One batch-8 step of the fp32 oracle: predicted latents, pre-clamp decoder image, uint8 frames."""
+    import os
+    from oracle import musetalk_ref as R
+    assert R.MUSETALK_V1 == MUSETALK_V1                      # the product's table and the checker's agree
+    usd, vsd = full_sd
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
+    lat, aud = W.make_musetalk_inputs(B, 11)
+    pred = R.unet_forward(usd, MUSETALK_V1["unet"], lat, torch.tensor([0]), R.add_positional_encoding(aud))
+    img = R.vae_decode(vsd, MUSETALK_V1["vae"], pred / MUSETALK_V1["vae"]["scaling_factor"])
+    u8 = R.decode_latents(vsd, MUSETALK_V1["vae"], pred)
+    return dict(lat=lat, aud=aud, pred=pred, img=img, u8=u8)
+
+
+def _step(unet, vae, lat, aud):
+    pred = unet.model(lat.cuda(), torch.tensor([0]).cuda(), encoder_hidden_states=unet.pe(aud.cuda())).sample
+    return pred, vae.decode_latents_device(pred)
+
+
+def test_full_unet_batch8_vs_oracle(hip_full, oracle_full):
+    unet, _ = hip_full
+    o = oracle_full
+    got = unet.model(o["lat"].cuda(), torch.tensor([0]).cuda(), encoder_hidden_states=unet.pe(o["aud"].cuda())).sample.cpu()
+    assert got.shape == o["pred"].shape == (B, 4, 32, 32)
+    err = (got - o["pred"]).abs().max().item()
+    print(f"MUSETALK_V1 UNet, batch {B}: latents L-inf vs oracle {err:.3e} (bound {TOL_LATENT})")
+    assert err <= TOL_LATENT, err
+    # batch-composition invariance at full size: frames 2 and 5 alone (other tile / split choices) agree with the batch-8 result
+    sub = unet.model(o["lat"][[2, 5]].cuda(), torch.tensor([0]).cuda(), encoder_hidden_states=unet.pe(o["aud"][[2, 5]].cuda())).sample.cpu()
+    assert (sub - got[[2, 5]]).abs().max().item() <= 2e-4
+
+
+def test_full_vae_batch8_vs_oracle(hip_full, oracle_full):
+    """The decoder alone on the ORACLE's latents (so the comparison isolates the VAE): pre-clamp image and uint8 BGR frames."""
+    _, vae = hip_full
+    o = oracle_full
+    frames, image = vae.decode_latents_device(o["pred"].cuda(), want_image=True)
+    ierr = (image.cpu() - o["img"]).abs().max().item()
+    got = frames.cpu().numpy()
+    assert got.shape == o["u8"].shape == (B, 256, 256, 3) and got.dtype == np.uint8
+    d = np.abs(got.astype(int) - o["u8"].astype(int))
+    print(f"sd-vae-ft-mse decoder, batch {B}: image L-inf {ierr:.3e} (bound {TOL_IMAGE}); uint8 max diff {d.max()}, "
+          f"differing pixels {100 * (d > 0).mean():.3f} %")
+    assert ierr <= TOL_IMAGE, ierr
+    assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
+    assert o["u8"].std() > 10                                 # the frames are not flat
+
+
+def test_full_step_graph_replay_vs_oracle(hip_full, oracle_full):
+    """musereal.py:100-108 end to end at batch 8: call 1 eager, call 2 captures the hipGraphs, calls 3-4 replay them."""
+    unet, vae = hip_full
+    o = oracle_full
+    outs = [_step(unet, vae, o["lat"], o["aud"])[1].cpu().numpy() for _ in range(4)]
+    for x in outs[1:]:
+        assert np.array_equal(x, outs[0])
+    d = np.abs(outs[0].astype(int) - o["u8"].astype(int))
+    print(f"full step, batch {B}, graph replay: uint8 max diff vs oracle {d.max()}, differing pixels {100 * (d > 0).mean():.3f} %")
+    assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
+
+
+def test_full_graphs_survive_other_batch_sizes(hip_full, oracle_full):
+    """split-K workspaces are sized by a batch-dependent cost model and a captured graph keeps the pointer it was captured
+    with.  Replay batch 8, run other batch sizes eagerly (they may outgrow a workspace), replay batch 8 again: identical frames."""
+    unet, vae = hip_full
+    o = oracle_full
+    first = [_step(unet, vae, o["lat"], o["aud"])[1].cpu().numpy() for _ in range(3)][-1]       # eager, capture, replay
+    for b in (1, 3, 5, 2):
+        for _ in range(2):
+            _step(unet, vae, o["lat"][:b], o["aud"][:b])
+    again = _step(unet, vae, o["lat"], o["aud"])[1].cpu().numpy()
+    assert np.array_equal(first, again)
+
+
+def test_full_vae_batch8_matches_batch1(hip_full):
+    """Batch 8 runs the resnet convs on the LDS-weights halo kernel's fat tiles (channel-slice split on the 32 x 32 levels); batch 1 takes the
+    implicit-GEMM twins.  Same latents -> same frames, to the uint8 rounding of the two summation orders."""
+    _, vae = hip_full
+    g = torch.Generator().manual_seed(5)
+    lat = (torch.randn(8, 4, 32, 32, generator=g) * 0.9).cuda()
+    f8 = vae.decode_latents_device(lat).clone()
+    assert float(f8.float().std()) > 10
+    for i in (0, 3, 7):
+        f1 = vae.decode_latents_device(lat[i:i + 1])
+        d = (f1[0].int() - f8[i].int()).abs()
+        assert int(d.max()) <= 2 and float((d > 0).float().mean()) < 0.02, (i, int(d.max()), float((d > 0).float().mean()))
+
+
+def test_algorithmic_flops_match_the_oracle_count(hip_full):
+    """bench.py's FLOP numerator comes from the handles' own op lists; it must equal the analytic count of SURVEY Appendix C."""
+    from mere_fusion_amd.musetalk.config import algorithmic_flops_per_frame
+    from oracle import musetalk_ref as R
+    fu, fv = algorithmic_flops_per_frame(*hip_full)
+    m = R.count_macs(MUSETALK_V1)
+    assert abs(fu / (2 * m["unet"]) - 1) < 5e-3 and abs(fv / (2 * m["vae"]) - 1) < 5e-3, (fu, 2 * m["unet"], fv, 2 * m["vae"])

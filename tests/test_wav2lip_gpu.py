@@ -214,3 +214,77 @@ def test_lip_session_driver(gpu_model_factory, sd0):
     img, melb = glue_ref.face_batch(faces[idx2], ref_chunks)
     want = glue_ref.frames_from_pred(R.wav2lip_forward(sd0, torch.from_numpy(melb), torch.from_numpy(img)).numpy())
     assert np.abs(frames2.cpu().numpy() - want).max() <= 255 * TOL_X3
+
+
+def test_eight_sessions_on_eight_streams_batch16(lib_built, sd0):
+    """BASELINE.json configs[3], per-GPU shape: 8 concurrent sessions, one hipStream + one generator handle + one face cache each, B = 16
+    mel chunks per step (lipreal.py runs one inference loop per session).  Two steps are enqueued on every stream before anything is
+    synchronised, so the sessions really overlap; EVERY session's frames are then held to the oracle (mirror-indexed faces included)."""
+    from mere_fusion_amd import lip_driver as D
+    from mere_fusion_amd.wav2lip.models import Wav2Lip
+    S, Bs = 8, 16
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    sessions, mels, faces = [], [], []
+    for s in range(S):
+        m = Wav2Lip(precision="bf16x3")
+        m.load_state_dict(sd0)
+        m = m.to("cuda").eval()
+        mel, _, u8 = W.make_lip_inputs(Bs, 300 + s)
+        f = np.random.default_rng(50 + s).integers(0, 256, (11 + s, 96, 96, 3), dtype=np.uint8)     # 11..18 cached crops: the walk mirrors
+        sessions.append(D.LipSession(m, f))
+        mels.append(mel)
+        faces.append(f)
+    torch.cuda.synchronize()
+    outs = [[] for _ in range(S)]
+    for step in range(2):
+        for s in range(S):
+            with torch.cuda.stream(streams[s]), torch.no_grad():
+                fr, idx = sessions[s].step(mels[s].cuda(non_blocking=True))
+                outs[s].append((fr, idx))
+    torch.cuda.synchronize()
+    worst = 0.0
+    for s in range(S):
+        for step in range(2):
+            fr, idx = outs[s][step]
+            want_idx = [glue_ref.mirror_index(len(faces[s]), step * Bs + i) for i in range(Bs)]
+            assert idx == want_idx
+            img, melb = glue_ref.face_batch(faces[s][want_idx], [m_[0] for m_ in mels[s].numpy()])
+            want = glue_ref.frames_from_pred(R.wav2lip_forward(sd0, torch.from_numpy(melb), torch.from_numpy(img)).numpy())
+            err = np.abs(fr.cpu().numpy() - want).max() / 255.0
+            worst = max(worst, err)
+            assert err <= TOL_X3, (s, step, err)
+    print(f"8 sessions x 8 streams x B16, 2 steps each: worst L-inf vs oracle {worst:.3e}")
+
+
+def test_graphs_survive_workspace_growth(lib_built, sd0):
+    """the split count comes from a batch-dependent cost model, so a SMALLER batch can need a LARGER split-K workspace
+    than a batch whose hipGraph is already captured.  Replay B = 32, run B = 16 / 8 / 24 (eager + capture), replay B = 32 again, and compare
+    with a handle that never uses graphs (MF_NO_GRAPH=1 at create time)."""
+    import os
+    from mere_fusion_amd.wav2lip.models import Wav2Lip
+
+    def model():
+        m = Wav2Lip(precision="bf16x3")
+        m.load_state_dict(sd0)
+        return m.to("cuda").eval()
+    mel, face, _ = W.make_lip_inputs(32, 21)
+    mel, face = mel.cuda(), face.cuda()
+    g = model()
+    with torch.no_grad():
+        first = [g(mel, face).cpu() for _ in range(3)][-1]                   # eager, capture, replay
+        for b in (16, 8, 24, 16):
+            for _ in range(2):
+                g(mel[:b], face[:b])
+        again = g(mel, face).cpu()
+        old = os.environ.get("MF_NO_GRAPH")
+        os.environ["MF_NO_GRAPH"] = "1"
+        try:
+            e = model()
+            eager = e(mel, face).cpu()
+        finally:
+            if old is None:
+                del os.environ["MF_NO_GRAPH"]
+            else:
+                os.environ["MF_NO_GRAPH"] = old
+    assert torch.equal(first, again)
+    assert torch.equal(eager, again)
