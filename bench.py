@@ -325,6 +325,44 @@ def wav2lip_report(args, device, world, rank, value=None, ms_per_step=None, run=
     return out
 
 
+def muse_multi_session(args, device):
+    """The north star's 8 sessions per GPU through the session driver (mere_fusion_amd/muse_driver.py): one UNet / VAE pair, every step
+    gathers each session's mirror-indexed cached latents + its Whisper chunks into ONE sessions x batch frame step (musereal.py:91-108 for all
+    sessions at once).  Second number: the same step with the paste-back of musereal.py:238-247 done on the device into 720p frames."""
+    from mere_fusion_amd import muse_driver as D
+    from mere_fusion_amd.paste import AvatarFrames
+    S, B = args.sessions, args.batch
+    big = MuseTalkRunner(args.precision, S * B, device)
+    rng = np.random.default_rng(0)
+    H_, W_, n = 720, 1280, 25
+    sessions, chunks = [], []
+    for s in range(S):
+        lats = W.make_musetalk_inputs(n, 500 + s)[0]
+        boxes = [(500 + i, 200 + i, 500 + i + 260, 200 + i + 270) for i in range(n)]
+        crops = [(b[0] - 26, b[1] - 27, b[2] + 26, b[3] + 27) for b in boxes]
+        masks = [np.repeat(rng.integers(0, 256, (c[3] - c[1], c[2] - c[0], 1), dtype=np.uint8), 3, axis=2) for c in crops]
+        av = AvatarFrames(torch.randint(0, 256, (n, H_, W_, 3), dtype=torch.uint8, device=device), boxes, masks, crops, device=device)
+        sessions.append(D.MuseSession(lats, avatar_frames=av))
+        chunks.append(W.make_musetalk_inputs(B, 700 + s)[1].to(device))
+    rep = {"sessions_per_step": S, "batch_per_session": B, "driver": "mere_fusion_amd.muse_driver.MuseBatcher", "unit": "frames/s"}
+    for key, paste in (("value", False), ("with_gpu_paste_back_720p", True)):
+        bat = D.MuseBatcher(big.unet, big.vae, sessions, batch_size=B, paste=paste, device=device)
+        el = harness.timed_steps(lambda: bat.step(chunks), 5, 2, sync_fn=torch.cuda.synchronize)
+        rep[key] = round(S * B * 5 / el, 1)
+        if not paste:
+            rep["ms_per_step"] = round(el / 5 * 1e3, 3)
+            rep["sessions_at_25fps"] = round(S * B * 5 / el / 25.0, 1)
+            rep["fps_per_session"] = round(B * 5 / el, 1)
+    rows_b = big.profile(2)
+    cb = [r for r in rows_b if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
+    tb, fb = sum(r["ms"] for r in cb), sum(r["flops"] for r in cb)
+    rep["unet_conv_blocks"] = {"achieved_tflops": round(fb / (tb * 1e-3) / 1e12, 1),
+                               "mfma_issue_frac_of_bf16_peak": round(MFMA_PASSES[args.precision] * fb / (tb * 1e-3) / 1e12 / BF16_DENSE_PEAK_TF, 3)}
+    del big
+    torch.cuda.empty_cache()
+    return rep
+
+
 def whisper_report(args, device):
     """H3 for the same batch: MuseASR.run_step's audio2feat on the B = 8 window ((2B + l + r) * 320 = 11520 samples -> feat (36, 5, 384),
     museasr.py:22-27) -- the reference pads every window to 30 s and runs the whole 1500-token encoder (transcribe.py:108)."""
@@ -577,19 +615,7 @@ def main():
                 # cross-session batching: the north star's 8 sessions per GPU x 8 frames in one step (what a node does with 64 sessions on
                 # 8 GPUs); the UNet's GEMMs get 8x the pixels per launch
                 if args.sessions > 0:
-                    ms_b = args.sessions * args.batch
-                    big = MuseTalkRunner(args.precision, ms_b, device)
-                    el3 = harness.timed_steps(big.step, 5, 2, sync_fn=torch.cuda.synchronize)
-                    rows_b = big.profile(2)
-                    cb = [r for r in rows_b if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
-                    tb, fb = sum(r["ms"] for r in cb), sum(r["flops"] for r in cb)
-                    line["multi_session"] = {"sessions_per_step": args.sessions, "batch": ms_b, "value": round(ms_b * 5 / el3, 1), "unit": "frames/s",
-                                             "ms_per_step": round(el3 / 5 * 1e3, 3), "sessions_at_25fps": round(ms_b * 5 / el3 / 25.0, 1),
-                                             "fps_per_session": round(args.batch * 5 / el3, 1),
-                                             "unet_conv_blocks": {"achieved_tflops": round(fb / (tb * 1e-3) / 1e12, 1),
-                                                                  "mfma_issue_frac_of_bf16_peak": round(MFMA_PASSES[args.precision] * fb / (tb * 1e-3) / 1e12 / BF16_DENSE_PEAK_TF, 3)}}
-                    del big
-                    torch.cuda.empty_cache()
+                    line["multi_session"] = muse_multi_session(args, device)
                 dl = args.dump_layers
                 args.dump_layers = dl + ".wav2lip.json" if dl else None
                 line["wav2lip"] = wav2lip_report(args, device, world, rank)

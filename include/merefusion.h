@@ -360,6 +360,41 @@ int mf_audio_encoder_create(const mf_tensor* weights, int n_weights, int use_att
 int mf_audio_encoder_forward(mf_audio_encoder* h, const float* auds, int n_windows, float* enc_a, void* stream);
 void mf_audio_encoder_destroy(mf_audio_encoder* h);
 
+/* ---- per-batch glue of the MuseTalk loop ------------------------------------------------ */
+/* musereal.py:92-97: `latent_batch = torch.cat([input_latent_list_cycle[__mirror_index(length, index + i)] ...])`.
+ * pool: device fp32 [n_pool_rows][row_elems] (every session's cached latents, 8*32*32 = 8192 floats per row);
+ * rows: HOST int[n], the pool row of each batch entry (mirror index + the session's offset); out: device fp32
+ * [n][row_elems].  row_elems must be a multiple of 4. */
+int mf_gather_rows_f32(const float* pool, int n_pool_rows, int64_t row_elems, const int* rows, int n, float* out, void* stream);
+
+/* Audio2Feature.feature2chunks / get_sliced_feature (musetalk/whisper/audio2feature.py:16-45, called at museasr.py:27)
+ * on the device: chunk i = feature rows [left_rows[i], left_rows[i] + rows_per_chunk), each clamped to [0, T-1]
+ * (`min(length - 1, max(0, idx))`), concatenated.  feat: device fp32 [T][row_elems] (row_elems = 5 * 384 for
+ * Whisper-tiny); left_rows: HOST int[n_chunks] = int(vid_idx * 50 / fps) - 2 * audio_feat_length[0]; out: device fp32
+ * [n_chunks][rows_per_chunk][row_elems] == [n_chunks][50][384]. */
+int mf_whisper_feature_chunks(const float* feat, int T, int row_elems, const int* left_rows, int rows_per_chunk, int n_chunks,
+                              float* out, void* stream);
+
+/* ---- paste-back of the generated face into the cached full frame --------------------------- */
+/* One output frame.  Wav2Lip (lipreal.py:207-214): `combine_frame = deepcopy(frame_list_cycle[idx]);
+ * res = cv2.resize(res_frame.astype(np.uint8), (x2 - x1, y2 - y1)); combine_frame[y1:y2, x1:x2] = res` -> mask == NULL.
+ * MuseTalk (musereal.py:238-247 + musetalk/utils/blending.py:103-125): the same resize, then
+ * `get_image_blending(ori_frame, res, bbox, mask, mask_crop_box)`: inside the crop box the frame becomes
+ * cv2.blendLinear(crop with the face pasted in, crop, gray(mask) / 255, 1 - gray(mask) / 255). */
+typedef struct mf_paste_job {
+    int frame_index;          /* cached full frame this output starts from (frame_list_cycle[idx]) */
+    int x1, y1, x2, y2;       /* face bbox, x / y order as blending.py:105 (lipreal.py's coords are (y1, y2, x1, x2): reorder) */
+    int cx1, cy1, cx2, cy2;   /* MuseTalk: mask crop box (x_s, y_s, x_e, y_e), blending.py:106; ignored when mask == NULL */
+    const uint8_t* mask;      /* device uint8 [cy2-cy1][cx2-cx1][3] BGR (mask_list_cycle[idx]), or NULL: rectangle copy */
+} mf_paste_job;
+/* res: device, n_jobs generated frames [res_h][res_w][3], uint8, or fp32 with res_is_f32 (Wav2Lip's pred * 255, truncated as
+ * `astype(np.uint8)` does); frames: device uint8 [n_frames][H][W][3] BGR; jobs: HOST array; out: device uint8
+ * [n_jobs][H][W][3].  Bit-exact with OpenCV's 8-bit INTER_LINEAR resize / BGR2GRAY / blendLinear (csrc/mf_blend.hip). */
+int mf_paste_frames(const void* res, int res_is_f32, int res_h, int res_w, const uint8_t* frames, int n_frames, int H, int W,
+                    const mf_paste_job* jobs, int n_jobs, uint8_t* out, void* stream);
+/* cv2.resize(src, (dw, dh)) for uint8 [sh][sw][3] with the default INTER_LINEAR (lipreal.py:211, musereal.py:241). */
+int mf_resize_linear_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

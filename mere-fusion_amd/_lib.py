@@ -48,6 +48,10 @@ class MfVaeConfig(C.Structure):
                 ("sample_size", C.c_int), ("scaling_factor", C.c_float)]
 
 
+class MfPasteJob(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("frame_index", "x1", "y1", "x2", "y2", "cx1", "cy1", "cx2", "cy2")] + [("mask", C.c_void_p)]
+
+
 def tensor_array(state_dict):
     """(ctypes array of MfTensor, keep-alive list) for a {name: fp32 cpu tensor} dict."""
     import torch
@@ -124,6 +128,11 @@ SIGNATURES = {
     "mf_audio_encoder_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mf_audio_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mf_audio_encoder_destroy": (None, [C.c_void_p]),
+    "mf_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p]),
+    "mf_whisper_feature_chunks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mf_paste_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(MfPasteJob), C.c_int,
+                                  C.c_void_p, C.c_void_p]),
+    "mf_resize_linear_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib = None

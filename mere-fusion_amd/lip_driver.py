@@ -63,12 +63,15 @@ class LipASRFrontend:
 
 
 class LipSession:
-    """One talking-head session: cached uint8 face crops on the device + the generator."""
+    """One talking-head session: cached uint8 face crops on the device + the generator.  With `avatar_frames`
+    (mere_fusion_amd.paste.AvatarFrames built from frame_list_cycle / coord_list_cycle with lip_order=True) `step_pasted` also does
+    process_frames' paste-back (lipreal.py:207-214) on the device."""
 
-    def __init__(self, model, faces_u8):
+    def __init__(self, model, faces_u8, avatar_frames=None):
         self.model = model
         self.faces = faces_u8 if torch.is_tensor(faces_u8) else torch.from_numpy(np.asarray(faces_u8))
         self.faces = self.faces.to(next(model.parameters()).device)
+        self.avatar_frames = avatar_frames
         self.index = 0
 
     def step(self, mel_batch):
@@ -80,3 +83,11 @@ class LipSession:
         self.index += B
         sel = self.faces[torch.tensor(idx, device=self.faces.device)]
         return self.model.forward_u8(mel_batch, sel), idx
+
+    def step_pasted(self, mel_batch):
+        """step() + lipreal.py:207-214: the full uint8 BGR frames [B, H, W, 3] with the generated mouth region resized into the bbox,
+        still on the device."""
+        if self.avatar_frames is None:
+            raise RuntimeError("LipSession.step_pasted needs AvatarFrames (full frames + coords)")
+        frames, idx = self.step(mel_batch)
+        return self.avatar_frames.paste(frames, idx), idx

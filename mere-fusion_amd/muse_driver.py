@@ -1,0 +1,151 @@
+"""Per-batch glue of the MuseTalk render loop, restated for the GPU path (8f rank 2).
+
+The reference runs this logic inside `MuseASR.run_step` (museasr.py:15-29) and `inference()` (musereal.py:53-122) around mp.Queues, one
+process per session, each with its own model copy.  The drop-in keeps those files untouched; this module is the queue-free equivalent
+that bench.py, the tests and a multi-session harness drive directly:
+
+  MuseASRFrontend   MuseASR.run_step: sliding audio window -> Whisper features -> one (50, 384) chunk per video frame, never leaving HBM
+  MuseSession       one avatar: cached latents (and, optionally, full frames + paste geometry) resident on the device, ping-pong index
+  MuseBatcher       ONE UNet + VAE pair serving N sessions: every step gathers each active session's latents by mirror index
+                    (mf_gather_rows_f32) and its audio chunks into one N * B-frame batch, runs musereal.py:100-108 once, and hands every
+                    session its own uint8 frames (optionally already pasted into the full frame, mf_paste_frames)
+
+Cross-session batching is what fills an MI355X: the UNet at 8 frames per step is launch-latency bound, at 64 it is not."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def mirror_index(size, index):
+    """`__mirror_index` (musereal.py:44-50, basereal.py:133-139): ping-pong walk over the cached frames."""
+    turn, res = divmod(index, size)
+    return res if turn % 2 == 0 else size - res - 1
+
+
+def chunk_left_rows(batch_size, fps, start, audio_feat_length=(2, 2)):
+    """First (unclamped) feature row of every chunk of one run_step: `center_idx = int(vid_idx * 50 / fps)`, `left_idx = center_idx -
+    audio_feat_length[0] * 2` with vid_idx = i + start (audio2feature.py:29-31, 93-96)."""
+    return [int((i + start) * 50 / fps) - audio_feat_length[0] * 2 for i in range(batch_size)]
+
+
+def feature_chunks_device(feat, left_rows, rows_per_chunk=10, out=None):
+    """Audio2Feature.feature2chunks on the device: feat [T, L+1, C] fp32 -> [B, rows_per_chunk * (L+1), C] (= [B, 50, 384])."""
+    if not feat.is_cuda:
+        raise RuntimeError("feature_chunks_device needs the Whisper features on the HIP device; no CPU path exists here")
+    feat = feat.float().contiguous()
+    T, L1, Cc = feat.shape
+    B = len(left_rows)
+    if out is None:
+        out = torch.empty((B, rows_per_chunk * L1, Cc), dtype=torch.float32, device=feat.device)
+    rows = (C.c_int * B)(*[int(r) for r in left_rows])
+    with torch.cuda.device(feat.device):
+        _lib.check(_lib.lib().mf_whisper_feature_chunks(feat.data_ptr(), T, L1 * Cc, rows, rows_per_chunk, B, out.data_ptr(),
+                                                        C.c_void_p(torch.cuda.current_stream(feat.device).cuda_stream)), "whisper_feature_chunks")
+    return out
+
+
+class MuseASRFrontend:
+    """MuseASR.run_step without the queues: 2B new 20 ms chunks in, B Whisper chunks [B, 50, 384] out (on the device)."""
+
+    def __init__(self, audio_processor, batch_size, fps=50, stride_left=10, stride_right=10):
+        self.audio_processor, self.batch_size, self.fps = audio_processor, batch_size, fps
+        self.l, self.r = stride_left, stride_right
+        self.frames = []
+
+    def warm_up(self, chunk=320):
+        """baseasr.py:53-59: prime the context with l + r silent chunks."""
+        self.frames = [np.zeros(chunk, dtype=np.float32) for _ in range(self.l + self.r)]
+
+    def run_step(self, new_chunks, out=None):
+        self.frames.extend(new_chunks)
+        if len(self.frames) <= self.l + self.r:                       # museasr.py:22-23
+            return None
+        feat = self.audio_processor.audio2feat_device(np.concatenate(self.frames))          # museasr.py:25-26
+        chunks = feature_chunks_device(feat, chunk_left_rows(self.batch_size, self.fps / 2, self.l / 2), out=out)   # museasr.py:27
+        self.frames = self.frames[-(self.l + self.r):]                # museasr.py:29
+        return chunks
+
+
+class MuseSession:
+    """One talking-head session: the avatar's cached latents (musereal.py:64 `torch.load(latents.pt)`: a list of [1, 8, 32, 32] tensors)
+    and its position in the ping-pong walk.  `avatar_frames` (mere_fusion_amd.paste.AvatarFrames) enables the GPU paste-back."""
+
+    def __init__(self, latents, avatar_frames=None):
+        lat = latents if torch.is_tensor(latents) else torch.cat([torch.as_tensor(x).reshape(1, *torch.as_tensor(x).shape[-3:]) for x in latents], dim=0)
+        self.latents = lat.float().contiguous()
+        self.length = self.latents.shape[0]
+        self.avatar_frames = avatar_frames
+        if avatar_frames is not None and avatar_frames.n != self.length:
+            raise RuntimeError("one cached full frame per cached latent is required (frame_list_cycle / input_latent_list_cycle)")
+        self.index = 0
+        self.pool_offset = None
+
+    def next_indices(self, n):
+        idx = [mirror_index(self.length, self.index + i) for i in range(n)]
+        self.index += n
+        return idx
+
+
+class MuseBatcher:
+    """N sessions through one UNet / VAE handle per step (BASELINE.json north star: 8 sessions per GPU)."""
+
+    def __init__(self, unet, vae, sessions, batch_size=8, paste=False, device="cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("MuseBatcher needs a HIP device; no CPU path exists here")
+        self.unet, self.vae, self.sessions, self.batch_size, self.paste = unet, vae, list(sessions), batch_size, paste
+        self.device = torch.device(device)
+        need = len(self.sessions) * batch_size
+        for h, what in ((unet.model.max_batch, "UNet"), (getattr(vae, "max_batch", need), "VAE")):
+            if h < need:
+                raise RuntimeError(f"{what} handle was created with max_batch {h}; {len(self.sessions)} sessions x {batch_size} frames need {need}")
+        off = 0
+        for s in self.sessions:
+            s.pool_offset = off
+            off += s.length
+        # every session's cached latents in one pool: a batch is one gather
+        self.pool = torch.cat([s.latents.reshape(s.length, -1) for s in self.sessions], dim=0).to(self.device).contiguous()
+        self.row_elems = self.pool.shape[1]
+        self.lat_shape = tuple(self.sessions[0].latents.shape[1:])
+        self.t0 = torch.tensor([0], device=self.device)
+
+    @torch.no_grad()
+    def step(self, whisper_chunks):
+        """whisper_chunks: one entry per session -- a device tensor [B, 50, 384] (MuseASRFrontend.run_step) or None for an all-silent batch
+        (musereal.py:82-86: the net is skipped, only the frame indices advance).  Returns one (frames, indices) per session:
+        frames = uint8 [B, 256, 256, 3] BGR on the device (`recon`, musereal.py:108), or, with paste=True, the composed full frames
+        [B, H, W, 3] (musereal.py:238-247); None for a silent session."""
+        B = self.batch_size
+        rows, idx_per, active = [], [], []
+        for k, (s, ch) in enumerate(zip(self.sessions, whisper_chunks)):
+            idx = s.next_indices(B)
+            idx_per.append(idx)
+            if ch is None:
+                continue
+            if ch.shape[0] != B or not ch.is_cuda:
+                raise RuntimeError(f"session {k}: expected a device tensor of {B} whisper chunks, got {tuple(ch.shape)} on {ch.device}")
+            active.append(k)
+            rows.extend(s.pool_offset + i for i in idx)
+        out = [(None, idx) for idx in idx_per]
+        if not active:
+            return out
+        n = len(rows)
+        lat = torch.empty((n,) + self.lat_shape, dtype=torch.float32, device=self.device)
+        crows = (C.c_int * n)(*rows)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mf_gather_rows_f32(self.pool.data_ptr(), self.pool.shape[0], self.row_elems, crows, n, lat.data_ptr(),
+                                                     C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "gather_rows_f32")
+        aud = whisper_chunks[active[0]] if len(active) == 1 else torch.cat([whisper_chunks[k] for k in active], dim=0)
+        pred = self.unet.model(lat, self.t0, encoder_hidden_states=self.unet.pe(aud)).sample              # musereal.py:102-107
+        frames = self.vae.decode_latents_device(pred)                                                   # musereal.py:108, frames stay in HBM
+        for j, k in enumerate(active):
+            fr = frames[j * B:(j + 1) * B]
+            s = self.sessions[k]
+            if self.paste:
+                if s.avatar_frames is None:
+                    raise RuntimeError(f"session {k} has no AvatarFrames to paste into")
+                fr = s.avatar_frames.paste(fr, idx_per[k])
+            out[k] = (fr, idx_per[k])
+        return out

@@ -84,6 +84,7 @@ class VAE:
         _lib.check(_lib.lib().mf_vae_create(C.byref(self._cfg), arr, len(keep), _lib.PRECISIONS[precision], int(max_batch), C.byref(h)),
                    "vae_create")
         self._h = h.value
+        self.max_batch = max_batch
         if use_float16:
             self.vae = self.vae.half()
 

@@ -57,9 +57,15 @@ class Audio2Feature:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _wav(self, audio):
+        """float32 waveform on the device: ndarray (museasr.py:25), list, or an already resident tensor."""
+        if torch.is_tensor(audio):
+            return audio.to(self.device, torch.float32).reshape(-1).contiguous()
+        return torch.as_tensor(np.asarray(audio, dtype=np.float32)).to(self.device).reshape(-1).contiguous()
+
     def log_mel_spectrogram(self, audio):
         """whisper/audio.py:92-125 for one <=30 s segment: (80, n // 160) float32 tensor on the device."""
-        wav = torch.as_tensor(np.asarray(audio, dtype=np.float32)).to(self.device).contiguous()
+        wav = self._wav(audio)
         n = wav.numel()
         out = torch.empty((80, n // 160), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
@@ -68,7 +74,7 @@ class Audio2Feature:
 
     def audio2feat_device(self, audio):
         """(T50, n_layer+1, n_state) float32 tensor on the device."""
-        wav = torch.as_tensor(np.asarray(audio, dtype=np.float32)).to(self.device).contiguous()
+        wav = self._wav(audio)
         outs = []
         # transcribe.py:103-126: 3000-frame (480000-sample) segments, each padded to 30 s
         for s0 in range(0, wav.numel(), N_SAMPLES_SEGMENT):
