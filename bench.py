@@ -365,21 +365,32 @@ def muse_multi_session(args, device):
 
 def whisper_report(args, device):
     """H3 for the same batch: MuseASR.run_step's audio2feat on the B = 8 window ((2B + l + r) * 320 = 11520 samples -> feat (36, 5, 384),
-    museasr.py:22-27) -- the reference pads every window to 30 s and runs the whole 1500-token encoder (transcribe.py:108)."""
+    museasr.py:22-27) -- the reference pads every window to 30 s and runs the whole 1500-token encoder (transcribe.py:108).
+    Reported per window: the literal evaluation, the exact one without the unconsumed work (one window, and 8 sessions' windows in one
+    call), and a shortened context with its measured error (never the default: the encoder's attention is global)."""
     from mere_fusion_amd.musetalk.whisper.audio2feature import Audio2Feature
     a2f = Audio2Feature(state_dict=W.make_whisper_encoder_state_dict(0), n_head=6, precision=args.precision, device=device)
     n = (2 * args.batch + 20) * 320
-    wav = torch.from_numpy(W.make_speech_like_wav(n, 0)).to(device)
-    rep = {"samples": n, "unit": "ms per run_step window"}
-    modes = [("exact_30s_context", {})]
-    if hasattr(a2f, "set_mode"):
-        modes = [(m, {"mode": m}) for m in a2f.MODES]
-    for name, kw in modes:
-        if kw:
-            a2f.set_mode(**kw)
-        f = lambda: a2f.audio2feat_device(wav)
+    S = max(args.sessions, 1)
+    wavs = torch.stack([torch.from_numpy(W.make_speech_like_wav(n, i)) for i in range(S)]).to(device)
+    rep = {"samples_per_window": n, "feature_rows_per_window": n // 320, "unit": "ms per window"}
+
+    def timed(f, windows):
         el = harness.timed_steps(f, 20, 3, sync_fn=torch.cuda.synchronize)
-        rep[name] = round(el / 20 * 1e3, 3)
+        return round(el / 20 * 1e3 / windows, 3)
+    a2f.set_mode("exact_full")
+    ref = a2f.audio2feat_windows_device(wavs[:1]).clone()
+    rep["exact_full_1500_tokens"] = timed(lambda: a2f.audio2feat_windows_device(wavs[:1]), 1)
+    a2f.set_mode("exact")
+    rep["exact_pruned"] = timed(lambda: a2f.audio2feat_windows_device(wavs[:1]), 1)
+    rep["exact_pruned_linf_vs_full"] = float((a2f.audio2feat_windows_device(wavs[:1]) - ref).abs().max())
+    if S > 1:
+        rep[f"exact_pruned_{S}_windows_per_call"] = timed(lambda: a2f.audio2feat_windows_device(wavs), S)
+    for ctx in (128, 512):
+        a2f.set_mode("windowed", ctx)
+        rep[f"windowed_{ctx}_tokens"] = {"ms": timed(lambda: a2f.audio2feat_windows_device(wavs[:1]), 1),
+                                         "linf_vs_exact": float((a2f.audio2feat_windows_device(wavs[:1]) - ref).abs().max()),
+                                         "feature_abs_max": float(ref.abs().max())}
     return rep
 
 

@@ -163,6 +163,18 @@ int mf_whisper_log_mel(mf_whisper* h, const float* wav, int n, float* out, void*
  * `encoder(segment, include_embeddings=True)`.  emb: device fp32 [n_layer+1][1500][n_state]
  * (= the reference's embeddings[0], model.py:158-168).  n <= 480000 samples (one 30 s segment). */
 int mf_whisper_encode_audio(mf_whisper* h, const float* wav, int n, float* emb, void* stream);
+
+/* The streaming form of the same stage: what `MuseASR.run_step` needs from `audio2feat` for the
+ * sliding windows of one or several sessions (museasr.py:25-26 -> audio2feature.py:99-112 -> transcribe.py:103-126).
+ * wav: device fp32 [n_windows][n], every window the same length (the render loop's (2B + l + r) * 320 samples);
+ * feat: device fp32 [n_windows][n/320][n_layer+1][n_state] -- `concatenated_array` of audio2feature.py:110 per window.
+ * ctx_tokens = 0 keeps the reference's 1500-token context; the result equals mf_whisper_encode_audio's first n/320 tokens
+ * (the last block evaluates only the consumed queries -- its keys / values still span the whole context -- and all
+ * windows share every launch).  ctx_tokens > 0 shortens the context to that many tokens: an approximation, because the
+ * encoder's attention is global and unmasked; bench.py reports its error next to its time.
+ * mf_whisper_set_batch sizes the workspace for up to max_windows windows per call (default 1). */
+int mf_whisper_set_batch(mf_whisper* h, int max_windows);
+int mf_whisper_encode_windows(mf_whisper* h, const float* wav, int n, int n_windows, int ctx_tokens, float* feat, void* stream);
 void mf_whisper_destroy(mf_whisper* h);
 
 /* ---- MuseTalk UNet (H4) and VAE decode (H5) --------------------------------------------------- */

@@ -89,6 +89,8 @@ SIGNATURES = {
     "mf_whisper_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mf_whisper_log_mel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mf_whisper_encode_audio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mf_whisper_set_batch": (C.c_int, [C.c_void_p, C.c_int]),
+    "mf_whisper_encode_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mf_whisper_destroy": (None, [C.c_void_p]),
     "mf_unet_create": (C.c_int, [C.POINTER(MfUnetConfig), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mf_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

@@ -323,7 +323,7 @@ int launch_qb(AttnArgs& a, int groups, bool x3, hipStream_t s) {
 bool mf_attention_supported(int dh) { return dh == 40 || dh == 64 || dh == 80 || dh == 160; }
 
 int mf_attention(const ActView& q, const ActView& k, const ActView& v, const ActView& out, int heads, int batch, int precision,
-                 hipStream_t s) {
+                 hipStream_t s, int tq, int tk) {
     const int C = q.C, dh = C / heads;
     MF_REQUIRE(heads > 0 && C % heads == 0 && k.C == C && v.C == C && out.C == C, "attention: channel mismatch");
     MF_REQUIRE(mf_attention_supported(dh), "attention: no fused kernel for head dim %d", dh);
@@ -343,6 +343,11 @@ int mf_attention(const ActView& q, const ActView& k, const ActView& v, const Act
     a.q_row = q.buf->C; a.k_row = k.buf->C; a.v_row = v.buf->C; a.o_row = out.buf->C;
     a.Tq = q.buf->H * q.buf->W; a.Tk = k.buf->H * k.buf->W; a.heads = heads;
     MF_REQUIRE(a.Tq > 0 && a.Tk > 0 && v.buf->H * v.buf->W == a.Tk && out.buf->H * out.buf->W == a.Tq, "attention: token count mismatch");
+    // sequence prefixes (Whisper's last block only needs the queries whose outputs are consumed; a shortened context): base
+    // pointers and batch strides stay those of the full buffers
+    MF_REQUIRE(tq >= 0 && tq <= a.Tq && tk >= 0 && tk <= a.Tk, "attention: prefix (%d queries, %d keys) exceeds the sequences (%d, %d)", tq, tk, a.Tq, a.Tk);
+    if (tq > 0) a.Tq = tq;
+    if (tk > 0) a.Tk = tk;
     a.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)dh));
     const int groups = batch * heads;
     switch (dh) {

@@ -175,5 +175,7 @@ struct GroupedGemm {
 int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream);
 
 // Enqueues the layer.  res may have buf == nullptr.
+// tokens > 0 (single-row sequences only, H == 1): compute only the first `tokens` output positions of every batch item -- a sequence
+// prefix.  The buffers keep their geometry (base pointers, batch strides); the GEMM simply has M = batch * tokens rows.
 int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
-                   int batch, hipStream_t stream);
+                   int batch, hipStream_t stream, int tokens = 0);

@@ -899,9 +899,13 @@ int mf_conv_launch_gn(ConvPlan* p, const ActView& in, const ActView& out, const 
 }
 
 int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
-                   int batch, hipStream_t stream) {
+                   int batch, hipStream_t stream, int tokens) {
     const ActBuf& ib = *in.buf;
     const ActBuf& ob = *out.buf;
+    MF_REQUIRE(tokens >= 0 && (tokens == 0 || (!p->halo && !p->up_hi && p->Hq == 1 && p->nphase == 1 && p->out_step == 1 && tokens <= p->Wq)),
+               "conv: a token prefix (%d) needs a single-row sequence layer on the implicit-GEMM path with at least that many positions", tokens);
+    const int Wq_eff = tokens > 0 ? tokens : p->Wq;       // output positions per batch item this launch computes
+    const int out_w_eff = tokens > 0 ? tokens : p->out_w;
     MF_REQUIRE(p->bound_in_ld == ib.C && p->bound_in_wp == ib.Wp(), "conv: plan not bound to this input geometry");
     MF_REQUIRE(in.C >= p->cin_pad && in.coff % 8 == 0 && in.coff + in.C <= ib.C, "conv: bad input view");
     // the epilogue stores channel quads: a cout that is not a multiple of 4 spills zero-weight channels
@@ -1008,8 +1012,8 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
     ConvArgs a{};
     a.x_hi = ib.hi + in.coff; a.x_lo = x3 ? ib.lo + in.coff : nullptr;
     a.w_hi = p->w_hi; a.w_lo = p->w_lo; a.bias = p->bias; a.goff = p->goff;
-    a.M = batch * p->Hq * p->Wq; a.N = p->d.cout; a.Npad = p->Npad;
-    a.HqWq = p->Hq * p->Wq; a.Wq = p->Wq;
+    a.M = batch * p->Hq * Wq_eff; a.N = p->d.cout; a.Npad = p->Npad;
+    a.HqWq = p->Hq * Wq_eff; a.Wq = Wq_eff;
     a.xb = ib.per_batch(); a.xi = p->in_step_h * ib.Wp() * ib.C; a.xj = p->in_step_w * ib.C;
     const int64_t ybase = ((int64_t)ob.halo * ob.Wp() + ob.halo) * ob.C + out.coff;
     a.y_hi = ob.hi + ybase; a.y_lo = x3 ? ob.lo + ybase : nullptr;
@@ -1033,7 +1037,15 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         goff_max = std::max(goff_max, p->ph[ph].ngroups);
     }
 
-    const ConvTile tc = mf_conv_pick_tile(p, batch);
+    ConvTile tc = mf_conv_pick_tile(p, batch);
+    if (tokens > 0) {
+        // the cost model priced the full sequence: re-balance the split for the rows actually computed
+        const int nt = cdiv(a.M, tc.bm) * cdiv(a.N, tc.bn);
+        int kt_min = p->ph[0].KT;
+        tc.nsplit = nt >= 256 ? 1 : std::max(1, std::min(std::min(kt_min, cdiv(512, nt)), 16));
+        if (tc.bm > 128 && a.M <= 256) { tc.bm = 64; tc.bn = 64; tc.wgm = 2; tc.wgn = 2; }
+        if (p->d.act == 5 && tc.bn < 32) tc.nsplit = 1;
+    }
     a.tiles_m = cdiv(a.M, tc.bm); a.tiles_n = cdiv(a.N, tc.bn);
     {
         // XCD tile order by which operand is heavier: weights N x K vs the input tensor M x Cin (both x planes)
@@ -1051,7 +1063,7 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
     bool fused = false;
     if (tc.nsplit > 1) {
         // fp32 partial tiles [split][B][Ho][Wo][N]; combined by k_splitk_epilogue below
-        const int64_t per_split = (int64_t)batch * p->out_h * p->out_w * a.N;
+        const int64_t per_split = (int64_t)batch * p->out_h * out_w_eff * a.N;
         const int64_t need = per_split * tc.nsplit;
         if (need > p->ws_cap) {
             // only reached on an eager (un-captured) launch: the first forward at a batch size runs eagerly.  The outgrown buffer is
@@ -1061,8 +1073,8 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
             p->ws_cap = need;
         }
         a.ws = p->ws; a.ws_split = per_split;
-        a.wsb = (int64_t)p->out_h * p->out_w * a.N;
-        a.wsi = p->out_step * p->out_w * a.N; a.wsj = p->out_step * a.N;
+        a.wsb = (int64_t)p->out_h * out_w_eff * a.N;
+        a.wsi = p->out_step * out_w_eff * a.N; a.wsj = p->out_step * a.N;
         // MF_SPLITK_FUSE=1: combine inside the conv kernel (the last workgroup of a tile re-reads the nsplit partial tiles).  Measured
         // SLOWER than the separate chip-wide pass (Wav2Lip 14.2 k -> 11.2 k frames/s, MuseTalk 322 -> 316: one workgroup re-reading
         // nsplit tiles after two fences and an atomic is a longer tail than a 5 us launch spread over every CU), so it stays opt-in.
@@ -1120,9 +1132,9 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
     if (tc.nsplit > 1 && !fused) {
         ConvArgs e = a;   // unit-grid strides for the combine pass
         e.yi = ob.Wp() * ob.C; e.yj = ob.C;
-        const int64_t total = (int64_t)batch * p->out_h * p->out_w * ((a.act == 5 ? a.N / 2 : a.N) / 4);
+        const int64_t total = (int64_t)batch * p->out_h * out_w_eff * ((a.act == 5 ? a.N / 2 : a.N) / 4);
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e,
-                           tc.nsplit, p->out_h, p->out_w, total);
+                           tc.nsplit, p->out_h, out_w_eff, total);
         MF_HIP(hipGetLastError());
     }
     return MF_OK;

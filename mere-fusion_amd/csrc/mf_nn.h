@@ -8,8 +8,9 @@
 #include "mf_conv.h"
 
 // y = (x - mean) / sqrt(var + eps) * gamma + beta over the C channels of every token (fp32 math)
+// tokens > 0: only the first `tokens` tokens of every batch item (a sequence prefix; the buffers keep their geometry)
 int mf_layernorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, float eps, int batch,
-                 hipStream_t s);
+                 hipStream_t s, int tokens = 0);
 
 // p[t][j] = softmax_j(scale * s[t][j]) for j < n_keys; columns n_keys..p.C-1 are written as zero
 int mf_softmax_rows(const ActView& scores, const ActView& probs, int n_keys, float scale, int batch, hipStream_t s);
@@ -24,6 +25,9 @@ int mf_gemm_plan_create(ConvPlan* p, int K, int N, int T, int precision);
 
 // (hi + lo) planes of the interior of a view -> fp32 [batch][T][C] row-major
 int mf_rows_to_f32(const ActView& x, float* dst, int batch, hipStream_t s);
+// Whisper's `encoder_embeddings` gather (audio2feature.py:103-110): the first `tokens` tokens of every batch item into
+// dst[b][t][layer][c] of an fp32 [batch][tokens][n_layers][C] tensor
+int mf_rows_to_f32_layered(const ActView& x, float* dst, int batch, int tokens, int layer, int n_layers, hipStream_t s);
 
 // fp32 [batch][T][C] row-major (+ optional addend [T][C], e.g. a positional encoding) -> planes of a view
 int mf_rows_from_f32(const float* src, const float* addend, const ActView& y, int batch, hipStream_t s);
@@ -53,7 +57,8 @@ int mf_vae_post_u8(const ActView& x, uint8_t* dst, int batch, hipStream_t s);
 
 // Fused softmax(q k^T / sqrt(dh)) v (mf_attn.hip) on contiguous (halo 0) token buffers; head dims 40 / 64 / 80 / 160.
 bool mf_attention_supported(int dh);
+// tq / tk > 0: only the first tq queries attend to only the first tk keys of every batch item (sequence prefixes)
 int mf_attention(const ActView& q, const ActView& k, const ActView& v, const ActView& out, int heads, int batch, int precision,
-                 hipStream_t s);
+                 hipStream_t s, int tq = 0, int tk = 0);
 
 inline int64_t mf_interior(const ActBuf& b) { return ((int64_t)b.halo * b.Wp() + b.halo) * b.C; }

@@ -425,10 +425,14 @@ Rows rows_of(const ActView& v) {
 }  // namespace
 
 int mf_layernorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, float eps, int batch,
-                 hipStream_t s) {
+                 hipStream_t s, int tokens) {
     MF_REQUIRE(x.buf->H * x.buf->W == y.buf->H * y.buf->W && x.C == y.C, "layernorm: shape mismatch");
     MF_REQUIRE(x.C <= 64 * MAXPL, "layernorm: C=%d exceeds %d", x.C, 64 * MAXPL);
-    const Rows xr = rows_of(x), yr = rows_of(y);
+    Rows xr = rows_of(x), yr = rows_of(y);
+    if (tokens > 0) {
+        MF_REQUIRE(tokens <= xr.T, "layernorm: prefix of %d tokens exceeds the sequence (%d)", tokens, xr.T);
+        xr.T = yr.T = tokens;
+    }
     const int total = batch * xr.T;
     const bool vec = x.C % 8 == 0 && x.coff % 8 == 0 && y.coff % 8 == 0 && x.buf->C % 8 == 0 && y.buf->C % 8 == 0 && x.C <= 2048;
     const dim3 grid((total + 3) / 4), block(256);
@@ -598,6 +602,27 @@ int mf_gemm_plan_create_grouped(ConvPlan* p, int K, int N, int T, int groups, in
     MF_HIP(hipMemset(p->bias, 0, p->Npad * sizeof(float)));
     MF_HIP(hipMalloc(&p->goff, p->goff_total * sizeof(int)));
     p->bound_in_ld = p->bound_in_wp = -1;
+    return MF_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_rows_to_f32_layered(Rows X, int C, float* dst, int layer, int n_layers, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int64_t r = idx / C;
+    const int t = (int)(r % X.T), b = (int)(r / X.T);
+    dst[((r * n_layers) + layer) * C + c] = ld(X.hi, X.lo, X.off(b, t) + c);
+}
+}  // namespace
+
+int mf_rows_to_f32_layered(const ActView& x, float* dst, int batch, int tokens, int layer, int n_layers, hipStream_t s) {
+    Rows xr = rows_of(x);
+    MF_REQUIRE(tokens > 0 && tokens <= xr.T && layer >= 0 && layer < n_layers, "rows_to_f32_layered: bad argument");
+    xr.T = tokens;
+    const int64_t total = (int64_t)batch * tokens * x.C;
+    hipLaunchKernelGGL(k_rows_to_f32_layered, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xr, x.C, dst, layer, n_layers, total);
+    MF_HIP(hipGetLastError());
     return MF_OK;
 }
 

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <string>
@@ -77,12 +78,14 @@ __device__ __forceinline__ float ord2f(unsigned o) {
 
 // one workgroup per STFT frame: reflect-padded centred frame, fp64 DFT, |.|^2, mel, log10(max(1e-10, .));
 // raw[m][t] fp32 and the global maximum (audio.py:117-123)
+// grid (frames, windows): window w reads wav + w * n, writes raw + w * raw_stride and gmax[w]
 __global__ __launch_bounds__(256) void k_wlogmel_raw(const float* __restrict__ wav, int n, int T, const double* win,
-                                                     const double* tw, const float* basis, float* raw, unsigned* gmax) {
+                                                     const double* tw, const float* basis, float* raw, unsigned* gmax, int64_t raw_stride) {
     __shared__ double s_x[W_NFFT];
     __shared__ double s_tw[2 * W_NFFT];
     __shared__ double s_pow[W_BINS + 7];
     const int t = blockIdx.x, tid = threadIdx.x;
+    wav += (int64_t)blockIdx.y * n; raw += (int64_t)blockIdx.y * raw_stride; gmax += blockIdx.y;
     for (int j = tid; j < W_NFFT; j += 256) {
         int p = t * W_HOP - W_NFFT / 2 + j;
         if (p < 0) p = -p;                       // torch.stft(center=True, pad_mode="reflect")
@@ -118,9 +121,12 @@ __global__ __launch_bounds__(256) void k_wlogmel_raw(const float* __restrict__ w
 // log_spec = max(log_spec, max - 8); (log_spec + 4) / 4; optional fp32 [80][T] copy and/or the padded NHWC
 // conv1 input (pad_or_trim to 3000 frames pads the NORMALISED spectrogram with zeros, transcribe.py:108)
 __global__ __launch_bounds__(256) void k_wlogmel_fin(const float* raw, const unsigned* gmax, int T, float* out_f32,
-                                                     bf16_t* mel_hi, bf16_t* mel_lo, int64_t tok0, int C, int total) {
+                                                     bf16_t* mel_hi, bf16_t* mel_lo, int64_t tok0, int C, int total, int64_t raw_stride,
+                                                     int64_t mel_stride) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
+    raw += (int64_t)blockIdx.y * raw_stride; gmax += blockIdx.y; tok0 += (int64_t)blockIdx.y * mel_stride;
+    if (out_f32) out_f32 += (int64_t)blockIdx.y * total;
     const int m = idx / T, t = idx - m * T;
     const float floor_v = ord2f(*gmax) - 8.0f;
     const float v = (fmaxf(raw[idx], floor_v) + 4.0f) / 4.0f;
@@ -151,8 +157,10 @@ struct mf_whisper {
     ConvPlan *conv1, *conv2, *scores, *pv;
     struct Layer { ConvPlan *qkv, *out, *fc1, *fc2; float *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
     std::vector<Layer> layers;
-    float* raw = nullptr;       // [80][3000] fp32 scratch of the log-mel
-    unsigned* gmax = nullptr;
+    float* raw = nullptr;       // [cap][80][3000] fp32 scratch of the log-mel
+    unsigned* gmax = nullptr;   // [cap]
+    int cap = 1;                // windows one call can encode (mf_whisper_set_batch)
+    std::vector<float> pos_host;   // sinusoids as NCHW [1][C][1][T], re-uploaded into every batch slot of `pos` when the workspace grows
     bool fused_attn = true;     // one k_attention launch per layer; false (MF_ATTN=composite or an unsupported head dim):
                                 // per-head pack + GEMM + softmax + pack + GEMM
 
@@ -171,9 +179,27 @@ struct mf_whisper {
     }
     int alloc() {
         for (auto& b : bufs) {
-            const size_t bytes = ((size_t)b->per_batch() + 64) * sizeof(bf16_t);
+            if (b->hi) { (void)hipFree(b->hi); b->hi = nullptr; }
+            if (b->lo) { (void)hipFree(b->lo); b->lo = nullptr; }
+            const size_t bytes = ((size_t)cap * b->per_batch() + 64) * sizeof(bf16_t);
             MF_HIP(hipMalloc(&b->hi, bytes)); MF_HIP(hipMemset(b->hi, 0, bytes));
             if (precision == MF_PREC_BF16X3) { MF_HIP(hipMalloc(&b->lo, bytes)); MF_HIP(hipMemset(b->lo, 0, bytes)); }
+        }
+        if (raw) (void)hipFree(raw);
+        if (gmax) (void)hipFree(gmax);
+        raw = nullptr; gmax = nullptr;
+        MF_HIP(hipMalloc(&raw, (size_t)cap * W_MELS * W_FRAMES * sizeof(float)));
+        MF_HIP(hipMalloc(&gmax, (size_t)cap * sizeof(unsigned)));
+        if (!pos_host.empty()) {
+            // the positional embedding is conv2's residual operand: one copy per batch slot (a residual view has a batch stride)
+            float* d = nullptr;
+            const size_t n1 = pos_host.size();
+            MF_HIP(hipMalloc(&d, (size_t)cap * n1 * sizeof(float)));
+            for (int b = 0; b < cap; ++b) MF_HIP(hipMemcpy(d + (size_t)b * n1, pos_host.data(), n1 * sizeof(float), hipMemcpyHostToDevice));
+            const int rc = mf_nchw_to_act(d, C, *pos, cap, nullptr);
+            MF_HIP(hipDeviceSynchronize());
+            (void)hipFree(d);
+            if (rc) return rc;
         }
         return MF_OK;
     }
@@ -184,8 +210,8 @@ struct mf_whisper {
         dev_f32.push_back(*dev);
         return MF_OK;
     }
-    int log_mel_into_input(const float* wav, int n, float* out_f32, bool to_input, hipStream_t s);
-    int encode(float* emb, hipStream_t s);
+    int log_mel_into_input(const float* wav, int n, float* out_f32, bool to_input, hipStream_t s, int S = 1);
+    int encode(float* emb, hipStream_t s, int S = 1, int ctx = 0, int keep = 0);
 };
 
 namespace {
@@ -210,50 +236,69 @@ int linear_plan(ConvPlan* p, const float* w, const float* b, int cin, int cout, 
 
 }  // namespace
 
-int mf_whisper::log_mel_into_input(const float* wav, int n, float* out_f32, bool to_input, hipStream_t s) {
+int mf_whisper::log_mel_into_input(const float* wav, int n, float* out_f32, bool to_input, hipStream_t s, int S) {
     const int T = n / W_HOP;   // stft gives 1 + n/160 frames, the last one is dropped (audio.py:117)
     MF_REQUIRE(T >= 1 && T <= W_FRAMES, "whisper: %d samples give %d frames; one segment holds 1..3000", n, T);
     MF_REQUIRE(n > W_NFFT / 2, "whisper: reflect padding needs more than %d samples", W_NFFT / 2);
+    MF_REQUIRE(S >= 1 && S <= cap, "whisper: %d windows exceed the handle's batch capacity %d (mf_whisper_set_batch)", S, cap);
     int dev = 0;
     MF_HIP(hipGetDevice(&dev));
     int rc = w_tables(dev);
     if (rc) return rc;
     const WTables& t = g_wt[dev];
-    MF_HIP(hipMemsetAsync(gmax, 0, sizeof(unsigned), s));   // 0 orders below every float
-    hipLaunchKernelGGL(k_wlogmel_raw, dim3(T), dim3(256), 0, s, wav, n, T, t.win, t.tw, t.basis, raw, gmax);
+    const int64_t raw_stride = (int64_t)W_MELS * W_FRAMES;
+    MF_HIP(hipMemsetAsync(gmax, 0, (size_t)S * sizeof(unsigned), s));   // 0 orders below every float
+    hipLaunchKernelGGL(k_wlogmel_raw, dim3(T, S), dim3(256), 0, s, wav, n, T, t.win, t.tw, t.basis, raw, gmax, raw_stride);
     MF_HIP(hipGetLastError());
     if (to_input) {
         // frames >= T of the 3000-frame segment are zero (pad_or_trim)
-        const size_t bytes = ((size_t)mel_in->per_batch() + 64) * sizeof(bf16_t);
+        const size_t bytes = ((size_t)S * mel_in->per_batch()) * sizeof(bf16_t);
         MF_HIP(hipMemsetAsync(mel_in->hi, 0, bytes, s));
         if (mel_in->lo) MF_HIP(hipMemsetAsync(mel_in->lo, 0, bytes, s));
     }
     const int total = W_MELS * T;
-    hipLaunchKernelGGL(k_wlogmel_fin, dim3((total + 255) / 256), dim3(256), 0, s, raw, gmax, T, out_f32,
-                       to_input ? mel_in->hi : nullptr, to_input ? mel_in->lo : nullptr, mf_interior(*mel_in), mel_in->C, total);
+    hipLaunchKernelGGL(k_wlogmel_fin, dim3((total + 255) / 256, S), dim3(256), 0, s, raw, gmax, T, out_f32,
+                       to_input ? mel_in->hi : nullptr, to_input ? mel_in->lo : nullptr, mf_interior(*mel_in), mel_in->C, total, raw_stride,
+                       mel_in->per_batch());
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
 
-int mf_whisper::encode(float* emb, hipStream_t s) {
+// S windows at once.  ctx = 0: the reference's full 1500-token context (transcribe.py:108 pads every window to 30 s); ctx > 0: only the
+// first ctx tokens exist (an APPROXIMATION: Whisper's encoder attention is global and unmasked, so the pad tokens a shorter context drops
+// do shift the result -- the bench reports by how much).  keep = 0: all tokens of all n_layer + 1 hidden states as [layer][T][C]
+// (one window only, the layout of `encoder_embeddings`); keep > 0: the first `keep` tokens as [S][keep][n_layer + 1][C] -- what
+// Audio2Feature.audio2feat slices out (audio2feature.py:103-110) -- and the LAST block then evaluates only those queries: its keys and
+// values still come from every token, so the kept outputs are exactly those of the full evaluation (no later layer reads the rest).
+int mf_whisper::encode(float* emb, hipStream_t s, int S, int ctx, int keep) {
     int rc;
     const int T = n_ctx;
+    const int tc = (ctx > 0 && ctx < T) ? ctx : 0;         // token prefix of every op (0 = the whole sequence)
+    const int Tc = tc ? tc : T;
+    MF_REQUIRE(S >= 1 && S <= cap, "whisper: %d windows exceed the handle's batch capacity %d", S, cap);
+    MF_REQUIRE(keep >= 0 && keep <= Tc, "whisper: keep = %d tokens exceeds the context (%d)", keep, Tc);
+    MF_REQUIRE(keep > 0 || S == 1, "whisper: the full-embedding layout is defined for one window");
+    MF_REQUIRE(fused_attn || (S == 1 && !tc && !keep), "whisper: batched / pruned encoding needs the fused attention kernel");
     const int64_t per_emb = (int64_t)T * C;
-    if ((rc = mf_conv_launch(conv1, W(mel_in), W(c1), ActView{}, 1, s))) return rc;       // gelu(conv1(x))
-    if ((rc = mf_conv_launch(conv2, W(c1), W(xa), W(pos), 1, s))) return rc;               // gelu(conv2(x)) + pos
-    if ((rc = mf_rows_to_f32(W(xa), emb, 1, s))) return rc;
+    auto emit = [&](ActBuf* x, int layer) {
+        return keep > 0 ? mf_rows_to_f32_layered(W(x), emb, S, keep, layer, n_layer + 1, s) : mf_rows_to_f32(W(x), emb + layer * per_emb, 1, s);
+    };
+    if ((rc = mf_conv_launch(conv1, W(mel_in), W(c1), ActView{}, S, s, tc ? std::min(2 * tc + 2, W_FRAMES) : 0))) return rc;   // gelu(conv1(x))
+    if ((rc = mf_conv_launch(conv2, W(c1), W(xa), W(pos), S, s, tc))) return rc;                 // gelu(conv2(x)) + pos
+    if ((rc = emit(xa, 0))) return rc;
     ActBuf* x = xa;
     ActBuf* y = xb;
     const int dh = C / n_head;
     const float scale = 1.0f / std::sqrt((float)dh);        // (dh^-0.25 on q) * (dh^-0.25 on k), model.py:91-93
     for (int l = 0; l < n_layer; ++l) {
         Layer& L = layers[l];
-        if ((rc = mf_layernorm(W(x), W(ln), L.ln1_g, L.ln1_b, 1e-5f, 1, s))) return rc;
-        if ((rc = mf_conv_launch(L.qkv, W(ln), W(qkv), ActView{}, 1, s))) return rc;
+        const int tq = (keep > 0 && l == n_layer - 1) ? keep : tc;      // rows the rest of this block computes (0 = all)
+        if ((rc = mf_layernorm(W(x), W(ln), L.ln1_g, L.ln1_b, 1e-5f, S, s, tc))) return rc;
+        if ((rc = mf_conv_launch(L.qkv, W(ln), W(qkv), ActView{}, S, s, tc))) return rc;
         // softmax(q k^T * dh^-0.5) v, all heads in one fused launch (mf_attn.hip); model.py:91-93 applies the same
         // scale as dh^-0.25 on q and on k
         if (fused_attn) {
-            if ((rc = mf_attention(ActView{qkv, 0, C}, ActView{qkv, C, C}, ActView{qkv, 2 * C, C}, ActView{ao, 0, C}, n_head, 1, precision, s))) return rc;
+            if ((rc = mf_attention(ActView{qkv, 0, C}, ActView{qkv, C, C}, ActView{qkv, 2 * C, C}, ActView{ao, 0, C}, n_head, S, precision, s, tq, tc))) return rc;
         } else {
             const int64_t q0 = mf_interior(*qkv);
             for (int h = 0; h < n_head; ++h) {
@@ -266,11 +311,11 @@ int mf_whisper::encode(float* emb, hipStream_t s) {
                 if ((rc = mf_conv_launch(pv, W(pm), ActView{ao, h * dh, dh}, ActView{}, 1, s))) return rc;
             }
         }
-        if ((rc = mf_conv_launch(L.out, W(ao), W(y), W(x), 1, s))) return rc;                 // x + attn(ln(x))
-        if ((rc = mf_layernorm(W(y), W(ln), L.ln2_g, L.ln2_b, 1e-5f, 1, s))) return rc;
-        if ((rc = mf_conv_launch(L.fc1, W(ln), W(h1), ActView{}, 1, s))) return rc;            // gelu(fc1)
-        if ((rc = mf_conv_launch(L.fc2, W(h1), W(x), W(y), 1, s))) return rc;                  // y + fc2(.) -> x
-        if ((rc = mf_rows_to_f32(W(x), emb + (l + 1) * per_emb, 1, s))) return rc;
+        if ((rc = mf_conv_launch(L.out, W(ao), W(y), W(x), S, s, tq))) return rc;                 // x + attn(ln(x))
+        if ((rc = mf_layernorm(W(y), W(ln), L.ln2_g, L.ln2_b, 1e-5f, S, s, tq))) return rc;
+        if ((rc = mf_conv_launch(L.fc1, W(ln), W(h1), ActView{}, S, s, tq))) return rc;            // gelu(fc1)
+        if ((rc = mf_conv_launch(L.fc2, W(h1), W(x), W(y), S, s, tq))) return rc;                  // y + fc2(.) -> x
+        if ((rc = emit(x, l + 1))) return rc;
     }
     return MF_OK;
 }
@@ -310,14 +355,10 @@ extern "C" int mf_whisper_create(const mf_tensor* weights, int n_weights, int n_
     h->mel_in = h->seq(W_MELS, W_FRAMES); h->c1 = h->seq(C, W_FRAMES); h->pos = h->seq(C, T);
     h->xa = h->seq(C, T); h->xb = h->seq(C, T); h->ln = h->seq(C, T); h->qkv = h->seq(3 * C, T);
     h->sc = h->seq((T + 7) / 8 * 8, T); h->pm = h->seq(Tp, T); h->ao = h->seq(C, T); h->h1 = h->seq(4 * C, T);
-    int rc = h->alloc();
-    if (rc) return rc;
-    MF_HIP(hipMalloc(&h->raw, (size_t)W_MELS * W_FRAMES * sizeof(float)));
-    MF_HIP(hipMalloc(&h->gmax, sizeof(unsigned)));
-
-    // sinusoids(n_ctx, C) (model.py:48-54), uploaded through the NCHW->planes pass
+    // sinusoids(n_ctx, C) (model.py:48-54), uploaded through the NCHW->planes pass by alloc()
     {
-        std::vector<float> pe((size_t)T * C);   // laid out as NCHW [1][C][1][T]
+        std::vector<float>& pe = h->pos_host;
+        pe.assign((size_t)T * C, 0.f);          // laid out as NCHW [1][C][1][T]
         const double inc = std::log(10000.0) / (C / 2 - 1);
         for (int t = 0; t < T; ++t)
             for (int c = 0; c < C / 2; ++c) {
@@ -327,14 +368,9 @@ extern "C" int mf_whisper_create(const mf_tensor* weights, int n_weights, int n_
                 pe[(size_t)c * T + t] = std::sin(st);
                 pe[(size_t)(c + C / 2) * T + t] = std::cos(st);
             }
-        float* d = nullptr;
-        MF_HIP(hipMalloc(&d, pe.size() * sizeof(float)));
-        MF_HIP(hipMemcpy(d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
-        rc = mf_nchw_to_act(d, C, *h->pos, 1, nullptr);
-        MF_HIP(hipDeviceSynchronize());
-        (void)hipFree(d);
-        if (rc) return rc;
     }
+    int rc = h->alloc();
+    if (rc) return rc;
 
     // conv1 / conv2: Conv1d(k=3) as a (1 x 3) convolution over the frame axis
     {
@@ -407,6 +443,27 @@ extern "C" int mf_whisper_encode_audio(mf_whisper* h, const float* wav, int n, f
     int rc = h->log_mel_into_input(wav, n, nullptr, true, s);
     if (rc) return rc;
     return h->encode(emb, s);
+}
+
+extern "C" int mf_whisper_set_batch(mf_whisper* h, int max_windows) {
+    MF_REQUIRE(h && max_windows >= 1 && max_windows <= 64, "whisper_set_batch: 1..64 windows");
+    if (max_windows == h->cap) return MF_OK;
+    MF_HIP(hipDeviceSynchronize());
+    h->cap = max_windows;
+    return h->alloc();
+}
+
+extern "C" int mf_whisper_encode_windows(mf_whisper* h, const float* wav, int n, int n_windows, int ctx_tokens, float* feat, void* stream) {
+    MF_REQUIRE(h && wav && feat, "whisper_encode_windows: null argument");
+    MF_REQUIRE(n_windows >= 1 && n_windows <= h->cap, "whisper_encode_windows: %d windows exceed the handle's capacity %d (mf_whisper_set_batch)",
+               n_windows, h->cap);
+    const int frames = n / W_HOP, keep = frames / 2;                          // audio2feature.py:104-106: int(end_frame - start_frame) / 2
+    MF_REQUIRE(keep >= 1, "whisper_encode_windows: %d samples hold no 20 ms feature row", n);
+    MF_REQUIRE(ctx_tokens == 0 || (ctx_tokens >= keep && ctx_tokens <= h->n_ctx), "whisper_encode_windows: context of %d tokens must cover the %d kept ones", ctx_tokens, keep);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = h->log_mel_into_input(wav, n, nullptr, true, s, n_windows);
+    if (rc) return rc;
+    return h->encode(feat, s, n_windows, ctx_tokens, keep);
 }
 
 extern "C" void mf_whisper_destroy(mf_whisper* h) { delete h; }

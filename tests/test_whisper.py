@@ -119,3 +119,50 @@ def test_hip_whisper_error_paths(a2f):
         a2f.log_mel_spectrogram(np.zeros(480160, np.float32))
     with pytest.raises(RuntimeError, match="float32 waveform"):
         a2f.audio2feat("some.wav")
+
+
+@pytest.mark.gpu
+def test_hip_streaming_windows_exact_modes_and_batch(a2f, wsd):
+    """the streaming form.  'exact' (pruned last block, only the consumed rows leave the device) equals the literal
+    'exact_full' evaluation; three sessions' windows in ONE call equal three separate calls; every window is held to the oracle."""
+    n = 11520                                                   # the B = 8 window of museasr.py: 36 feature rows
+    wavs = np.stack([W.make_speech_like_wav(n, s) for s in (0, 5, 9)])
+    try:
+        a2f.set_mode("exact_full")
+        full = a2f.audio2feat_windows_device(torch.from_numpy(wavs)).cpu().numpy()
+        a2f.set_mode("exact")
+        one = np.stack([a2f.audio2feat(wavs[i]) for i in range(3)])
+        bat = a2f.audio2feat_windows_device(torch.from_numpy(wavs)).cpu().numpy()
+        again = a2f.audio2feat_windows_device(torch.from_numpy(wavs[:2])).cpu().numpy()     # a smaller batch on the grown workspace
+    finally:
+        a2f.set_mode("exact")
+    assert full.shape == one.shape == bat.shape == (3, 36, 5, 384)
+    assert np.abs(one - full).max() <= 2e-4 and np.abs(bat - full).max() <= 2e-4           # same arithmetic, other GEMM tilings
+    assert np.abs(again - bat[:2]).max() <= 2e-4
+    for i in range(3):
+        assert np.abs(bat[i] - R.audio2feat(wsd, wavs[i])).max() <= TOL_FEAT, i
+
+
+@pytest.mark.gpu
+def test_hip_windowed_context_is_an_approximation_and_says_so(a2f, wsd):
+    """A shortened context is NOT the reference's result (global unmasked attention over 1500 tokens): the error is measured, it is
+    well above the exact modes' and it shrinks as the context grows; full context through the same code path is exact again."""
+    wav = W.make_speech_like_wav(11520, 2)
+    want = R.audio2feat(wsd, wav)
+    errs = {}
+    try:
+        for ctx in (64, 512, 1500):
+            a2f.set_mode("windowed", ctx)
+            errs[ctx] = float(np.abs(a2f.audio2feat(wav) - want).max())
+    finally:
+        a2f.set_mode("exact")
+    print("windowed-context L-inf vs oracle:", errs)
+    assert errs[1500] <= TOL_FEAT
+    assert errs[64] > 10 * TOL_FEAT or errs[64] > errs[1500] * 5
+    assert np.isfinite(list(errs.values())).all()
+
+
+@pytest.mark.gpu
+def test_hip_long_audio_is_refused(a2f):
+    with pytest.raises(RuntimeError, match="30 s"):
+        a2f.audio2feat(np.zeros(480000 + 320, np.float32))
