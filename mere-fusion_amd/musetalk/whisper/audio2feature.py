@@ -132,6 +132,12 @@ class Audio2Feature:
                                "streaming windows of museasr.py, long-file transcription stays with the reference")
         return self.audio2feat_windows_device(wav[None])[0]
 
+    def audio2feat(self, audio_path):
+        if isinstance(audio_path, str):
+            raise RuntimeError("Audio2Feature.audio2feat: file decoding (ffmpeg) is outside the hot path; pass the "
+                               "float32 waveform as museasr.py:25-26 does")
+        return self.audio2feat_device(audio_path).cpu().numpy()
+
     # ---- audio2feature.py:16-45, 82-97: index arithmetic only, kept on the host ---------------------------
     def get_sliced_feature(self, feature_array, vid_idx, audio_feat_length=[2, 2], fps=25):
         length = len(feature_array)
