@@ -168,24 +168,39 @@ def make_speech_like_wav(n, seed=0):
 
 
 # ---- MuseTalk UNet2DConditionModel / AutoencoderKL decoder (diffusers key names) -----
-def _mt_gen(seed):
+def _mt_gen(seed, shapes_only=False):
+    """shapes_only: meta tensors (names + shapes, no storage) -- the key manifest of a checkpoint without drawing 850 M numbers."""
     rng = np.random.default_rng(seed)
+    meta = lambda *shape: torch.empty(shape, dtype=torch.float32, device="meta")
 
     def f(a):
         return torch.from_numpy(np.asarray(a, dtype=np.float32))
 
     def conv(sd, p, ci, co, k, gain=1.0, bias=True):
+        if shapes_only:
+            sd[p + ".weight"] = meta(co, ci, k, k)
+            if bias:
+                sd[p + ".bias"] = meta(co)
+            return
         # float32 draws: the full-size UNet has 860 M parameters
         sd[p + ".weight"] = torch.from_numpy(rng.standard_normal((co, ci, k, k), dtype=np.float32) * np.float32(gain / np.sqrt(ci * k * k)))
         if bias:
             sd[p + ".bias"] = f(rng.standard_normal(co) * 0.05)
 
     def lin(sd, p, ci, co, gain=1.0, bias=True):
+        if shapes_only:
+            sd[p + ".weight"] = meta(co, ci)
+            if bias:
+                sd[p + ".bias"] = meta(co)
+            return
         sd[p + ".weight"] = torch.from_numpy(rng.standard_normal((co, ci), dtype=np.float32) * np.float32(gain / np.sqrt(ci)))
         if bias:
             sd[p + ".bias"] = f(rng.standard_normal(co) * 0.05)
 
     def norm(sd, p, c):
+        if shapes_only:
+            sd[p + ".weight"] = meta(c); sd[p + ".bias"] = meta(c)
+            return
         sd[p + ".weight"] = f(rng.uniform(0.8, 1.2, c))
         sd[p + ".bias"] = f(rng.standard_normal(c) * 0.05)
 
@@ -200,9 +215,9 @@ def _mt_gen(seed):
     return rng, f, conv, lin, norm, resnet
 
 
-def make_musetalk_unet_state_dict(cfg, seed=0):
+def make_musetalk_unet_state_dict(cfg, seed=0, shapes_only=False):
     u = cfg["unet"] if "unet" in cfg else cfg
-    rng, f, conv, lin, norm, resnet = _mt_gen(11000 + seed)
+    rng, f, conv, lin, norm, resnet = _mt_gen(11000 + seed, shapes_only)
     boc, L, X = u["block_out_channels"], u["layers_per_block"], u["cross_attention_dim"]
     temb = boc[0] * 4
     sd = {}
@@ -245,9 +260,9 @@ def make_musetalk_unet_state_dict(cfg, seed=0):
     return sd
 
 
-def make_musetalk_vae_state_dict(cfg, seed=0):
+def make_musetalk_vae_state_dict(cfg, seed=0, shapes_only=False):
     v = cfg["vae"] if "vae" in cfg else cfg
-    rng, f, conv, lin, norm, resnet = _mt_gen(12000 + seed)
+    rng, f, conv, lin, norm, resnet = _mt_gen(12000 + seed, shapes_only)
     boc, L, Z = v["block_out_channels"], v["layers_per_block"], v["latent_channels"]
     sd = {}
     conv(sd, "post_quant_conv", Z, Z, 1, 2.0)

@@ -5,7 +5,10 @@
  * golden vectors, and the reference ships no fixtures for them.  Each function below follows the cited
  * kernel statement by statement, one loop iteration per CUDA thread; what pins it are the hand-derived known-answer tests
  * in tests/test_ernerf.py (slab intersections, Morton codes, SH constants, grid interpolation of affine tables,
- * closed-form compositing).
+ * closed-form compositing) and, for march_rays, expectations derived from the DDA GEOMETRY alone -- which samples an
+ * axis-aligned ray must emit through an occupied voxel slab, and where a two-cascade grid must switch levels (|x| = 1) --
+ * which the HIP kernel is ALSO held to directly, without this file in the loop (test_hip_march_dda_geometry_kats): that
+ * breaks the common mode of two transcriptions by one author.
  *
  * Built with -ffp-contract=off: the HIP kernels are built the same way, so float results agree bit for bit wherever
  * only +,-,*,/ and exact libm functions (frexpf, scalbnf, floorf, ceil) are involved; expf / sinf differ by an ulp or two

@@ -17,6 +17,13 @@ or vectors for this function.  What is restated here is librosa's published algo
 Known-answer checks in tests/test_mel.py: silence -> -4 everywhere; a pure tone peaks in the
 mel band containing its frequency; frame count T = 1 + n//200; the steady-state windows the
 streaming loop consumes (frames 16..79 of 84) do not depend on pad_mode.
+
+Still unpinned against librosa itself, but no longer single-source: tests/test_mel.py also holds this file
+against two independent implementations present in the image --
+  * `torch.stft` (centred, periodic Hann, constant / reflect padding): the STFT to 1e-10;
+  * `transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")` -- a published
+    re-implementation of `librosa.filters.mel` -- for the (80, 401) basis to 2e-7, and
+    `transformers.audio_utils.spectrogram` for the whole magnitude -> mel -> dB chain to 1e-5.
 """
 import numpy as np
 from scipy import signal

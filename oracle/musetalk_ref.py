@@ -18,6 +18,11 @@ upsampling, stride-2 downsampling convs, sinusoidal timestep embedding with flip
 resnets, GroupNorm/SiLU/conv_out), restated from its documentation with diffusers' state-dict key names so
 real checkpoints map onto it [upstream-knowledge, SURVEY Appendix C].  The configuration is a parameter:
 `MUSETALK_V1` is the assumed production config; tests also run a reduced one.
+
+What pins it short of diffusers itself (tests/test_musetalk_manifest.py, tests/test_musetalk.py): the state-dict manifest it consumes
+has the public SD-1.x UNet's 686 tensors and exactly 859,520,964 + 11,520 (in_channels 8) - 9,584,640 (cross-attention dim 384)
+= 849,947,844 parameters, the decoder manifest sd-vae-ft-mse's 49,490,179, and a list of published (name, shape) entries; `_gn` /
+`attention_core` agree with `torch.nn.GroupNorm` / `F.scaled_dot_product_attention`; the MAC count reproduces SURVEY Appendix C.
 """
 import math
 

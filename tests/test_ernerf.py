@@ -183,6 +183,124 @@ def test_oracle_composite_closed_form(ref):
     assert acc2["amb_aud_sum"][1] == 3 and acc2["amb_eye_sum"][1] == 6          # ambient terms are plain sums (raymarching.cu:2207-2208)
 
 
+# ---- known answers for march_rays derived from the DDA GEOMETRY, not from either transcription of the kernel -----------------------
+def _morton_np(x, y, z):
+    def expand(v):
+        v = v.astype(np.uint64)
+        v = (v | (v << 16)) & 0xFF0000FF
+        v = (v | (v << 8)) & 0x0F00F00F
+        v = (v | (v << 4)) & 0xC30C30C3
+        v = (v | (v << 2)) & 0x49249249
+        return v
+    return (expand(x) | (expand(y) << 1) | (expand(z) << 2)).astype(np.int64)
+
+
+def _bitfield(H, cascades, occupied):
+    """occupied(level, nx, ny, nz) -> bool array over the full index grid; Morton order inside each cascade (raymarching.cu:894-895)."""
+    bits = np.zeros(cascades * H ** 3, np.uint8)
+    n = np.arange(H)
+    nx, ny, nz = np.meshgrid(n, n, n, indexing="ij")
+    for lvl in range(cascades):
+        idx = lvl * H ** 3 + _morton_np(nx.ravel(), ny.ravel(), nz.ravel())
+        bits[idx] = occupied(lvl, nx.ravel(), ny.ravel(), nz.ravel())
+    return np.packbits(bits.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+
+
+def dda_case_slab():
+    """One cascade, bound 1, H = 128: a ray along +x enters the box at x = -1 (t = 1).  With dt_gamma = 1/256 and max_steps = 16 the step
+    is pinned to dt_max = dt_min = 2 sqrt(3) / 128 = 0.02706 > one voxel (1/64), so in empty space every DDA skip advances by exactly one
+    step: t_k = 1 + k * dt.  Only the voxel slab nx in [96, 100) -- x in [0.5, 0.5625) -- is occupied: the ray's positions x_k = -1 + k dt
+    fall inside it for k = 56, 57 only (56 dt = 1.5155, 57 dt = 1.5426, 58 dt = 1.5697 > 1.5625).  Expected: exactly two samples."""
+    H = 128
+    grid = _bitfield(H, 1, lambda lvl, nx, ny, nz: ((nx >= 96) & (nx < 100)).astype(np.uint8))
+    ro = np.array([[-2.0, 0.1, 0.1]], np.float32)
+    rd = np.array([[1.0, 1e-9, 1e-9]], np.float32)
+    dt = np.float32(2 * np.sqrt(np.float32(3.0)) / 128)
+    t = np.float32(1.0)
+    ts = []
+    for k in range(60):                                   # the algorithm's own accumulation: t += dt in fp32
+        if k in (56, 57):
+            ts.append(t)
+        t = np.float32(t + dt)
+    want_x = np.array([np.float32(-2.0) + tk for tk in ts], np.float32)
+    return dict(H=H, grid=grid, ro=ro, rd=rd, bound=1.0, cascades=1, max_steps=16, dt_gamma=1 / 256, n_step=8, dt=dt, want_t=np.array(ts, np.float32),
+                want_x=want_x)
+
+
+def dda_case_cascade_switch():
+    """Two cascades, bound 2, H = 128, dt_gamma = 0, max_steps = 1024: dt = dt_min = 2 sqrt(3) / 1024 = 0.003383, small enough that the
+    mip level comes from the POSITION alone (mip_from_dt: dt * H / 2 = 0.2165 < 0.5 -> level 0).  Cascade 1 (|x| in [1, 2)) is fully
+    occupied, cascade 0 (|x| < 1) is empty, so a ray along +x must emit samples exactly while |x| >= 1: for t in [1, 2) and [4, 5) of
+    o = (-3, .1, .1), none in between -- the switch sits at |x| = 1 to within one step."""
+    H = 128
+    grid = _bitfield(H, 2, lambda lvl, nx, ny, nz: np.full(nx.shape, lvl == 1, np.uint8))
+    ro = np.array([[-3.0, 0.1, 0.1]], np.float32)
+    rd = np.array([[1.0, 1e-9, 1e-9]], np.float32)
+    return dict(H=H, grid=grid, ro=ro, rd=rd, bound=2.0, cascades=2, max_steps=1024, dt_gamma=0.0, n_step=700, dt=np.float32(2 * np.sqrt(3.0) / 1024))
+
+
+def _check_slab(xyzs, dirs, deltas, c):
+    d = deltas.reshape(-1, 2)
+    n = int((d[:, 0] > 0).sum())
+    assert n == 2, n                                                            # exactly the two positions inside the occupied slab
+    np.testing.assert_allclose(d[:2, 0], c["dt"], rtol=1e-6)
+    np.testing.assert_allclose(d[:2, 1], c["want_t"] + c["dt"], rtol=1e-6)       # deltas[1] = t after the step (depth)
+    np.testing.assert_allclose(xyzs.reshape(-1, 3)[:2, 0], c["want_x"], atol=2e-6)
+    np.testing.assert_allclose(xyzs.reshape(-1, 3)[:2, 1:], 0.1, atol=1e-6)
+    assert (xyzs.reshape(-1, 3)[2:] == 0).all() and (d[2:] == 0).all()           # the rest of the slot stays zero-filled (raymarching.py:383-385)
+    np.testing.assert_array_equal(dirs.reshape(-1, 3)[:2], np.repeat(c["rd"], 2, axis=0))
+
+
+def _check_cascade_switch(xyzs, deltas, c):
+    d = deltas.reshape(-1, 2)
+    live = d[:, 0] > 0
+    x = xyzs.reshape(-1, 3)[live, 0]
+    dt = float(c["dt"])
+    assert np.all(np.abs(x) >= 1.0 - 1e-6) and np.all(np.abs(x) < 2.0 + 1e-6)     # never a sample from the empty inner cascade
+    left, right = x[x < 0], x[x > 0]
+    # each outer segment is 1 long: 1 / dt = 295.6 steps; the DDA re-entry can cost at most a step at either end
+    assert abs(len(left) - 1.0 / dt) <= 2 and abs(len(right) - 1.0 / dt) <= 2, (len(left), len(right))
+    assert left.max() < -1.0 + 1e-6 and left.max() > -1.0 - 1.5 * dt               # last sample before the switch at x = -1
+    assert right.min() >= 1.0 - 1e-6 and right.min() < 1.0 + 1.5 * dt              # first sample after the switch at x = +1
+    np.testing.assert_allclose(np.diff(left), dt, rtol=2e-3)
+    np.testing.assert_allclose(np.diff(right), dt, rtol=2e-3)
+
+
+def test_oracle_march_dda_geometry_kats(ref):
+    c = dda_case_slab()
+    aabb = np.array([-1, -0.5, -1, 1, 0.5, 1], np.float32)
+    nears, fars = o_near_far(ref, c["ro"], c["rd"], aabb, 0.05)
+    assert nears[0] == 1.0 and fars[0] == 3.0
+    out = o_march(ref, c["n_step"], np.zeros(1, np.int32), nears, c["ro"], c["rd"], c["bound"], c["dt_gamma"], c["max_steps"], c["cascades"], c["H"],
+                  c["grid"], nears, fars, np.zeros(1, np.float32))
+    _check_slab(*out, c)
+    c = dda_case_cascade_switch()
+    aabb = np.array([-2, -1, -2, 2, 1, 2], np.float32)
+    nears, fars = o_near_far(ref, c["ro"], c["rd"], aabb, 0.05)
+    assert nears[0] == 1.0 and fars[0] == 5.0
+    xyzs, dirs, deltas = o_march(ref, c["n_step"], np.zeros(1, np.int32), nears, c["ro"], c["rd"], c["bound"], c["dt_gamma"], c["max_steps"],
+                                 c["cascades"], c["H"], c["grid"], nears, fars, np.zeros(1, np.float32))
+    _check_cascade_switch(xyzs, deltas, c)
+
+
+@pytest.mark.gpu
+def test_hip_march_dda_geometry_kats(lib_built):
+    """The same geometry-derived expectations on the HIP kernel directly (no oracle in the loop: breaks the common mode of two transcriptions)."""
+    from mere_fusion_amd.ernerf import _raymarching_face as rm
+    for c, aabb, check in ((dda_case_slab(), [-1, -0.5, -1, 1, 0.5, 1], "slab"), (dda_case_cascade_switch(), [-2, -1, -2, 2, 1, 2], "switch")):
+        ro, rd = _cu(c["ro"]), _cu(c["rd"])
+        nears, fars = torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
+        rm.near_far_from_aabb(ro, rd, _cu(np.array(aabb, np.float32)), 1, 0.05, nears, fars)
+        n_step = c["n_step"]
+        xyzs, dirs, deltas = (torch.zeros(n_step, k, device="cuda") for k in (3, 3, 2))
+        rm.march_rays(1, n_step, _cu(np.zeros(1, np.int32)), nears.clone(), ro, rd, c["bound"], c["dt_gamma"], c["max_steps"], c["cascades"], c["H"],
+                      _cu(c["grid"]), nears, fars, xyzs, dirs, deltas, torch.zeros(1, device="cuda"))
+        if check == "slab":
+            _check_slab(xyzs.cpu().numpy(), dirs.cpu().numpy(), deltas.cpu().numpy(), c)
+        else:
+            _check_cascade_switch(xyzs.cpu().numpy(), deltas.cpu().numpy(), c)
+
+
 def _scene(n_rays, seed, H=128, cascades=1, density=0.3):
     rng = np.random.default_rng(seed)
     ro = (rng.standard_normal((n_rays, 3)) * 0.1 + [0, 0, -2.2]).astype(np.float32)

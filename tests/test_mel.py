@@ -77,3 +77,45 @@ def test_hip_mel_kats(lib_built):
     assert int(m[:, 40].argmax()) == 10
     with pytest.raises(RuntimeError, match="empty"):
         audio.melspectrogram(np.zeros(0, np.float32))
+
+
+# ---- cross-checks against two INDEPENDENT implementations available in the image (the oracle is no longer single-source) ----
+def test_oracle_stft_matches_torch_stft():
+    """torch.stft with librosa's defaults -- centred, periodic Hann, zero ("constant") or reflect padding -- is an independent
+    implementation of the transform `librosa.stft(y, n_fft=800, hop_length=200, win_length=800)` names (wav2lip/audio.py:61)."""
+    y = torch.from_numpy(_wav(16640, 7)).double()
+    for mode in ("constant", "reflect"):
+        want = torch.stft(y, n_fft=800, hop_length=200, win_length=800, window=torch.hann_window(800, periodic=True, dtype=torch.float64),
+                          center=True, pad_mode=mode, return_complex=True).numpy()
+        got = mel_ref.stft(y.numpy(), mode)
+        assert got.shape == want.shape == (401, 84)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
+
+
+def test_oracle_mel_basis_matches_transformers_filter_bank():
+    """`transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")` is a published re-implementation of
+    `librosa.filters.mel` (its docstring says so); it returns the transpose (401, 80)."""
+    from transformers.audio_utils import mel_filter_bank
+    want = mel_filter_bank(num_frequency_bins=401, num_mel_filters=80, min_frequency=55, max_frequency=7600, sampling_rate=16000,
+                           norm="slaney", mel_scale="slaney").T
+    got = mel_ref.mel_basis()
+    assert got.shape == want.shape == (80, 401)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-7)
+
+
+def test_oracle_melspectrogram_matches_transformers_spectrogram():
+    """The whole chain after the pre-emphasis through transformers' `spectrogram` (magnitude STFT -> mel -> 20 log10 with a floor), then
+    the reference's own affine normalisation (wav2lip/audio.py:103-116)."""
+    from scipy import signal
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+    wav = _wav(16640, 11)
+    y = signal.lfilter([1, -0.97], [1], wav)
+    fb = mel_filter_bank(num_frequency_bins=401, num_mel_filters=80, min_frequency=55, max_frequency=7600, sampling_rate=16000,
+                         norm="slaney", mel_scale="slaney")
+    mel = spectrogram(y, window_function(800, "hann", periodic=True), frame_length=800, hop_length=200, fft_length=800, power=1.0, center=True,
+                      pad_mode="constant", mel_filters=fb, mel_floor=1e-5, dtype=np.float64)           # (80, 84) magnitudes, floored at 10^(-100/20)
+    S = 20 * np.log10(mel) - 20
+    want = np.clip(8 * ((S + 100) / 100) - 4, -4, 4)
+    got = mel_ref.melspectrogram(wav, "constant")
+    assert got.shape == want.shape == (80, 84)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
