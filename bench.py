@@ -370,6 +370,66 @@ def muse_multi_session(args, device):
     return rep
 
 
+def _transport_producer(q, n, shape, batched):
+    frames = np.random.default_rng(0).integers(0, 256, (8,) + shape, dtype=np.uint8)
+    audio = [(np.zeros(320, np.float32), 0)] * 16
+    if batched:
+        for i in range(0, n, 8):
+            q.put_batch(frames, list(range(i, i + 8)), audio)
+    else:
+        for i in range(n):
+            q.put((frames[i % 8], i, audio[:2]))
+    q.put((None, -1, []))
+
+
+def transport_report(args, device):
+    """the reference's `res_frame_queue` (pickled (frame, idx, audio_frames) tuples through mp.Queue, musereal.py:116,153)
+    against the shared-memory FrameRing behind the same tuple contract, one producer process -> this process, 256 x 256 x 3 uint8 frames;
+    and the device -> ring leg of one batch (page-locked slots, one pitched DMA)."""
+    import multiprocessing as mp
+    from mere_fusion_amd.transport import FrameRing
+    ctx = mp.get_context("spawn")
+    shape, n = (256, 256, 3), 2000
+    rep = {"frame_bytes": int(np.prod(shape)), "frames": n, "unit": "frames/s (one producer process -> one consumer)"}
+    for name, make, batched in (("mp_queue_pickled", lambda: ctx.Queue(16), False), ("frame_ring", lambda: FrameRing(16, shape, ctx=ctx), False),
+                                ("frame_ring_put_batch", lambda: FrameRing(16, shape, ctx=ctx), True)):
+        q = make()
+        p = ctx.Process(target=_transport_producer, args=(q, n, shape, batched))
+        p.start()
+        q.get(timeout=120)                                            # first item: the producer is up
+        t0, got = time.perf_counter(), 1
+        while True:
+            f, idx, _ = q.get(timeout=60)
+            if idx == -1:
+                break
+            got += 1
+        rep[name] = round((got - 1) / (time.perf_counter() - t0), 0)
+        p.join(30)
+        if hasattr(q, "close") and isinstance(q, FrameRing):
+            q.close()
+    ring = FrameRing(16, shape, ctx=ctx)
+    frames = torch.randint(0, 256, (args.batch,) + shape, dtype=torch.uint8, device=device)
+    audio = [(np.zeros(320, np.float32), 0)] * (2 * args.batch)
+
+    def one():
+        ring.put_batch(frames, list(range(args.batch)), audio)
+        for _ in range(args.batch):
+            ring.get(timeout=5, copy=False)
+            ring.release()
+    for _ in range(3):
+        one()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        one()
+    rep["device_batch_to_ring_and_out_ms"] = round((time.perf_counter() - t0) / 50 * 1e3, 3)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        frames.cpu().numpy()                                          # vae.py:105
+    rep["device_batch_cpu_numpy_ms"] = round((time.perf_counter() - t0) / 50 * 1e3, 3)
+    ring.close()
+    return rep
+
+
 def whisper_report(args, device):
     """H3 for the same batch: MuseASR.run_step's audio2feat on the B = 8 window ((2B + l + r) * 320 = 11520 samples -> feat (36, 5, 384),
     museasr.py:22-27) -- the reference pads every window to 30 s and runs the whole 1500-token encoder (transcribe.py:108).
@@ -663,6 +723,7 @@ def main():
                                 "note": "step + vae.py:105's `.cpu().numpy()` of the uint8 frames (pageable host memory, one sync per step)"}
             if extras:
                 line["whisper"] = whisper_report(args, device)
+                line["frame_transport"] = transport_report(args, device)
             if args.dump_layers:
                 with open(args.dump_layers, "w") as f_:
                     json.dump({"musetalk_rows": rows, "by_kernel": by}, f_, indent=1)

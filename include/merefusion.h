@@ -407,6 +407,20 @@ int mf_paste_frames(const void* res, int res_is_f32, int res_h, int res_w, const
 /* cv2.resize(src, (dw, dh)) for uint8 [sh][sw][3] with the default INTER_LINEAR (lipreal.py:211, musereal.py:241). */
 int mf_resize_linear_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, void* stream);
 
+/* ---- frame transport ----------------------------------------------------------------------- */
+/* Host-side plumbing of the shared-memory frame ring that replaces the pickled `res_frame_queue` items of
+ * lipreal.py:136,161 / musereal.py:116,153 (mere-fusion_amd/transport.py keeps the (res_frame, idx, audio_frames) tuple
+ * contract).  mf_host_register page-locks a host range (the ring's shared-memory block) once, so that
+ * mf_copy_d2h_async of a batch of frames is one asynchronous DMA into the slot the consumer reads;
+ * mf_stream_synchronize is the fence before the slot is published. */
+int mf_host_register(void* host, size_t bytes);
+int mf_host_unregister(void* host);
+int mf_copy_d2h_async(const void* dev, void* host, size_t bytes, void* stream);
+/* `rows` pieces of width_bytes each: dense on the device (dev_pitch apart), one ring slot apart on the host (host_pitch): a batch of
+ * frames into consecutive slots as one DMA. */
+int mf_copy_d2h_2d_async(const void* dev, size_t dev_pitch, void* host, size_t host_pitch, size_t width_bytes, size_t rows, void* stream);
+int mf_stream_synchronize(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,11 @@ SIGNATURES = {
     "mf_whisper_feature_chunks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mf_paste_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(MfPasteJob), C.c_int,
                                   C.c_void_p, C.c_void_p]),
+    "mf_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "mf_host_unregister": (C.c_int, [C.c_void_p]),
+    "mf_copy_d2h_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mf_copy_d2h_2d_async": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "mf_stream_synchronize": (C.c_int, [C.c_void_p]),
     "mf_resize_linear_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }
 

@@ -32,3 +32,36 @@ extern "C" int mf_init(int device) {
     }
     return MF_OK;
 }
+
+// ---- frame transport: host-side plumbing of the shared-memory frame ring (mere-fusion_amd/transport.py) -------------
+// The reference pickles every generated frame through `mp.Queue` (lipreal.py:136,161, musereal.py:116,153).  The ring keeps the frame
+// bytes in one shared-memory block that the inference process page-locks ONCE, so the device -> host copy of a batch is a single
+// asynchronous DMA straight into the slot the consumer will read; only a small descriptor travels through the queue.
+extern "C" int mf_host_register(void* p, size_t bytes) {
+    MF_REQUIRE(p && bytes > 0, "host_register: null / empty range");
+    MF_HIP(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return MF_OK;
+}
+
+extern "C" int mf_host_unregister(void* p) {
+    MF_REQUIRE(p, "host_unregister: null pointer");
+    MF_HIP(hipHostUnregister(p));
+    return MF_OK;
+}
+
+extern "C" int mf_copy_d2h_async(const void* dev, void* host, size_t bytes, void* stream) {
+    MF_REQUIRE(dev && host && bytes > 0, "copy_d2h_async: null / empty argument");
+    MF_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return MF_OK;
+}
+
+extern "C" int mf_copy_d2h_2d_async(const void* dev, size_t dev_pitch, void* host, size_t host_pitch, size_t width_bytes, size_t rows, void* stream) {
+    MF_REQUIRE(dev && host && width_bytes > 0 && rows > 0 && dev_pitch >= width_bytes && host_pitch >= width_bytes, "copy_d2h_2d_async: bad argument");
+    MF_HIP(hipMemcpy2DAsync(host, host_pitch, dev, dev_pitch, width_bytes, rows, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return MF_OK;
+}
+
+extern "C" int mf_stream_synchronize(void* stream) {
+    MF_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return MF_OK;
+}

@@ -57,6 +57,7 @@ struct ConvArgs {
     int tiles_m, tiles_n;
     unsigned long long* dbg;  // MF_DBG_TIMES: 4 s_memtime stamps per workgroup, or null
     int m_fastest;            // XCD tile order: pixel tiles fastest (weight-heavy layers), see k_conv_igemm
+    int wide_store;           // output view starts on an 8-channel group and N % 8 == 0: 16-byte epilogue stores (lane pairs exchange halves)
     int goff_total;
     // grouped launch (attention: one GEMM per (batch, head) on blockIdx.z): element offsets per group
     int zgroups, zheads;
@@ -86,6 +87,7 @@ struct HaloArgs {
     float* ws; int64_t ws_split; int nsplit;
     // LDS-weights kernel only: GroupNorm + SiLU of the INPUT applied to the halo image in LDS, v = silu(x * gn_scale[b][c] + gn_shift[b][c]); null = none
     const float* gn_scale; const float* gn_shift; int gn_C;
+    unsigned long long* dbg;                    // MF_DBG_TIMES: 4 s_memtime stamps per workgroup (entry, loop start, loop end, exit), or null
 };
 struct HaloTile { int ph, bn, wgm, wgn; };
 HaloTile mf_halo_pick_tile(int H, int W, int N, int batch, int cin = 0);

@@ -102,6 +102,22 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const float (&
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Epilogue stores, 16 bytes per lane.  A lane of the 16 x 16 accumulator tile owns 4 consecutive channels (8 bytes of bf16) of one pixel in
+// every fragment; lanes fk and fk ^ 1 (lane ^ 16) own the two halves of one 8-channel group.  For a fragment PAIR (p0, p1) the even lane
+// takes both halves of p0's group, the odd lane both halves of p1's: one exchange, then ONE dwordx4 store where two dwordx2 went before.
+// The store tail is issue-bound (MI355X_MICROARCH.md: 16 x dwordx2 per lane ~ 9.3k cycles; dwordx4 halves it) and is 20-45 % of the
+// UNet's small GEMMs.  `c16` = first channel of the 16-channel block of p0; p1's block starts `blk` channels later.
+__device__ __forceinline__ void store_pair16(bf16_t* base, int64_t yo, int c16, int blk, int fk, uint2 p0, uint2 p1, int N, bool ok) {
+    const bool odd = fk & 1;
+    const uint2 send = odd ? p0 : p1;
+    uint2 recv;
+    recv.x = (uint32_t)__shfl_xor((int)send.x, 16);
+    recv.y = (uint32_t)__shfl_xor((int)send.y, 16);
+    const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+    const int cw = c16 + (odd ? blk : 0) + (fk & ~1) * 4;
+    if (ok && cw < N) *reinterpret_cast<uint4*>(base + yo + cw) = out;
+}
+
 // NST = LDS ring depth.  2: DMA of tile k+1 under the MFMAs of tile k, drained at a __syncthreads().
 // >= 3: NST-1 tiles in flight; each wave waits only for ITS OWN share of the tile it is about to read
 // (counted s_waitcnt vmcnt, every wave issues the same number of DMA instructions per tile) and a raw
@@ -363,84 +379,134 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
             const int m = m0 + pm0 + j * 16 + fr;
-            if (m >= a.M) continue;
-            const int b = m / a.HqWq;
-            const int rem = m - b * a.HqWq;
+            const bool row_ok = m < a.M;
+            const int mc = row_ok ? m : a.M - 1;
+            const int b = mc / a.HqWq;
+            const int rem = mc - b * a.HqWq;
             const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
             const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
+            uint2 pk_hi[FN / 2 > 0 ? FN / 2 : 1], pk_lo[FN / 2 > 0 ? FN / 2 : 1];
 #pragma unroll
             for (int i = 0; i + 1 < FN; i += 2) {
-                const int c = n0 + cn0 + i * 16 + fk * 4;
-                if (c >= a.N) continue;
                 const float v[4] = {(acc[i][j][0] + bq[i].x) * gelu_erf(acc[i + 1][j][0] + bq[i + 1].x), (acc[i][j][1] + bq[i].y) * gelu_erf(acc[i + 1][j][1] + bq[i + 1].y),
                                     (acc[i][j][2] + bq[i].z) * gelu_erf(acc[i + 1][j][2] + bq[i + 1].z), (acc[i][j][3] + bq[i].w) * gelu_erf(acc[i + 1][j][3] + bq[i + 1].w)};
-                const int co = (n0 + cn0 + i * 16) / 2 + fk * 4;
                 uint32_t h[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
-                *reinterpret_cast<uint2*>(a.y_hi + yo + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                pk_hi[i / 2] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
                 if (X3) {
                     uint32_t l[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
-                    *reinterpret_cast<uint2*>(a.y_lo + yo + co) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                    pk_lo[i / 2] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                }
+            }
+            const int NO = a.N >> 1;                                  // output channels
+            if (FN % 4 == 0 && a.wide_store) {
+#pragma unroll
+                for (int q = 0; q + 1 < FN / 2; q += 2) {
+                    const int c16 = (n0 + cn0 + 2 * q * 16) / 2;      // output block of fragment pair q; pair q + 1's block is 16 channels on
+                    store_pair16(a.y_hi, yo, c16, 16, fk, pk_hi[q], pk_hi[q + 1], NO, row_ok);
+                    if (X3) store_pair16(a.y_lo, yo, c16, 16, fk, pk_lo[q], pk_lo[q + 1], NO, row_ok);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < FN / 2; ++q) {
+                    const int c = n0 + cn0 + 2 * q * 16 + fk * 4;
+                    if (!row_ok || c >= a.N) continue;
+                    const int co = (n0 + cn0 + 2 * q * 16) / 2 + fk * 4;
+                    *reinterpret_cast<uint2*>(a.y_hi + yo + co) = pk_hi[q];
+                    if (X3) *reinterpret_cast<uint2*>(a.y_lo + yo + co) = pk_lo[q];
                 }
             }
         }
     } else {
-        constexpr bool GEGLU = false;
+        // Residual loads of a whole row group go out in one burst BEFORE that group's stores: a load issued behind a store also waits for
+        // the store's acknowledgement (loads and stores retire through one in-order vmcnt on gfx9), so "load row j, store row j, load row
+        // j + 1, ..." pays a store round trip per row.  Groups are sized to <= 64 VGPRs of residual.
+        constexpr int RB = (FM * FN >= 32) ? 16 : 32;      // (the 256 x 256 tile already sits at the register limit: smaller bursts, no extra spills)
+        constexpr int JG = (FM * FN * NP <= RB) ? FM : (RB / (FN * NP) >= 1 ? RB / (FN * NP) : 1);
+        const bool has_res = a.r_hi != nullptr;
+        const bool after = a.res_after_act;
 #pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            const int m = m0 + pm0 + j * 16 + fr;
-            if (m >= a.M) continue;
-            const int b = m / a.HqWq;
-            const int rem = m - b * a.HqWq;
-            const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
-            const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
-            const int64_t ro = (int64_t)b * a.rb + (int64_t)qi * a.ri + (int64_t)qj * a.rj;
-            uint2 rh[FN], rl[FN];
-            const bool has_res = !GEGLU && a.r_hi != nullptr;
+        for (int j0 = 0; j0 < FM; j0 += JG) {
+            uint2 rh[JG][FN], rl[JG][FN];
             if (has_res) {
 #pragma unroll
-                for (int i = 0; i < FN; ++i) {
-                    int c = n0 + cn0 + i * 16 + fk * 4;
-                    c = c < a.N ? c : 0;
-                    rh[i] = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
-                    if (X3) rl[i] = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
+                for (int jj = 0; jj < JG; ++jj) {
+                    if (j0 + jj >= FM) break;
+                    int m = m0 + pm0 + (j0 + jj) * 16 + fr;
+                    m = m < a.M ? m : a.M - 1;                      // clamped, never branched around: the stores are masked
+                    const int b = m / a.HqWq;
+                    const int rem = m - b * a.HqWq;
+                    const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+                    const int64_t ro = (int64_t)b * a.rb + (int64_t)qi * a.ri + (int64_t)qj * a.rj;
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) {
+                        int c = n0 + cn0 + i * 16 + fk * 4;
+                        c = c < a.N ? c : 0;
+                        rh[jj][i] = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
+                        if (X3) rl[jj][i] = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
+                    }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const int c = n0 + cn0 + i * 16 + fk * 4;
-                float v[4] = {acc[i][j][0] + bq[i].x, acc[i][j][1] + bq[i].y, acc[i][j][2] + bq[i].z, acc[i][j][3] + bq[i].w};
-                float r[4] = {0.f, 0.f, 0.f, 0.f};
-                if (has_res) {
-                    r[0] = bf2f(rh[i].x & 0xffffu); r[1] = bf2f(rh[i].x >> 16); r[2] = bf2f(rh[i].y & 0xffffu); r[3] = bf2f(rh[i].y >> 16);
+            for (int jj = 0; jj < JG; ++jj) {
+                const int j = j0 + jj;
+                if (j >= FM) break;
+                const int m = m0 + pm0 + j * 16 + fr;
+                const bool row_ok = m < a.M;
+                const int mc = row_ok ? m : a.M - 1;
+                const int b = mc / a.HqWq;
+                const int rem = mc - b * a.HqWq;
+                const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+                const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
+                uint2 pk_hi[FN], pk_lo[FN];
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    float v[4] = {acc[i][j][0] + bq[i].x, acc[i][j][1] + bq[i].y, acc[i][j][2] + bq[i].z, acc[i][j][3] + bq[i].w};
+                    float r[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (has_res) {
+                        r[0] = bf2f(rh[jj][i].x & 0xffffu); r[1] = bf2f(rh[jj][i].x >> 16); r[2] = bf2f(rh[jj][i].y & 0xffffu); r[3] = bf2f(rh[jj][i].y >> 16);
+                        if (X3) {
+                            r[0] += bf2f(rl[jj][i].x & 0xffffu); r[1] += bf2f(rl[jj][i].x >> 16); r[2] += bf2f(rl[jj][i].y & 0xffffu); r[3] += bf2f(rl[jj][i].y >> 16);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = v[e] + (after ? 0.f : r[e]);
+                        if (ACT == 1) x = fmaxf(x, 0.f);
+                        else if (ACT == 2) x = 1.f / (1.f + __expf(-x));
+                        else if (ACT == 3) x = gelu_erf(x);
+                        else if (ACT == 4) x = x / (1.f + expf(-x));
+                        v[e] = x + (after ? r[e] : 0.f);
+                    }
+                    uint32_t h[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
+                    pk_hi[i] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
                     if (X3) {
-                        r[0] += bf2f(rl[i].x & 0xffffu); r[1] += bf2f(rl[i].x >> 16); r[2] += bf2f(rl[i].y & 0xffffu); r[3] += bf2f(rl[i].y >> 16);
+                        uint32_t l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
+                        pk_lo[i] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
                     }
                 }
-                const bool after = a.res_after_act;
+                if (FN % 2 == 0 && a.wide_store) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = v[e] + (after ? 0.f : r[e]);
-                    if (ACT == 1) x = fmaxf(x, 0.f);
-                    else if (ACT == 2) x = 1.f / (1.f + __expf(-x));
-                    else if (ACT == 3) x = gelu_erf(x);
-                    else if (ACT == 4) x = x / (1.f + expf(-x));
-                    v[e] = x + (after ? r[e] : 0.f);
-                }
-                if (c >= a.N) continue;
-                const int co = GEGLU ? (n0 + cn0 + i * 16) / 2 + fk * 4 : c;
-                uint32_t h[4];
+                    for (int i = 0; i + 1 < FN; i += 2) {
+                        const int c16 = n0 + cn0 + i * 16;
+                        store_pair16(a.y_hi, yo, c16, 16, fk, pk_hi[i], pk_hi[i + 1], a.N, row_ok);
+                        if (X3) store_pair16(a.y_lo, yo, c16, 16, fk, pk_lo[i], pk_lo[i + 1], a.N, row_ok);
+                    }
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
-                *reinterpret_cast<uint2*>(a.y_hi + yo + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                if (X3) {
-                    uint32_t l[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
-                    *reinterpret_cast<uint2*>(a.y_lo + yo + co) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                    for (int i = 0; i < FN; ++i) {
+                        const int c = n0 + cn0 + i * 16 + fk * 4;
+                        if (!row_ok || c >= a.N) continue;
+                        *reinterpret_cast<uint2*>(a.y_hi + yo + c) = pk_hi[i];
+                        if (X3) *reinterpret_cast<uint2*>(a.y_lo + yo + c) = pk_lo[i];
+                    }
                 }
             }
         }
@@ -1028,6 +1094,11 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
     }
     a.act = p->d.act;
     a.res_after_act = p->d.residual == 2;
+    {
+        static const bool narrow = [] { const char* e = getenv("MF_STORE16"); return e && atoi(e) == 0; }();   // A/B: MF_STORE16=0 keeps 8-byte stores
+        const int n_out = p->d.act == 5 ? p->d.cout / 2 : p->d.cout;
+        a.wide_store = !narrow && out.coff % 8 == 0 && ob.C % 8 == 0 && n_out % 8 == 0 && p->d.cout % 16 == 0;
+    }
     a.goff_total = p->goff_total;
     int goff_max = 0;
     for (int ph = 0; ph < p->nphase; ++ph) {

@@ -270,44 +270,75 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4 && (PH / WGM) * (BN
         if (keep == 1234.5f) a.y_hi[0] = 1;
         return;
     }
+    // Loads ahead of the stores they do not depend on (see mf_conv_halo2.hip's epilogue): bias quads once, the residuals of a row group
+    // in one burst, then that group's stores -- a load issued behind a store waits for the store's acknowledgement too (one in-order vmcnt).
+    float4 bq[FN];
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const int oy = y0 + row0 + j, ox = x0 + fr;
-        if (oy >= a.H || ox >= a.W) continue;
-        const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
-        const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)ox * a.rj;
+    for (int i = 0; i < FN; ++i) {
+        int c = n0 + cn0 + i * 16 + fk * 4;
+        c = c < a.Npad - 3 ? c : a.Npad - 4;
+        bq[i] = *reinterpret_cast<const float4*>(a.bias + c);
+    }
+    const bool has_res = a.r_hi != nullptr && !(MF_HALO_ABLATE & 0);
+    const int ox = x0 + fr;
+    constexpr int JG = (FM * FN * NP <= 32) ? FM : (32 / (FN * NP) >= 1 ? 32 / (FN * NP) : 1);   // rows per residual burst
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            const int c = n0 + cn0 + i * 16 + fk * 4;
-            if (c >= a.N) continue;
-            const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
-            float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-            if (a.r_hi) {
-                const uint2 rh = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
-                v[0] += hbf2f(rh.x & 0xffffu); v[1] += hbf2f(rh.x >> 16);
-                v[2] += hbf2f(rh.y & 0xffffu); v[3] += hbf2f(rh.y >> 16);
-                if (X3) {
-                    const uint2 rl = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
-                    v[0] += hbf2f(rl.x & 0xffffu); v[1] += hbf2f(rl.x >> 16);
-                    v[2] += hbf2f(rl.y & 0xffffu); v[3] += hbf2f(rl.y >> 16);
+    for (int j0 = 0; j0 < FM; j0 += JG) {
+        uint2 rh[JG][FN], rl[JG][FN];
+        if (has_res) {
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj) {
+                const int j = j0 + jj;
+                if (j >= FM) break;
+                int oy = y0 + row0 + j, oxc = ox;
+                oy = oy < a.H ? oy : a.H - 1; oxc = oxc < a.W ? oxc : a.W - 1;      // clamped, never branched around: the stores are masked
+                const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)oxc * a.rj;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    int c = n0 + cn0 + i * 16 + fk * 4;
+                    c = c < a.N ? c : 0;
+                    rh[jj][i] = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
+                    if (X3) rl[jj][i] = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
                 }
             }
-            if (a.act == 1) {
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (a.act == 2) {
+        for (int jj = 0; jj < JG; ++jj) {
+            const int j = j0 + jj;
+            if (j >= FM) break;
+            const int oy = y0 + row0 + j;
+            const bool row_ok = oy < a.H && ox < a.W;
+            const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
-            }
-            uint32_t h[4];
+            for (int i = 0; i < FN; ++i) {
+                const int c = n0 + cn0 + i * 16 + fk * 4;
+                float v[4] = {acc[i][j][0] + bq[i].x, acc[i][j][1] + bq[i].y, acc[i][j][2] + bq[i].z, acc[i][j][3] + bq[i].w};
+                if (has_res) {
+                    v[0] += hbf2f(rh[jj][i].x & 0xffffu); v[1] += hbf2f(rh[jj][i].x >> 16);
+                    v[2] += hbf2f(rh[jj][i].y & 0xffffu); v[3] += hbf2f(rh[jj][i].y >> 16);
+                    if (X3) {
+                        v[0] += hbf2f(rl[jj][i].x & 0xffffu); v[1] += hbf2f(rl[jj][i].x >> 16);
+                        v[2] += hbf2f(rl[jj][i].y & 0xffffu); v[3] += hbf2f(rl[jj][i].y >> 16);
+                    }
+                }
+                if (a.act == 1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = hf2bf(v[e]);
-            *reinterpret_cast<uint2*>(a.y_hi + yo + c) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-            if (X3) {
-                uint32_t l[4];
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (a.act == 2) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) l[e] = hf2bf(v[e] - hbf2f(h[e]));
-                *reinterpret_cast<uint2*>(a.y_lo + yo + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                    for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+                }
+                if (!row_ok || c >= a.N) continue;
+                uint32_t h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = hf2bf(v[e]);
+                *reinterpret_cast<uint2*>(a.y_hi + yo + c) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                if (X3) {
+                    uint32_t l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = hf2bf(v[e] - hbf2f(h[e]));
+                    *reinterpret_cast<uint2*>(a.y_lo + yo + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                }
             }
         }
     }

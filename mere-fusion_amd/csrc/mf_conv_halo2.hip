@@ -13,6 +13,9 @@
 // source address and again on the ds_read side, exactly as in the other two conv kernels.
 #include "mf_conv.h"
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -86,6 +89,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long* dbg = a.dbg ? a.dbg + 4 * ((size_t)blockIdx.x + gridDim.x * (size_t)blockIdx.y) : nullptr;
+    if (dbg && threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memtime();
 
     // XCD-aware order, n tile fastest
     const int nt = a.n_patches * a.tiles_n;
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     load_halo(s_begin, 0);
     load_wrow(s_begin, 0, 0);
     __syncthreads();                           // drains the DMA (vmcnt) and publishes halo stage 0 + weight row 0
+    if (dbg && threadIdx.x == 0) dbg[1] = __builtin_amdgcn_s_memtime();
     int wbuf = 0;
     for (int slice = s_begin; slice < s_end; ++slice) {
         const bool more = slice + 1 < s_end;
@@ -329,6 +335,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
+    if (dbg && threadIdx.x == 0) dbg[2] = __builtin_amdgcn_s_memtime();
     if (MF_HALO_ABLATE & 1) {
         float keep = 0.f;
 #pragma unroll
@@ -355,46 +362,85 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         }
         return;
     }
+    // Every global LOAD of the epilogue is issued ahead of the stores it does not depend on.  Written the obvious way -- per (row, fragment):
+    // bias quad, residual (hi, lo), store (hi, lo) -- each load sits behind the previous fragment's stores: the output may alias the
+    // residual, so the compiler cannot hoist it, and on gfx9 loads and stores retire through ONE in-order counter (vmcnt), so the wait for
+    // that load is also a wait for the store acknowledgements in front of it.  32 fragments x (store ack + load) was ~95 us of a 205 us
+    // tile on the VAE's 256-channel layers (fit over the 8- and 16-slice launches of the r02a profile; 42 us without a residual: the
+    // bias quads alone).  Now: bias quads once, residuals of a whole row group (<= 64 VGPRs) in one burst, then that group's stores.
+    float4 bq[FN];
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const int oy = y0 + row0 + j, ox = x0 + fr;
-        if (oy >= a.H || ox >= a.W) continue;
-        const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
-        const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)ox * a.rj;
+    for (int i = 0; i < FN; ++i) {
+        int c = n0 + cn0 + i * 16 + fk * 4;
+        c = c < a.Npad - 3 ? c : a.Npad - 4;
+        bq[i] = *reinterpret_cast<const float4*>(a.bias + c);
+    }
+    const bool has_res = a.r_hi != nullptr && !(MF_HALO_ABLATE & 16);
+    const int ox = x0 + fr;
+    constexpr int JG = (FM * FN * NP <= 32) ? FM : (32 / (FN * NP) >= 1 ? 32 / (FN * NP) : 1);   // rows per residual burst
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            const int c = n0 + cn0 + i * 16 + fk * 4;
-            if (c >= a.N) continue;
-            const float4 bv = *reinterpret_cast<const float4*>(a.bias + c);
-            float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-            if (a.r_hi && !(MF_HALO_ABLATE & 16)) {
-                const uint2 rh = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
-                v[0] += hbf2f(rh.x & 0xffffu); v[1] += hbf2f(rh.x >> 16);
-                v[2] += hbf2f(rh.y & 0xffffu); v[3] += hbf2f(rh.y >> 16);
-                if (X3) {
-                    const uint2 rl = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
-                    v[0] += hbf2f(rl.x & 0xffffu); v[1] += hbf2f(rl.x >> 16);
-                    v[2] += hbf2f(rl.y & 0xffffu); v[3] += hbf2f(rl.y >> 16);
+    for (int j0 = 0; j0 < FM; j0 += JG) {
+        uint2 rh[JG][FN], rl[JG][FN];
+        if (has_res) {
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj) {
+                const int j = j0 + jj;
+                if (j >= FM) break;
+                int oy = y0 + row0 + j, oxc = ox;
+                oy = oy < a.H ? oy : a.H - 1; oxc = oxc < a.W ? oxc : a.W - 1;      // clamped, never branched around: the stores are masked
+                const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)oxc * a.rj;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    int c = n0 + cn0 + i * 16 + fk * 4;
+                    c = c < a.N ? c : 0;
+                    rh[jj][i] = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
+                    if (X3) rl[jj][i] = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
                 }
             }
-            if (a.act == 1) {
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (a.act == 2) {
+        for (int jj = 0; jj < JG; ++jj) {
+            const int j = j0 + jj;
+            if (j >= FM) break;
+            const int oy = y0 + row0 + j;
+            const bool row_ok = oy < a.H && ox < a.W;
+            const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
-            }
-            uint32_t h[4];
+            for (int i = 0; i < FN; ++i) {
+                const int c = n0 + cn0 + i * 16 + fk * 4;
+                float v[4] = {acc[i][j][0] + bq[i].x, acc[i][j][1] + bq[i].y, acc[i][j][2] + bq[i].z, acc[i][j][3] + bq[i].w};
+                if (has_res) {
+                    v[0] += hbf2f(rh[jj][i].x & 0xffffu); v[1] += hbf2f(rh[jj][i].x >> 16);
+                    v[2] += hbf2f(rh[jj][i].y & 0xffffu); v[3] += hbf2f(rh[jj][i].y >> 16);
+                    if (X3) {
+                        v[0] += hbf2f(rl[jj][i].x & 0xffffu); v[1] += hbf2f(rl[jj][i].x >> 16);
+                        v[2] += hbf2f(rl[jj][i].y & 0xffffu); v[3] += hbf2f(rl[jj][i].y >> 16);
+                    }
+                }
+                if (a.act == 1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = hf2bf(v[e]);
-            *reinterpret_cast<uint2*>(a.y_hi + yo + c) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-            if (X3) {
-                uint32_t l[4];
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (a.act == 2) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) l[e] = hf2bf(v[e] - hbf2f(h[e]));
-                *reinterpret_cast<uint2*>(a.y_lo + yo + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                    for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+                }
+                if (!row_ok || c >= a.N) continue;
+                uint32_t h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = hf2bf(v[e]);
+                *reinterpret_cast<uint2*>(a.y_hi + yo + c) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                if (X3) {
+                    uint32_t l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = hf2bf(v[e] - hbf2f(h[e]));
+                    *reinterpret_cast<uint2*>(a.y_lo + yo + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                }
             }
         }
+    }
+    if (dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // measurement only: the stamp includes the store acknowledgements
+        if (threadIdx.x == 0) dbg[3] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -413,8 +459,38 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     constexpr int CK = X3 ? 32 : 64, RPC = 1024 / (CK * 2), NP = X3 ? 2 : 1;
     constexpr int HCH = ((PH + 2) * (PW + 2) + RPC - 1) / RPC;
     const size_t lds = (size_t)HS * NP * HCH * 1024 + (size_t)2 * TR * NP * BN * CK * 2;
-    hipLaunchKernelGGL(kern, dim3(a.n_patches * a.tiles_n, a.nsplit > 1 ? a.nsplit : 1), dim3(WGM * WGN * 64), lds, s, a);
+    static const bool dbg_times = getenv("MF_DBG_TIMES") != nullptr;
+    HaloArgs aa = a;
+    const size_t nwg = (size_t)a.n_patches * a.tiles_n * (a.nsplit > 1 ? a.nsplit : 1);
+    if (dbg_times && nwg <= 65536) {
+        static unsigned long long* dbg_buf = nullptr;
+        if (!dbg_buf) MF_HIP(hipMalloc(&dbg_buf, (size_t)4 * 65536 * sizeof(unsigned long long)));
+        aa.dbg = dbg_buf;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_patches * a.tiles_n, a.nsplit > 1 ? a.nsplit : 1), dim3(WGM * WGN * 64), lds, s, aa);
     MF_HIP(hipGetLastError());
+    if (aa.dbg) {
+        static int reports = 0;
+        if (++reports > 3 && reports <= 6) {   // skip the warm-up launches
+            MF_HIP(hipStreamSynchronize(s));
+            std::vector<unsigned long long> t(4 * nwg);
+            MF_HIP(hipMemcpy(t.data(), aa.dbg, t.size() * sizeof(t[0]), hipMemcpyDeviceToHost));
+            unsigned long long lo = ~0ull, hi = 0;
+            std::vector<double> d[3], start, end;
+            for (size_t w = 0; w < nwg; ++w) {
+                lo = std::min(lo, t[4 * w]); hi = std::max(hi, t[4 * w + 3]);
+                for (int k = 0; k < 3; ++k) d[k].push_back((double)(t[4 * w + k + 1] - t[4 * w + k]));
+            }
+            for (size_t w = 0; w < nwg; ++w) { start.push_back((double)(t[4 * w] - lo)); end.push_back((double)(t[4 * w + 3] - lo)); }
+            auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            auto mx = [](const std::vector<double>& v) { return *std::max_element(v.begin(), v.end()); };
+            // s_memtime ticks at 100 MHz on gfx9: 10 ns per tick
+            fprintf(stderr, "[MF_DBG_TIMES halo_w<%d,%d,%d,%d>] %zu WGs, %d slices: span %.1f; prologue med %.1f max %.1f; loop med %.1f max %.1f; "
+                            "epilogue (to store acks) med %.1f max %.1f; WG start med %.1f max %.1f; WG end med %.1f (s_memtime ticks)\n",
+                    PH, BN, WGM, WGN, nwg, a.n_slices, (hi - lo) * 1.0, med(d[0]), mx(d[0]), med(d[1]), mx(d[1]), med(d[2]),
+                    mx(d[2]), med(start), mx(start), med(end));
+        }
+    }
     return MF_OK;
 }
 

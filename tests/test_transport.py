@@ -1,0 +1,110 @@
+"""Frame transport: the shared-memory ring that stands where `res_frame_queue = mp.Queue(batch_size * 2)` stood
+(lipreal.py:161, musereal.py:153), behind the same `(res_frame | None, idx, audio_frames)` tuple contract."""
+import multiprocessing as mp
+import queue
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from mere_fusion_amd.transport import FrameRing
+
+
+def _audio(i):
+    return [((np.arange(320, dtype=np.float32) + i) / 1000, 0), (np.zeros(320, np.float32), 1)]     # two (pcm, type) pairs per frame (lipreal.py:136)
+
+
+def _producer(ring, n, shape, seed):
+    """The inference process of lipreal.py:85-141 in miniature: frames, a silent chunk (None frame), frames."""
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        frame = None if i % 5 == 3 else rng.integers(0, 256, shape, dtype=np.uint8)
+        ring.put((frame, i, _audio(i)))
+    ring.put((None, -1, []))                                        # end marker
+
+
+def test_ring_keeps_the_tuple_contract_across_processes():
+    shape = (256, 256, 3)
+    ring = FrameRing(slots=4, frame_shape=shape)                    # far fewer slots than frames: the producer must block and resume
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_producer, args=(ring, 23, shape, 7))
+    p.start()
+    rng = np.random.default_rng(7)
+    got = 0
+    while True:
+        frame, idx, audio = ring.get(block=True, timeout=30)        # process_frames: res_frame, idx, audio_frames = queue.get(block=True, timeout=1)
+        if idx == -1:
+            break
+        assert idx == got
+        want = None if idx % 5 == 3 else rng.integers(0, 256, shape, dtype=np.uint8)
+        if want is None:
+            assert frame is None
+        else:
+            assert frame.dtype == np.uint8 and frame.shape == shape and np.array_equal(frame, want)
+        assert len(audio) == 2 and audio[0][1] == 0 and audio[1][1] == 1 and np.array_equal(audio[0][0], _audio(idx)[0][0])
+        got += 1
+    p.join(30)
+    assert got == 23 and p.exitcode == 0
+    with pytest.raises(queue.Empty):
+        ring.get(block=True, timeout=0.05)
+    ring.close()
+
+
+def test_ring_bounds_and_views():
+    ring = FrameRing(slots=2, frame_shape=(96, 96, 3), dtype=np.float32)      # Wav2Lip: float32 `pred * 255` frames (lipreal.py:126)
+    a, b = np.full((96, 96, 3), 1.5, np.float32), np.full((96, 96, 3), 2.5, np.float32)
+    ring.put((a, 0, []))
+    ring.put((b, 1, []))
+    with pytest.raises(queue.Full):
+        ring.put((a, 2, []), block=True, timeout=0.05)              # the reference's bounded queue blocks the producer the same way
+    time.sleep(0.05)                                                # (mp.Queue hands items to its feeder thread asynchronously)
+    view, idx, _ = ring.get(timeout=5, copy=False)                  # zero-copy read: a view into the ring
+    assert idx == 0 and view.dtype == np.float32 and float(view[3, 4, 1]) == 1.5 and not view.flags.owndata
+    with pytest.raises(queue.Full):
+        ring.put((a, 2, []), block=True, timeout=0.05)              # still held by the consumer
+    del view
+    ring.release()
+    ring.put((a * 2, 2, []), timeout=5)                              # slot 0 again
+    f1, i1, _ = ring.get(timeout=5)
+    f2, i2, _ = ring.get(timeout=5)
+    assert (i1, i2) == (1, 2) and float(f1[0, 0, 0]) == 2.5 and float(f2[0, 0, 0]) == 3.0
+    with pytest.raises(ValueError, match="does not fit"):
+        ring.put((np.zeros((97, 96, 3), np.float32), 3, []))
+    ring.close()
+
+
+def test_ring_put_batch_host_frames():
+    ring = FrameRing(slots=16, frame_shape=(256, 256, 3))
+    frames = np.random.default_rng(1).integers(0, 256, (8, 256, 256, 3), dtype=np.uint8)
+    audio = [(np.zeros(320, np.float32), 0)] * 16
+    for rep in range(3):                                            # the third batch wraps around the ring
+        ring.put_batch(frames, list(range(8 * rep, 8 * rep + 8)), audio)
+        for i in range(8):
+            f, idx, au = ring.get(timeout=5)
+            assert idx == 8 * rep + i and np.array_equal(f, frames[i]) and len(au) == 2
+    ring.close()
+
+
+@pytest.mark.gpu
+def test_ring_takes_device_frames_by_dma(lib_built):
+    """uint8 frames straight from HBM into the page-locked ring (single put and put_batch incl. the wrap-around split into two DMAs)."""
+    ring = FrameRing(slots=12, frame_shape=(256, 256, 3))
+    frames = torch.randint(0, 256, (8, 256, 256, 3), dtype=torch.uint8, device="cuda")
+    host = frames.cpu().numpy()
+    ring.put((frames[3], 42, _audio(1)))
+    f, idx, _ = ring.get(timeout=5)
+    assert idx == 42 and np.array_equal(f, host[3])
+    audio = [(np.zeros(320, np.float32), 0)] * 16
+    for rep in range(4):                                            # 1 + 8 * rep slots in: reps 1.. cross the end of the 12-slot ring
+        ring.put_batch(frames, list(range(8)), audio)
+        for i in range(8):
+            f, idx, _ = ring.get(timeout=5)
+            assert idx == i and np.array_equal(f, host[i]), (rep, i)
+    f32 = torch.rand(2, 96, 96, 3, device="cuda") * 255
+    ring2 = FrameRing(slots=4, frame_shape=(96, 96, 3), dtype=np.float32)
+    ring2.put_batch(f32, [0, 1], audio[:4])
+    for i in range(2):
+        f, idx, _ = ring2.get(timeout=5)
+        assert f.dtype == np.float32 and np.array_equal(f, f32[i].cpu().numpy())
+    ring.close(); ring2.close()

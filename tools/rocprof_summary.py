@@ -31,7 +31,7 @@ def main(path, top=60):
     sel = ", ".join(grid + wg)
     rows = c.execute(f"select name, {sel}, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
                      f"group by name, {sel} order by sum(duration) desc limit {top}").fetchall()
-    print(f"\n## by (kernel, grid {'x'.join(g[-1] for g in grid)} in work-items, workgroup) -- top {top} by total time\n")
+    print(f"\n## by (kernel, grid x * y * z in work-items, workgroup) -- top {top} by total time\n")
     print("| kernel | grid | workgroup | calls | total ms | avg us | min us | max us | % |")
     print("|---|---|---|---:|---:|---:|---:|---:|---:|")
     for r in rows:
