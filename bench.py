@@ -192,18 +192,19 @@ def roofline(rows, precision, only_mfma=False):
     }, by
 
 
-def pmc_traffic(kernel, workload, precision, batch_args):
+def pmc_traffic(kernel, workload, precision, batch_args, want_clock=True):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC counters, collected as MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE
     and WRITE_SIZE in SEPARATE passes (they do not fit one), --kernel-trace only beside --pmc, values in KiB; on gfx950 FETCH_SIZE
     tallies 128-byte requests of wide coalesced reads at 64 bytes, so the read side is doubled.  WRITE_SIZE is uncalibrated (guide).
-    Each pass re-runs this script for 2 steps in a child process under rocprofv3."""
+    A third pass reads GRBM_GUI_ACTIVE: effective clock = busy cycles / dispatch wall time (the guide's DVFS note) -- MFMA-dense kernels run
+    power-capped well under the 2.4 GHz the nominal peak assumes.  Each pass re-runs this script for 2 steps in a child process."""
     import csv, glob, shutil, subprocess, tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", None
     want = "void" + kernel.replace(" ", "")[:-1]                # "voidk_conv_igemm<256,256,2,4,true,32" (+ ",<ring depth>>" or ">")
-    vals = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    vals, clock = {}, None
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE") + (("GRBM_GUI_ACTIVE",) if want_clock else ()):
         d = tempfile.mkdtemp(prefix="mf_pmc_")
         cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
                "--workload", workload, "--precision", precision, "--steps", "2", "--warmup", "1", "--extras", "0", "--cpu-seconds", "0",
@@ -211,20 +212,34 @@ def pmc_traffic(kernel, workload, precision, batch_args):
         env = dict(os.environ, TMPDIR="/tmp")
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
-            tot, n = 0.0, 0
+            tot, n, ns = 0.0, 0, 0.0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     kn = r.get("Kernel_Name", "").replace(" ", "")
                     if r.get("Counter_Name") == ctr and kn.startswith(want) and kn[len(want):len(want) + 1] in (",", ">"):
                         tot += float(r["Counter_Value"]); n += 1
+                        if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                            ns += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
             if n == 0:
-                return None, f"no {ctr} rows for {kernel}"
-            vals[ctr] = tot / n * 1024.0
+                if ctr == "GRBM_GUI_ACTIVE":
+                    continue
+                return None, f"no {ctr} rows for {kernel}", None
+            if ctr == "GRBM_GUI_ACTIVE":
+                if ns > 0:
+                    ghz = tot / ns                                   # cycles per ns
+                    if ghz > 4.0:                                    # (summed over the 8 XCDs)
+                        ghz /= 8.0
+                    clock = round(ghz, 3)
+            else:
+                vals[ctr] = tot / n * 1024.0
         except Exception as e:   # measurement leg only: the bench line is still valid without it
-            return None, f"{ctr} pass failed: {type(e).__name__}"
+            if ctr == "GRBM_GUI_ACTIVE":
+                continue
+            return None, f"{ctr} pass failed: {type(e).__name__}", None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate rocprofv3 --pmc passes, per launch"
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate rocprofv3 --pmc passes, per launch",
+            clock)
 
 
 def parity_error(runner_model, batch=2):
@@ -295,7 +310,7 @@ def wav2lip_report(args, device, world, rank, value=None, ms_per_step=None, run=
     rows = run.profile(args.profile_iters)
     rf, by = roofline(rows, args.precision)
     if world == 1 and args.pmc_traffic and bool(args.extras):
-        rf["traffic"], rf["traffic_note"] = pmc_traffic(rf["kernel"], "wav2lip", args.precision, ["--w2l-batch", str(args.w2l_batch)])
+        rf["traffic"], rf["traffic_note"], _ = pmc_traffic(rf["kernel"], "wav2lip", args.precision, ["--w2l-batch", str(args.w2l_batch)], want_clock=False)
         if rf["traffic"]:
             rf["traffic"] = round(rf["traffic"])
             rf["traffic_gbytes_per_s"] = round(rf["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9, 1)
@@ -617,6 +632,14 @@ def ernerf_report(args, device, world, rank, value=None, ms_per_step=None, run=N
     return rep
 
 
+_T0 = time.perf_counter()
+
+
+def _stage(name):
+    """Wall-clock of the bench's own stages on stderr (the JSON line on stdout stays alone)."""
+    print(f"[bench +{time.perf_counter() - _T0:6.1f} s] {name}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -684,8 +707,11 @@ def main():
                     line[k] = rep[k]
             print(json.dumps(line), flush=True)
     else:
+        _stage("build MuseTalk handles")
         run = MuseTalkRunner(args.precision, args.batch, device, seed=rank)
+        _stage("timed steps")
         elapsed = harness.timed_steps(run.step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=device)
+        _stage("per-op profile")
         value = harness.aggregate_value(args.batch, args.steps, elapsed, world)
         if rank == 0:
             gf_frame = run.gflop_per_frame()      # summed over the handles' own op lists (tests/test_musetalk_full.py holds it to SURVEY Appendix C)
@@ -705,16 +731,24 @@ def main():
             rows = run.profile(args.profile_iters)
             rf, by = roofline(rows, args.precision, only_mfma=True)
             if extras and args.pmc_traffic:
-                rf["traffic"], rf["traffic_note"] = pmc_traffic(rf["kernel"], "musetalk", args.precision, ["--batch", str(args.batch)])
+                _stage("musetalk PMC traffic passes")
+                rf["traffic"], rf["traffic_note"], clk = pmc_traffic(rf["kernel"], "musetalk", args.precision, ["--batch", str(args.batch)])
                 if rf["traffic"]:
                     rf["traffic"] = round(rf["traffic"])
                     rf["traffic_gbytes_per_s"] = round(rf["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9, 1)
+                if clk:
+                    # the nominal peak assumes 2.4 GHz; under this kernel's MFMA load the chip clocks to its power budget (DVFS)
+                    rf["effective_clock_ghz"] = clk
+                    rf["peak_at_effective_clock"] = round(rf["peak"] * clk / 2.4, 1)
+                    rf["frac_of_peak_at_effective_clock"] = round(rf["achieved"] / (rf["peak"] * clk / 2.4), 4)
+                    rf["clock_note"] = "GRBM_GUI_ACTIVE / dispatch wall time under rocprofv3 (profiled passes clock ~3 % lower than un-profiled ones)"
             line["roofline"] = rf
             conv_rows = [r for r in rows if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
             if conv_rows:
                 t = sum(r["ms"] for r in conv_rows); f = sum(r["flops"] for r in conv_rows)
                 line["unet_conv_blocks"] = {"achieved_tflops": round(f / (t * 1e-3) / 1e12, 1), "ms": round(t, 3),
                                             "mfma_issue_frac_of_bf16_peak": round(MFMA_PASSES[args.precision] * f / (t * 1e-3) / 1e12 / BF16_DENSE_PEAK_TF, 3)}
+            _stage("parity vs oracle")
             line["parity"] = run.parity()
             # the same step bracketed as the reference brackets it (musereal.py:99-115): uint8 frames copied to the host inside the timed region
             el_h = harness.timed_steps(run.step_d2h, max(args.steps // 2, 1), 2, sync_fn=torch.cuda.synchronize)
@@ -722,18 +756,22 @@ def main():
                                 "ms_per_step": round(el_h / max(args.steps // 2, 1) * 1e3, 3),
                                 "note": "step + vae.py:105's `.cpu().numpy()` of the uint8 frames (pageable host memory, one sync per step)"}
             if extras:
+                _stage("whisper")
                 line["whisper"] = whisper_report(args, device)
+                _stage("frame transport")
                 line["frame_transport"] = transport_report(args, device)
             if args.dump_layers:
                 with open(args.dump_layers, "w") as f_:
                     json.dump({"musetalk_rows": rows, "by_kernel": by}, f_, indent=1)
             if extras:
                 if args.cpu_seconds > 0:
+                    _stage("cpu baseline")
                     line["cpu_baseline"] = run.cpu_baseline(args.cpu_seconds, args.cpu_threads)
                 usd, vsd = run.usd, run.vsd
                 del run
                 torch.cuda.empty_cache()
                 other = "bf16" if args.precision == "bf16x3" else "bf16x3"
+                _stage("alt precision")
                 alt = MuseTalkRunner(other, args.batch, device)
                 el2 = harness.timed_steps(alt.step, max(args.steps // 2, 1), 3, sync_fn=torch.cuda.synchronize)
                 par = alt.parity()
@@ -744,11 +782,15 @@ def main():
                 # cross-session batching: the north star's 8 sessions per GPU x 8 frames in one step (what a node does with 64 sessions on
                 # 8 GPUs); the UNet's GEMMs get 8x the pixels per launch
                 if args.sessions > 0:
+                    _stage("multi session")
                     line["multi_session"] = muse_multi_session(args, device)
                 dl = args.dump_layers
                 args.dump_layers = dl + ".wav2lip.json" if dl else None
+                _stage("wav2lip leg")
                 line["wav2lip"] = wav2lip_report(args, device, world, rank)
+                _stage("ernerf leg")
                 line["ernerf"] = ernerf_report(args, device, world, rank)
+                _stage("done")
             print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
