@@ -9,7 +9,7 @@ import json
 
 import torch
 
-from ... import _lib
+from ... import _lib, ops
 
 # diffusers config of the public MuseTalk v1 UNet [upstream-knowledge, SURVEY Appendix C]; the reference reads
 # ./models/musetalk/musetalk.json (musetalk/utils/utils.py:69), which does not ship
@@ -104,13 +104,9 @@ class HipUNetModel:
             raise RuntimeError("the MI355X MuseTalk UNet is built for timesteps=[0] (musereal.py:59)")
         if not sample.is_cuda or not encoder_hidden_states.is_cuda:
             raise RuntimeError("UNet needs HIP device tensors; no CPU path exists here")
-        lat = sample.float().contiguous()
-        aud = encoder_hidden_states.float().contiguous()
-        B = lat.shape[0]
-        out = torch.empty((B, self._cfg.out_channels, lat.shape[2], lat.shape[3]), dtype=torch.float32, device=lat.device)
-        with torch.cuda.device(lat.device):
-            _lib.check(_lib.lib().mf_unet_forward(self._h, lat.data_ptr(), aud.data_ptr(), int(self.fuse_pe), out.data_ptr(), B,
-                                                  C.c_void_p(torch.cuda.current_stream(lat.device).cuda_stream)), "unet_forward")
+        if sample.shape[0] > self.max_batch:
+            raise RuntimeError(f"unet_forward: batch {sample.shape[0]} exceeds the handle's max_batch {self.max_batch}")
+        out = ops.unet_forward(self._h, sample, encoder_hidden_states, bool(self.fuse_pe), int(self._cfg.out_channels))   # merefusion::unet_forward
         return _Sample(out.to(self.dtype))
 
 

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from ... import _lib
+from ... import _lib, ops
 
 SD_VAE_FT_MSE = dict(latent_channels=4, out_channels=3, block_out_channels=[128, 256, 512, 512], layers_per_block=2,
                      norm_num_groups=32, scaling_factor=0.18215, sample_size=32)
@@ -99,6 +99,8 @@ class VAE:
         """uint8 frames [B, 8S, 8S, 3] BGR on the device (+ the pre-clamp fp32 image [B,3,8S,8S] if asked)."""
         if not latents.is_cuda:
             raise RuntimeError("VAE.decode_latents needs HIP device tensors; no CPU path exists here")
+        if not want_image:
+            return ops.vae_decode_latents(self._h, latents)               # merefusion::vae_decode_latents
         lat = latents.float().contiguous()
         B, S = lat.shape[0], lat.shape[2] * 8
         frames = torch.empty((B, S, S, 3), dtype=torch.uint8, device=lat.device)

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ... import _lib
+from ... import _lib, ops
 
 N_SAMPLES_SEGMENT = 480000   # 30 s at 16 kHz = 3000 mel frames (whisper/audio.py:13-19)
 
@@ -108,10 +108,7 @@ class Audio2Feature:
             return torch.stack([self._audio2feat_full(w[i]) for i in range(S)], dim=0)
         ctx = 0 if mode == "exact" else max(self.ctx_tokens, n // 320)
         self._ensure_batch(S)
-        feat = torch.empty((S, n // 320, self.n_layer + 1, self.n_state), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().mf_whisper_encode_windows(self._h, w.data_ptr(), n, S, ctx, feat.data_ptr(), self._stream()), "whisper_encode_windows")
-        return feat
+        return ops.whisper_encode_windows(self._h, w, int(ctx), self.n_layer + 1, self.n_state)     # merefusion::whisper_encode_windows
 
     def _audio2feat_full(self, wav):
         n = wav.numel()

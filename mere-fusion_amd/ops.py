@@ -91,3 +91,69 @@ def melspec(wav: torch.Tensor, pad_mode: int) -> torch.Tensor:
 @melspec.register_fake
 def _(wav, pad_mode):
     return wav.new_empty((80, 1 + wav.shape[0] // 200), dtype=torch.float32)
+
+
+# ---- MuseTalk / Whisper stages as custom ops too (the drop-in modules call these; handles are the C ABI's opaque pointers) ----------
+@torch.library.custom_op("merefusion::unet_forward", mutates_args=())
+def unet_forward(handle: int, latents: torch.Tensor, audio: torch.Tensor, add_pe: bool, out_channels: int) -> torch.Tensor:
+    """unet.model(latent_batch, timesteps=[0], encoder_hidden_states=audio).sample (musereal.py:105-107): latents [B,8,S,S], audio [B,T,384]
+    (+ the positional encoding of unet.py:12-27 when add_pe) -> [B,4,S,S] fp32."""
+    _require_cuda("unet_forward", latents, audio)
+    if latents.dim() != 4 or audio.dim() != 3 or audio.shape[0] != latents.shape[0]:
+        raise RuntimeError(f"unet_forward: latents [B,C,S,S] and audio [B,T,D] expected, got {tuple(latents.shape)} / {tuple(audio.shape)}")
+    lat, aud = latents.contiguous().float(), audio.contiguous().float()
+    B = lat.shape[0]
+    out = torch.empty((B, out_channels, lat.shape[2], lat.shape[3]), dtype=torch.float32, device=lat.device)
+    if B == 0:
+        return out
+    with torch.cuda.device(lat.device):
+        _lib.check(_lib.lib().mf_unet_forward(handle, lat.data_ptr(), aud.data_ptr(), int(add_pe), out.data_ptr(), B, _stream_ptr(lat.device)),
+                   "unet_forward")
+    return out
+
+
+@unet_forward.register_fake
+def _(handle, latents, audio, add_pe, out_channels):
+    return latents.new_empty((latents.shape[0], out_channels, latents.shape[2], latents.shape[3]), dtype=torch.float32)
+
+
+@torch.library.custom_op("merefusion::vae_decode_latents", mutates_args=())
+def vae_decode_latents(handle: int, latents: torch.Tensor) -> torch.Tensor:
+    """VAE.decode_latents (musetalk/models/vae.py:96-108) up to the host copy: latents [B,4,S,S] -> uint8 BGR frames [B,8S,8S,3] on the device."""
+    _require_cuda("vae_decode_latents", latents)
+    if latents.dim() != 4:
+        raise RuntimeError(f"vae_decode_latents: latents [B,4,S,S] expected, got {tuple(latents.shape)}")
+    lat = latents.contiguous().float()
+    B, S = lat.shape[0], lat.shape[2] * 8
+    frames = torch.empty((B, S, S, 3), dtype=torch.uint8, device=lat.device)
+    if B == 0:
+        return frames
+    with torch.cuda.device(lat.device):
+        _lib.check(_lib.lib().mf_vae_decode_latents(handle, lat.data_ptr(), frames.data_ptr(), None, B, _stream_ptr(lat.device)), "vae_decode_latents")
+    return frames
+
+
+@vae_decode_latents.register_fake
+def _(handle, latents):
+    return latents.new_empty((latents.shape[0], latents.shape[2] * 8, latents.shape[3] * 8, 3), dtype=torch.uint8)
+
+
+@torch.library.custom_op("merefusion::whisper_encode_windows", mutates_args=())
+def whisper_encode_windows(handle: int, wavs: torch.Tensor, ctx_tokens: int, n_layers1: int, n_state: int) -> torch.Tensor:
+    """Audio2Feature.audio2feat for S windows in one encoder call (museasr.py:25-26 -> audio2feature.py:99-112): wavs fp32 [S, n] ->
+    [S, n // 320, n_layer + 1, n_state].  The handle's workspace must hold S windows (mf_whisper_set_batch)."""
+    _require_cuda("whisper_encode_windows", wavs)
+    if wavs.dim() != 2:
+        raise RuntimeError(f"whisper_encode_windows: wavs [S, n] expected, got {tuple(wavs.shape)}")
+    w = wavs.contiguous().float()
+    S, n = w.shape
+    feat = torch.empty((S, n // 320, n_layers1, n_state), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.lib().mf_whisper_encode_windows(handle, w.data_ptr(), n, S, int(ctx_tokens), feat.data_ptr(), _stream_ptr(w.device)),
+                   "whisper_encode_windows")
+    return feat
+
+
+@whisper_encode_windows.register_fake
+def _(handle, wavs, ctx_tokens, n_layers1, n_state):
+    return wavs.new_empty((wavs.shape[0], wavs.shape[1] // 320, n_layers1, n_state), dtype=torch.float32)
