@@ -112,6 +112,8 @@ typedef struct mf_conv2d_desc {
                            * (diffusers GEGLU of the UNet feed-forward), cout % 32 == 0, the output has cout/2 channels */
     int in_h, in_w;       /* spatial size of the input this layer is built for */
     int upsample;         /* 1: nearest-neighbour 2x upsampling in front of a 3x3 s1 p1 conv (diffusers Upsample2D) */
+    int pad_hi;           /* extra zero rows / columns at the BOTTOM / RIGHT only (diffusers Downsample2D of the VAE encoder: F.pad(x, (0, 1, 0, 1)) +
+                           * conv k3 s2 p0); 0 for every other layer.  (ABI version 2) */
 } mf_conv2d_desc;
 
 /* weight: host fp32, [cout,cin,kh,kw] (Conv2d) or [cin,cout,kh,kw] (ConvTranspose2d);
@@ -371,6 +373,22 @@ int mf_audio_encoder_create(const mf_tensor* weights, int n_weights, int use_att
  * (8 windows with the attention net, 1 without) -> enc_a device fp32 [32]. */
 int mf_audio_encoder_forward(mf_audio_encoder* h, const float* auds, int n_windows, float* enc_a, void* stream);
 void mf_audio_encoder_destroy(mf_audio_encoder* h);
+
+/* ---- sd-vae encoder: avatar preparation -------------------------------------------------------- */
+typedef struct mf_vae_encoder mf_vae_encoder;
+/* Replaces `self.vae.encode(image).latent_dist` of musetalk/models/vae.py:84-94 (diffusers AutoencoderKL.encode: Encoder +
+ * quant_conv; used once per avatar frame by mere_musetalk.py:175-188, 303-304).  cfg as for mf_vae_create (sample_size = the
+ * LATENT grid, 32; the image is sample_size * 2^(n_blocks-1) = 256); weights: the `encoder.*` and `quant_conv.*` tensors. */
+int mf_vae_encoder_create(const mf_vae_config* cfg, const mf_tensor* weights, int n_weights, int precision, int max_batch,
+                          mf_vae_encoder** out);
+/* Exactly one of image / image_u8_bgr: image = device fp32 [B,3,256,256], already normalised (the tensor vae.py:84 receives);
+ * image_u8_bgr = device uint8 [B,256,256,3] BGR crops, preprocessed on the device as vae.py:52-82 does (RGB, / 255.,
+ * half_mask: rows >= 128 zeroed, Normalize(.5, .5)).  moments: device fp32 [B, 2 * latent_channels, 32, 32] = (mean | logvar) of
+ * `latent_dist`; `sample()` = mean + exp(0.5 * clamp(logvar, -30, 20)) * noise and the scaling factor stay with the caller. */
+int mf_vae_encode(mf_vae_encoder* h, const float* image, const uint8_t* image_u8_bgr, int half_mask, float* moments, int batch,
+                  void* stream);
+int mf_vae_encoder_image_size(const mf_vae_encoder* h);
+void mf_vae_encoder_destroy(mf_vae_encoder* h);
 
 /* ---- per-batch glue of the MuseTalk loop ------------------------------------------------ */
 /* musereal.py:92-97: `latent_batch = torch.cat([input_latent_list_cycle[__mirror_index(length, index + i)] ...])`.

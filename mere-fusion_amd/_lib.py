@@ -21,7 +21,7 @@ class MfTensor(C.Structure):
 class MfConv2dDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "cin", "cout", "kh", "kw", "stride_h", "stride_w", "pad_h", "pad_w", "transposed",
-        "output_padding", "residual", "act", "in_h", "in_w", "upsample")]
+        "output_padding", "residual", "act", "in_h", "in_w", "upsample", "pad_hi")]
 
 
 class MfUnetConfig(C.Structure):
@@ -104,6 +104,10 @@ SIGNATURES = {
     "mf_vae_op_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double)]),
     "mf_vae_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "mf_vae_destroy": (None, [C.c_void_p]),
+    "mf_vae_encoder_create": (C.c_int, [C.POINTER(MfVaeConfig), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mf_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mf_vae_encoder_image_size": (C.c_int, [C.c_void_p]),
+    "mf_vae_encoder_destroy": (None, [C.c_void_p]),
     "mf_melspec": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_melspec_frames": (C.c_int, [C.c_int]),
     "mf_attention_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),

@@ -19,3 +19,7 @@ int mf_faces_u8_to_act(const uint8_t* faces, const ActBuf& dst, int batch, hipSt
 // w: device fp32 [3][cin], b: device fp32 [3].
 int mf_head_1x1_sigmoid(const ActView& src, const float* w, const float* b, float* dst, int hwc255,
                         int batch, hipStream_t s);
+
+// VAE.preprocess_img (musetalk/models/vae.py:52-82) for an in-memory crop: uint8 [B,H,W,3] BGR -> RGB, / 255., optional half mask (rows >= H/2
+// zeroed BEFORE the normalisation, vae.py:75-76), Normalize(mean .5, std .5) -> the padded NHWC planes of `dst` (channels 3.. zero).
+int mf_vae_image_u8_to_act(const uint8_t* img, const ActBuf& dst, int half_mask, int batch, hipStream_t s);

@@ -78,6 +78,35 @@ __global__ void k_faces_u8(const uint8_t* __restrict__ faces, int H, int W, bf16
     if (lo) *reinterpret_cast<uint4*>(lo + o) = make_uint4(l[0] | l[1] << 16, l[2] | l[3] << 16, l[4] | l[5] << 16, l[6] | l[7] << 16);
 }
 
+// VAE.preprocess_img (vae.py:52-82) on an in-memory uint8 BGR crop: RGB order, x = fp32(u8 / 255.) (numpy divides in double, FloatTensor rounds
+// once), rows >= H/2 zeroed when half_mask (x * (mask > 0.5), vae.py:75-76), then transforms.Normalize: (x - 0.5) / 0.5 in fp32
+__global__ void k_vae_image_u8(const uint8_t* __restrict__ img, int H, int W, int half_mask, bf16_t* hi, bf16_t* lo, int halo, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = idx % W;
+    int64_t t = idx / W;
+    const int y = t % H;
+    const int b = t / H;
+    const uint8_t* px = img + (((int64_t)b * H + y) * W + x) * 3;
+    const bool keep = !half_mask || y < H / 2;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float f = (float)((double)px[2 - c] / 255.0);      // BGR -> RGB
+        f = keep ? f : 0.f;
+        v[c] = (f - 0.5f) / 0.5f;
+    }
+#pragma unroll
+    for (int c = 3; c < 8; ++c) v[c] = 0.f;
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { h[e] = f2bf_d(v[e]); l[e] = f2bf_d(v[e] - bf2f_d(h[e])); }
+    const int Wp = W + 2 * halo, Hp = H + 2 * halo;
+    const int64_t o = (((int64_t)b * Hp + y + halo) * Wp + x + halo) * 8;
+    *reinterpret_cast<uint4*>(hi + o) = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
+    if (lo) *reinterpret_cast<uint4*>(lo + o) = make_uint4(l[0] | l[1] << 16, l[2] | l[3] << 16, l[4] | l[5] << 16, l[6] | l[7] << 16);
+}
+
 // one thread per pixel: 32-channel dot products against 3 filters held in registers
 template <int CIN>
 __global__ void k_head(const bf16_t* hi, const bf16_t* lo, int Cbuf, int coff, int H, int W, int halo,
@@ -142,6 +171,14 @@ int mf_faces_u8_to_act(const uint8_t* faces, const ActBuf& dst, int batch, hipSt
     const int64_t total = (int64_t)batch * dst.H * dst.W;
     hipLaunchKernelGGL(k_faces_u8, dim3(blocks_for(total, 256)), dim3(256), 0, s, faces, dst.H, dst.W, dst.hi,
                        dst.lo, dst.halo, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+int mf_vae_image_u8_to_act(const uint8_t* img, const ActBuf& dst, int half_mask, int batch, hipStream_t s) {
+    MF_REQUIRE(dst.C == 8, "vae_image_u8_to_act: destination must have 8 channels");
+    const int64_t total = (int64_t)batch * dst.H * dst.W;
+    hipLaunchKernelGGL(k_vae_image_u8, dim3(blocks_for(total, 256)), dim3(256), 0, s, img, dst.H, dst.W, half_mask, dst.hi, dst.lo, dst.halo, total);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

@@ -658,8 +658,9 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
             }
         p->in_halo_need = 1;
     } else if (!d.transposed) {
-        p->out_h = (d.in_h + 2 * d.pad_h - d.kh) / d.stride_h + 1;
-        p->out_w = (d.in_w + 2 * d.pad_w - d.kw) / d.stride_w + 1;
+        MF_REQUIRE(d.pad_hi >= 0, "conv: pad_hi must be >= 0");
+        p->out_h = (d.in_h + 2 * d.pad_h + d.pad_hi - d.kh) / d.stride_h + 1;     // pad_hi: extra zeros bottom / right only (VAE encoder downsamplers)
+        p->out_w = (d.in_w + 2 * d.pad_w + d.pad_hi - d.kw) / d.stride_w + 1;
         MF_REQUIRE(p->out_h > 0 && p->out_w > 0, "conv: empty output");
         p->Hq = p->out_h; p->Wq = p->out_w;
         p->out_step = 1; p->in_step_h = d.stride_h; p->in_step_w = d.stride_w;

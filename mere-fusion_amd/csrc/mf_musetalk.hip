@@ -46,6 +46,7 @@ struct Net {
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     bool use_graph = true;
+    int next_pad_hi = 0;        // consumed by the next conv(): extra zero rows / columns bottom-right (the VAE encoder's Downsample2D)
     std::string err;
 
     ~Net() {
@@ -135,6 +136,7 @@ struct Net {
         mf_conv2d_desc d{};
         d.cin = cin; d.cout = cout; d.kh = d.kw = k; d.stride_h = d.stride_w = stride; d.pad_h = d.pad_w = pad;
         d.act = act; d.residual = res.buf ? 1 : 0; d.in_h = in.buf->H; d.in_w = in.buf->W; d.upsample = upsample;
+        d.pad_hi = next_pad_hi; next_pad_hi = 0;
         ConvPlan* p = new_plan();
         int rc = mf_conv_plan_create(p, d, w, bb.data(), nullptr, nullptr, nullptr, nullptr, precision);
         if (rc) return rc;
@@ -766,3 +768,98 @@ extern "C" int mf_vae_profile(mf_vae* h, int batch, int iters, float* ms_per_op,
     return h->net.profile(batch, iters, ms_per_op, (hipStream_t)stream);
 }
 extern "C" void mf_vae_destroy(mf_vae* h) { delete h; }
+
+
+// ==========================================================================================================
+// sd-vae ENCODER (avatar preparation): `vae.encode(image).latent_dist` of musetalk/models/vae.py:84-94 -- diffusers
+// AutoencoderKL.encode = Encoder (conv_in, 4 DownEncoderBlock2D of 2 resnets (+ Downsample2D: F.pad(x, (0, 1, 0, 1)), conv k3 s2 p0),
+// mid resnet - attention - resnet, GroupNorm + SiLU, conv_out -> 2 * latent channels) followed by quant_conv; the result holds the
+// distribution's (mean | logvar) "moments".  Sampling (mean + std * noise, then * scaling_factor) stays with the caller, who owns the RNG.
+struct mf_vae_encoder {
+    mf_vae_config cfg{};
+    Net net;
+    ActBuf* in_img = nullptr;
+    ActBuf* out_buf = nullptr;
+    int image_size = 0;
+};
+
+extern "C" int mf_vae_encoder_create(const mf_vae_config* c, const mf_tensor* weights, int n_weights, int precision, int max_batch,
+                                     mf_vae_encoder** out) {
+    MF_REQUIRE(c && weights && out && n_weights > 0 && max_batch > 0, "vae_encoder_create: bad argument");
+    MF_REQUIRE(c->n_blocks >= 1 && c->n_blocks <= 4, "vae_encoder_create: bad config");
+    *out = nullptr;
+    std::unique_ptr<mf_vae_encoder> h(new mf_vae_encoder());
+    h->cfg = *c;
+    Net& net = h->net;
+    int rc = net.init(weights, n_weights, precision, max_batch, c->norm_num_groups);
+    if (rc) return rc;
+    const int nb = c->n_blocks, L = c->layers_per_block, G = c->norm_num_groups, Z = c->latent_channels;
+    const int* boc = c->block_out_channels;
+    int s = c->sample_size << (nb - 1);                     // image size: the latent grid times 2 per downsampler
+    h->image_size = s;
+    h->in_img = net.buf(c->out_channels, s, s, 1);          // RGB image, channels padded to 8
+    ActBuf* x0 = net.buf(boc[0], s, s, 1);
+    if (!h->in_img || !x0) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+    NET_TRY(net.conv("encoder.conv_in", ActView{h->in_img, 0, h->in_img->C}, ActView{x0, 0, boc[0]}, c->out_channels, boc[0], 3, 1, 1, 0, ActView{}));
+    ActView x{x0, 0, boc[0]};
+    int ch = boc[0];
+    for (int b = 0; b < nb; ++b) {
+        for (int i = 0; i < L; ++i) {
+            ActBuf* y = net.buf(boc[b], s, s, 1);
+            if (!y) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+            NET_TRY(net.resnet("encoder.down_blocks." + std::to_string(b) + ".resnets." + std::to_string(i), x, ActView{y, 0, boc[b]}, ch, boc[b], G, 1e-6f, nullptr));
+            ch = boc[b];
+            x = ActView{y, 0, ch};
+        }
+        if (b < nb - 1) {
+            ActBuf* y = net.buf(ch, s / 2, s / 2, 1);
+            if (!y) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+            net.next_pad_hi = 1;                            // F.pad(x, (0, 1, 0, 1)) + conv(k3, s2, p0): the buffer's own zero ring is the pad
+            NET_TRY(net.conv("encoder.down_blocks." + std::to_string(b) + ".downsamplers.0.conv", x, ActView{y, 0, ch}, ch, ch, 3, 2, 0, 0, ActView{}));
+            s /= 2;
+            x = ActView{y, 0, ch};
+        }
+    }
+    ActBuf *m0 = net.buf(ch, s, s, 1), *m1 = net.buf(ch, s, s, 1);
+    if (!m0 || !m1) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+    NET_TRY(net.resnet("encoder.mid_block.resnets.0", x, ActView{m0, 0, ch}, ch, ch, G, 1e-6f, nullptr));
+    {   // single-head attention over all channels, with residual (as the decoder's mid block)
+        const std::string a = "encoder.mid_block.attentions.0";
+        ActBuf *g0 = net.tmp("va.gn", ch, s, s, 0), *qkv = net.tmp("va.qkv", 3 * ch, s, s, 0), *ao = net.tmp("va.ao", ch, s, s, 0);
+        if (!g0 || !qkv || !ao) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+        NET_TRY(net.gn(a + ".group_norm", ActView{m0, 0, ch}, ActView{g0, 0, ch}, G, 1e-6f, false));
+        const float *wq = net.T(a + ".to_q.weight", (int64_t)ch * ch), *wk = net.T(a + ".to_k.weight", (int64_t)ch * ch), *wv = net.T(a + ".to_v.weight", (int64_t)ch * ch);
+        const float *bq = net.T(a + ".to_q.bias", ch), *bk = net.T(a + ".to_k.bias", ch), *bv = net.T(a + ".to_v.bias", ch);
+        if (!wq || !wk || !wv || !bq || !bk || !bv) { mf_set_error("%s", net.err.c_str()); return MF_ERR_INVALID; }
+        std::vector<float> w((size_t)3 * ch * ch), b((size_t)3 * ch);
+        std::copy(wq, wq + (size_t)ch * ch, w.begin()); std::copy(wk, wk + (size_t)ch * ch, w.begin() + (size_t)ch * ch);
+        std::copy(wv, wv + (size_t)ch * ch, w.begin() + (size_t)2 * ch * ch);
+        std::copy(bq, bq + ch, b.begin()); std::copy(bk, bk + ch, b.begin() + ch); std::copy(bv, bv + ch, b.begin() + 2 * ch);
+        NET_TRY(net.linear_raw(w.data(), b.data(), ActView{g0, 0, ch}, ActView{qkv, 0, 3 * ch}, ch, 3 * ch, ActView{}));
+        NET_TRY(net.attention(ActView{qkv, 0, ch}, ActView{qkv, ch, ch}, ActView{qkv, 2 * ch, ch}, ActView{ao, 0, ch}, 1));
+        NET_TRY(net.conv(a + ".to_out.0", ActView{ao, 0, ch}, ActView{m1, 0, ch}, ch, ch, 1, 1, 0, 0, ActView{m0, 0, ch}));
+    }
+    NET_TRY(net.resnet("encoder.mid_block.resnets.1", ActView{m1, 0, ch}, ActView{m0, 0, ch}, ch, ch, G, 1e-6f, nullptr));
+    ActBuf *t = net.buf(ch, s, s, 1), *co = net.buf(2 * Z, s, s, 1);
+    h->out_buf = net.buf(2 * Z, s, s, 1);
+    if (!t || !co || !h->out_buf) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+    NET_TRY(net.gn("encoder.conv_norm_out", ActView{m0, 0, ch}, ActView{t, 0, ch}, G, 1e-6f, true));
+    NET_TRY(net.conv("encoder.conv_out", ActView{t, 0, ch}, ActView{co, 0, 2 * Z}, ch, 2 * Z, 3, 1, 1, 0, ActView{}));
+    NET_TRY(net.conv("quant_conv", ActView{co, 0, 2 * Z}, ActView{h->out_buf, 0, 2 * Z}, 2 * Z, 2 * Z, 1, 1, 0, 0, ActView{}));
+    *out = h.release();
+    return MF_OK;
+}
+
+extern "C" int mf_vae_encode(mf_vae_encoder* h, const float* image, const uint8_t* image_u8_bgr, int half_mask, float* moments, int batch, void* stream) {
+    MF_REQUIRE(h && moments && (image || image_u8_bgr) && !(image && image_u8_bgr), "vae_encode: give exactly one of image / image_u8_bgr, and moments");
+    MF_REQUIRE(batch > 0 && batch <= h->net.cap, "vae_encode: batch %d exceeds the handle's max_batch %d", batch, h->net.cap);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (image) { if ((rc = mf_nchw_to_act(image, h->cfg.out_channels, *h->in_img, batch, s))) return rc; }
+    else if ((rc = mf_vae_image_u8_to_act(image_u8_bgr, *h->in_img, half_mask, batch, s))) return rc;
+    if ((rc = h->net.run(batch, s))) return rc;
+    return mf_act_to_nchw(ActView{h->out_buf, 0, 2 * h->cfg.latent_channels}, moments, batch, s);
+}
+
+extern "C" int mf_vae_encoder_image_size(const mf_vae_encoder* h) { return h ? h->image_size : 0; }
+extern "C" void mf_vae_encoder_destroy(mf_vae_encoder* h) { delete h; }

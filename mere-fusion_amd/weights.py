@@ -284,6 +284,31 @@ def make_musetalk_vae_state_dict(cfg, seed=0, shapes_only=False):
     return sd
 
 
+def make_musetalk_vae_encoder_state_dict(cfg, seed=0, shapes_only=False):
+    """`encoder.*` + `quant_conv.*` of diffusers AutoencoderKL (avatar preparation, musetalk/models/vae.py:84-94)."""
+    v = cfg["vae"] if "vae" in cfg else cfg
+    rng, f, conv, lin, norm, resnet = _mt_gen(12500 + seed, shapes_only)
+    boc, L, Z = v["block_out_channels"], v["layers_per_block"], v["latent_channels"]
+    sd = {}
+    conv(sd, "encoder.conv_in", v["out_channels"], boc[0], 3)
+    c = boc[0]
+    for b, co in enumerate(boc):
+        for i in range(L):
+            resnet(sd, f"encoder.down_blocks.{b}.resnets.{i}", c, co); c = co
+        if b < len(boc) - 1:
+            conv(sd, f"encoder.down_blocks.{b}.downsamplers.0.conv", c, c, 3)
+    resnet(sd, "encoder.mid_block.resnets.0", c, c)
+    a = "encoder.mid_block.attentions.0"
+    norm(sd, a + ".group_norm", c)
+    for n_ in ("to_q", "to_k", "to_v"):
+        lin(sd, a + "." + n_, c, c, 1.3)
+    lin(sd, a + ".to_out.0", c, c, 0.7)
+    resnet(sd, "encoder.mid_block.resnets.1", c, c)
+    norm(sd, "encoder.conv_norm_out", c); conv(sd, "encoder.conv_out", c, 2 * Z, 3, 0.6)
+    conv(sd, "quant_conv", 2 * Z, 2 * Z, 1, 1.0)
+    return sd
+
+
 def make_musetalk_inputs(batch, seed=0, hw=32):
     """cfg-3 inputs: latents [B,8,hw,hw] ~ N(0,1)*0.18215-scaled pairs (vae.py:117-121),
     whisper chunks [B,50,384] ~ N(0,1) before the positional encoding."""

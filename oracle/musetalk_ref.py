@@ -212,6 +212,43 @@ def musetalk_step(unet_sd, vae_sd, cfg, latent_batch, whisper_batch):
     return decode_latents(vae_sd, cfg["vae"], pred), pred
 
 
+# ---- AutoencoderKL.encode: avatar preparation (musetalk/models/vae.py:52-94, 110-122) --------------------------------------------
+def preprocess_img(img_bgr_u8, half_mask=False):
+    """vae.py:52-82 for an in-memory crop: BGR uint8 [256, 256, 3] -> fp32 [1, 3, 256, 256] RGB, / 255., half mask, Normalize(.5, .5)."""
+    x = np.asarray([np.asarray(img_bgr_u8)[:, :, ::-1]]) / 255.
+    x = torch.squeeze(torch.FloatTensor(np.transpose(x, (3, 0, 1, 2))))
+    if half_mask:
+        m = torch.zeros((x.shape[1], x.shape[2]))
+        m[:x.shape[1] // 2, :] = 1
+        x = x * (m > 0.5)
+    return ((x - 0.5) / 0.5).unsqueeze(0)
+
+
+@torch.no_grad()
+def vae_encode_moments(sd, cfg, image):
+    """diffusers AutoencoderKL.encode up to the distribution parameters: Encoder (conv_in; per block 2 resnets + Downsample2D with
+    F.pad(x, (0, 1, 0, 1)) and a stride-2 pad-0 conv; mid resnet - attention - resnet; GroupNorm, SiLU, conv_out) then quant_conv.
+    Returns (mean | logvar) [B, 2 * latent, 32, 32]."""
+    G, boc, L = cfg["norm_num_groups"], cfg["block_out_channels"], cfg["layers_per_block"]
+    h = _conv(sd, "encoder.conv_in", image)
+    for b in range(len(boc)):
+        for i in range(L):
+            h = _resnet(sd, f"encoder.down_blocks.{b}.resnets.{i}", h, None, G, 1e-6)
+        if b < len(boc) - 1:
+            h = _conv(sd, f"encoder.down_blocks.{b}.downsamplers.0.conv", F.pad(h, (0, 1, 0, 1)), stride=2, padding=0)
+    h = _resnet(sd, "encoder.mid_block.resnets.0", h, None, G, 1e-6)
+    h = _vae_attention(sd, "encoder.mid_block.attentions.0", h, G)
+    h = _resnet(sd, "encoder.mid_block.resnets.1", h, None, G, 1e-6)
+    h = _conv(sd, "encoder.conv_out", F.silu(_gn(sd, "encoder.conv_norm_out", h, G, 1e-6)))
+    return _conv(sd, "quant_conv", h, padding=0)
+
+
+def sample_latents(moments, scaling_factor, noise):
+    """DiagonalGaussianDistribution.sample() with a given noise tensor, times the scaling factor (vae.py:92-93)."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    return scaling_factor * (mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise)
+
+
 def count_macs(cfg, hw=32, ctx_len=50):
     """Analytic conv/linear/attention MACs per frame of unet_forward + vae_decode (the FLOP numerator)."""
     u, v = cfg["unet"], cfg["vae"]
