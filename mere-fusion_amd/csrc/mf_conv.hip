@@ -29,6 +29,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // Swizzled LDS byte offset of the 16-byte slot (row, kg) of a [rows][BK] bf16 tile.  The XOR terms
 // make every 16-lane service group of ds_read_b128 (rows l&15 at one or two kg values) hit 16
@@ -122,7 +123,13 @@ __device__ __forceinline__ void store_pair16(bf16_t* base, int64_t yo, int c16, 
 // >= 3: NST-1 tiles in flight; each wave waits only for ITS OWN share of the tile it is about to read
 // (counted s_waitcnt vmcnt, every wave issues the same number of DMA instructions per tile) and a raw
 // s_barrier publishes it -- nothing ever drains the queue inside the loop.
-template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST>
+// LD = how the operand tiles reach LDS.  0: LDS-DMA (global_load_lds).  1: through registers -- global_load_dwordx4 of tile k+2 in
+// flight while tile k+1 sits in staging VGPRs / is written to the other LDS stage and tile k is multiplied.  A DMA piece costs its wave
+// 100-185 issue cycles inside a loaded phase (MI355X_MICROARCH.md); with 6 pieces per wave per 32-deep tile and only 24 MFMAs to cover
+// them, the small tiles' loop ran at 1840 cycles per K tile.  A plain load issues in a few cycles and the ds_write_b128 in 13.
+// 2: through registers into ONE LDS stage (two barriers per tile): half the LDS, so a 64-deep bf16x3 tile (128-byte rows: every request
+// a full line) still leaves room for 2-3 workgroups per CU, whose MFMAs cover each other's barriers.
+template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST, int LD = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a) {
     constexpr int NW = WGM * WGN;         // waves per workgroup
     constexpr int NT = NW * 64;
@@ -143,7 +150,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
     constexpr int NPC = (PCH + NW - 1) / NW, NWC = (WCH + NW - 1) / NW;      // ... per wave
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* s_goff = reinterpret_cast<int*>(smem + NST * STAGE);
+    constexpr int LDS_STAGES = LD == 2 ? 1 : NST;
+    int* s_goff = reinterpret_cast<int*>(smem + LDS_STAGES * STAGE);
     // MF_DBG_TIMES: s_memtime stamps of (entry, loop start, loop end, exit) per workgroup
     unsigned long long* dbg = a.dbg ? a.dbg + 4 * ((size_t)blockIdx.x + gridDim.x * ((size_t)blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
     if (dbg && threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memtime();
@@ -271,7 +279,75 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
     __syncthreads();   // s_goff visible
     if (dbg && threadIdx.x == 0) dbg[1] = __builtin_amdgcn_s_memtime();
     const int nk = kt_end - kt_begin;
-    if (NST == 2) {
+    if constexpr (LD != 0) {
+        static_assert(NST == 2 && (LD == 1 || LD == 2), "register-staged tiles: double buffer (LD 1) or one stage (LD 2)");
+        u32x4 rp[NP][NPC], rw[NP][NWC];
+        auto gload = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const int c = wave + NW * i;
+                if (PCH % NW == 0 || c < PCH) {
+                    const bf16_t* src = xp[i] + s_goff[kt * KG + p_kg[i]];
+                    rp[0][i] = *reinterpret_cast<const u32x4*>(src);
+                    if (X3) rp[NP - 1][i] = *reinterpret_cast<const u32x4*>(src + x_delta);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NWC; ++i) {
+                const int c = wave + NW * i;
+                if (WCH % NW == 0 || c < WCH) {
+                    const bf16_t* src = BK == 64 ? wp[i] + kt * w_kstep : wp[i] + (kt >> 1) * w_kstep + (kt & 1) * 32;
+                    rw[0][i] = *reinterpret_cast<const u32x4*>(src);
+                    if (X3) rw[NP - 1][i] = *reinterpret_cast<const u32x4*>(src + w_delta);
+                }
+            }
+        };
+        auto lstore = [&](int s) __attribute__((always_inline)) {
+            char* base = smem + s * STAGE + lane * 16;
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const int c = wave + NW * i;
+                if (PCH % NW == 0 || c < PCH) {
+                    *reinterpret_cast<u32x4*>(base + c * 1024) = rp[0][i];
+                    if (X3) *reinterpret_cast<u32x4*>(base + PLANE + c * 1024) = rp[NP - 1][i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NWC; ++i) {
+                const int c = wave + NW * i;
+                if (WCH % NW == 0 || c < WCH) {
+                    *reinterpret_cast<u32x4*>(base + P_BYTES + c * 1024) = rw[0][i];
+                    if (X3) *reinterpret_cast<u32x4*>(base + PLANE + P_BYTES + c * 1024) = rw[NP - 1][i];
+                }
+            }
+        };
+        if (LD == 1) {
+            if (nk > 0) {
+                gload(kt_begin);
+                lstore(0);
+                if (nk > 1) gload(kt_begin + 1);
+                __syncthreads();
+                for (int kt = kt_begin; kt < kt_end; ++kt) {
+                    const int s = (kt - kt_begin) & 1;
+                    if (kt + 1 < kt_end) {
+                        lstore(s ^ 1);                           // tile kt+1: loaded a whole iteration ago; everyone left that stage at the last barrier
+                        if (kt + 2 < kt_end) gload(kt + 2);      // in flight under this tile's MFMAs and the next iteration's
+                    }
+                    compute(s);
+                    __syncthreads();
+                }
+            }
+        } else {
+            if (nk > 0) gload(kt_begin);
+            for (int kt = kt_begin; kt < kt_end; ++kt) {
+                if (kt > kt_begin) __syncthreads();              // everyone is done reading the previous tile
+                lstore(0);
+                if (kt + 1 < kt_end) gload(kt + 1);              // in flight under this tile's MFMAs
+                __syncthreads();
+                compute(0);
+            }
+        }
+    } else if (NST == 2) {
         if (nk > 0) {
             stage(kt_begin, 0);
             __syncthreads();   // drains the DMA (vmcnt) and publishes stage 0
@@ -562,16 +638,16 @@ struct RingDepth {
     static constexpr int value = !countable ? 2 : (4 * stage_bytes <= 72 * 1024 ? 4 : (3 * stage_bytes <= 76 * 1024 ? 3 : (4 * stage_bytes <= 150 * 1024 ? 4 : (3 * stage_bytes <= 150 * 1024 ? 3 : 2))));
 };
 
-template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST>
+template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST, int LD = 0>
 int launch_cfg_n(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = k_conv_igemm<BM, BN, WGM, WGN, X3, BK, NST>;
+    auto kern = k_conv_igemm<BM, BN, WGM, WGN, X3, BK, NST, LD>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    const size_t lds = (size_t)NST * (BM + BN) * BK * 2 * (X3 ? 2 : 1) + (size_t)goff_max * 4;
+    const size_t lds = (size_t)(LD == 2 ? 1 : NST) * (BM + BN) * BK * 2 * (X3 ? 2 : 1) + (size_t)goff_max * 4;
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.zgroups ? a.zgroups : nphase);
     hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, a);
     MF_HIP(hipGetLastError());
@@ -585,6 +661,12 @@ int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStrea
     static const bool deep = [] { const char* e = getenv("MF_RING"); return e && !strcmp(e, "deep"); }();
     constexpr int NST = RingDepth<BM, BN, WGM, WGN, X3, BK>::value;
     if (deep && NST != 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, NST>(a, nphase, nsplit, goff_max, s);
+    // 4-wave tiles: operands through registers (MF_IGEMM_LD=0 keeps the LDS-DMA loop for A/B); the 8-wave 256-wide tiles have no VGPRs to spare
+    static const int regs = [] { const char* e = getenv("MF_IGEMM_LD"); return e ? atoi(e) : 1; }();
+    if constexpr (WGM * WGN == 4) {
+        if (regs == 1 && 2 * RingDepth<BM, BN, WGM, WGN, X3, BK>::stage_bytes <= 150 * 1024) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 1>(a, nphase, nsplit, goff_max, s);
+        if (regs == 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 2>(a, nphase, nsplit, goff_max, s);
+    }
     return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2>(a, nphase, nsplit, goff_max, s);
 }
 
@@ -593,6 +675,11 @@ int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3
     // bf16x3 doubles the LDS image: 64-deep tiles only where two stages of (hi, lo) still leave >= 2
     // workgroups per CU (the small tiles of the long-K layers), 32-deep otherwise
     constexpr bool deep = (BM + BN) <= 128;
+    // MF_IGEMM_BK=64: 64-deep bf16x3 tiles (128-byte operand rows) on every 4-wave tile
+    static const bool bk64 = [] { const char* e = getenv("MF_IGEMM_BK"); return e && atoi(e) == 64; }();
+    if constexpr (WGM * WGN == 4 && !deep) {
+        if (x3 && bk64) return launch_cfg<BM, BN, WGM, WGN, true, 64>(a, nphase, nsplit, goff_max, s);
+    }
     return x3 ? launch_cfg<BM, BN, WGM, WGN, true, deep ? 64 : 32>(a, nphase, nsplit, goff_max, s)
               : launch_cfg<BM, BN, WGM, WGN, false, 64>(a, nphase, nsplit, goff_max, s);
 }
