@@ -425,6 +425,33 @@ int mf_paste_frames(const void* res, int res_is_f32, int res_h, int res_w, const
 /* cv2.resize(src, (dw, dh)) for uint8 [sh][sw][3] with the default INTER_LINEAR (lipreal.py:211, musereal.py:241). */
 int mf_resize_linear_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, void* stream);
 
+/* ---- ER-NeRF audio front-end: wav2vec2 / HuBERT CTC network ----------------------------------- */
+/* Replaces `self.processor(frame, ...)` + `self.model(inputs.input_values)` of NerfASR.__frame_to_text (nerfasr.py:128-143):
+ * transformers' Wav2Vec2FeatureExtractor normalisation, then Wav2Vec2ForCTC (`.logits`) or HubertModel (`.last_hidden_state`, out_hidden = 1)
+ * -- feature extractor (conv -> LayerNorm -> GELU per layer, feat_extract_norm = "layer"), feature projection, weight-normed grouped
+ * positional convolution, pre-LN ("do_stable_layer_norm") or post-LN transformer layers, final LayerNorm, lm_head.  Field names follow
+ * transformers' Wav2Vec2Config; weights = the model's state dict ("wav2vec2." / "hubert." prefixes accepted, the positional conv as
+ * `weight`, `weight_g` / `weight_v` or `parametrizations.weight.original0 / 1`).  (ABI version 3) */
+typedef struct mf_wav2vec2 mf_wav2vec2;
+typedef struct {
+    int hidden, n_layer, n_head, ffn, vocab;            /* hidden_size, num_hidden_layers, num_attention_heads, intermediate_size, vocab_size */
+    int n_conv, conv_dim[8], conv_kernel[8], conv_stride[8], conv_bias;
+    int feat_norm_layer;                                /* 1: feat_extract_norm == "layer" (required) */
+    int stable_ln;                                      /* do_stable_layer_norm */
+    int pos_k, pos_groups;                              /* num_conv_pos_embeddings, num_conv_pos_embedding_groups */
+    float layer_norm_eps;
+    int do_normalize;                                   /* the processor's zero-mean / unit-variance step */
+    int out_hidden;                                     /* 0: logits [T][vocab]; 1: the final hidden state [T][hidden] */
+} mf_wav2vec2_config;
+/* One handle serves windows of exactly n_samples samples (NerfASR feeds (l + m + r) * 320 every step), up to max_windows per call. */
+int mf_wav2vec2_create(const mf_wav2vec2_config* cfg, const mf_tensor* weights, int n_weights, int n_samples, int max_windows, int precision,
+                       mf_wav2vec2** out);
+/* frames per window (20 ms each) and the width of an output row */
+int mf_wav2vec2_frames(const mf_wav2vec2* h, int* n_frames, int* width);
+/* wav: device fp32 [n_windows][n_samples] (raw samples: the normalisation happens here); out: device fp32 [n_windows][n_frames][width]. */
+int mf_wav2vec2_forward(mf_wav2vec2* h, const float* wav, int n_samples, int n_windows, float* out, void* stream);
+void mf_wav2vec2_destroy(mf_wav2vec2* h);
+
 /* ---- frame transport ----------------------------------------------------------------------- */
 /* Host-side plumbing of the shared-memory frame ring that replaces the pickled `res_frame_queue` items of
  * lipreal.py:136,161 / musereal.py:116,153 (mere-fusion_amd/transport.py keeps the (res_frame, idx, audio_frames) tuple

@@ -48,6 +48,13 @@ class MfVaeConfig(C.Structure):
                 ("sample_size", C.c_int), ("scaling_factor", C.c_float)]
 
 
+class MfWav2Vec2Config(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("n_layer", C.c_int), ("n_head", C.c_int), ("ffn", C.c_int), ("vocab", C.c_int), ("n_conv", C.c_int),
+                ("conv_dim", C.c_int * 8), ("conv_kernel", C.c_int * 8), ("conv_stride", C.c_int * 8), ("conv_bias", C.c_int),
+                ("feat_norm_layer", C.c_int), ("stable_ln", C.c_int), ("pos_k", C.c_int), ("pos_groups", C.c_int), ("layer_norm_eps", C.c_float),
+                ("do_normalize", C.c_int), ("out_hidden", C.c_int)]
+
+
 class MfPasteJob(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("frame_index", "x1", "y1", "x2", "y2", "cx1", "cy1", "cx2", "cy2")] + [("mask", C.c_void_p)]
 
@@ -92,6 +99,10 @@ SIGNATURES = {
     "mf_whisper_set_batch": (C.c_int, [C.c_void_p, C.c_int]),
     "mf_whisper_encode_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mf_whisper_destroy": (None, [C.c_void_p]),
+    "mf_wav2vec2_create": (C.c_int, [C.POINTER(MfWav2Vec2Config), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mf_wav2vec2_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mf_wav2vec2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mf_wav2vec2_destroy": (None, [C.c_void_p]),
     "mf_unet_create": (C.c_int, [C.POINTER(MfUnetConfig), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mf_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_unet_num_ops": (C.c_int, [C.c_void_p]),

@@ -661,8 +661,10 @@ int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStrea
     static const bool deep = [] { const char* e = getenv("MF_RING"); return e && !strcmp(e, "deep"); }();
     constexpr int NST = RingDepth<BM, BN, WGM, WGN, X3, BK>::value;
     if (deep && NST != 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, NST>(a, nphase, nsplit, goff_max, s);
-    // 4-wave tiles: operands through registers (MF_IGEMM_LD=0 keeps the LDS-DMA loop for A/B); the 8-wave 256-wide tiles have no VGPRs to spare
-    static const int regs = [] { const char* e = getenv("MF_IGEMM_LD"); return e ? atoi(e) : 1; }();
+    // 4-wave tiles: operands through registers into one LDS stage (MF_IGEMM_LD=0 keeps the LDS-DMA loop, 1 the two-stage register path, for A/B);
+    // the 8-wave 256-wide tiles have no VGPRs to spare.  Per-op A/B at batch 8 (tools/igemm_ld_ab.sh): UNet 11.05 -> 10.62 ms with 64-deep tiles,
+    // Wav2Lip 14.6 k -> 15.1 k frames/s; every variant within +-15 % per layer -- the loop is bound by where the operands come FROM.
+    static const int regs = [] { const char* e = getenv("MF_IGEMM_LD"); return e ? atoi(e) : 2; }();
     if constexpr (WGM * WGN == 4) {
         if (regs == 1 && 2 * RingDepth<BM, BN, WGM, WGN, X3, BK>::stage_bytes <= 150 * 1024) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 1>(a, nphase, nsplit, goff_max, s);
         if (regs == 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 2>(a, nphase, nsplit, goff_max, s);
@@ -675,8 +677,8 @@ int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3
     // bf16x3 doubles the LDS image: 64-deep tiles only where two stages of (hi, lo) still leave >= 2
     // workgroups per CU (the small tiles of the long-K layers), 32-deep otherwise
     constexpr bool deep = (BM + BN) <= 128;
-    // MF_IGEMM_BK=64: 64-deep bf16x3 tiles (128-byte operand rows) on every 4-wave tile
-    static const bool bk64 = [] { const char* e = getenv("MF_IGEMM_BK"); return e && atoi(e) == 64; }();
+    // 64-deep bf16x3 tiles (128-byte operand rows: every request a full line) on every 4-wave tile; MF_IGEMM_BK=32 restores the 32-deep ones
+    static const bool bk64 = [] { const char* e = getenv("MF_IGEMM_BK"); return !e || atoi(e) == 64; }();
     if constexpr (WGM * WGN == 4 && !deep) {
         if (x3 && bk64) return launch_cfg<BM, BN, WGM, WGN, true, 64>(a, nphase, nsplit, goff_max, s);
     }

@@ -9,8 +9,9 @@
 
 // y = (x - mean) / sqrt(var + eps) * gamma + beta over the C channels of every token (fp32 math)
 // tokens > 0: only the first `tokens` tokens of every batch item (a sequence prefix; the buffers keep their geometry)
+// act = 3: GELU (erf form) applied to the normalised value (wav2vec2's conv -> LayerNorm -> GELU feature layers)
 int mf_layernorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, float eps, int batch,
-                 hipStream_t s, int tokens = 0);
+                 hipStream_t s, int tokens = 0, int act = 0);
 
 // p[t][j] = softmax_j(scale * s[t][j]) for j < n_keys; columns n_keys..p.C-1 are written as zero
 int mf_softmax_rows(const ActView& scores, const ActView& probs, int n_keys, float scale, int batch, hipStream_t s);

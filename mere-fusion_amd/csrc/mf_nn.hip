@@ -48,8 +48,12 @@ struct Rows {
 };
 
 // one wave per token
+__device__ __forceinline__ float ln_act(float o, int act) {   // 0 none, 3 GELU (erf form): wav2vec2's conv layers are conv -> LayerNorm -> GELU
+    return act == 3 ? 0.5f * o * (1.f + erff(o * 0.70710678118654752f)) : o;
+}
+
 __global__ __launch_bounds__(256) void k_layernorm(Rows X, Rows Y, const float* gamma, const float* beta, float eps,
-                                                   int C, int total) {
+                                                   int C, int total, int act) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= total) return;
     const int T = X.T;
@@ -77,13 +81,13 @@ __global__ __launch_bounds__(256) void k_layernorm(Rows X, Rows Y, const float* 
 #pragma unroll
     for (int i = 0; i < MAXPL; ++i) {
         const int c = lane + 64 * i;
-        if (c < C) st(yh, yl, yo + c, (v[i] - mean) * rstd * gamma[c] + beta[c]);
+        if (c < C) st(yh, yl, yo + c, ln_act((v[i] - mean) * rstd * gamma[c] + beta[c], act));
     }
 }
 
 // one wave per token, 8 channels (16 bytes per plane) per lane and step: C % 8 == 0, views 16-byte aligned
 template <int NCH>
-__global__ __launch_bounds__(256) void k_layernorm_v8(Rows X, Rows Y, const float* gamma, const float* beta, float eps, int C, int total) {
+__global__ __launch_bounds__(256) void k_layernorm_v8(Rows X, Rows Y, const float* gamma, const float* beta, float eps, int C, int total, int act) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= total) return;
     const int T = X.T;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) void k_layernorm_v8(Rows X, Rows Y, const floa
             uint32_t hb[8], lb[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float o = (v[j][e] - mean) * rstd * gg[e] + bb[e];
+                const float o = ln_act((v[j][e] - mean) * rstd * gg[e] + bb[e], act);
                 hb[e] = nf2bf(o);
                 lb[e] = nf2bf(o - nbf2f(hb[e]));
             }
@@ -425,7 +429,8 @@ Rows rows_of(const ActView& v) {
 }  // namespace
 
 int mf_layernorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, float eps, int batch,
-                 hipStream_t s, int tokens) {
+                 hipStream_t s, int tokens, int act) {
+    MF_REQUIRE(act == 0 || act == 3, "layernorm: activation %d (0 none, 3 GELU)", act);
     MF_REQUIRE(x.buf->H * x.buf->W == y.buf->H * y.buf->W && x.C == y.C, "layernorm: shape mismatch");
     MF_REQUIRE(x.C <= 64 * MAXPL, "layernorm: C=%d exceeds %d", x.C, 64 * MAXPL);
     Rows xr = rows_of(x), yr = rows_of(y);
@@ -436,10 +441,10 @@ int mf_layernorm(const ActView& x, const ActView& y, const float* gamma, const f
     const int total = batch * xr.T;
     const bool vec = x.C % 8 == 0 && x.coff % 8 == 0 && y.coff % 8 == 0 && x.buf->C % 8 == 0 && y.buf->C % 8 == 0 && x.C <= 2048;
     const dim3 grid((total + 3) / 4), block(256);
-    if (vec && x.C <= 512) hipLaunchKernelGGL(k_layernorm_v8<1>, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total);
-    else if (vec && x.C <= 1024) hipLaunchKernelGGL(k_layernorm_v8<2>, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total);
-    else if (vec) hipLaunchKernelGGL(k_layernorm_v8<4>, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total);
-    else hipLaunchKernelGGL(k_layernorm, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total);
+    if (vec && x.C <= 512) hipLaunchKernelGGL(k_layernorm_v8<1>, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total, act);
+    else if (vec && x.C <= 1024) hipLaunchKernelGGL(k_layernorm_v8<2>, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total, act);
+    else if (vec) hipLaunchKernelGGL(k_layernorm_v8<4>, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total, act);
+    else hipLaunchKernelGGL(k_layernorm, grid, block, 0, s, xr, yr, gamma, beta, eps, x.C, total, act);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

@@ -411,3 +411,65 @@ def make_ernerf_torso_state_dict(n_embeddings, seed=0, individual_dim=8, grid_si
     if individual_dim:
         sd["individual_codes_torso"] = torch.from_numpy((rng.standard_normal((4, individual_dim)) * 0.1).astype(np.float32))
     return sd
+
+
+# ---- wav2vec2 / HuBERT CTC network of NerfASR (nerfasr.py:41-45; transformers' Wav2Vec2ForCTC key names) ---------------------------------
+# cpierse/wav2vec2-large-xlsr-53-esperanto (app.py:660) is the XLSR-53 "large" architecture with a 44-symbol head (nerfasr.py:19-20: audio_dim 44)
+WAV2VEC2_XLSR_LARGE = dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, vocab_size=44,
+                           conv_dim=(512,) * 7, conv_kernel=(10, 3, 3, 3, 3, 2, 2), conv_stride=(5, 2, 2, 2, 2, 2, 2), conv_bias=True,
+                           feat_extract_norm="layer", do_stable_layer_norm=True, num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16,
+                           layer_norm_eps=1e-5)
+# reduced twin for quick tests: same structure, head dim 64 (the fused attention kernel's), 2 layers
+WAV2VEC2_SMALL = dict(WAV2VEC2_XLSR_LARGE, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=44,
+                      conv_dim=(64,) * 7, num_conv_pos_embedding_groups=2)
+
+
+def make_wav2vec2_state_dict(cfg, seed=0, shapes_only=False):
+    """Seeded Wav2Vec2ForCTC weights under transformers' own state-dict names (the positional conv in torch's parametrised weight-norm form).
+    shapes_only: {name: shape} without drawing anything (manifest tests)."""
+    rng = np.random.default_rng(12000 + seed)
+    C, F, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    sd = {}
+
+    def put(name, shape, scale=None, kind="normal"):
+        if shapes_only:
+            sd[name] = tuple(shape)
+            return
+        if kind == "gamma":
+            a = rng.uniform(0.8, 1.2, shape)
+        else:
+            a = rng.standard_normal(shape) * scale
+        sd[name] = torch.from_numpy(np.asarray(a, dtype=np.float32))
+
+    cin = 1
+    for i, (co, k) in enumerate(zip(cfg["conv_dim"], cfg["conv_kernel"])):
+        p = f"wav2vec2.feature_extractor.conv_layers.{i}."
+        put(p + "conv.weight", (co, cin, k), 1.4 / np.sqrt(cin * k))
+        if cfg["conv_bias"]:
+            put(p + "conv.bias", (co,), 0.05)
+        put(p + "layer_norm.weight", (co,), kind="gamma"); put(p + "layer_norm.bias", (co,), 0.05)
+        cin = co
+    put("wav2vec2.masked_spec_embed", (C,), 1.0)                                   # training-only parameter of the real checkpoints
+    put("wav2vec2.feature_projection.layer_norm.weight", (cin,), kind="gamma"); put("wav2vec2.feature_projection.layer_norm.bias", (cin,), 0.05)
+    put("wav2vec2.feature_projection.projection.weight", (C, cin), 1.0 / np.sqrt(cin)); put("wav2vec2.feature_projection.projection.bias", (C,), 0.05)
+    K, G = cfg["num_conv_pos_embeddings"], cfg["num_conv_pos_embedding_groups"]
+    pc = "wav2vec2.encoder.pos_conv_embed.conv."
+    put(pc + "bias", (C,), 0.05)
+    put(pc + "parametrizations.weight.original0", (1, 1, K), 0.0)                  # g, set below
+    put(pc + "parametrizations.weight.original1", (C, C // G, K), 1.0)             # v
+    if not shapes_only:
+        # g[k] = gain * ||v[:, :, k]||: an effective weight of std gain / sqrt(fan_in)
+        v = sd[pc + "parametrizations.weight.original1"].numpy()
+        nrm = np.sqrt((v.astype(np.float64) ** 2).sum((0, 1)))
+        sd[pc + "parametrizations.weight.original0"] = torch.from_numpy((nrm * (0.7 / np.sqrt(C // G * K)) * rng.uniform(0.8, 1.2, K)).astype(np.float32).reshape(1, 1, K))
+    put("wav2vec2.encoder.layer_norm.weight", (C,), kind="gamma"); put("wav2vec2.encoder.layer_norm.bias", (C,), 0.05)
+    for l in range(cfg["num_hidden_layers"]):
+        p = f"wav2vec2.encoder.layers.{l}."
+        for n, g in (("q_proj", 1.5), ("k_proj", 1.5), ("v_proj", 1.0), ("out_proj", 0.7)):
+            put(p + f"attention.{n}.weight", (C, C), g / np.sqrt(C)); put(p + f"attention.{n}.bias", (C,), 0.05)
+        put(p + "layer_norm.weight", (C,), kind="gamma"); put(p + "layer_norm.bias", (C,), 0.05)
+        put(p + "feed_forward.intermediate_dense.weight", (F, C), 1.0 / np.sqrt(C)); put(p + "feed_forward.intermediate_dense.bias", (F,), 0.05)
+        put(p + "feed_forward.output_dense.weight", (C, F), 0.7 / np.sqrt(F)); put(p + "feed_forward.output_dense.bias", (C,), 0.05)
+        put(p + "final_layer_norm.weight", (C,), kind="gamma"); put(p + "final_layer_norm.bias", (C,), 0.05)
+    put("lm_head.weight", (V, C), 1.0 / np.sqrt(C)); put("lm_head.bias", (V,), 0.05)
+    return sd
