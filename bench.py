@@ -610,6 +610,35 @@ class ErNeRFRunner:
                 "sample": f"{n} frames of {width}x{width} rays through the C / torch restatement, scaled by ray count to {self.width}x{self.width}"}
 
 
+def wav2vec2_report(args, device):
+    """NerfASR's per-step network call (nerfasr.py:105-143): one (l + m + r) x 20 ms window = 8960 samples through the XLSR-53-large CTC network
+    every m = 8 video-rate steps (160 ms of audio); 1 window and 8 sessions' windows per call; logits against transformers on the CPU."""
+    from mere_fusion_amd.ernerf.asr import HipWav2Vec2ForCTC
+    from oracle import wav2vec2_ref as R
+    cfg = W.WAV2VEC2_XLSR_LARGE
+    sd = W.make_wav2vec2_state_dict(cfg, 0)
+    wav = np.stack([W.make_speech_like_wav(8960, s) for s in range(8)])
+    m = HipWav2Vec2ForCTC(cfg, sd, max_windows=8, precision=args.precision, device=device)
+    x1, x8 = torch.from_numpy(wav[:1]).to(device), torch.from_numpy(wav).to(device)
+    rep = {"network": "Wav2Vec2ForCTC, XLSR-53 large (24 x 1024, 315 M parameters), 44 symbols; seeded random-init weights", "samples_per_window": 8960,
+           "audio_ms_per_call": 160, "unit": "ms per call"}
+    for tag, x in (("one_window", x1), ("eight_windows_per_call", x8)):
+        el = harness.timed_steps(lambda: m(x), 20, 3, sync_fn=torch.cuda.synchronize)
+        rep[tag] = round(el / 20 * 1e3, 3)
+    t0 = time.perf_counter()
+    torch.set_num_threads(host_threads(args.cpu_threads))
+    ref_model = R.build(cfg, sd)
+    want = R.frame_to_logits(ref_model, wav[:1])
+    t1 = time.perf_counter()
+    for _ in range(3):
+        R.frame_to_logits(ref_model, wav[:1])
+    rep["cpu_transformers_ms_per_window"] = round((time.perf_counter() - t1) / 3 * 1e3, 1)
+    rep["logits_linf_vs_transformers"] = float(np.abs(m(x1).logits.cpu().numpy() - want).max())
+    del m
+    torch.cuda.empty_cache()
+    return rep
+
+
 def ernerf_report(args, device, world, rank, value=None, ms_per_step=None, run=None):
     """The configs[4] leg (ER-NeRF 512x512).  Headline when --workload ernerf, else an extra object."""
     if run is None:
@@ -625,6 +654,8 @@ def ernerf_report(args, device, world, rank, value=None, ms_per_step=None, run=N
            "samples_per_frame": int(smp), "march_iterations": len(run.trace), "loop": run.loop,
            "field_tflops_algorithmic": round(smp * 46368 * value / max(world, 1) / 1e12, 2)}
     rep["parity"] = run.parity()
+    if getattr(args, "extras", 1):
+        rep["asr_frontend"] = wav2vec2_report(args, device)
     if args.profile_iters > 0:
         rep["roofline"] = run.roofline(args.profile_iters)
     if args.cpu_seconds > 0:
