@@ -88,6 +88,7 @@ struct HaloArgs {
     // LDS-weights kernel only: GroupNorm + SiLU of the INPUT applied to the halo image in LDS, v = silu(x * gn_scale[b][c] + gn_shift[b][c]); null = none
     const float* gn_scale; const float* gn_shift; int gn_C;
     unsigned long long* dbg;                    // MF_DBG_TIMES: 4 s_memtime stamps per workgroup (entry, loop start, loop end, exit), or null
+    int stagger;                                // LDS-weights kernel, 8-wave tiles: the second wave of every SIMD issues its weight DMA mid-tap (filled by the launcher)
 };
 struct HaloTile { int ph, bn, wgm, wgn; };
 HaloTile mf_halo_pick_tile(int H, int W, int N, int batch, int cin = 0);

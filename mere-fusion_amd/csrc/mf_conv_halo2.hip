@@ -214,7 +214,19 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         }
     };
     // the TR taps of ring slot `step` (taps step*TR ...): pixel fragments from the halo image at the tap's shift, weights from ring buffer `buf`
-    auto compute_row = [&](int stage, int step, int buf) __attribute__((always_inline)) {
+    constexpr int NSTEP = NT / TR;
+    // the next ring slot (of this slice, or slot 0 of the next) into the other ring buffer: everyone left it at the last barrier
+    auto issue_next = [&](int slice, int step, bool more, int buf) __attribute__((always_inline)) {
+        if (step < NSTEP - 1) load_wrow(slice, step + 1, buf ^ 1);
+        else if (more) load_wrow(slice + 1, 0, buf ^ 1);
+    };
+    // Two waves share a SIMD in the 8-wave tiles and run the same program: both would spend the first few hundred cycles of every tap
+    // issuing their LDS-DMA pieces (100-185 cycles each inside a loaded phase, MI355X_MICROARCH.md) with the matrix pipe idle.  The second
+    // wave of each SIMD (waves NW/2 ...) issues its pieces in the MIDDLE of the tap instead, under its partner's MFMAs.  MEASURED (VAE, batch 8):
+    // halo_w convs 7.78 -> 8.00 ms -- moving issue slots between the two waves of a SIMD is negative-sum here too, as the guide warns; opt-in only
+    // (MF_HALO_STAGGER=1).
+    const bool late_dma = NW == 8 && TR == 1 && a.stagger && wave >= NW / 2;
+    auto compute_row = [&](int stage, int step, int buf, int slice, bool more) __attribute__((always_inline)) {
         const char* base = smem + stage * STAGE;
         const char* wb = wring + buf * WROW;
 #pragma unroll
@@ -240,6 +252,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
                 }
 #pragma unroll
                 for (int j = 0; j < FM; ++j) {
+                    if (NW == 8 && TR == 1 && j == FM / 2 && late_dma) issue_next(slice, step, more, buf);
                     if (PF) {
                         if (j + 1 < FM) {
                             const char* p = base + lane_off[dx][kk] + (j + 1 + dy) * HW * ROWB;
@@ -318,13 +331,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             __syncthreads();
         }
         if (a.res_from_halo) add_residual(st, slice);
-        constexpr int NSTEP = NT / TR;
 #pragma unroll
         for (int step = 0; step < NSTEP; ++step) {
-            // the next slot (of this slice, or slot 0 of the next) into the other ring buffer: everyone left it at the last barrier
-            if (step < NSTEP - 1) load_wrow(slice, step + 1, wbuf ^ 1);
-            else if (more) load_wrow(slice + 1, 0, wbuf ^ 1);
-            compute_row(st, step, wbuf);
+            if (!late_dma) issue_next(slice, step, more, wbuf);
+            compute_row(st, step, wbuf, slice, more);
             if (step < NSTEP - 1 || more) __syncthreads();   // next slot (and, at the last step, the next halo image) landed; this one is released
             if (HS == 1 && step == NSTEP - 1 && more) {      // single image: reload it now that every wave is done with it
                 load_halo(slice + 1, 0);
@@ -461,6 +471,8 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     const size_t lds = (size_t)HS * NP * HCH * 1024 + (size_t)2 * TR * NP * BN * CK * 2;
     static const bool dbg_times = getenv("MF_DBG_TIMES") != nullptr;
     HaloArgs aa = a;
+    static const bool stagger = [] { const char* e = getenv("MF_HALO_STAGGER"); return e && atoi(e) != 0; }();   // opt-in: measured 2.7 % SLOWER
+    aa.stagger = stagger ? 1 : 0;
     const size_t nwg = (size_t)a.n_patches * a.tiles_n * (a.nsplit > 1 ? a.nsplit : 1);
     if (dbg_times && nwg <= 65536) {
         static unsigned long long* dbg_buf = nullptr;
