@@ -452,6 +452,40 @@ int mf_wav2vec2_frames(const mf_wav2vec2* h, int* n_frames, int* width);
 int mf_wav2vec2_forward(mf_wav2vec2* h, const float* wav, int n_samples, int n_windows, float* out, void* stream);
 void mf_wav2vec2_destroy(mf_wav2vec2* h);
 
+/* ---- avatar preparation: static CNN graphs --------------------------------------------------------- */
+/* The S3FD face detector (`s3fd.forward`, face_detection/detection/sfd/net_s3fd.py:72-129; called through `detect` / `batch_detect`,
+ * sfd/detect.py:19-92, from genavatar.py:61-99 and musetalk/utils/preprocessing.py:63,104) and the BiSeNet face parser (`BiSeNet.forward`,
+ * musetalk/utils/face_parsing/model.py:245-262 over resnet.py:60-95; called at face_parsing/__init__.py:51) are plain Python module trees
+ * in the reference.  The drop-in modules (mere-fusion_amd/avatar/) walk the same trees and emit one op per module through this builder; all
+ * arithmetic runs in the library.  Buffers are padded NHWC (hi, lo) planes; `coff` arguments select channel slices (torch.cat = two
+ * producers writing slices of one buffer).  Build: mf_net_create, mf_net_buffer (returns a buffer id >= 0), ops in execution order.
+ * Run: mf_net_set_input -> mf_net_run (captured into a hipGraph per batch size) -> mf_net_get_output*.  (ABI version 3) */
+typedef struct mf_net mf_net;
+int mf_net_create(int max_batch, int precision, mf_net** out);
+int mf_net_buffer(mf_net* h, int C, int H, int W, int halo);
+/* nn.Conv2d (+ eval-mode BatchNorm2d folded when bn_* are given, + residual, + d->act) on the MFMA kernels; in_h / in_w of `d` are taken from
+ * the input buffer; bias may be NULL; res_buf < 0: no residual. */
+int mf_net_conv(mf_net* h, const mf_conv2d_desc* d, const float* weight, const float* bias, const float* bn_gamma, const float* bn_beta,
+                const float* bn_mean, const float* bn_var, int in_buf, int in_coff, int out_buf, int out_coff, int res_buf, int res_coff,
+                const char* name);
+int mf_net_maxpool(mf_net* h, int in_buf, int out_buf, int k, int stride, int pad);                       /* F.max_pool2d / nn.MaxPool2d */
+int mf_net_l2norm(mf_net* h, int in_buf, int out_buf, const float* weight, int C, float eps);            /* L2Norm, net_s3fd.py:6-19 */
+int mf_net_global_avgpool(mf_net* h, int in_buf, int in_coff, int C, int out_buf);                       /* F.avg_pool2d(x, x.size()[2:]) -> 1x1 map */
+/* out = x * s[b][c] + t + v[b][c]: s, v are 1x1 maps (channel attention `torch.mul(feat, atten)`, the nearest-upsampled global feature of
+ * model.py:103-107), t a map of x's size (`feat_atten + feat`, `feat16_arm + feat32_up`); any of s_buf / t_buf / v_buf may be < 0 */
+int mf_net_scale_add(mf_net* h, int x_buf, int x_coff, int C, int s_buf, int t_buf, int t_coff, int v_buf, int out_buf, int out_coff);
+int mf_net_upsample_nearest(mf_net* h, int in_buf, int out_buf);                                         /* F.interpolate(x, size, mode='nearest') */
+int mf_net_num_ops(const mf_net* h);
+double mf_net_flops_per_item(const mf_net* h);                                                           /* 2 x MACs of the convolutions, one batch item */
+int mf_net_set_input(mf_net* h, int buf, const float* nchw, int C, int batch, void* stream);             /* device fp32 [batch][C][H][W] */
+int mf_net_run(mf_net* h, int batch, void* stream);
+int mf_net_get_output(mf_net* h, int buf, int coff, int C, float* nchw, int batch, void* stream);        /* device fp32 [batch][C][H][W] */
+/* F.interpolate(x, (H, W), mode='bilinear', align_corners=True) of a channel slice -> device fp32 [batch][C][H][W] (model.py:257-259) */
+int mf_net_get_output_bilinear(mf_net* h, int buf, int coff, int C, float* nchw, int H, int W, int batch, void* stream);
+/* "max-out background label" of net_s3fd.py:123-126: device fp32 [batch][4][hw] -> [batch][2][hw] = (max(c0, c1, c2), c3) */
+int mf_s3fd_maxout_bg(const float* cls4, float* cls2, int batch, int hw, void* stream);
+void mf_net_destroy(mf_net* h);
+
 /* ---- frame transport ----------------------------------------------------------------------- */
 /* Host-side plumbing of the shared-memory frame ring that replaces the pickled `res_frame_queue` items of
  * lipreal.py:136,161 / musereal.py:116,153 (mere-fusion_amd/transport.py keeps the (res_frame, idx, audio_frames) tuple

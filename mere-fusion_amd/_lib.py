@@ -103,6 +103,23 @@ SIGNATURES = {
     "mf_wav2vec2_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mf_wav2vec2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mf_wav2vec2_destroy": (None, [C.c_void_p]),
+    "mf_net_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mf_net_buffer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mf_net_conv": (C.c_int, [C.c_void_p, C.POINTER(MfConv2dDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]),
+    "mf_net_maxpool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mf_net_l2norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float]),
+    "mf_net_global_avgpool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mf_net_scale_add": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mf_net_upsample_nearest": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mf_net_num_ops": (C.c_int, [C.c_void_p]),
+    "mf_net_flops_per_item": (C.c_double, [C.c_void_p]),
+    "mf_net_set_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mf_net_run": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mf_net_get_output": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mf_net_get_output_bilinear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mf_s3fd_maxout_bg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mf_net_destroy": (None, [C.c_void_p]),
     "mf_unet_create": (C.c_int, [C.POINTER(MfUnetConfig), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mf_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_unet_num_ops": (C.c_int, [C.c_void_p]),

@@ -473,3 +473,67 @@ def make_wav2vec2_state_dict(cfg, seed=0, shapes_only=False):
         put(p + "final_layer_norm.weight", (C,), kind="gamma"); put(p + "final_layer_norm.bias", (C,), 0.05)
     put("lm_head.weight", (V, C), 1.0 / np.sqrt(C)); put("lm_head.bias", (V,), 0.05)
     return sd
+
+
+# ---- avatar preparation: S3FD (net_s3fd.py:22-70) and BiSeNet (face_parsing/model.py + resnet.py) under the reference's module names -------
+_S3FD_CONVS = [("conv1_1", 3, 64, 3), ("conv1_2", 64, 64, 3), ("conv2_1", 64, 128, 3), ("conv2_2", 128, 128, 3), ("conv3_1", 128, 256, 3),
+               ("conv3_2", 256, 256, 3), ("conv3_3", 256, 256, 3), ("conv4_1", 256, 512, 3), ("conv4_2", 512, 512, 3), ("conv4_3", 512, 512, 3),
+               ("conv5_1", 512, 512, 3), ("conv5_2", 512, 512, 3), ("conv5_3", 512, 512, 3), ("fc6", 512, 1024, 3), ("fc7", 1024, 1024, 1),
+               ("conv6_1", 1024, 256, 1), ("conv6_2", 256, 512, 3), ("conv7_1", 512, 128, 1), ("conv7_2", 128, 256, 3),
+               ("conv3_3_norm_mbox_conf", 256, 4, 3), ("conv3_3_norm_mbox_loc", 256, 4, 3), ("conv4_3_norm_mbox_conf", 512, 2, 3),
+               ("conv4_3_norm_mbox_loc", 512, 4, 3), ("conv5_3_norm_mbox_conf", 512, 2, 3), ("conv5_3_norm_mbox_loc", 512, 4, 3),
+               ("fc7_mbox_conf", 1024, 2, 3), ("fc7_mbox_loc", 1024, 4, 3), ("conv6_2_mbox_conf", 512, 2, 3), ("conv6_2_mbox_loc", 512, 4, 3),
+               ("conv7_2_mbox_conf", 256, 2, 3), ("conv7_2_mbox_loc", 256, 4, 3)]
+
+
+def make_s3fd_state_dict(seed=0, shapes_only=False):
+    rng = np.random.default_rng(14000 + seed)
+    sd = {}
+
+    def put(name, shape, scale):
+        sd[name] = tuple(shape) if shapes_only else torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+
+    for name, ci, co, k in _S3FD_CONVS:
+        head = "mbox" in name
+        put(name + ".weight", (co, ci, k, k), (0.3 if head else 1.0) * np.sqrt(2.0 / (ci * k * k)))
+        put(name + ".bias", (co,), 0.3 if head else 0.05)
+    for name, ch, scale in (("conv3_3_norm", 256, 10.0), ("conv4_3_norm", 512, 8.0), ("conv5_3_norm", 512, 5.0)):
+        sd[name + ".weight"] = (ch,) if shapes_only else torch.from_numpy((scale * rng.uniform(0.8, 1.2, ch)).astype(np.float32))
+    return sd
+
+
+def make_bisenet_state_dict(seed=0, n_classes=19, shapes_only=False):
+    rng = np.random.default_rng(15000 + seed)
+    sd = {}
+
+    def conv(name, co, ci, k, gain=1.0):
+        sd[name] = (co, ci, k, k) if shapes_only else torch.from_numpy((rng.standard_normal((co, ci, k, k)) * gain * np.sqrt(2.0 / (ci * k * k))).astype(np.float32))
+
+    def bn(p, ch):
+        for key, gen in (("weight", lambda: rng.uniform(0.8, 1.2, ch)), ("bias", lambda: rng.standard_normal(ch) * 0.1),
+                         ("running_mean", lambda: rng.standard_normal(ch) * 0.1), ("running_var", lambda: rng.uniform(0.5, 1.5, ch))):
+            sd[f"{p}.{key}"] = (ch,) if shapes_only else torch.from_numpy(gen().astype(np.float32))
+
+    def cbr(p, ci, co, k):
+        conv(p + ".conv.weight", co, ci, k); bn(p + ".bn", co)
+
+    conv("cp.resnet.conv1.weight", 64, 3, 7); bn("cp.resnet.bn1", 64)
+    cin = 64
+    for li, (co, stride) in enumerate(((64, 1), (128, 2), (256, 2), (512, 2)), 1):
+        for bi in range(2):
+            p = f"cp.resnet.layer{li}.{bi}"
+            conv(p + ".conv1.weight", co, cin, 3); bn(p + ".bn1", co)
+            conv(p + ".conv2.weight", co, co, 3, 0.7); bn(p + ".bn2", co)
+            if bi == 0 and (cin != co or stride != 1):
+                conv(p + ".downsample.0.weight", co, cin, 1); bn(p + ".downsample.1", co)
+            cin = co
+    for p, ci in (("cp.arm16", 256), ("cp.arm32", 512)):
+        cbr(p + ".conv", ci, 128, 3)
+        conv(p + ".conv_atten.weight", 128, 128, 1); bn(p + ".bn_atten", 128)
+    cbr("cp.conv_head32", 128, 128, 3); cbr("cp.conv_head16", 128, 128, 3); cbr("cp.conv_avg", 512, 128, 1)
+    cbr("ffm.convblk", 256, 256, 1)
+    conv("ffm.conv1.weight", 64, 256, 1); conv("ffm.conv2.weight", 256, 64, 1)
+    for p, ci, mid in (("conv_out", 256, 256), ("conv_out16", 128, 64), ("conv_out32", 128, 64)):
+        cbr(p + ".conv", ci, mid, 3)
+        conv(p + ".conv_out.weight", n_classes, mid, 1, 2.0)
+    return sd
