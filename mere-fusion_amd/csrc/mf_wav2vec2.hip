@@ -87,6 +87,10 @@ struct mf_wav2vec2 {
         for (auto& p : plans) mf_conv_plan_destroy(p.get());
         for (auto& b : bufs) { if (b->hi) (void)hipFree(b->hi); if (b->lo) (void)hipFree(b->lo); }
         for (float* f : dev_f32) (void)hipFree(f);
+        for (auto& g : graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (ev_in) (void)hipEventDestroy(ev_in);
+        if (ev_out) (void)hipEventDestroy(ev_out);
     }
     ActBuf* seq(int C, int T_, int halo = 0) {
         bufs.emplace_back(new ActBuf());
@@ -110,6 +114,14 @@ struct mf_wav2vec2 {
         return MF_OK;
     }
     int forward(const float* wav, int S, float* out, hipStream_t s);
+    int body(int S, hipStream_t s, ActBuf** last);
+    // the ~240 launches between the input normalisation and the output copy replay as one hipGraph per window count (first call eager: split-K
+    // workspaces are sized there; second call captures)
+    std::map<int, hipGraphExec_t> graphs;
+    std::map<int, ActBuf*> graph_last;
+    hipStream_t cap_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    bool use_graph = true;
 };
 
 namespace {
@@ -138,6 +150,40 @@ int mf_wav2vec2::forward(const float* wav, int S, float* out, hipStream_t s) {
     hipLaunchKernelGGL(k_w2v_normalize, dim3(S), dim3(1024), 0, s, wav, n, cfg.do_normalize, wav_in->hi + mf_interior(*wav_in),
                        wav_in->lo ? wav_in->lo + mf_interior(*wav_in) : nullptr, wav_in->C, wav_in->per_batch());
     MF_HIP(hipGetLastError());
+    ActBuf* cur = nullptr;
+    if (!use_graph) {
+        if ((rc = body(S, s, &cur))) return rc;
+    } else {
+        auto it = graphs.find(S);
+        if (it == graphs.end()) {
+            graphs.emplace(S, nullptr);
+            if ((rc = body(S, s, &cur))) return rc;
+            graph_last[S] = cur;
+        } else {
+            if (!it->second) {
+                hipGraph_t graph = nullptr;
+                MF_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+                rc = body(S, cap_stream, &cur);
+                hipError_t e = hipStreamEndCapture(cap_stream, &graph);
+                if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+                MF_HIP(e);
+                MF_HIP(hipGraphInstantiate(&it->second, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+            }
+            cur = graph_last[S];
+            MF_HIP(hipEventRecord(ev_in, s));
+            MF_HIP(hipStreamWaitEvent(cap_stream, ev_in, 0));
+            MF_HIP(hipGraphLaunch(it->second, cap_stream));
+            MF_HIP(hipEventRecord(ev_out, cap_stream));
+            MF_HIP(hipStreamWaitEvent(s, ev_out, 0));
+        }
+    }
+    if (cfg.out_hidden) return mf_rows_to_f32(V(cur), out, S, s);
+    return mf_rows_to_f32(ActView{logit, 0, cfg.vocab}, out, S, s);
+}
+
+int mf_wav2vec2::body(int S, hipStream_t s, ActBuf** last) {
+    int rc;
     // feature extractor: conv -> LayerNorm over channels -> GELU (Wav2Vec2LayerNormConvLayer)
     ActBuf* x = wav_in;
     for (int i = 0; i < cfg.n_conv; ++i) {
@@ -184,9 +230,9 @@ int mf_wav2vec2::forward(const float* wav, int S, float* out, hipStream_t s) {
         if ((rc = mf_layernorm(V(cur), V(oth), enc_g, enc_b, cfg.layer_norm_eps, S, s))) return rc;
         std::swap(cur, oth);
     }
-    if (cfg.out_hidden) return mf_rows_to_f32(V(cur), out, S, s);
-    if ((rc = mf_conv_launch(head, V(cur), ActView{logit, 0, vocab_pad}, ActView{}, S, s))) return rc;
-    return mf_rows_to_f32(ActView{logit, 0, cfg.vocab}, out, S, s);
+    *last = cur;
+    if (cfg.out_hidden) return MF_OK;
+    return mf_conv_launch(head, V(cur), ActView{logit, 0, vocab_pad}, ActView{}, S, s);
 }
 
 extern "C" int mf_wav2vec2_create(const mf_wav2vec2_config* cfg, const mf_tensor* weights, int n_weights, int n_samples, int max_windows, int precision,
@@ -214,6 +260,10 @@ extern "C" int mf_wav2vec2_create(const mf_wav2vec2_config* cfg, const mf_tensor
     }
     std::unique_ptr<mf_wav2vec2> h(new mf_wav2vec2());
     h->cfg = c; h->precision = precision; h->n = n_samples; h->cap = max_windows;
+    MF_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    MF_HIP(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    MF_HIP(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+    { const char* e = getenv("MF_NO_GRAPH"); h->use_graph = !(e && atoi(e) != 0); }
     int L = n_samples;
     for (int i = 0; i < c.n_conv; ++i) {
         MF_REQUIRE(c.conv_kernel[i] >= 1 && c.conv_stride[i] >= 1 && c.conv_dim[i] % 8 == 0, "wav2vec2_create: bad conv layer %d", i);
