@@ -661,9 +661,10 @@ int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStrea
     static const bool deep = [] { const char* e = getenv("MF_RING"); return e && !strcmp(e, "deep"); }();
     constexpr int NST = RingDepth<BM, BN, WGM, WGN, X3, BK>::value;
     if (deep && NST != 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, NST>(a, nphase, nsplit, goff_max, s);
-    // 4-wave tiles: operands through registers into one LDS stage (MF_IGEMM_LD=0 keeps the LDS-DMA loop, 1 the two-stage register path, for A/B);
-    // the 8-wave 256-wide tiles have no VGPRs to spare.  Per-op A/B at batch 8 (tools/igemm_ld_ab.sh): UNet 11.05 -> 10.62 ms with 64-deep tiles,
-    // Wav2Lip 14.6 k -> 15.1 k frames/s; every variant within +-15 % per layer -- the loop is bound by where the operands come FROM.
+    // 4-wave tiles: operands through registers into ONE LDS stage, so that 64-deep bf16x3 tiles (128-byte operand rows) still leave 2-3 workgroups
+    // per CU (MF_IGEMM_LD=0 keeps the LDS-DMA ring, 1 the two-stage register path, for A/B); the 8-wave 256-wide tiles have no VGPRs to spare.
+    // Per-op A/B at batch 8 (tools/igemm_ld_ab.sh): UNet 11.05 -> 10.62 ms, Wav2Lip 14.6 k -> 15.1 k frames/s; every variant within +-15 % per layer.
+    // Choosing DMA for the weight-heavy layers only (a.m_fastest) measured 1.4 % slower over the UNet than registers everywhere (10.80 vs 10.64 ms).
     static const int regs = [] { const char* e = getenv("MF_IGEMM_LD"); return e ? atoi(e) : 2; }();
     if constexpr (WGM * WGN == 4) {
         if (regs == 1 && 2 * RingDepth<BM, BN, WGM, WGN, X3, BK>::stage_bytes <= 150 * 1024) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 1>(a, nphase, nsplit, goff_max, s);
