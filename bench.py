@@ -192,6 +192,21 @@ def roofline(rows, precision, only_mfma=False):
     }, by
 
 
+def mfma_only_ceiling(precision):
+    """What a kernel issuing nothing but matrix instructions sustains on this device (random operand bits), in TFLOP/s of the convolution's own
+    arithmetic, for the shipped operand format and for the two fewer-pass formats DESIGN.md proposes (mf_probe_mfma_ceiling): the nominal peak of
+    `roofline.peak` assumes 2.4 GHz, which an MFMA-dense kernel never holds."""
+    l = _lib.lib()
+    out = {}
+    for mix, key in ((0, "bf16x3_12_bf16_mfma_per_128k"), (1, "f16_plus_2_mx_fp8"), (2, "f16_plus_2_mx_fp6")):
+        v = C.c_float()
+        _lib.check(l.mf_probe_mfma_ceiling(mix, C.byref(v)), "probe_mfma_ceiling")
+        out[key] = round(float(v.value), 1)
+    if precision == "bf16":
+        out["bf16_single_pass"] = round(3 * out["bf16x3_12_bf16_mfma_per_128k"], 1)
+    return out
+
+
 def pmc_traffic(kernel, workload, precision, batch_args, want_clock=True):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC counters, collected as MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE
     and WRITE_SIZE in SEPARATE passes (they do not fit one), --kernel-trace only beside --pmc, values in KiB; on gfx950 FETCH_SIZE
@@ -773,6 +788,15 @@ def main():
                     rf["peak_at_effective_clock"] = round(rf["peak"] * clk / 2.4, 1)
                     rf["frac_of_peak_at_effective_clock"] = round(rf["achieved"] / (rf["peak"] * clk / 2.4), 4)
                     rf["clock_note"] = "GRBM_GUI_ACTIVE / dispatch wall time under rocprofv3 (profiled passes clock ~3 % lower than un-profiled ones)"
+            if extras:
+                # the ceiling a kernel of pure matrix instructions reaches on this device, next to the nominal peak
+                ceil = mfma_only_ceiling(args.precision)
+                rf["mfma_only_ceiling_tflops"] = ceil
+                ref = ceil.get("bf16_single_pass", ceil["bf16x3_12_bf16_mfma_per_128k"])
+                rf["frac_of_mfma_only_ceiling"] = round(rf["achieved"] / ref, 4)
+                rf["ceiling_note"] = ("mf_probe_mfma_ceiling: TFLOP/s of the convolution's own arithmetic from a loop of nothing but MFMAs (8 waves per CU, random "
+                                      "operand bits) for the instruction mix of one product: 3 bf16 MFMAs as shipped; f16 + two block-scaled FP8 / FP6 correction terms "
+                                      "(not built: numerics in tools/numerics_split_study.py, layouts in tools/mx_cross_probe.hip)")
             line["roofline"] = rf
             conv_rows = [r for r in rows if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
             if conv_rows:

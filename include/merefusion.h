@@ -486,6 +486,12 @@ int mf_net_get_output_bilinear(mf_net* h, int buf, int coff, int C, float* nchw,
 int mf_s3fd_maxout_bg(const float* cls4, float* cls2, int batch, int hw, void* stream);
 void mf_net_destroy(mf_net* h);
 
+/* ---- measurement seam --------------------------------------------------------------------------------------------- */
+/* TFLOP/s of the convolution's own arithmetic that a kernel issuing NOTHING but matrix instructions sustains on this device (random operand bits, 8
+ * waves per CU) for the instruction mix one product costs: mix 0 = bf16x3 as shipped (3 bf16 MFMAs), 1 = f16 + two FP8 block-scaled correction
+ * terms, 2 = f16 + two FP6 ones.  bench.py reports it beside the nominal peak.  (ABI version 3) */
+int mf_probe_mfma_ceiling(int mix, float* tflops_algorithmic);
+
 /* ---- frame transport ----------------------------------------------------------------------- */
 /* Host-side plumbing of the shared-memory frame ring that replaces the pickled `res_frame_queue` items of
  * lipreal.py:136,161 / musereal.py:116,153 (mere-fusion_amd/transport.py keeps the (res_frame, idx, audio_frames) tuple

@@ -120,6 +120,7 @@ SIGNATURES = {
     "mf_net_get_output_bilinear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mf_s3fd_maxout_bg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mf_net_destroy": (None, [C.c_void_p]),
+    "mf_probe_mfma_ceiling": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
     "mf_unet_create": (C.c_int, [C.POINTER(MfUnetConfig), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mf_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_unet_num_ops": (C.c_int, [C.c_void_p]),
