@@ -10,6 +10,7 @@
 //                 output pixel's input anchor; staged in LDS by every workgroup.
 #pragma once
 #include "mf_common.h"
+#include <map>
 #include <vector>
 #include <utility>
 
@@ -57,6 +58,7 @@ struct ConvArgs {
     int tiles_m, tiles_n;
     unsigned long long* dbg;  // MF_DBG_TIMES: 4 s_memtime stamps per workgroup, or null
     int m_fastest;            // XCD tile order: pixel tiles fastest (weight-heavy layers), see k_conv_igemm
+    int ld;                   // operand path of the 4-wave tiles (k_conv_igemm's LD): -1 = the library default, 0 / 1 / 2 = measured choice (mf_conv_tune)
     int wide_store;           // output view starts on an 8-channel group and N % 8 == 0: 16-byte epilogue stores (lane pairs exchange halves)
     int goff_total;
     // grouped launch (attention: one GEMM per (batch, head) on blockIdx.z): element offsets per group
@@ -102,6 +104,9 @@ bool mf_conv_can_fuse_gn(const struct ConvPlan* p, int batch);
 int mf_conv_launch_gn(struct ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, const float* gn_scale,
                       const float* gn_shift, hipStream_t stream);   // phase 0..3: one phase of upsample + 3x3
 
+struct ConvTile { int bm, bn, wgm, wgn, nsplit; };
+struct ConvTuned { ConvTile tile; int ld; };   // a measured launch configuration (mf_conv_tune)
+
 struct ConvPlan {
     mf_conv2d_desc d{};
     int precision = 0;
@@ -146,6 +151,7 @@ struct ConvPlan {
     int goff_total = 0;
     // binding-dependent (built by mf_conv_bind)
     int bound_in_ld = -1, bound_in_wp = -1;
+    std::map<int, ConvTuned> tuned;           // batch -> configuration measured on this device (mf_conv_tune); empty: the cost model decides
 };
 
 // Folds BN, packs weights, uploads.  Returns mf_status.
@@ -158,11 +164,16 @@ void mf_conv_plan_destroy(ConvPlan* p);
 // row stride = Wp*C).  Must be called once before launch; rebinding to another geometry is allowed.
 int mf_conv_bind(ConvPlan* p, const ActBuf& in);
 
-struct ConvTile { int bm, bn, wgm, wgn, nsplit; };
 // rocprofv3-style name of the kernel mf_conv_launch will use at this batch size
 void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap);
 // Workgroup tile the launch will use for this batch size (kernel = k_conv_igemm<bm,bn,wgm,wgn,x3>).
 ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch);
+// Measures the implicit-GEMM launch configurations (tile x split-K x operand path) of this layer at this batch ON the bound buffers and keeps the
+// fastest in p->tuned (layers that run on the halo kernels are left alone).  Eager only: call between two uncaptured forwards.  The cost model
+// behind mf_conv_pick_tile was fitted to one kernel generation; on the UNet's small GEMMs its pick is 0-15 % off per layer in either direction.
+int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, hipStream_t stream);
+// MF_AUTOTUNE=0 turns the measured configurations off (the cost model alone decides); default on
+bool mf_autotune_enabled();
 // Algorithmic FLOPs of the layer (2 x MACs of the convolution itself; BN/ReLU/residual excluded).
 double mf_conv_flops(const ConvPlan* p, int batch);
 

@@ -665,7 +665,8 @@ int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStrea
     // per CU (MF_IGEMM_LD=0 keeps the LDS-DMA ring, 1 the two-stage register path, for A/B); the 8-wave 256-wide tiles have no VGPRs to spare.
     // Per-op A/B at batch 8 (tools/igemm_ld_ab.sh): UNet 11.05 -> 10.62 ms, Wav2Lip 14.6 k -> 15.1 k frames/s; every variant within +-15 % per layer.
     // Choosing DMA for the weight-heavy layers only (a.m_fastest) measured 1.4 % slower over the UNet than registers everywhere (10.80 vs 10.64 ms).
-    static const int regs = [] { const char* e = getenv("MF_IGEMM_LD"); return e ? atoi(e) : 2; }();
+    static const int regs_default = [] { const char* e = getenv("MF_IGEMM_LD"); return e ? atoi(e) : 2; }();
+    const int regs = a.ld >= 0 ? a.ld : regs_default;
     if constexpr (WGM * WGN == 4) {
         if (regs == 1 && 2 * RingDepth<BM, BN, WGM, WGN, X3, BK>::stage_bytes <= 150 * 1024) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 1>(a, nphase, nsplit, goff_max, s);
         if (regs == 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 2>(a, nphase, nsplit, goff_max, s);
@@ -1200,6 +1201,11 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
     }
 
     ConvTile tc = mf_conv_pick_tile(p, batch);
+    a.ld = -1;
+    {
+        auto it = p->tuned.find(batch);
+        if (it != p->tuned.end()) a.ld = it->second.ld;
+    }
     if (tokens > 0) {
         // the cost model priced the full sequence: re-balance the split for the rows actually computed
         const int nt = cdiv(a.M, tc.bm) * cdiv(a.N, tc.bn);
@@ -1314,6 +1320,7 @@ int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream
     a.y_hi = g.y_hi; a.y_lo = x3 ? g.y_lo : nullptr;
     a.yb = 0; a.yi = 0; a.yj = g.y_row;
     a.act = 0;
+    a.ld = -1;
     a.goff_total = p->goff_total;
     a.ph[0] = p->ph[0];
     a.zgroups = g.groups; a.zheads = g.heads;
@@ -1340,6 +1347,11 @@ int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream
 // fitted to 386 measured (shape, tile, split) points of the MuseTalk UNet / VAE layers (mean loss vs the best measured
 // configuration 3.5 %).
 ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
+    {
+        static const bool forced = getenv("MF_FORCE_TILE") || getenv("MF_FORCE_SPLIT");
+        auto it = p->tuned.find(batch);
+        if (!forced && it != p->tuned.end()) return it->second.tile;
+    }
     const int M = batch * p->Hq * p->Wq, N = p->d.cout;
     int kt_min = p->ph[0].KT;
     double kt_sum = 0;
@@ -1384,6 +1396,76 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
     if (nt < 256 && kt_min >= 2) t.nsplit = std::max(1, std::min(std::min(kt_min, cdiv(512, nt)), 16));
     if (force_split) t.nsplit = std::max(1, std::min(std::min(kt_min, force_split), 16));
     return t;
+}
+
+bool mf_autotune_enabled() {
+    static const bool on = [] { const char* e = getenv("MF_AUTOTUNE"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
+int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, hipStream_t stream) {
+    static const bool forced = getenv("MF_FORCE_TILE") || getenv("MF_FORCE_SPLIT");
+    if (p->halo || p->up_hi || forced) return MF_OK;                                 // halo-kernel layers keep their own tile choice
+    const int M = batch * p->Hq * p->Wq, N = p->d.cout;
+    if (N <= 32 || (M <= 16 && p->d.act != 5)) return MF_OK;                          // the narrow special tiles have no alternatives
+    p->tuned.erase(batch);
+    const ConvTile base = mf_conv_pick_tile(p, batch);                                // what the cost model would launch
+    int kt_min = p->ph[0].KT;
+    for (int ph = 0; ph < p->nphase; ++ph) kt_min = std::min(kt_min, p->ph[ph].KT);
+    struct Cand { int bm, bn, wgm, wgn; };
+    static const Cand tiles[] = {{64, 64, 2, 2}, {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 128, 4, 2}, {256, 256, 2, 4}};
+    static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    hipEvent_t e0, e1;
+    MF_HIP(hipEventCreate(&e0)); MF_HIP(hipEventCreate(&e1));
+    auto measure = [&](const ConvTuned& c, float* us) -> int {
+        p->tuned[batch] = c;
+        int rc = mf_conv_launch(p, in, out, res, batch, stream);                     // warm-up: also sizes the split-K workspace
+        if (rc) return rc;
+        float best = 1e30f;
+        for (int i = 0; i < 3; ++i) {
+            MF_HIP(hipEventRecord(e0, stream));
+            if ((rc = mf_conv_launch(p, in, out, res, batch, stream))) return rc;
+            MF_HIP(hipEventRecord(e1, stream));
+            MF_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            MF_HIP(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms * 1e3f);
+        }
+        *us = best;
+        return MF_OK;
+    };
+    ConvTuned best_c{base, -1};
+    float base_us = 0.f;
+    int rc = measure(best_c, &base_us);
+    float best_us = base_us;
+    for (const Cand& t : tiles) {
+        if (rc) break;
+        if (t.bn == 128 && t.bm == 128 && N % 128) continue;
+        if (t.bm >= 256 && M < 256) continue;
+        const int64_t nt = (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn) * p->nphase;
+        for (int S : splits) {
+            if (S > kt_min || (S > 1 && nt >= 1024) || nt * S > 4096) continue;
+            if (p->d.act == 5 && t.bn < 32 && S > 1) continue;
+            for (int ld : {2, 0}) {
+                if (t.wgm * t.wgn == 8 && ld != 0) continue;                        // the 8-wave tiles only have the LDS-DMA loop
+                const ConvTuned c{ConvTile{t.bm, t.bn, t.wgm, t.wgn, S}, ld};
+                float us = 0.f;
+                if ((rc = measure(c, &us))) break;
+                if (us < best_us) { best_us = us; best_c = c; }
+            }
+            if (rc) break;
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc) { p->tuned.erase(batch); return rc; }
+    // keep the model's pick unless the measured winner is clearly ahead (event timing of a 10-100 us launch is good to ~1 us)
+    if (best_us > 0.97f * base_us) p->tuned.erase(batch);
+    else p->tuned[batch] = best_c;
+    static const bool verbose = getenv("MF_TUNE_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "[mf_conv_tune] M %d N %d K %d: model %dx%d split %d %.1f us -> %s %dx%d split %d ld %d %.1f us\n", M, N, kt_min * 64, base.bm, base.bn, base.nsplit,
+                base_us, p->tuned.count(batch) ? "tuned" : "kept", best_c.tile.bm, best_c.tile.bn, best_c.tile.nsplit, best_c.ld, best_us);
+    return MF_OK;
 }
 
 void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {

@@ -46,6 +46,10 @@ struct Net {
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     bool use_graph = true;
+    // implicit-GEMM layers with their bound views: measured launch configurations (mf_conv_tune) on the first forward at a batch size
+    struct Tunable { ConvPlan* p; ActView in, out, res; };
+    std::vector<Tunable> tunables;
+    bool autotune = false;
     int next_pad_hi = 0;        // consumed by the next conv(): extra zero rows / columns bottom-right (the VAE encoder's Downsample2D)
     std::string err;
 
@@ -145,6 +149,7 @@ struct Net {
         char kn[96];
         mf_conv_kernel_name(p, cap, kn, sizeof(kn));
         push(name, kn, mf_conv_flops(p, 1), [p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
+        tunables.push_back(Tunable{p, in, out, res});
         return MF_OK;
     }
     // GroupNorm(+SiLU) `gname` of x followed by the 3x3 conv `cname`.  Where the conv runs on the LDS-weights halo kernel's fat tiles at the
@@ -374,6 +379,7 @@ struct Net {
         mf_conv_kernel_name(p, cap, kn, sizeof(kn));
         push("fused linear " + std::to_string(cin) + "->" + std::to_string(cout), kn, mf_conv_flops(p, 1),
              [p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
+        tunables.push_back(Tunable{p, in, out, res});
         return MF_OK;
     }
 
@@ -413,7 +419,16 @@ struct Net {
     int run(int B, hipStream_t s) {
         if (!use_graph) return run_body(B, s);
         auto it = graphs.find(B);
-        if (it == graphs.end()) { graphs.emplace(B, nullptr); return run_body(B, s); }   // first call eager
+        if (it == graphs.end()) {                                                        // first call eager
+            graphs.emplace(B, nullptr);
+            int rc = run_body(B, s);
+            if (rc || !autotune) return rc;
+            // every buffer now holds real data: measure each implicit-GEMM layer's launch configurations in place, then run once more so that
+            // the outputs are those of the configurations the graph will capture
+            for (auto& t : tunables)
+                if ((rc = mf_conv_tune(t.p, t.in, t.out, t.res, B, s))) return rc;
+            return run_body(B, s);
+        }
         if (!it->second) {
             hipGraph_t graph = nullptr;
             MF_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
@@ -457,6 +472,8 @@ struct Net {
         MF_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
         const char* ng = std::getenv("MF_NO_GRAPH");
         use_graph = !(ng && ng[0] == '1');
+        const char* at = std::getenv("MF_AUTOTUNE");                 // read per handle (tests switch it per case); default on
+        autotune = !at || at[0] != '0';
         return MF_OK;
     }
 };

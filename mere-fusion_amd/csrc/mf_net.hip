@@ -156,6 +156,8 @@ struct mf_net {
     std::vector<float*> dev;
     typedef std::function<int(int, hipStream_t)> Op;
     std::vector<Op> ops;
+    struct Tunable { ConvPlan* p; ActView in, out, res; };
+    std::vector<Tunable> tunables;
     std::vector<std::string> names;
     std::vector<double> flops;
     std::map<int, hipGraphExec_t> graphs;
@@ -224,6 +226,7 @@ extern "C" int mf_net_conv(mf_net* h, const mf_conv2d_desc* d, const float* weig
     const ActView in{ib, in_coff, (dd.cin + 7) / 8 * 8 <= ib->C - in_coff ? (dd.cin + 7) / 8 * 8 : dd.cin}, out{ob, out_coff, dd.cout};
     const ActView res = rb ? ActView{rb, res_coff, dd.cout} : ActView{};
     h->ops.push_back([p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
+    h->tunables.push_back(mf_net::Tunable{p, in, out, res});
     h->names.push_back(name ? name : "conv");
     h->flops.push_back(mf_conv_flops(p, 1));
     return MF_OK;
@@ -329,7 +332,15 @@ extern "C" int mf_net_run(mf_net* h, int batch, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!h->use_graph) return h->run_body(batch, s);
     auto it = h->graphs.find(batch);
-    if (it == h->graphs.end()) { h->graphs.emplace(batch, nullptr); return h->run_body(batch, s); }      // first call eager (split-K workspaces grow here)
+    if (it == h->graphs.end()) {                                                                        // first call eager (split-K workspaces grow here)
+        h->graphs.emplace(batch, nullptr);
+        int rc = h->run_body(batch, s);
+        const char* at = getenv("MF_AUTOTUNE");
+        if (rc || (at && at[0] == '0')) return rc;
+        for (auto& t : h->tunables)                                                                     // measured launch configurations, then the real outputs again
+            if ((rc = mf_conv_tune(t.p, t.in, t.out, t.res, batch, s))) return rc;
+        return h->run_body(batch, s);
+    }
     if (!it->second) {
         hipGraph_t graph = nullptr;
         MF_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));

@@ -239,6 +239,14 @@ int mf_wav2lip::run(int batch, hipStream_t s) {
         // first forward at this batch size runs eagerly (it also sets the kernels' LDS attributes,
         // which must not happen inside a capture); the second one captures
         graphs.emplace(batch, nullptr);
+        int rc = run_body(batch, s);
+        const char* at = std::getenv("MF_AUTOTUNE");
+        if (rc || (at && at[0] == '0')) return rc;
+        // the buffers hold real data now: measure every implicit-GEMM layer's launch configurations in place (mf_conv_tune), then run once more
+        // so that the outputs belong to the configurations the graph will capture
+        MF_HIP(hipStreamSynchronize(side));
+        for (auto& st : steps)
+            if ((rc = mf_conv_tune(&st->plan, st->in, st->out, st->res, batch, s))) return rc;
         return run_body(batch, s);
     }
     if (it->second == nullptr) {

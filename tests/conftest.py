@@ -12,9 +12,20 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The library measures its implicit-GEMM launch configurations on the first forward of every (handle, batch size) -- seconds per full-size network.
+# The suite builds dozens of handles, so it runs with the cost model alone unless a test asks for the production default (the `autotuned`
+# fixture: tests/test_musetalk_full.py, tests/test_autotune.py).  Handles read the variable when they are created.
+os.environ.setdefault("MF_AUTOTUNE", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture()
+def autotuned(monkeypatch):
+    """handles created inside this test use the production default: measured launch configurations"""
+    monkeypatch.setenv("MF_AUTOTUNE", "1")
 
 
 @pytest.fixture(scope="session")

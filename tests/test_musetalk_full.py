@@ -25,11 +25,22 @@ def full_sd():
 
 @pytest.fixture(scope="module")
 def hip_full(lib_built, full_sd):
+    """The handles of this module run as production does: launch configurations measured on the first forward (MF_AUTOTUNE default, which the
+    rest of the suite switches off for speed)."""
+    import os
     from mere_fusion_amd.musetalk.models.unet import UNet
     from mere_fusion_amd.musetalk.models.vae import VAE
     usd, vsd = full_sd
-    unet = UNet(unet_config_json(MUSETALK_V1["unet"]), usd, max_batch=B)
-    vae = VAE(config=vae_config_json(MUSETALK_V1["vae"]), state_dict=vsd, max_batch=B)
+    old = os.environ.get("MF_AUTOTUNE")
+    os.environ["MF_AUTOTUNE"] = "1"
+    try:
+        unet = UNet(unet_config_json(MUSETALK_V1["unet"]), usd, max_batch=B)
+        vae = VAE(config=vae_config_json(MUSETALK_V1["vae"]), state_dict=vsd, max_batch=B)
+    finally:
+        if old is None:
+            os.environ.pop("MF_AUTOTUNE", None)
+        else:
+            os.environ["MF_AUTOTUNE"] = old
     return unet, vae
 
 
