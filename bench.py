@@ -28,6 +28,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The library measures its GEMM launch configurations on the first forward at a batch size (mf_conv_tune).  One cache file per bench run keeps the child
+# processes of the PMC passes (and a profiled re-run that names the same file) on the parent's configurations, with no tuning launches of their own.
+import tempfile  # noqa: E402
+os.environ.setdefault("MF_TUNE_CACHE", os.path.join(tempfile.gettempdir(), f"mf_tune_cache_{os.getpid()}.txt"))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

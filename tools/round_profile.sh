@@ -5,6 +5,9 @@
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
 cd $R
+# one tuning cache for the bench run and the profiled re-runs: the profiles then hold the production launch configurations and no tuning launches
+export MF_TUNE_CACHE=$R/gpurun_out/${TAG}_tune_cache.txt
+rm -f $MF_TUNE_CACHE
 timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.txt
 python bench.py --dump-layers gpurun_out/${TAG}_layers.json > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_err.txt
 cd /tmp && export TMPDIR=/tmp
