@@ -1561,7 +1561,10 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
         snprintf(buf, cap, "4 x k_conv3x3_halo_w<%d,%d,%d,%d,%s,1,phase>", tw.ph, tw.bn, tw.wgm, tw.wgn, x3);
     } else {
         const ConvTile t = mf_conv_pick_tile(p, batch);
-        const int bk = (p->precision == MF_PREC_BF16X3 && t.bm + t.bn > 128) ? 32 : 64;
+        // tile depth as launch_prec picks it: 64 everywhere except the 8-wave bf16x3 tiles (and the 4-wave ones under MF_IGEMM_BK=32)
+        static const bool bk64 = [] { const char* e = getenv("MF_IGEMM_BK"); return !e || atoi(e) == 64; }();
+        const bool x3b = p->precision == MF_PREC_BF16X3;
+        const int bk = (x3b && t.bm + t.bn > 128 && !(t.wgm * t.wgn == 4 && bk64)) ? 32 : 64;
         snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s,%d>", t.bm, t.bn, t.wgm, t.wgn, x3, bk);
     }
 }

@@ -47,7 +47,7 @@ struct Net {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     bool use_graph = true;
     // implicit-GEMM layers with their bound views: measured launch configurations (mf_conv_tune) on the first forward at a batch size
-    struct Tunable { ConvPlan* p; ActView in, out, res; };
+    struct Tunable { ConvPlan* p; ActView in, out, res; int op; };
     std::vector<Tunable> tunables;
     bool autotune = false;
     int next_pad_hi = 0;        // consumed by the next conv(): extra zero rows / columns bottom-right (the VAE encoder's Downsample2D)
@@ -149,7 +149,7 @@ struct Net {
         char kn[96];
         mf_conv_kernel_name(p, cap, kn, sizeof(kn));
         push(name, kn, mf_conv_flops(p, 1), [p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
-        tunables.push_back(Tunable{p, in, out, res});
+        tunables.push_back(Tunable{p, in, out, res, (int)ops.size() - 1});
         return MF_OK;
     }
     // GroupNorm(+SiLU) `gname` of x followed by the 3x3 conv `cname`.  Where the conv runs on the LDS-weights halo kernel's fat tiles at the
@@ -379,7 +379,7 @@ struct Net {
         mf_conv_kernel_name(p, cap, kn, sizeof(kn));
         push("fused linear " + std::to_string(cin) + "->" + std::to_string(cout), kn, mf_conv_flops(p, 1),
              [p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
-        tunables.push_back(Tunable{p, in, out, res});
+        tunables.push_back(Tunable{p, in, out, res, (int)ops.size() - 1});
         return MF_OK;
     }
 
@@ -425,8 +425,12 @@ struct Net {
             if (rc || !autotune) return rc;
             // every buffer now holds real data: measure each implicit-GEMM layer's launch configurations in place, then run once more so that
             // the outputs are those of the configurations the graph will capture
-            for (auto& t : tunables)
+            for (auto& t : tunables) {
                 if ((rc = mf_conv_tune(t.p, t.in, t.out, t.res, B, s))) return rc;
+                char kn[96];
+                mf_conv_kernel_name(t.p, B, kn, sizeof(kn));               // the measurement seam names the kernel that actually runs
+                info[t.op].kernel = kn;
+            }
             return run_body(B, s);
         }
         if (!it->second) {
