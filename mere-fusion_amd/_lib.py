@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(HERE, "libmerefusion_hip.so")
 
 MF_PREC_BF16 = 0
 MF_PREC_BF16X3 = 1
-PRECISIONS = {"bf16": MF_PREC_BF16, "bf16x3": MF_PREC_BF16X3}
+MF_PREC_F16Q = 2
+PRECISIONS = {"bf16": MF_PREC_BF16, "bf16x3": MF_PREC_BF16X3, "f16q": MF_PREC_F16Q}
 
 
 class MfTensor(C.Structure):

@@ -23,3 +23,7 @@ int mf_head_1x1_sigmoid(const ActView& src, const float* w, const float* b, floa
 // VAE.preprocess_img (musetalk/models/vae.py:52-82) for an in-memory crop: uint8 [B,H,W,3] BGR -> RGB, / 255., optional half mask (rows >= H/2
 // zeroed BEFORE the normalisation, vae.py:75-76), Normalize(mean .5, std .5) -> the padded NHWC planes of `dst` (channels 3.. zero).
 int mf_vae_image_u8_to_act(const uint8_t* img, const ActBuf& dst, int half_mask, int batch, hipStream_t s);
+
+// MF_PREC_F16Q input planes from fp32 NCHW (test seam): hi plane = f16(x); lo plane = per pixel and 32-channel block 64 bytes
+// [q6(x - f16(x)) : 24 B of e2m3 codes, E8M0 scale byte, 7 B pad | q6(f16(x)) likewise] (OCP-MX: the block maximum scaled into [4, 8))
+int mf_nchw_to_act_q(const float* src, int C, const ActBuf& dst, int batch, hipStream_t s);

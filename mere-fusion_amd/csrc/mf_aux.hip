@@ -193,3 +193,70 @@ int mf_head_1x1_sigmoid(const ActView& src, const float* w, const float* b, floa
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
+
+namespace {
+// e2m3 code of y (already divided by the block scale): sign, 2 exponent bits (bias 1), 3 mantissa bits; round to nearest, saturate at 7.5
+__device__ __forceinline__ uint32_t enc_e2m3(float y) {
+    const uint32_t sgn = y < 0.f ? 0x20u : 0u;
+    float a = fminf(fabsf(y), 7.5f);
+    uint32_t code;
+    if (a < 1.f) code = (uint32_t)rintf(a * 8.f);                                  // subnormal step 0.125 (8 -> exponent 1, mantissa 0: same bit pattern)
+    else {
+        const int e = a < 2.f ? 0 : (a < 4.f ? 1 : 2);                             // value = (1 + m / 8) * 2^e
+        const uint32_t m = (uint32_t)rintf((a * (e == 0 ? 1.f : (e == 1 ? 0.5f : 0.25f)) - 1.f) * 8.f);   // 0..8
+        code = ((uint32_t)(e + 1) << 3) + m;                                       // m == 8 carries into the exponent
+        if (code > 0x1fu) code = 0x1fu;
+    }
+    return sgn | code;
+}
+// one thread = one pixel x one 32-channel block
+__global__ void k_nchw_to_act_q(const float* __restrict__ src, int C, int H, int W, bf16_t* hi, bf16_t* lo, int Cbuf, int halo, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int nblk = Cbuf / 32;
+    const int x = idx % W;
+    int64_t t = idx / W;
+    const int y = t % H; t /= H;
+    const int g = t % nblk;
+    const int b = t / nblk;
+    const int Wp = W + 2 * halo, Hp = H + 2 * halo;
+    float vh[32], vl[32];
+    float mh = 0.f, ml = 0.f;
+    for (int e = 0; e < 32; ++e) {
+        const int c = g * 32 + e;
+        const float v = c < C ? src[(((int64_t)b * C + c) * H + y) * W + x] : 0.f;
+        const _Float16 h = (_Float16)v;
+        vh[e] = (float)h; vl[e] = v - vh[e];
+        mh = fmaxf(mh, fabsf(vh[e])); ml = fmaxf(ml, fabsf(vl[e]));
+    }
+    const int64_t o = (((int64_t)b * Hp + y + halo) * Wp + x + halo) * Cbuf + g * 32;
+    uint16_t* ph = reinterpret_cast<uint16_t*>(hi + o);
+    for (int e = 0; e < 32; ++e) { const _Float16 h = (_Float16)vh[e]; ph[e] = __builtin_bit_cast(uint16_t, h); }
+    uint8_t* pl = reinterpret_cast<uint8_t*>(lo + o);                               // 64 bytes: [residual block | hi block]
+    for (int blk = 0; blk < 2; ++blk) {
+        const float* v = blk == 0 ? vl : vh;
+        const float m = blk == 0 ? ml : mh;
+        int ex = 0;
+        if (m > 0.f) { (void)frexpf(m, &ex); ex = 3 - ex; }                        // m * 2^ex in [4, 8)
+        const float sc = ldexpf(1.f, ex);
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int e = 0; e < 32; ++e) {
+            const uint32_t code = enc_e2m3(v[e] * sc);
+            const int bit = 6 * e;
+            w[bit >> 5] |= code << (bit & 31);
+            if ((bit & 31) > 26) w[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+        }
+        w[6] = (uint32_t)(127 - ex) & 0xffu;                                       // E8M0: value = code * 2^(scale - 127)
+        uint32_t* d = reinterpret_cast<uint32_t*>(pl + 32 * blk);
+        for (int k = 0; k < 8; ++k) d[k] = w[k];
+    }
+}
+}  // namespace
+
+int mf_nchw_to_act_q(const float* src, int C, const ActBuf& dst, int batch, hipStream_t s) {
+    MF_REQUIRE(dst.C % 32 == 0 && dst.lo, "nchw_to_act_q: the destination needs 32-channel blocks and a second plane");
+    const int64_t total = (int64_t)batch * (dst.C / 32) * dst.H * dst.W;
+    hipLaunchKernelGGL(k_nchw_to_act_q, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, src, C, dst.H, dst.W, dst.hi, dst.lo, dst.C, dst.halo, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}

@@ -90,6 +90,7 @@ struct HaloArgs {
     // LDS-weights kernel only: GroupNorm + SiLU of the INPUT applied to the halo image in LDS, v = silu(x * gn_scale[b][c] + gn_shift[b][c]); null = none
     const float* gn_scale; const float* gn_shift; int gn_C;
     unsigned long long* dbg;                    // MF_DBG_TIMES: 4 s_memtime stamps per workgroup (entry, loop start, loop end, exit), or null
+    int q;                                      // operands in the f16 + FP6-residual format (MF_PREC_F16Q): x_lo / w_lo hold [q6 block | q6 block] rows
     int stagger;                                // LDS-weights kernel, 8-wave tiles: the second wave of every SIMD issues its weight DMA mid-tap (filled by the launcher)
 };
 struct HaloTile { int ph, bn, wgm, wgn; };
@@ -121,6 +122,7 @@ struct ConvPlan {
     bf16_t* w_lo = nullptr;
     float* bias = nullptr;
     int* goff = nullptr;
+    bool q = false;       // MF_PREC_F16Q: w_hi = f16 [slice][tap][Npad][32], w_lo = [slice][tap][Npad][q6(wh) 32 B | q6(wl) 32 B] (24 B codes + E8M0 byte + pad)
     bool halo = false;    // 3x3 s1 p1 on a >= 16x16 map: LDS halo-tile kernel, weights packed [slice][tap][Npad][CK]
     bf16_t* up_hi = nullptr;  // nearest-2x-upsample + 3x3 layers that qualify for the fat halo tiles: [phase][slice][4 taps][Npad][CK], pre-summed taps
     bf16_t* up_lo = nullptr;

@@ -701,7 +701,7 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
                         const float* bn_var, int precision) {
     MF_REQUIRE(d.cin > 0 && d.cout > 0 && d.kh > 0 && d.kw > 0, "conv: bad channel/kernel size");
     MF_REQUIRE(d.stride_h > 0 && d.stride_w > 0 && d.in_h > 0 && d.in_w > 0, "conv: bad stride/input size");
-    MF_REQUIRE(precision == MF_PREC_BF16 || precision == MF_PREC_BF16X3, "conv: unknown precision %d", precision);
+    MF_REQUIRE(precision == MF_PREC_BF16 || precision == MF_PREC_BF16X3 || precision == MF_PREC_F16Q, "conv: unknown precision %d", precision);
     std::vector<float> gw, gb;
     if (d.act == 5) {
         // GEGLU (diffusers): out = x[:, :cout/2] * gelu(x[:, cout/2:]).  Rows are re-ordered into alternating blocks of 16
@@ -827,7 +827,7 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
         }
     }
 
-    const int HCK = precision == MF_PREC_BF16X3 ? 32 : 64;   // channel slice of the halo kernel
+    const int HCK = precision != MF_PREC_BF16 ? 32 : 64;   // channel slice of the halo kernel
     const int BK = 64, KG = BK / 8;                            // packed K tile of the implicit-GEMM kernel
     p->BK = BK;
     // up to 256 channels: the register-weights halo kernel (mf_conv_halo.hip) or the LDS-weights one (mf_conv_halo2.hip);
@@ -853,6 +853,59 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
         p->goff_total = 0;
         const int64_t total = (int64_t)p->n_slices * 9 * p->Npad * HCK;
         std::vector<bf16_t> hi(total, 0), lo(total, 0);
+        if (precision == MF_PREC_F16Q) {
+            // f16 + FP6 residual format: plane 0 = f16(w) in the same [slice][tap][Npad][32] order; plane 1 = per (slice, tap, row) 64 bytes
+            // [q6(f16(w)) | q6(w - f16(w))], each 24 B of e2m3 codes (value t in bits [6t, 6t+6)) + the block's E8M0 byte + pad.  The pixel side
+            // stores [q6(x - f16(x)) | q6(f16(x))], so K block 0 of the correction instruction is q6(wh).xl and block 1 is wl.q6(xh).
+            MF_REQUIRE(d.cin % 32 == 0 && d.cout % 128 == 0 && !d.residual, "conv (f16q): the experimental format serves 3x3 layers with cin %% 32 == 0, cout %% 128 == 0 and no residual from the input");
+            p->q = true;
+            auto enc = [](float y) -> uint32_t {
+                const uint32_t sgn = y < 0.f ? 0x20u : 0u;
+                const float a = std::fmin(std::fabs(y), 7.5f);
+                uint32_t code;
+                if (a < 1.f) code = (uint32_t)std::nearbyint(a * 8.f);
+                else {
+                    const int e = a < 2.f ? 0 : (a < 4.f ? 1 : 2);
+                    const uint32_t m = (uint32_t)std::nearbyint((a * (e == 0 ? 1.f : (e == 1 ? 0.5f : 0.25f)) - 1.f) * 8.f);
+                    code = ((uint32_t)(e + 1) << 3) + m;
+                    if (code > 0x1fu) code = 0x1fu;
+                }
+                return sgn | code;
+            };
+            std::vector<float> blk_h(32), blk_l(32);
+            for (int sl = 0; sl < p->n_slices; ++sl)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int n = 0; n < d.cout; ++n) {
+                        const int64_t row = (((int64_t)sl * 9 + tap) * p->Npad + n) * HCK;
+                        float mh = 0.f, ml = 0.f;
+                        for (int e = 0; e < 32; ++e) {
+                            const int c = sl * 32 + e;
+                            const float wf = c < d.cin ? weight[(((int64_t)n * d.cin + c) * 3 + tap / 3) * 3 + tap % 3] * scale[n] : 0.f;
+                            const _Float16 h = (_Float16)wf;
+                            blk_h[e] = (float)h; blk_l[e] = wf - blk_h[e];
+                            uint16_t bits; __builtin_memcpy(&bits, &h, 2);
+                            hi[row + e] = bits;
+                            mh = std::fmax(mh, std::fabs(blk_h[e])); ml = std::fmax(ml, std::fabs(blk_l[e]));
+                        }
+                        uint32_t* dst = reinterpret_cast<uint32_t*>(&lo[row]);     // 64 bytes
+                        for (int b = 0; b < 2; ++b) {
+                            const std::vector<float>& v = b == 0 ? blk_h : blk_l;
+                            const float m = b == 0 ? mh : ml;
+                            int ex = 0;
+                            if (m > 0.f) { (void)std::frexp(m, &ex); ex = 3 - ex; }
+                            const float sc = std::ldexp(1.f, ex);
+                            uint32_t w8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                            for (int e = 0; e < 32; ++e) {
+                                const uint32_t code = enc(v[e] * sc);
+                                const int bit = 6 * e;
+                                w8[bit >> 5] |= code << (bit & 31);
+                                if ((bit & 31) > 26) w8[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+                            }
+                            w8[6] = (uint32_t)(127 - ex) & 0xffu;
+                            for (int k = 0; k < 8; ++k) dst[8 * b + k] = w8[k];
+                        }
+                    }
+        } else
         for (int c = 0; c < d.cin; ++c)
             for (int tap = 0; tap < 9; ++tap)
                 for (int n = 0; n < d.cout; ++n) {
@@ -864,14 +917,14 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
                 }
         MF_HIP(hipMalloc(&p->w_hi, total * sizeof(bf16_t)));
         MF_HIP(hipMemcpy(p->w_hi, hi.data(), total * sizeof(bf16_t), hipMemcpyHostToDevice));
-        if (precision == MF_PREC_BF16X3) {
+        if (precision != MF_PREC_BF16) {
             MF_HIP(hipMalloc(&p->w_lo, total * sizeof(bf16_t)));
             MF_HIP(hipMemcpy(p->w_lo, lo.data(), total * sizeof(bf16_t), hipMemcpyHostToDevice));
         }
         MF_HIP(hipMalloc(&p->bias, p->Npad * sizeof(float)));
         MF_HIP(hipMemcpy(p->bias, fbias.data(), p->Npad * sizeof(float), hipMemcpyHostToDevice));
         p->bound_in_ld = p->bound_in_wp = -1;
-        if (want_alt) {
+        if (want_alt && precision != MF_PREC_F16Q) {
             p->alt = new ConvPlan();
             g_no_halo_wide = true;
             const int rc = mf_conv_plan_create(p->alt, d, weight, bias, bn_gamma, bn_beta, bn_mean, bn_var, precision);
@@ -1072,11 +1125,13 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
     // into the next (up to 3) channels of the buffer, which must exist
     MF_REQUIRE(out.C == (p->d.act == 5 ? p->d.cout / 2 : p->d.cout) && out.coff % 4 == 0 && out.coff + (out.C + 3) / 4 * 4 <= ob.C, "conv: bad output view");
     MF_REQUIRE(ob.H == p->out_h && ob.W == p->out_w, "conv: output buffer %dx%d != %dx%d", ob.H, ob.W, p->out_h, p->out_w);
-    const bool x3 = p->precision == MF_PREC_BF16X3;
+    const bool x3 = p->precision != MF_PREC_BF16;                      // two planes per tensor (bf16x3, and the f16 + FP6 format)
     MF_REQUIRE(!x3 || (ib.lo && ob.lo), "conv: BF16X3 needs lo planes");
+    MF_REQUIRE(p->precision != MF_PREC_F16Q || p->halo, "conv (f16q): only wide 3x3 stride-1 layers have a kernel in this format");
 
     if (p->halo) {
         HaloArgs ha{};
+        ha.q = p->q ? 1 : 0;
         ha.x_hi = ib.hi + in.coff; ha.x_lo = x3 ? ib.lo + in.coff : nullptr;
         ha.w_hi = p->w_hi; ha.w_lo = p->w_lo; ha.bias = p->bias;
         ha.batch = batch; ha.H = p->out_h; ha.W = p->out_w; ha.N = p->d.cout; ha.Npad = p->Npad; ha.n_slices = p->n_slices;
@@ -1098,6 +1153,13 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         ha.act = p->d.act;
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         ha.gn_scale = g_gn_scale; ha.gn_shift = g_gn_shift; ha.gn_C = p->d.cin;
+        if (p->q) {                             // the f16 + FP6 format has one kernel: the 8-wave 16 x 16 x 128-channel tile
+            MF_REQUIRE(!ha.res_from_halo && !g_gn_scale, "conv (f16q): residual-from-input / GroupNorm fusion are not built for this format");
+            // 8 waves of 64 px x 64 ch (default; measured 338 / 396 / 316 us on 256->256 @128^2, 128->128 @256^2, 512->512 @64^2 at batch 8 against
+            // 313 / 370 / 290 us for bf16x3 on its best tiles); MF_Q_TILE=12822: 4 waves of 128 px x 64 ch, one workgroup per CU (359 / 418 / 331 us)
+            static const int qt = [] { const char* e = getenv("MF_Q_TILE"); return e ? atoi(e) : 12842; }();
+            return mf_halo_w_launch(ha, qt == 12822 ? HaloTile{16, 128, 2, 2} : HaloTile{16, 128, 4, 2}, true, stream);
+        }
         if (tw.ph) return mf_halo_w_launch(ha, tw, x3, stream);
         MF_REQUIRE(!g_gn_scale, "conv: GroupNorm fusion requested but the fat halo tile was not picked");
         // Wide layer on a map too small to give every CU a 16 x 16 patch (the VAE's 512-channel 32 x 32 levels at batch 8: 64 patches x

@@ -34,7 +34,8 @@ extern "C" int mf_conv2d_create(const mf_conv2d_desc* desc, const float* weight,
     if (desc->residual)
         MF_REQUIRE(desc->cin == desc->cout && h->plan.out_h == desc->in_h && h->plan.out_w == desc->in_w,
                    "conv2d_create: residual needs matching input/output shapes");
-    h->in.C = h->plan.cin_pad; h->in.H = desc->in_h; h->in.W = desc->in_w;
+    MF_REQUIRE(precision != MF_PREC_F16Q || h->plan.q, "conv2d_create: MF_PREC_F16Q serves wide 3x3 stride-1 layers only (cin %% 32 == 0, cout %% 128 == 0)");
+    h->in.C = h->plan.q ? (h->plan.cin_pad + 31) / 32 * 32 : h->plan.cin_pad; h->in.H = desc->in_h; h->in.W = desc->in_w;
     h->in.halo = std::max(1, h->plan.in_halo_need);
     h->out.C = (out_channels(*desc) + 7) / 8 * 8; h->out.H = h->plan.out_h; h->out.W = h->plan.out_w; h->out.halo = 1;
     if ((rc = mf_conv_bind(&h->plan, h->in))) return rc;
@@ -55,7 +56,7 @@ extern "C" int mf_conv2d_forward(mf_conv2d* h, const float* x, float* y, int bat
             const size_t bytes = ((size_t)batch * b->per_batch() + 64) * sizeof(bf16_t);
             MF_HIP(hipMalloc(&b->hi, bytes));
             MF_HIP(hipMemset(b->hi, 0, bytes));
-            if (h->plan.precision == MF_PREC_BF16X3) {
+            if (h->plan.precision != MF_PREC_BF16) {
                 MF_HIP(hipMalloc(&b->lo, bytes));
                 MF_HIP(hipMemset(b->lo, 0, bytes));
             }
@@ -64,7 +65,8 @@ extern "C" int mf_conv2d_forward(mf_conv2d* h, const float* x, float* y, int bat
         h->cap = batch;
     }
     int rc;
-    if ((rc = mf_nchw_to_act(x, h->plan.d.cin, h->in, batch, s))) return rc;
+    if (h->plan.q) { if ((rc = mf_nchw_to_act_q(x, h->plan.d.cin, h->in, batch, s))) return rc; }
+    else if ((rc = mf_nchw_to_act(x, h->plan.d.cin, h->in, batch, s))) return rc;
     ActView in{&h->in, 0, h->in.C}, out{&h->out, 0, out_channels(h->plan.d)};
     ActView res = h->plan.d.residual ? ActView{&h->in, 0, h->plan.d.cout} : ActView{};
     if ((rc = mf_conv_launch(&h->plan, in, out, res, batch, s))) return rc;

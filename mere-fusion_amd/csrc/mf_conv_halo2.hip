@@ -19,6 +19,9 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 // timing-only ablation builds (tools/halo_ablate.sh): bit 0 = no epilogue stores / residual reads, bit 4 = no residual reads only
 #ifndef MF_HALO_ABLATE
@@ -57,7 +60,11 @@ __device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
 // HS = halo images in LDS: 2 (the next slice's image lands under this slice's MFMAs) or 1 (half the LDS: two 4-wave workgroups per CU, each
 // other's DMA waits and epilogues hidden by the neighbour's MFMAs)
 // GN: GroupNorm + SiLU of the input folded in (a separate instantiation: its extra live registers must not touch the plain kernel)
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false>
+// Q: operands in the f16 + FP6-residual format (MF_PREC_F16Q).  Plane 0 rows are 32 f16 channels, plane 1 rows two 32-byte FP6 blocks
+// ([q6(wh) | q6(wl)] for weights, [q6(xl) | q6(xh)] for pixels: 24 B of e2m3 codes + the block's E8M0 byte).  Per tap and accumulator tile:
+// ONE v_mfma_f32_16x16x32_f16 (wh.xh) + ONE v_mfma_scale_f32_16x16x128_f8f6f4 whose K blocks 0 / 1 are q6(wh).xl / wl.q6(xh) and whose blocks
+// 2 / 3 are switched off by a zero scale -- 32 matrix cycles where bf16x3 spends 48, with the loop, ring and DMA of the bf16x3 kernel unchanged.
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false, bool Q = false>
 __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_halo_w(const HaloArgs a) {
     constexpr int NW = WGM * WGN;                           // waves per workgroup
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -235,6 +242,39 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             const int dy = PHASE < 0 ? tap / 3 : (PHASE >> 1) + (tap >> 1), dx = PHASE < 0 ? tap % 3 : (PHASE & 1) + (tap & 1);
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
+                if constexpr (Q) {
+                    static_assert(!Q || (X3 && KK == 1 && TR == 1 && PHASE < 0 && !GN), "f16 + FP6 format: the plain 3x3 bf16x3-shaped tile only");
+                    // lane (fr, fk): f16 fragments as the bf16 ones; the FP6 fragment of its row is the 32-byte block fk & 1 of the plane-1 row, and
+                    // lane groups 2, 3 (K blocks that carry nothing) read the same bytes with their scale forced to 2^-127
+                    const int blk = fk & 1;
+                    f16x8 wh16[FN];
+                    i32x8 w6[FN];
+                    int wsc[FN];
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) {
+                        const int r = cn0 + i * 16 + fr;
+                        wh16[i] = *reinterpret_cast<const f16x8*>(wb + (t3 * NP) * WT_BYTES + wlane[i][kk]);
+                        const char* q = wb + (t3 * NP + 1) * WT_BYTES + r * ROWB + (((2 * blk) ^ hswz<CK>(r)) << 4);
+                        const i32x4 q0 = *reinterpret_cast<const i32x4*>(q), q1 = *reinterpret_cast<const i32x4*>(q + 16);
+                        w6[i] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, -1, -1);
+                        wsc[i] = fk < 2 ? q1[2] : 0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) {
+                        const int hx = fr + dx;
+                        const char* p0 = base + ((row0 + j + dy) * HW + hx) * ROWB;
+                        const f16x8 xh16 = *reinterpret_cast<const f16x8*>(p0 + (((kk * 4 + fk) ^ hswz<CK>(hx)) << 4));
+                        const char* q = p0 + H_BYTES + (((2 * blk) ^ hswz<CK>(hx)) << 4);
+                        const i32x4 q0 = *reinterpret_cast<const i32x4*>(q), q1 = *reinterpret_cast<const i32x4*>(q + 16);
+                        const i32x8 x6 = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, -1, -1);
+                        const int xsc = fk < 2 ? q1[2] : 0;
+#pragma unroll
+                        for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w6[i], x6, acc[i][j], 2, 2, 0, wsc[i], 0, xsc);
+#pragma unroll
+                        for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh16[i], xh16, acc[i][j], 0, 0, 0);
+                    }
+                    continue;
+                }
                 bf16x8 whi[FN], wlo[FN];
 #pragma unroll
                 for (int i = 0; i < FN; ++i) {
@@ -457,10 +497,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false>
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false, bool Q = false>
 int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE, HS, GN>;
+    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE, HS, GN, Q>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -533,6 +573,15 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
     a.tiles_n = (a.N + t.bn - 1) / t.bn;
 #define MF_HCASE(PH, BN, WGM, WGN, TR) \
     if (t.ph == PH && t.bn == BN && t.wgm == WGM) return halo_w_launch_prec<PH, BN, WGM, WGN, TR>(a, x3, s);
+    if (a.q) {
+        if (phase >= 0 || a.nsplit > 1 || a.gn_scale) { mf_set_error("halo conv (f16 + FP6 format): plain unsplit 3x3 layers only"); return MF_ERR_INVALID; }
+        // (16 x 16 x 256 as four waves of 128 px x 128 ch -- 64 accumulator tiles per wave -- spills 456 bytes even with 512 registers: not instantiated)
+        if (t.ph == 16 && t.bn == 128 && t.wgm == 4) return halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, true>(a, s);
+        // 16 x 16 pixels x 128 channels as four waves of 128 px x 64 ch, ONE workgroup per CU (a wave per SIMD, up to 512 registers)
+        if (t.ph == 16 && t.bn == 128 && t.wgm == 2 && t.wgn == 2) return halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, false, true>(a, s);
+        mf_set_error("halo conv (f16 + FP6 format): no kernel for this tile");
+        return MF_ERR_INVALID;
+    }
     if (a.gn_scale) {
         // GroupNorm folded in: the three fat tiles, plain 3x3 only
         if (phase >= 0 || a.nsplit > 1) { mf_set_error("halo conv (LDS weights): GroupNorm fusion is for plain, unsplit 3x3 layers"); return MF_ERR_INVALID; }

@@ -4,6 +4,7 @@
 torch convolution of the same inputs.  Tolerance: 1e-3 of the output range for bf16x3 (observed ~7e-6), 3e-2 for bf16."""
 import ctypes as C
 
+import numpy as np
 import pytest
 import torch
 
@@ -55,3 +56,37 @@ def test_wide_conv3x3_matches_fp64(lib_built, cin, cout, H, W, B, res, up, preci
         assert err2 <= (1e-3 if precision == "bf16x3" else 3e-2), err2
     finally:
         l.mf_conv2d_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,hw", [(256, 256, 64), (128, 128, 96), (512, 256, 32)])
+def test_f16q_experimental_format_vs_fp64(lib_built, cin, cout, hw):
+    """MF_PREC_F16Q (experimental, this test seam only): operands as f16 + FP6 (e2m3, MX block scales) residuals, one f16 MFMA + one block-scaled
+    16x16x128 MFMA per tap where bf16x3 issues three.  Expected error ~2.5x bf16x3's (numerics study + tools/mx_gemm_probe.hip)."""
+    import ctypes as C
+    from mere_fusion_amd import _lib
+    l = _lib.lib()
+    _lib.init_device(0)
+    rng = np.random.default_rng(cin + hw)
+    w = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    x = torch.from_numpy(rng.standard_normal((2, cin, hw, hw)).astype(np.float32))
+    x = x * torch.sigmoid(x)                                                       # SiLU-shaped, like the VAE's conv inputs
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+    errs = {}
+    for prec in ("bf16x3", "f16q"):
+        d = _lib.MfConv2dDesc(cin=cin, cout=cout, kh=3, kw=3, stride_h=1, stride_w=1, pad_h=1, pad_w=1, act=0, in_h=hw, in_w=hw)
+        h = C.c_void_p()
+        _lib.check(l.mf_conv2d_create(C.byref(d), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), None, None, None, None, _lib.PRECISIONS[prec], C.byref(h)))
+        xd, y = x.cuda(), torch.empty(2, cout, hw, hw, device="cuda")
+        _lib.check(l.mf_conv2d_forward(h, C.c_void_p(xd.data_ptr()), C.c_void_p(y.data_ptr()), 2, None))
+        torch.cuda.synchronize()
+        errs[prec] = float((y.cpu() - ref).abs().max())
+        l.mf_conv2d_destroy(h)
+    print(f"[f16q {cin}->{cout} @{hw}] L-inf vs fp64: bf16x3 {errs['bf16x3']:.2e}, f16 + FP6 {errs['f16q']:.2e} (max |y| {float(ref.abs().max()):.2f})")
+    assert errs["f16q"] <= 3e-4 and errs["f16q"] <= 6 * errs["bf16x3"] + 1e-5
+    # layers the format has no kernel for are refused, not approximated
+    d = _lib.MfConv2dDesc(cin=64, cout=64, kh=1, kw=1, stride_h=1, stride_w=1, pad_h=0, pad_w=0, act=0, in_h=hw, in_w=hw)
+    h = C.c_void_p()
+    w1 = torch.zeros(64, 64, 1, 1)
+    assert l.mf_conv2d_create(C.byref(d), C.c_void_p(w1.data_ptr()), None, None, None, None, None, _lib.PRECISIONS["f16q"], C.byref(h)) != 0
