@@ -1131,7 +1131,10 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
 
     if (p->halo) {
         HaloArgs ha{};
-        ha.q = p->q ? 1 : 0;
+        {
+            static const int qmode = [] { const char* e = getenv("MF_Q_PAIR"); return e ? atoi(e) : 1; }();   // A/B: 0 = one tap per correction instruction
+            ha.q = p->q ? (qmode ? 2 : 1) : 0;
+        }
         ha.x_hi = ib.hi + in.coff; ha.x_lo = x3 ? ib.lo + in.coff : nullptr;
         ha.w_hi = p->w_hi; ha.w_lo = p->w_lo; ha.bias = p->bias;
         ha.batch = batch; ha.H = p->out_h; ha.W = p->out_w; ha.N = p->d.cout; ha.Npad = p->Npad; ha.n_slices = p->n_slices;

@@ -64,7 +64,7 @@ __device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
 // ([q6(wh) | q6(wl)] for weights, [q6(xl) | q6(xh)] for pixels: 24 B of e2m3 codes + the block's E8M0 byte).  Per tap and accumulator tile:
 // ONE v_mfma_f32_16x16x32_f16 (wh.xh) + ONE v_mfma_scale_f32_16x16x128_f8f6f4 whose K blocks 0 / 1 are q6(wh).xl / wl.q6(xh) and whose blocks
 // 2 / 3 are switched off by a zero scale -- 32 matrix cycles where bf16x3 spends 48, with the loop, ring and DMA of the bf16x3 kernel unchanged.
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false, bool Q = false>
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false, int Q = 0>   // Q: 0 off, 1 one tap per correction MFMA, 2 tap pairs
 __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_halo_w(const HaloArgs a) {
     constexpr int NW = WGM * WGN;                           // waves per workgroup
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             const int dy = PHASE < 0 ? tap / 3 : (PHASE >> 1) + (tap >> 1), dx = PHASE < 0 ? tap % 3 : (PHASE & 1) + (tap & 1);
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
-                if constexpr (Q) {
+                if constexpr (Q == 1) {
                     static_assert(!Q || (X3 && KK == 1 && TR == 1 && PHASE < 0 && !GN), "f16 + FP6 format: the plain 3x3 bf16x3-shaped tile only");
                     // lane (fr, fk): f16 fragments as the bf16 ones; the FP6 fragment of its row is the 32-byte block fk & 1 of the plane-1 row, and
                     // lane groups 2, 3 (K blocks that carry nothing) read the same bytes with their scale forced to 2^-127
@@ -319,6 +319,56 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         }
     };
 
+    // f16 + FP6 format, TWO taps per correction instruction: K blocks 0 / 1 of the 16x16x128 MFMA carry tap A (q6(wh).xl, wl.q6(xh)), blocks 2 / 3 tap B, so
+    // every lane group reads bytes that are used -- 32 operand bytes per fragment and tap, as in bf16x3 -- and a pair of taps costs two f16 MFMAs + one
+    // correction MFMA (48 matrix cycles where bf16x3 spends 96).  Lane group fk reads tap (fk >> 1), block (fk & 1); a lone tap (the ninth) leaves blocks
+    // 2 / 3 switched off by a zero scale.  tA / tB index the 3x3 taps, sA / sB the ring slots that hold their weights.
+    auto compute_pair = [&](int stage, int tA, int tB, int sA, int sB) __attribute__((always_inline)) {
+        const char* base = smem + stage * STAGE;
+        const char* wA = wring + sA * WROW;
+        const char* wB = wring + sB * WROW;
+        const bool second = fk >= 2, pairB = tB >= 0;
+        const int blk = fk & 1;
+        const int dyA = tA / 3, dxA = tA % 3, dyB = pairB ? tB / 3 : dyA, dxB = pairB ? tB % 3 : dxA;
+        const char* wq = (second && pairB ? wB : wA) + WT_BYTES;
+        f16x8 whA[FN], whB[FN];
+        i32x8 w6[FN];
+        int wsc[FN];
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int r = cn0 + i * 16 + fr;
+            whA[i] = *reinterpret_cast<const f16x8*>(wA + wlane[i][0]);
+            if (pairB) whB[i] = *reinterpret_cast<const f16x8*>(wB + wlane[i][0]);
+            const char* q = wq + r * ROWB + (((2 * blk) ^ hswz<CK>(r)) << 4);
+            const i32x4 q0 = *reinterpret_cast<const i32x4*>(q), q1 = *reinterpret_cast<const i32x4*>(q + 16);
+            w6[i] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, -1, -1);
+            wsc[i] = (second && !pairB) ? 0 : q1[2];
+        }
+        const int hxA = fr + dxA, hxB = fr + dxB;
+        const int hxq = second ? hxB : hxA, dyq = second ? dyB : dyA;
+        const int offA = (dyA * HW + hxA) * ROWB + ((fk ^ hswz<CK>(hxA)) << 4);
+        const int offB = (dyB * HW + hxB) * ROWB + ((fk ^ hswz<CK>(hxB)) << 4);
+        const int offq = (dyq * HW + hxq) * ROWB + H_BYTES + (((2 * blk) ^ hswz<CK>(hxq)) << 4);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const char* prow = base + (row0 + j) * HW * ROWB;
+            const f16x8 xhA = *reinterpret_cast<const f16x8*>(prow + offA);
+            f16x8 xhB;
+            if (pairB) xhB = *reinterpret_cast<const f16x8*>(prow + offB);
+            const i32x4 q0 = *reinterpret_cast<const i32x4*>(prow + offq), q1 = *reinterpret_cast<const i32x4*>(prow + offq + 16);
+            const i32x8 x6 = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, -1, -1);
+            const int xsc = (second && !pairB) ? 0 : q1[2];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w6[i], x6, acc[i][j], 2, 2, 0, wsc[i], 0, xsc);
+#pragma unroll
+            for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whA[i], xhA, acc[i][j], 0, 0, 0);
+            if (pairB) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whB[i], xhB, acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
     // GroupNorm + SiLU of the input, folded in: once a halo image has landed, every 16-byte slot of it (8 channels of one pixel, hi and lo
     // planes) is rewritten in place as silu(x * scale[b][c] + shift[b][c]).  Pixels outside the image stay zero: the convolution pads the
     // NORMALISED tensor.  ~3 slots per thread and slice, against ~27 k MFMA cycles per slice.
@@ -359,6 +409,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     const int s_end = a.nsplit > 1 ? (int)((int64_t)a.n_slices * (blockIdx.y + 1) / a.nsplit) : a.n_slices;
     load_halo(s_begin, 0);
     load_wrow(s_begin, 0, 0);
+    if (Q == 2) load_wrow(s_begin, 1, 1);
     __syncthreads();                           // drains the DMA (vmcnt) and publishes halo stage 0 + weight row 0
     if (dbg && threadIdx.x == 0) dbg[1] = __builtin_amdgcn_s_memtime();
     int wbuf = 0;
@@ -371,6 +422,22 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             __syncthreads();
         }
         if (a.res_from_halo) add_residual(st, slice);
+        if constexpr (Q == 2) {
+            {
+                // taps in pairs (0,1) (2,3) (4,5) (6,7) (8): four ring slots, the pair being multiplied in slots {2 wbuf, 2 wbuf + 1} while the next pair
+                // lands in the other two (everyone left those at the previous barrier); one barrier per PAIR
+#pragma unroll
+                for (int p = 0; p < 5; ++p) {
+                    const int nb = 2 * (wbuf ^ 1);
+                    if (p < 4) { load_wrow(slice, 2 * p + 2, nb); if (2 * p + 3 <= 8) load_wrow(slice, 2 * p + 3, nb + 1); }
+                    else if (more) { load_wrow(slice + 1, 0, nb); load_wrow(slice + 1, 1, nb + 1); }
+                    compute_pair(st, 2 * p, p < 4 ? 2 * p + 1 : -1, 2 * wbuf, 2 * wbuf + 1);
+                    if (p < 4 || more) __syncthreads();
+                    wbuf ^= 1;
+                }
+                continue;
+            }
+        }
 #pragma unroll
         for (int step = 0; step < NSTEP; ++step) {
             if (!late_dma) issue_next(slice, step, more, wbuf);
@@ -497,7 +564,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false, bool Q = false>
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false, int Q = 0>
 int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     static bool attr_done = false;
     auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE, HS, GN, Q>;
@@ -508,7 +575,7 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     }
     constexpr int CK = X3 ? 32 : 64, RPC = 1024 / (CK * 2), NP = X3 ? 2 : 1;
     constexpr int HCH = ((PH + 2) * (PW + 2) + RPC - 1) / RPC;
-    const size_t lds = (size_t)HS * NP * HCH * 1024 + (size_t)2 * TR * NP * BN * CK * 2;
+    const size_t lds = (size_t)HS * NP * HCH * 1024 + (size_t)(Q ? 4 : 2) * TR * NP * BN * CK * 2;   // (the two-taps-per-instruction loop of the f16 + FP6 format: four ring slots)
     static const bool dbg_times = getenv("MF_DBG_TIMES") != nullptr;
     HaloArgs aa = a;
     static const bool stagger = [] { const char* e = getenv("MF_HALO_STAGGER"); return e && atoi(e) != 0; }();   // opt-in: measured 2.7 % SLOWER
@@ -576,9 +643,11 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
     if (a.q) {
         if (phase >= 0 || a.nsplit > 1 || a.gn_scale) { mf_set_error("halo conv (f16 + FP6 format): plain unsplit 3x3 layers only"); return MF_ERR_INVALID; }
         // (16 x 16 x 256 as four waves of 128 px x 128 ch -- 64 accumulator tiles per wave -- spills 456 bytes even with 512 registers: not instantiated)
-        if (t.ph == 16 && t.bn == 128 && t.wgm == 4) return halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, true>(a, s);
+        if (t.ph == 16 && t.bn == 128 && t.wgm == 4)
+            return a.q == 2 ? halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 2>(a, s) : halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 1>(a, s);
         // 16 x 16 pixels x 128 channels as four waves of 128 px x 64 ch, ONE workgroup per CU (a wave per SIMD, up to 512 registers)
-        if (t.ph == 16 && t.bn == 128 && t.wgm == 2 && t.wgn == 2) return halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, false, true>(a, s);
+        if (t.ph == 16 && t.bn == 128 && t.wgm == 2 && t.wgn == 2)
+            return a.q == 2 ? halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, false, 2>(a, s) : halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, false, 1>(a, s);
         mf_set_error("halo conv (f16 + FP6 format): no kernel for this tile");
         return MF_ERR_INVALID;
     }
