@@ -27,3 +27,7 @@ int mf_vae_image_u8_to_act(const uint8_t* img, const ActBuf& dst, int half_mask,
 // MF_PREC_F16Q input planes from fp32 NCHW (test seam): hi plane = f16(x); lo plane = per pixel and 32-channel block 64 bytes
 // [q6(x - f16(x)) : 24 B of e2m3 codes, E8M0 scale byte, 7 B pad | q6(f16(x)) likewise] (OCP-MX: the block maximum scaled into [4, 8))
 int mf_nchw_to_act_q(const float* src, int C, const ActBuf& dst, int batch, hipStream_t s);
+
+// The producer side of MF_PREC_F16Q inside a network: v = x * scale[b][c] + shift[b][c] (a finalised GroupNorm, mf_groupnorm_affine), optional SiLU, written
+// straight into the f16 + FP6-block planes of `dst` (same geometry as x) -- the GroupNorm-apply pass of a resnet whose convolution reads the new format.
+int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* shift, int silu, const ActBuf& dst, int batch, hipStream_t s);

@@ -209,6 +209,16 @@ __device__ __forceinline__ uint32_t enc_e2m3(float y) {
     }
     return sgn | code;
 }
+// the same code by integer arithmetic on the float's bits (round half up instead of half even: irrelevant at 3 mantissa bits of a residual): |y| < 1 goes
+// through 1 + |y|, whose mantissa IS |y| in fixed point; 6 integer ops instead of a compare chain -- the GroupNorm-apply producer encodes 2 codes per element
+__device__ __forceinline__ uint32_t enc_e2m3_fast(float y) {
+    const uint32_t u = __float_as_uint(y), sgn = (u >> 26) & 0x20u;
+    const float a = fminf(__uint_as_float(u & 0x7fffffffu), 7.5f);
+    const bool sub = a < 1.f;
+    const uint32_t b = __float_as_uint(sub ? a + 1.f : a) + 0x00080000u;
+    const uint32_t code = (b >> 20) - (sub ? (127u << 3) : (126u << 3));
+    return sgn | (code > 31u ? 31u : code);
+}
 // one thread = one pixel x one 32-channel block
 __global__ void k_nchw_to_act_q(const float* __restrict__ src, int C, int H, int W, bf16_t* hi, bf16_t* lo, int Cbuf, int halo, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,6 +267,111 @@ int mf_nchw_to_act_q(const float* src, int C, const ActBuf& dst, int batch, hipS
     MF_REQUIRE(dst.C % 32 == 0 && dst.lo, "nchw_to_act_q: the destination needs 32-channel blocks and a second plane");
     const int64_t total = (int64_t)batch * (dst.C / 32) * dst.H * dst.W;
     hipLaunchKernelGGL(k_nchw_to_act_q, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, src, C, dst.H, dst.W, dst.hi, dst.lo, dst.C, dst.halo, total);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+namespace {
+// one thread = one pixel x one 32-channel block (blocks fastest: a wave reads 4 KB of contiguous channels per plane)
+__global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, int xC, int xcoff, int xhalo, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int C, int silu, int H, int W, bf16_t* yh, bf16_t* yl, int yC, int yhalo, int64_t total) {
+    // A thread owns one 32-channel block (64 bytes per plane), but a wave moves its 64 blocks as 16-byte pieces with consecutive lanes on consecutive
+    // pieces (piece q * 64 + lane belongs to thread (q * 64 + lane) / 4): global requests are whole lines; a wave-private LDS image does the transposition.
+    __shared__ uint4 s_img[2][4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t idx_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = idx_raw < total;
+    const int64_t idx = valid ? idx_raw : total - 1;
+    const int nblk = C / 32;
+    const int g = idx % nblk;
+    int64_t t = idx / nblk;
+    const int x = t % W; t /= W;
+    const int y = t % H;
+    const int b = t / H;
+    const int64_t xo = (((int64_t)b * (H + 2 * xhalo) + y + xhalo) * (W + 2 * xhalo) + x + xhalo) * xC + xcoff + g * 32;
+    const int64_t yo = (((int64_t)b * (H + 2 * yhalo) + y + yhalo) * (W + 2 * yhalo) + x + yhalo) * yC + g * 32;
+    const float* sc = scale + (int64_t)b * C + g * 32;
+    const float* sh = shift + (int64_t)b * C + g * 32;
+    float vh[32], vl[32];
+    float mh = 0.f, ml = 0.f;
+    uint32_t hbits[16];
+    uint4 av[4], cv[4];
+    float4 scv[8], shv[8];
+    const int sub = lane & 3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int owner = (q * 64 + lane) >> 2;
+        const int64_t o = __shfl(xo, owner) + 8 * sub;
+        s_img[0][wv][q * 64 + lane] = *reinterpret_cast<const uint4*>(xh + o);
+        s_img[1][wv][q * 64 + lane] = xl ? *reinterpret_cast<const uint4*>(xl + o) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { av[q] = s_img[0][wv][lane * 4 + q]; cv[q] = s_img[1][wv][lane * 4 + q]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { scv[q] = *reinterpret_cast<const float4*>(sc + 4 * q); shv[q] = *reinterpret_cast<const float4*>(sh + 4 * q); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t aw[4] = {av[q].x, av[q].y, av[q].z, av[q].w}, cw[4] = {cv[q].x, cv[q].y, cv[q].z, cv[q].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * q + e;
+            const uint32_t hw = (e & 1) ? aw[e >> 1] >> 16 : aw[e >> 1] & 0xffffu, lw = (e & 1) ? cw[e >> 1] >> 16 : cw[e >> 1] & 0xffffu;
+            const float4 s4 = scv[k >> 2], t4 = shv[k >> 2];
+            const float sck = (k & 3) == 0 ? s4.x : ((k & 3) == 1 ? s4.y : ((k & 3) == 2 ? s4.z : s4.w));
+            const float shk = (k & 3) == 0 ? t4.x : ((k & 3) == 1 ? t4.y : ((k & 3) == 2 ? t4.z : t4.w));
+            float v = bf2f_d(hw) + bf2f_d(lw);
+            v = v * sck + shk;
+            if (silu) v = v / (1.f + __expf(-v));
+            const _Float16 h = (_Float16)v;
+            vh[k] = (float)h; vl[k] = v - vh[k];
+            mh = fmaxf(mh, fabsf(vh[k])); ml = fmaxf(ml, fabsf(vl[k]));
+            const uint32_t hb = __builtin_bit_cast(uint16_t, h);
+            if (k & 1) hbits[k >> 1] |= hb << 16; else hbits[k >> 1] = hb;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_img[0][wv][lane * 4 + q] = make_uint4(hbits[4 * q], hbits[4 * q + 1], hbits[4 * q + 2], hbits[4 * q + 3]);
+    uint32_t w[16];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const float* v = blk == 0 ? vl : vh;
+        const float m = blk == 0 ? ml : mh;
+        // m * 2^ex in [4, 8): ex = 2 - floor(log2 m) = 129 - (biased exponent of m); the scale itself by writing its exponent field
+        const int be = (int)((__float_as_uint(m) >> 23) & 0xffu);
+        const int ex = be >= 3 ? 129 - be : 0;                                       // (a block of zeros / denormals keeps scale 1)
+        const float scq = __uint_as_float((uint32_t)(127 + ex) << 23);
+        uint32_t* o = w + 8 * blk;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = 0;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const uint32_t code = enc_e2m3_fast(v[e] * scq);
+            const int bit = 6 * e;
+            o[bit >> 5] |= code << (bit & 31);
+            if ((bit & 31) > 26) o[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+        }
+        o[6] = (uint32_t)(127 - ex) & 0xffu;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_img[1][wv][lane * 4 + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int owner = (q * 64 + lane) >> 2;
+        const int64_t o = __shfl(yo, owner) + 8 * sub;
+        const bool ok = __shfl((int)valid, owner) != 0;
+        const uint4 ph = s_img[0][wv][q * 64 + lane], pl = s_img[1][wv][q * 64 + lane];
+        if (ok) { *reinterpret_cast<uint4*>(yh + o) = ph; *reinterpret_cast<uint4*>(yl + o) = pl; }
+    }
+}
+}  // namespace
+
+int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* shift, int silu, const ActBuf& dst, int batch, hipStream_t s) {
+    const ActBuf& xb = *x.buf;
+    MF_REQUIRE(x.C % 32 == 0 && x.coff % 8 == 0 && dst.C == x.C && dst.H == xb.H && dst.W == xb.W && dst.lo && scale && shift,
+               "affine_silu_to_act_q: needs 32-channel blocks, matching geometry and a second plane");
+    const int64_t total = (int64_t)batch * xb.H * xb.W * (x.C / 32);
+    hipLaunchKernelGGL(k_affine_silu_to_q, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xb.hi, xb.lo, xb.C, x.coff, xb.halo, scale, shift, x.C, silu, xb.H, xb.W, dst.hi,
+                       dst.lo, dst.C, dst.halo, total);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

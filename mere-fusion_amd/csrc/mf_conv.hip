@@ -857,7 +857,7 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
             // f16 + FP6 residual format: plane 0 = f16(w) in the same [slice][tap][Npad][32] order; plane 1 = per (slice, tap, row) 64 bytes
             // [q6(f16(w)) | q6(w - f16(w))], each 24 B of e2m3 codes (value t in bits [6t, 6t+6)) + the block's E8M0 byte + pad.  The pixel side
             // stores [q6(x - f16(x)) | q6(f16(x))], so K block 0 of the correction instruction is q6(wh).xl and block 1 is wl.q6(xh).
-            MF_REQUIRE(d.cin % 32 == 0 && d.cout % 128 == 0 && !d.residual, "conv (f16q): the experimental format serves 3x3 layers with cin %% 32 == 0, cout %% 128 == 0 and no residual from the input");
+            MF_REQUIRE(d.cin % 32 == 0 && d.cout % 128 == 0, "conv (f16q): the format serves 3x3 layers with cin %% 32 == 0 and cout %% 128 == 0");
             p->q = true;
             auto enc = [](float y) -> uint32_t {
                 const uint32_t sgn = y < 0.f ? 0x20u : 0u;
@@ -1609,7 +1609,8 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
 }
 
 void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
-    const char* x3 = p->precision == MF_PREC_BF16X3 ? "true" : "false";
+    const char* x3 = p->precision != MF_PREC_BF16 ? "true" : "false";
+    if (p->q) { snprintf(buf, cap, "k_conv3x3_halo_w<16,128,4,2,true,1> f16+fp6"); return; }
     if (p->halo) {
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         if (!tw.ph && mf_halo_split_count(p, batch)) {

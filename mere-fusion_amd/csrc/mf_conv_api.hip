@@ -34,7 +34,7 @@ extern "C" int mf_conv2d_create(const mf_conv2d_desc* desc, const float* weight,
     if (desc->residual)
         MF_REQUIRE(desc->cin == desc->cout && h->plan.out_h == desc->in_h && h->plan.out_w == desc->in_w,
                    "conv2d_create: residual needs matching input/output shapes");
-    MF_REQUIRE(precision != MF_PREC_F16Q || h->plan.q, "conv2d_create: MF_PREC_F16Q serves wide 3x3 stride-1 layers only (cin %% 32 == 0, cout %% 128 == 0)");
+    MF_REQUIRE(precision != MF_PREC_F16Q || (h->plan.q && !desc->residual), "conv2d_create: MF_PREC_F16Q serves wide 3x3 stride-1 layers only (cin %% 32 == 0, cout %% 128 == 0, no residual from the input)");
     h->in.C = h->plan.q ? (h->plan.cin_pad + 31) / 32 * 32 : h->plan.cin_pad; h->in.H = desc->in_h; h->in.W = desc->in_w;
     h->in.halo = std::max(1, h->plan.in_halo_need);
     h->out.C = (out_channels(*desc) + 7) / 8 * 8; h->out.H = h->plan.out_h; h->out.W = h->plan.out_w; h->out.halo = 1;

@@ -50,6 +50,7 @@ struct Net {
     struct Tunable { ConvPlan* p; ActView in, out, res; int op; };
     std::vector<Tunable> tunables;
     bool autotune = false;
+    bool q_allowed = false;     // the f16 + FP6 conv format: the VAE decoder's resnets (set by the builder of a network whose parity was established with it)
     int next_pad_hi = 0;        // consumed by the next conv(): extra zero rows / columns bottom-right (the VAE encoder's Downsample2D)
     std::string err;
 
@@ -161,6 +162,44 @@ struct Net {
                 ActView res, const std::vector<float>* extra_bias = nullptr) {
         const ActView tv{t, 0, cin};
         const bool same_geom = x.coff == 0 && x.buf->C == t->C && x.buf->halo == t->halo && x.buf->H == t->H && x.buf->W == t->W && x.C == cin;
+        // f16 + FP6 operand format for the wide 3x3 convs on large maps (MF_CONV_Q=0: bf16x3 everywhere): GroupNorm-apply writes the conv's input in the new
+        // format, the conv runs one f16 + half a block-scaled FP6 MFMA per tap where bf16x3 runs three; outputs and residuals stay bf16 (hi, lo).
+        static const bool q_on = [] { const char* e = getenv("MF_CONV_Q"); return !e || atoi(e) != 0; }();
+        if (q_on && q_allowed && precision == MF_PREC_BF16X3 && cin % 32 == 0 && cout % 128 == 0 && t->C == cin && t->H * t->W >= 64 * 64 &&
+            (int64_t)cap * ((t->H + 15) / 16) * ((t->W + 15) / 16) * (cout / 128) >= 256) {
+            const float* g = T(gname + ".weight", cin);
+            const float* b = T(gname + ".bias", cin);
+            const float* w = T(cname + ".weight", (int64_t)cin * cout * 9);
+            const float* cb = T(cname + ".bias", cout);
+            if (!g || !b || !w || !cb) return MF_ERR_INVALID;
+            float* dg = upload(g, cin);
+            float* db = upload(b, cin);
+            if (!dg || !db) return MF_ERR_HIP;
+            if (gn_count >= GN_MAX_OPS) { err = "more GroupNorm layers than GN_MAX_OPS"; return MF_ERR_INVALID; }
+            double* st = gn_stats + (size_t)(gn_count++) * gn_slice;
+            float* aff = nullptr;
+            if (hipMalloc(&aff, (size_t)2 * cap * cin * sizeof(float)) != hipSuccess) { err = "hipMalloc failed for a GroupNorm affine"; return MF_ERR_HIP; }
+            dev.push_back(aff);
+            float *scale = aff, *shift = aff + (size_t)cap * cin;
+            std::vector<float> bb(cout);
+            for (int i = 0; i < cout; ++i) bb[i] = cb[i] + (extra_bias ? (*extra_bias)[i] : 0.f);
+            mf_conv2d_desc d{};
+            d.cin = cin; d.cout = cout; d.kh = d.kw = 3; d.stride_h = d.stride_w = 1; d.pad_h = d.pad_w = 1; d.residual = res.buf ? 1 : 0; d.in_h = t->H; d.in_w = t->W;
+            ConvPlan* p = new_plan();
+            int rc = mf_conv_plan_create(p, d, w, bb.data(), nullptr, nullptr, nullptr, nullptr, MF_PREC_F16Q);
+            if (rc) return rc;
+            if (!p->q) { err = cname + ": no kernel in the f16 + FP6 format for this layer"; return MF_ERR_INVALID; }
+            if ((rc = mf_conv_bind(p, *t))) return rc;
+            const ActBuf* tq = t;
+            push(gname, "k_gn_stats+k_affine_silu_to_q", 0.0, [=](int B, hipStream_t s) {
+                const int r1 = mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s);
+                return r1 ? r1 : mf_affine_silu_to_act_q(x, scale, shift, 1, *tq, B, s);
+            });
+            char kn[96];
+            mf_conv_kernel_name(p, cap, kn, sizeof(kn));
+            push(cname, kn, mf_conv_flops(p, 1), [=](int B, hipStream_t s) { return mf_conv_launch(p, tv, out, res, B, s); });
+            return MF_OK;
+        }
         static const bool on = [] { const char* e = getenv("MF_GN_FUSE"); return e && atoi(e) != 0; }();
         if (!on || !same_geom) {
             int rc = gn(gname, x, tv, groups, eps, true);
@@ -712,6 +751,7 @@ extern "C" int mf_vae_create(const mf_vae_config* c, const mf_tensor* weights, i
     Net& net = h->net;
     int rc = net.init(weights, n_weights, precision, max_batch, c->norm_num_groups);
     if (rc) return rc;
+    net.q_allowed = true;        // decoder resnet convs on maps >= 64 x 64 in the f16 + FP6 format (tests/test_musetalk_full.py holds the parity bound with it)
     const int nb = c->n_blocks, L = c->layers_per_block, G = c->norm_num_groups, Z = c->latent_channels;
     const int* boc = c->block_out_channels;
     int s = c->sample_size, ch = boc[nb - 1];
