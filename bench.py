@@ -183,7 +183,10 @@ def roofline(rows, precision, only_mfma=False):
     dom = max(by, key=lambda k: by[k]["ms"])
     d = by[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    peak = BF16_DENSE_PEAK_TF / MFMA_PASSES[precision]
+    # MFMA pass-equivalents per product of the DOMINANT kernel's operand format: 3 bf16 MFMAs (bf16x3), or one f16 MFMA + half a block-scaled FP6
+    # MFMA at 4x the rate (the VAE decoder's resnet convs, "f16+fp6" in the kernel's name) = 1.5
+    passes = 1.5 if "f16+fp6" in dom else MFMA_PASSES[precision]
+    peak = BF16_DENSE_PEAK_TF / passes
     total_ms = sum(r["ms"] for r in rows)
     return {
         "bound": "mfma", "kernel": dom, "launches_per_step": d["launches"],
@@ -191,7 +194,8 @@ def roofline(rows, precision, only_mfma=False):
         "alg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 4),
         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": None,
-        "mfma_passes_per_product": MFMA_PASSES[precision],
+        "mfma_passes_per_product": passes,
+        "operand_format": "f16 + FP6 (e2m3, MX block scales) correction terms" if "f16+fp6" in dom else precision,
         "kernel_share_of_step": round(d["ms"] / total_ms, 3),
         "sum_of_launches_ms": round(total_ms, 4),
     }, by
@@ -222,7 +226,7 @@ def pmc_traffic(kernel, workload, precision, batch_args, want_clock=True):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found", None
-    want = "void" + kernel.replace(" ", "")[:-1]                # "voidk_conv_igemm<256,256,2,4,true,32" (+ ",<ring depth>>" or ">")
+    want = "void" + kernel.split(" f16+fp6")[0].replace(" ", "")[:-1]                # "voidk_conv_igemm<256,256,2,4,true,32" (+ ",<ring depth>>" or ">")
     vals, clock = {}, None
     for ctr in ("FETCH_SIZE", "WRITE_SIZE") + (("GRBM_GUI_ACTIVE",) if want_clock else ()):
         d = tempfile.mkdtemp(prefix="mf_pmc_")
@@ -776,6 +780,10 @@ def main():
                                "algorithmic_gflop_per_frame": round(gf_frame, 1),
                                "parallelism": f"{world} independent replicas, sessions sharded by GPU, no collective"},
                     "net_tflops": round(value / world * gf_frame / 1e3, 1)}
+            if args.precision == "bf16x3" and os.environ.get("MF_CONV_Q", "1") != "0":
+                line["dtype_note"] = ("bf16x3 (hi, lo bf16 pairs, three MFMAs per product) everywhere except the VAE decoder's 3x3 resnet convs on maps >= 64 x 64: "
+                                      "f16 + FP6 (e2m3, MX block scales) correction terms, 1.5 pass-equivalents per product, outputs bf16 (hi, lo); "
+                                      "parity bound unchanged (tests/test_musetalk_full.py)")
             if args.profile_iters <= 0:          # child of a PMC pass: the timed steps above are all it needs to run
                 print(json.dumps(line), flush=True)
                 return
@@ -797,11 +805,11 @@ def main():
                 # the ceiling a kernel of pure matrix instructions reaches on this device, next to the nominal peak
                 ceil = mfma_only_ceiling(args.precision)
                 rf["mfma_only_ceiling_tflops"] = ceil
-                ref = ceil.get("bf16_single_pass", ceil["bf16x3_12_bf16_mfma_per_128k"])
+                ref = ceil["f16_plus_2_mx_fp6"] if "f16+fp6" in rf["kernel"] else ceil.get("bf16_single_pass", ceil["bf16x3_12_bf16_mfma_per_128k"])
                 rf["frac_of_mfma_only_ceiling"] = round(rf["achieved"] / ref, 4)
                 rf["ceiling_note"] = ("mf_probe_mfma_ceiling: TFLOP/s of the convolution's own arithmetic from a loop of nothing but MFMAs (8 waves per CU, random "
                                       "operand bits) for the instruction mix of one product: 3 bf16 MFMAs as shipped; f16 + two block-scaled FP8 / FP6 correction terms "
-                                      "(not built: numerics in tools/numerics_split_study.py, layouts in tools/mx_cross_probe.hip)")
+                                      "(the FP6 form is what the VAE decoder's resnet convs run; numerics in tools/numerics_split_study.py, layouts in tools/mx_cross_probe.hip)")
             line["roofline"] = rf
             conv_rows = [r for r in rows if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
             if conv_rows:
