@@ -91,6 +91,7 @@ struct HaloArgs {
     const float* gn_scale; const float* gn_shift; int gn_C;
     unsigned long long* dbg;                    // MF_DBG_TIMES: 4 s_memtime stamps per workgroup (entry, loop start, loop end, exit), or null
     int q;                                      // operands in the f16 + FP6-residual format (MF_PREC_F16Q): x_lo / w_lo hold [q6 block | q6 block] rows
+    double* gn_out; int gn_out_cpg, gn_out_groups;   // f16 + FP6 kernel: (sum, sum of squares) of the OUTPUT per (sample, group) added here for the consumer GroupNorm; null = off
     int stagger;                                // LDS-weights kernel, 8-wave tiles: the second wave of every SIMD issues its weight DMA mid-tap (filled by the launcher)
 };
 struct HaloTile { int ph, bn, wgm, wgn; };
@@ -122,6 +123,7 @@ struct ConvPlan {
     bf16_t* w_lo = nullptr;
     float* bias = nullptr;
     int* goff = nullptr;
+    double* out_stats = nullptr; int out_stats_groups = 0;   // f16 + FP6 kernel: GroupNorm (sum, sum of squares) of the output accumulated by the epilogue (set by the network builder)
     bool q = false;       // MF_PREC_F16Q: w_hi = f16 [slice][tap][Npad][32], w_lo = [slice][tap][Npad][q6(wh) 32 B | q6(wl) 32 B] (24 B codes + E8M0 byte + pad)
     bool halo = false;    // 3x3 s1 p1 on a >= 16x16 map: LDS halo-tile kernel, weights packed [slice][tap][Npad][CK]
     bf16_t* up_hi = nullptr;  // nearest-2x-upsample + 3x3 layers that qualify for the fat halo tiles: [phase][slice][4 taps][Npad][CK], pre-summed taps

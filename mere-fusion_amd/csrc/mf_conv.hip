@@ -1160,6 +1160,12 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
             MF_REQUIRE(!ha.res_from_halo && !g_gn_scale, "conv (f16q): residual-from-input / GroupNorm fusion are not built for this format");
             // 8 waves of 64 px x 64 ch (default; measured 338 / 396 / 316 us on 256->256 @128^2, 128->128 @256^2, 512->512 @64^2 at batch 8 against
             // 313 / 370 / 290 us for bf16x3 on its best tiles); MF_Q_TILE=12822: 4 waves of 128 px x 64 ch, one workgroup per CU (359 / 418 / 331 us)
+            if (p->out_stats) {
+                const int cpg = p->d.cout / p->out_stats_groups;
+                MF_REQUIRE(p->d.cout % p->out_stats_groups == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && out.coff == 0 && !ha.ws,
+                           "conv (f16q): fused GroupNorm statistics need 4, 8 or 16 channels per group (cout %d, groups %d)", p->d.cout, p->out_stats_groups);
+                ha.gn_out = p->out_stats; ha.gn_out_cpg = cpg; ha.gn_out_groups = p->out_stats_groups;
+            }
             static const int qt = [] { const char* e = getenv("MF_Q_TILE"); return e ? atoi(e) : 12842; }();
             return mf_halo_w_launch(ha, qt == 12822 ? HaloTile{16, 128, 2, 2} : HaloTile{16, 128, 4, 2}, true, stream);
         }

@@ -494,6 +494,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     }
     const bool has_res = a.r_hi != nullptr && !(MF_HALO_ABLATE & 16);
     const int ox = x0 + fr;
+    // GroupNorm statistics of the OUTPUT for the layer's consumer (a.gn_out): per-thread fp32 (sum, sum of squares) of its channel quads
+    float gs[Q ? FN : 1], gq[Q ? FN : 1];
+#pragma unroll
+    for (int i = 0; i < (Q ? FN : 1); ++i) { gs[i] = 0.f; gq[i] = 0.f; }
     constexpr int JG = (FM * FN * NP <= 32) ? FM : (32 / (FN * NP) >= 1 ? 32 / (FN * NP) : 1);   // rows per residual burst
 #pragma unroll
     for (int j0 = 0; j0 < FM; j0 += JG) {
@@ -542,6 +546,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
                     for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
                 }
                 if (!row_ok || c >= a.N) continue;
+                if constexpr (Q != 0) {
+                    gs[i] += (v[0] + v[1]) + (v[2] + v[3]);
+                    gq[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
                 uint32_t h[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h[e] = hf2bf(v[e]);
@@ -552,6 +560,37 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
                     for (int e = 0; e < 4; ++e) l[e] = hf2bf(v[e] - hbf2f(h[e]));
                     *reinterpret_cast<uint2*>(a.y_lo + yo + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
                 }
+            }
+        }
+    }
+    if constexpr (Q != 0) {
+        // The consumer's GroupNorm statistics from the accumulators instead of a second pass over the tensor (k_gn_stats re-reads 4 bytes per
+        // value: 268 MB on the 256^2 maps).  A thread's quad lies in one group (channels per group 4, 8 or 16); sum over the wave's 16 pixel
+        // columns, park per (wave, quad) in LDS, then one fp64 atomic per (workgroup, group, moment) -- the granularity k_gn_stats has.
+        if (a.gn_out) {
+            __shared__ float s_gn[NW][FN * 4][2];
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) { gs[i] += __shfl_xor(gs[i], off); gq[i] += __shfl_xor(gq[i], off); }
+            if (fr == 0) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) { s_gn[wave][i * 4 + fk][0] = gs[i]; s_gn[wave][i * 4 + fk][1] = gq[i]; }
+            }
+            __syncthreads();
+            const int qpg = a.gn_out_cpg >> 2;                     // quads per group
+            const int ng = BN / a.gn_out_cpg;                      // groups this workgroup's channel tile covers
+            if (tid < 2 * ng) {
+                const int gl = tid >> 1, m = tid & 1;
+                double acc_d = 0.0;
+                for (int k = 0; k < qpg; ++k) {
+                    const int qd = gl * qpg + k;                   // quad within the channel tile: wave_n * (FN * 4) + i * 4 + fk
+                    const int wn = qd / (FN * 4), sl = qd - wn * (FN * 4);
+#pragma unroll
+                    for (int wm = 0; wm < WGM; ++wm) acc_d += (double)s_gn[wn * WGM + wm][sl][m];
+                }
+                const int g = n0 / a.gn_out_cpg + gl;
+                if (g < a.gn_out_groups) atomicAdd(a.gn_out + 2 * ((size_t)b * a.gn_out_groups + g) + m, acc_d);
             }
         }
     }
@@ -570,7 +609,7 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE, HS, GN, Q>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (Q ? 158 : 160) * 1024));   // Q: 1-2 KiB of static LDS (s_gn) beside the dynamic block
         attr_done = true;
     }
     constexpr int CK = X3 ? 32 : 64, RPC = 1024 / (CK * 2), NP = X3 ? 2 : 1;

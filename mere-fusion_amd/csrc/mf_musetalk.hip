@@ -50,6 +50,9 @@ struct Net {
     struct Tunable { ConvPlan* p; ActView in, out, res; int op; };
     std::vector<Tunable> tunables;
     bool autotune = false;
+    // the last f16 + FP6 conv and the buffer it filled: a GroupNorm that reads exactly that buffer next takes its statistics from the conv's
+    // epilogue (ConvPlan::out_stats) instead of a pass over the tensor.  Cleared by any other op that writes the buffer.
+    ConvPlan* stats_src = nullptr; const ActBuf* stats_buf = nullptr;
     bool q_allowed = false;     // the f16 + FP6 conv format: the VAE decoder's resnets (set by the builder of a network whose parity was established with it)
     int next_pad_hi = 0;        // consumed by the next conv(): extra zero rows / columns bottom-right (the VAE encoder's Downsample2D)
     std::string err;
@@ -142,6 +145,7 @@ struct Net {
         d.cin = cin; d.cout = cout; d.kh = d.kw = k; d.stride_h = d.stride_w = stride; d.pad_h = d.pad_w = pad;
         d.act = act; d.residual = res.buf ? 1 : 0; d.in_h = in.buf->H; d.in_w = in.buf->W; d.upsample = upsample;
         d.pad_hi = next_pad_hi; next_pad_hi = 0;
+        if (stats_buf == out.buf) { stats_src = nullptr; stats_buf = nullptr; }
         ConvPlan* p = new_plan();
         int rc = mf_conv_plan_create(p, d, w, bb.data(), nullptr, nullptr, nullptr, nullptr, precision);
         if (rc) return rc;
@@ -158,6 +162,16 @@ struct Net {
     // apply pass, `t` untouched; otherwise GroupNorm writes `t` and the conv reads it, as two launches in one op.  Opt-in (MF_GN_FUSE=1): frames
     // agree to 1 uint8 level, per-op time of (GroupNorm + conv) drops 3-5 %, but the replayed step does not move (23.9 -> 23.6 ms in one run,
     // 339 -> 336 frames/s in another): the in-LDS transform costs the conv about what the apply pass cost the memory system.
+    // statistics for GroupNorm(groups) of `x` come from its producer's epilogue?  (MF_GN_EPI=0: off)
+    bool take_stats(const ActView& x, int groups, double* st) {
+        static const bool on = [] { const char* e = getenv("MF_GN_EPI"); return !e || atoi(e) != 0; }();
+        if (!on || !stats_src || stats_buf != x.buf || x.coff != 0 || x.C != x.buf->C || stats_src->d.cout != x.C || stats_src->out_stats) return false;
+        const int cpg = x.C / groups;
+        if (x.C % groups || (cpg != 4 && cpg != 8 && cpg != 16)) return false;
+        stats_src->out_stats = st; stats_src->out_stats_groups = groups;
+        stats_src = nullptr; stats_buf = nullptr;
+        return true;
+    }
     int gn_conv(const std::string& gname, const std::string& cname, ActView x, ActBuf* t, ActView out, int cin, int cout, int groups, float eps,
                 ActView res, const std::vector<float>* extra_bias = nullptr) {
         const ActView tv{t, 0, cin};
@@ -191,13 +205,16 @@ struct Net {
             if (!p->q) { err = cname + ": no kernel in the f16 + FP6 format for this layer"; return MF_ERR_INVALID; }
             if ((rc = mf_conv_bind(p, *t))) return rc;
             const ActBuf* tq = t;
-            push(gname, "k_gn_stats+k_affine_silu_to_q", 0.0, [=](int B, hipStream_t s) {
-                const int r1 = mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s);
+            const bool epi = take_stats(x, groups, st);
+            push(gname, epi ? "k_affine_silu_to_q (statistics from the producer's epilogue)" : "k_gn_stats+k_affine_silu_to_q", 0.0, [=](int B, hipStream_t s) {
+                const int r1 = mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s, epi);
                 return r1 ? r1 : mf_affine_silu_to_act_q(x, scale, shift, 1, *tq, B, s);
             });
             char kn[96];
             mf_conv_kernel_name(p, cap, kn, sizeof(kn));
             push(cname, kn, mf_conv_flops(p, 1), [=](int B, hipStream_t s) { return mf_conv_launch(p, tv, out, res, B, s); });
+            if (stats_buf == out.buf) { stats_src = nullptr; stats_buf = nullptr; }
+            if (out.coff == 0 && out.C == out.buf->C) { stats_src = p; stats_buf = out.buf; }
             return MF_OK;
         }
         static const bool on = [] { const char* e = getenv("MF_GN_FUSE"); return e && atoi(e) != 0; }();
@@ -249,7 +266,10 @@ struct Net {
         if (!dg || !db) return MF_ERR_HIP;
         if (gn_count >= GN_MAX_OPS) { err = "more GroupNorm layers than GN_MAX_OPS"; return MF_ERR_INVALID; }
         double* st = gn_stats + (size_t)(gn_count++) * gn_slice;
-        push(name, "k_gn_stats+k_gn_apply", 0.0, [=](int B, hipStream_t s) { return mf_groupnorm(in, out, dg, db, groups, eps, silu, st, B, s); });
+        const bool epi = take_stats(in, groups, st);
+        if (stats_buf == out.buf) { stats_src = nullptr; stats_buf = nullptr; }
+        push(name, epi ? "k_gn_apply (statistics from the producer's epilogue)" : "k_gn_stats+k_gn_apply", 0.0,
+             [=](int B, hipStream_t s) { return mf_groupnorm(in, out, dg, db, groups, eps, silu, st, B, s, epi); });
         return MF_OK;
     }
     int ln(const std::string& name, ActView in, ActView out) {

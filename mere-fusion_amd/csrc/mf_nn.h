@@ -37,10 +37,11 @@ int mf_rows_from_f32(const float* src, const float* addend, const ActView& y, in
 // `stats` is a device scratch of batch*groups*2 doubles owned by the caller and must be ZERO on entry (mf_zero_f64;
 // a kernel, not hipMemsetAsync -- memset nodes corrupted captured graphs on ROCm 7.2).
 int mf_zero_f64(double* p, int n, hipStream_t s);
+// have_stats: `stats` already holds the sums (the producing conv's epilogue added them, ConvPlan::out_stats): no statistics pass
 int mf_groupnorm_affine(const ActView& x, const float* gamma, const float* beta, int groups, float eps, double* stats, float* scale, float* shift,
-                        int batch, hipStream_t s);
+                        int batch, hipStream_t s, bool have_stats = false);
 int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, int groups, float eps,
-                 bool silu, double* stats, int batch, hipStream_t s);
+                 bool silu, double* stats, int batch, hipStream_t s, bool have_stats = false);
 
 // GEGLU (diffusers): y[t][c] = x[t][c] * gelu(x[t][C + c]) for c < C = x.C / 2
 int mf_geglu(const ActView& x, const ActView& y, int batch, hipStream_t s);

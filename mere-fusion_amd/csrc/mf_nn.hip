@@ -569,14 +569,14 @@ __global__ void k_gn_affine(const double* __restrict__ stats, const float* __res
 // GroupNorm folded into the consumer conv (mf_conv_halo2.hip): statistics as in mf_groupnorm, then the per-(sample, channel) affine the
 // conv applies (with SiLU) to its halo image in LDS.  scale / shift: [batch][C] fp32 device arrays.
 int mf_groupnorm_affine(const ActView& x, const float* gamma, const float* beta, int groups, float eps, double* stats, float* scale, float* shift,
-                        int batch, hipStream_t s) {
+                        int batch, hipStream_t s, bool have_stats) {
     MF_REQUIRE(x.C % groups == 0 && x.C % 8 == 0 && x.coff % 8 == 0, "groupnorm: C=%d groups=%d", x.C, groups);
     const Rows xr = rows_of(x);
     const int cpg = x.C / groups;
     MF_REQUIRE(groups <= 64 && x.C <= 8 * 256 * GN_MAXCOL, "groupnorm: groups=%d / C=%d beyond the kernel's limits", groups, x.C);
     const int cols = std::min(256, x.C / 8), ppi = 256 / cols;
     int P = std::max(ppi, std::min(64 * ppi, (xr.T * batch + 1023) / 1024));
-    hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, cpg, x.C, P, stats);
+    if (!have_stats) hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, cpg, x.C, P, stats);
     const int total = batch * x.C;
     hipLaunchKernelGGL(k_gn_affine, dim3((total + 255) / 256), dim3(256), 0, s, stats, gamma, beta, 1.0 / ((double)xr.T * cpg), eps, groups, cpg, x.C, total,
                        scale, shift);
@@ -585,7 +585,7 @@ int mf_groupnorm_affine(const ActView& x, const float* gamma, const float* beta,
 }
 
 int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, int groups, float eps,
-                 bool silu, double* stats, int batch, hipStream_t s) {
+                 bool silu, double* stats, int batch, hipStream_t s, bool have_stats) {
     MF_REQUIRE(x.C == y.C && x.C % groups == 0 && x.C % 8 == 0 && x.coff % 8 == 0 && y.coff % 8 == 0, "groupnorm: C=%d groups=%d", x.C, groups);
     MF_REQUIRE(x.buf->H == y.buf->H && x.buf->W == y.buf->W, "groupnorm: spatial mismatch");
     const Rows xr = rows_of(x), yr = rows_of(y);
@@ -596,7 +596,7 @@ int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const f
         // GroupNorms take 1.09 ms this way against 0.91-0.95 ms as two launches -- a workgroup per (item, group) is two chains of load round
         // trips over 4-byte pieces, the two-launch path spreads the same bytes over the whole chip twice.
         static const int small_max = [] { const char* e = getenv("MF_GN_SMALL"); return e ? atoi(e) : 0; }();
-        if (cpg % 2 == 0 && (int64_t)xr.T * cpg <= small_max && batch * groups >= 128) {
+        if (!have_stats && cpg % 2 == 0 && (int64_t)xr.T * cpg <= small_max && batch * groups >= 128) {
             hipLaunchKernelGGL(k_gn_small, dim3(groups, batch), dim3(1024), 0, s, xr, yr, gamma, beta, eps, cpg, silu ? 1 : 0);
             MF_HIP(hipGetLastError());
             return MF_OK;
@@ -605,7 +605,7 @@ int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const f
     // pixels per workgroup: enough workgroups to fill the chip, at most 64 pixels per thread column
     const int cols = std::min(256, x.C / 8), ppi = 256 / cols;
     int P = std::max(ppi, std::min(64 * ppi, (xr.T * batch + 1023) / 1024));
-    hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, cpg, x.C, P, stats);
+    if (!have_stats) hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, cpg, x.C, P, stats);
     MF_HIP(hipGetLastError());
     {
         // four tokens per thread once the tensor is big enough to fill the chip that way; small maps keep one token per thread
