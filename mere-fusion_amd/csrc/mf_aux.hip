@@ -279,34 +279,50 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restri
     // pieces (piece q * 64 + lane belongs to thread (q * 64 + lane) / 4): global requests are whole lines; a wave-private LDS image does the transposition.
     __shared__ uint4 s_img[2][4][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t idx_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = idx_raw < total;
-    const int64_t idx = valid ? idx_raw : total - 1;
+    // 32-bit index arithmetic throughout (the host checks that both tensors stay below 2^31 elements): 64-bit divisions are emulated
+    const int idx_raw = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = idx_raw < (int)total;
+    const int idx = valid ? idx_raw : (int)total - 1;
     const int nblk = C / 32;
     const int g = idx % nblk;
-    int64_t t = idx / nblk;
+    int t = idx / nblk;
     const int x = t % W; t /= W;
     const int y = t % H;
     const int b = t / H;
-    const int64_t xo = (((int64_t)b * (H + 2 * xhalo) + y + xhalo) * (W + 2 * xhalo) + x + xhalo) * xC + xcoff + g * 32;
-    const int64_t yo = (((int64_t)b * (H + 2 * yhalo) + y + yhalo) * (W + 2 * yhalo) + x + yhalo) * yC + g * 32;
-    const float* sc = scale + (int64_t)b * C + g * 32;
-    const float* sh = shift + (int64_t)b * C + g * 32;
-    float vh[32], vl[32];
+    const int xo = ((b * (H + 2 * xhalo) + y + xhalo) * (W + 2 * xhalo) + x + xhalo) * xC + xcoff + g * 32;
+    const int yo = ((b * (H + 2 * yhalo) + y + yhalo) * (W + 2 * yhalo) + x + yhalo) * yC + g * 32;
+    const float* sc = scale + b * C + g * 32;
+    const float* sh = shift + b * C + g * 32;
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    typedef _Float16 v32h __attribute__((ext_vector_type(32)));
+    typedef unsigned v6u __attribute__((ext_vector_type(6)));
+    typedef unsigned v16u __attribute__((ext_vector_type(16)));
+    v16f le, lod;                                   // residuals x - f16(x): even / odd channels (the f32 conversion interleaves its two sources)
     float mh = 0.f, ml = 0.f;
-    uint32_t hbits[16];
+    v16u hbits;
     uint4 av[4], cv[4];
     float4 scv[8], shv[8];
     const int sub = lane & 3;
+    // piece p of the wave's image sits at p ^ ((p >> 4) & 3): 16 consecutive lanes hit 16 different 16-byte bank groups on both the
+    // (piece = lane) global side and the (piece = 4 * lane + q) owner side
+    {
+        // all eight loads in flight before the first LDS write (written as load; store per piece the compiler waits for each load in turn)
+        uint4 in_h[4], in_l[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int owner = (q * 64 + lane) >> 2;
-        const int64_t o = __shfl(xo, owner) + 8 * sub;
-        s_img[0][wv][q * 64 + lane] = *reinterpret_cast<const uint4*>(xh + o);
-        s_img[1][wv][q * 64 + lane] = xl ? *reinterpret_cast<const uint4*>(xl + o) : make_uint4(0, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            const int o = __shfl(xo, (q * 64 + lane) >> 2) + 8 * sub;
+            in_h[q] = *reinterpret_cast<const uint4*>(xh + o);
+            in_l[q] = *reinterpret_cast<const uint4*>(xl + o);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pc = q * 64 + lane;
+            s_img[0][wv][pc ^ ((pc >> 4) & 3)] = in_h[q];
+            s_img[1][wv][pc ^ ((pc >> 4) & 3)] = in_l[q];
+        }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { av[q] = s_img[0][wv][lane * 4 + q]; cv[q] = s_img[1][wv][lane * 4 + q]; }
+    for (int q = 0; q < 4; ++q) { const int pc = lane * 4 + q; av[q] = s_img[0][wv][pc ^ ((pc >> 4) & 3)]; cv[q] = s_img[1][wv][pc ^ ((pc >> 4) & 3)]; }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { scv[q] = *reinterpret_cast<const float4*>(sc + 4 * q); shv[q] = *reinterpret_cast<const float4*>(sh + 4 * q); }
 #pragma unroll
@@ -321,45 +337,36 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restri
             const float shk = (k & 3) == 0 ? t4.x : ((k & 3) == 1 ? t4.y : ((k & 3) == 2 ? t4.z : t4.w));
             float v = bf2f_d(hw) + bf2f_d(lw);
             v = v * sck + shk;
-            if (silu) v = v / (1.f + __expf(-v));
+            if (silu) v = v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
             const _Float16 h = (_Float16)v;
-            vh[k] = (float)h; vl[k] = v - vh[k];
-            mh = fmaxf(mh, fabsf(vh[k])); ml = fmaxf(ml, fabsf(vl[k]));
+            const float vhk = (float)h, vlk = v - vhk;
+            mh = fmaxf(mh, fabsf(vhk)); ml = fmaxf(ml, fabsf(vlk));
+            if (k & 1) lod[k >> 1] = vlk; else le[k >> 1] = vlk;
             const uint32_t hb = __builtin_bit_cast(uint16_t, h);
             if (k & 1) hbits[k >> 1] |= hb << 16; else hbits[k >> 1] = hb;
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s_img[0][wv][lane * 4 + q] = make_uint4(hbits[4 * q], hbits[4 * q + 1], hbits[4 * q + 2], hbits[4 * q + 3]);
-    uint32_t w[16];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const float* v = blk == 0 ? vl : vh;
-        const float m = blk == 0 ? ml : mh;
-        // m * 2^ex in [4, 8): ex = 2 - floor(log2 m) = 129 - (biased exponent of m); the scale itself by writing its exponent field
-        const int be = (int)((__float_as_uint(m) >> 23) & 0xffu);
-        const int ex = be >= 3 ? 129 - be : 0;                                       // (a block of zeros / denormals keeps scale 1)
-        const float scq = __uint_as_float((uint32_t)(127 + ex) << 23);
-        uint32_t* o = w + 8 * blk;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = 0;
-#pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const uint32_t code = enc_e2m3_fast(v[e] * scq);
-            const int bit = 6 * e;
-            o[bit >> 5] |= code << (bit & 31);
-            if ((bit & 31) > 26) o[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
-        }
-        o[6] = (uint32_t)(127 - ex) & 0xffu;
+    for (int q = 0; q < 4; ++q) { const int pc = lane * 4 + q; s_img[0][wv][pc ^ ((pc >> 4) & 3)] = make_uint4(hbits[4 * q], hbits[4 * q + 1], hbits[4 * q + 2], hbits[4 * q + 3]); }
+    // Block scale 2^(floor(log2 max) - 2) puts the block's largest value in [4, 8) (e2m3 tops out at 7.5); the gfx950 conversions divide by
+    // 2^exponent(scale operand), round to nearest even and saturate (tools/cvt_fp6_probe.hip), 32 values per instruction, packed 6 bits each in
+    // channel order -- the layout the block-scaled MFMA reads.  The E8M0 byte is that exponent.  (A block of zeros / denormals: exponent 0.)
+    const uint32_t bl = max((__float_as_uint(ml) >> 23) & 0xffu, 2u) - 2u, bh = max((__float_as_uint(mh) >> 23) & 0xffu, 2u) - 2u;
+    const v6u ql = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(le, lod, __uint_as_float(bl << 23));
+    const v6u qh = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(v32h, hbits), __uint_as_float(bh << 23));
+    {
+        const int p0 = lane * 4;
+        s_img[1][wv][(p0 + 0) ^ ((p0 >> 4) & 3)] = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+        s_img[1][wv][(p0 + 1) ^ ((p0 >> 4) & 3)] = make_uint4(ql[4], ql[5], bl, 0u);
+        s_img[1][wv][(p0 + 2) ^ ((p0 >> 4) & 3)] = make_uint4(qh[0], qh[1], qh[2], qh[3]);
+        s_img[1][wv][(p0 + 3) ^ ((p0 >> 4) & 3)] = make_uint4(qh[4], qh[5], bh, 0u);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s_img[1][wv][lane * 4 + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-#pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int owner = (q * 64 + lane) >> 2;
-        const int64_t o = __shfl(yo, owner) + 8 * sub;
+        const int pc = q * 64 + lane, owner = pc >> 2;
+        const int o = __shfl(yo, owner) + 8 * sub;
         const bool ok = __shfl((int)valid, owner) != 0;
-        const uint4 ph = s_img[0][wv][q * 64 + lane], pl = s_img[1][wv][q * 64 + lane];
+        const uint4 ph = s_img[0][wv][pc ^ ((pc >> 4) & 3)], pl = s_img[1][wv][pc ^ ((pc >> 4) & 3)];
         if (ok) { *reinterpret_cast<uint4*>(yh + o) = ph; *reinterpret_cast<uint4*>(yl + o) = pl; }
     }
 }
@@ -367,8 +374,10 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restri
 
 int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* shift, int silu, const ActBuf& dst, int batch, hipStream_t s) {
     const ActBuf& xb = *x.buf;
-    MF_REQUIRE(x.C % 32 == 0 && x.coff % 8 == 0 && dst.C == x.C && dst.H == xb.H && dst.W == xb.W && dst.lo && scale && shift,
-               "affine_silu_to_act_q: needs 32-channel blocks, matching geometry and a second plane");
+    MF_REQUIRE(x.C % 32 == 0 && x.coff % 8 == 0 && dst.C == x.C && dst.H == xb.H && dst.W == xb.W && dst.lo && xb.lo && scale && shift,
+               "affine_silu_to_act_q: needs 32-channel blocks, matching geometry and a second plane on both sides");
+    MF_REQUIRE((int64_t)batch * xb.per_batch() < ((int64_t)1 << 31) && (int64_t)batch * dst.per_batch() < ((int64_t)1 << 31),
+               "affine_silu_to_act_q: tensors of 2^31 elements or more are not supported (32-bit offsets)");
     const int64_t total = (int64_t)batch * xb.H * xb.W * (x.C / 32);
     hipLaunchKernelGGL(k_affine_silu_to_q, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xb.hi, xb.lo, xb.C, x.coff, xb.halo, scale, shift, x.C, silu, xb.H, xb.W, dst.hi,
                        dst.lo, dst.C, dst.halo, total);
