@@ -126,6 +126,10 @@ int mf_conv2d_create(const mf_conv2d_desc* desc, const float* weight, const floa
 /* x: device fp32 NCHW [B,cin,in_h,in_w]; y: device fp32 NCHW [B,cout,out_h,out_w]. */
 int mf_conv2d_forward(mf_conv2d* h, const float* x, float* y, int batch, void* stream);
 int mf_conv2d_out_shape(const mf_conv2d* h, int* out_h, int* out_w);
+/* The same layer as the producer of a GroupNorm(groups) (diffusers ResnetBlock2D: conv -> norm): besides y, the launch leaves the (sum, sum of
+ * squares) of the stored output per (sample, group) in stats -- device fp64 [B][groups][2] -- from the kernel's epilogue or split-K combine
+ * where the chosen configuration can, else from a statistics pass behind it (test seam of what the UNet / VAE schedules do between layers). */
+int mf_conv2d_forward_stats(mf_conv2d* h, const float* x, float* y, int groups, double* stats, int batch, void* stream);
 /* Measurement seam: mean milliseconds of the convolution launch alone (layout passes excluded) over
  * `iters` repeats on the buffers of the last mf_conv2d_forward, bracketed by hipEvents on `stream`. */
 int mf_conv2d_time(mf_conv2d* h, int batch, int iters, float* ms, void* stream);

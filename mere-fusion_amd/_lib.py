@@ -90,6 +90,7 @@ SIGNATURES = {
     "mf_wav2lip_destroy": (None, [C.c_void_p]),
     "mf_conv2d_create": (C.c_int, [C.POINTER(MfConv2dDesc)] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(C.c_void_p)]),
     "mf_conv2d_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mf_conv2d_forward_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_conv2d_out_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mf_conv2d_time": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "mf_conv2d_destroy": (None, [C.c_void_p]),

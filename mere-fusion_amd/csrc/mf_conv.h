@@ -67,6 +67,9 @@ struct ConvArgs {
     float* ws;                // split-K fp32 partials [split][B][Ho][Wo][N], or null
     int64_t ws_split, wsb; int wsi, wsj;
     int* tile_cnt;            // fused split-K combine: arrivals per (phase, tile); the last workgroup reduces and resets it (null: k_splitk_epilogue)
+    // GroupNorm statistics of the OUTPUT for the layer's consumer: (sum, sum of squares) per (sample, group) added to gn_out[2 * (b * groups + g)]
+    // by the epilogue (4-wave tiles whose pixel tile lies in one sample) or by the split-K combine; null = off
+    double* gn_out; int gn_out_cpg, gn_out_groups;
     ConvPhase ph[MF_MAX_PHASE];
 };
 
@@ -123,7 +126,8 @@ struct ConvPlan {
     bf16_t* w_lo = nullptr;
     float* bias = nullptr;
     int* goff = nullptr;
-    double* out_stats = nullptr; int out_stats_groups = 0;   // f16 + FP6 kernel: GroupNorm (sum, sum of squares) of the output accumulated by the epilogue (set by the network builder)
+    double* out_stats = nullptr; int out_stats_groups = 0;   // GroupNorm (sum, sum of squares) of the output, left in out_stats by every launch (set by the network builder): from the
+                                                             // epilogue where the kernel can (f16 + FP6 tiles, 4-wave implicit-GEMM tiles, split-K combine), else by a k_gn_stats pass behind the conv
     bool q = false;       // MF_PREC_F16Q: w_hi = f16 [slice][tap][Npad][32], w_lo = [slice][tap][Npad][q6(wh) 32 B | q6(wl) 32 B] (24 B codes + E8M0 byte + pad)
     bool halo = false;    // 3x3 s1 p1 on a >= 16x16 map: LDS halo-tile kernel, weights packed [slice][tap][Npad][CK]
     bf16_t* up_hi = nullptr;  // nearest-2x-upsample + 3x3 layers that qualify for the fat halo tiles: [phase][slice][4 taps][Npad][CK], pre-summed taps
@@ -192,6 +196,8 @@ struct GroupedGemm {
 };
 int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream);
 
+// GroupNorm statistics pass alone (mf_nn.hip): (sum, sum of squares) per (sample, group) of view x ADDED to stats[2 * (b * groups + g)]
+int mf_groupnorm_stats(const ActView& x, int groups, double* stats, int batch, hipStream_t s);
 // Enqueues the layer.  res may have buf == nullptr.
 // tokens > 0 (single-row sequences only, H == 1): compute only the first `tokens` output positions of every batch item -- a sequence
 // prefix.  The buffers keep their geometry (base pointers, batch strides); the GEMM simply has M = batch * tokens rows.

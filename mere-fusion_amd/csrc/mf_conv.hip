@@ -72,9 +72,8 @@ __device__ __forceinline__ void add_residual(const ConvArgs& a, float (&v)[4], i
 // act: 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf form, torch.nn.GELU default), 4 SiLU
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
 
-__device__ __forceinline__ void epilogue_store(const ConvArgs& a, const float (&v0)[4], int64_t yo, int64_t ro,
-                                               int c, bool x3) {
-    float v[4] = {v0[0], v0[1], v0[2], v0[3]};
+// residual / activation / (hi, lo) store of one channel quad; v holds the stored values on return
+__device__ __forceinline__ void epilogue_store_v(const ConvArgs& a, float (&v)[4], int64_t yo, int64_t ro, int c, bool x3) {
     if (a.r_hi && !a.res_after_act) add_residual(a, v, ro, c, x3);
     if (a.act == 1) {
 #pragma unroll
@@ -100,6 +99,11 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const float (&
         for (int e = 0; e < 4; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
         *reinterpret_cast<uint2*>(a.y_lo + yo + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
     }
+}
+__device__ __forceinline__ void epilogue_store(const ConvArgs& a, const float (&v0)[4], int64_t yo, int64_t ro,
+                                               int c, bool x3) {
+    float v[4] = {v0[0], v0[1], v0[2], v0[3]};
+    epilogue_store_v(a, v, yo, ro, c, x3);
 }
 
 template <int N>
@@ -506,6 +510,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
         constexpr int JG = (FM * FN * NP <= RB) ? FM : (RB / (FN * NP) >= 1 ? RB / (FN * NP) : 1);
         const bool has_res = a.r_hi != nullptr;
         const bool after = a.res_after_act;
+        // GroupNorm statistics of the output for the layer's consumer (a.gn_out): per-lane fp32 (sum, sum of squares) of its FN channel quads over
+        // its FM pixel rows.  4-wave tiles up to 128 x 64 only: the 8-wave tiles sit at the register limit and the 128 x 128 tile would drop from
+        // two workgroups per CU to one (184 + 64 -> 206 + 64 registers); the launcher runs k_gn_stats behind those.
+        constexpr bool ST = NW == 4 && FM * FN < 16;
+        float gs[ST ? FN : 1][4], gq[ST ? FN : 1][4];
+#pragma unroll
+        for (int i = 0; i < (ST ? FN : 1); ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gs[i][e] = 0.f; gq[i][e] = 0.f; }
 #pragma unroll
         for (int j0 = 0; j0 < FM; j0 += JG) {
             uint2 rh[JG][FN], rl[JG][FN];
@@ -559,6 +572,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
                         else if (ACT == 4) x = x / (1.f + expf(-x));
                         v[e] = x + (after ? r[e] : 0.f);
                     }
+                    if (ST && row_ok) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { gs[i][e] += v[e]; gq[i][e] += v[e] * v[e]; }
+                    }
                     uint32_t h[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
@@ -586,6 +603,42 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
                         if (X3) *reinterpret_cast<uint2*>(a.y_lo + yo + c) = pk_lo[i];
                     }
                 }
+            }
+        }
+        if (ST && a.gn_out) {
+            // sum over the wave's 16 pixel columns, park per (wave row, channel) in LDS (the ring is drained), then one thread per (group, moment)
+            // adds its channels in a fixed order and issues ONE fp64 atomic -- the granularity k_gn_stats has.  The launcher guarantees that a
+            // pixel tile lies inside one sample (HqWq % BM == 0).
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) { gs[i][e] += __shfl_xor(gs[i][e], off); gq[i][e] += __shfl_xor(gq[i][e], off); }
+            __syncthreads();                                   // every wave is done reading the last K tile
+            float* sb = reinterpret_cast<float*>(smem);        // [WGM][BN][2]
+            if (fr == 0) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int cl = cn0 + i * 16 + fk * 4 + e;
+                        *reinterpret_cast<float2*>(sb + ((size_t)wave_m * BN + cl) * 2) = make_float2(gs[i][e], gq[i][e]);
+                    }
+            }
+            __syncthreads();
+            const int cpg = a.gn_out_cpg;
+            const int c_end = min(a.N, n0 + BN);               // channels [n0, c_end) of this tile exist
+            const int g_first = n0 / cpg, ng = (c_end - 1) / cpg - g_first + 1;
+            if (tid < 2 * ng) {
+                const int g = g_first + (tid >> 1), mo = tid & 1;
+                const int c_lo = max(g * cpg, n0), c_hi = min((g + 1) * cpg, c_end);
+                double acc_d = 0.0;
+                for (int c = c_lo; c < c_hi; ++c)
+#pragma unroll
+                    for (int wm = 0; wm < WGM; ++wm) acc_d += (double)sb[((size_t)wm * BN + (c - n0)) * 2 + mo];
+                const int b = m0 / a.HqWq;
+                atomicAdd(a.gn_out + 2 * ((size_t)b * a.gn_out_groups + g) + mo, acc_d);
             }
         }
     }
@@ -624,6 +677,59 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int n
     const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
     const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)ox * a.rj;
     epilogue_store(a, v, yo, ro, co, a.y_lo != nullptr);
+}
+
+// The same combine for a layer whose consumer is a GroupNorm (a.gn_out): the (sum, sum of squares) of the stored values per (sample, group)
+// come out of this pass instead of a k_gn_stats pass over the tensor.  grid (pixel blocks of P, batch); a thread owns a channel quad and walks
+// the block's pixels pp, pp + ppi, ... (one pixel's quads are contiguous: coalesced as in k_gn_stats); fp32 partials over <= 64 pixels, then
+// fp64 LDS bins per group and one global fp64 atomic per (workgroup, group, moment).  No GEGLU (its consumer is a Linear).
+__global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const ConvArgs a, int nsplit, int Ho, int Wo, int P) {
+    __shared__ double bins[2 * 64];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int nq = a.N >> 2;
+    const int cols = nq < 256 ? nq : 256;
+    const int ppi = 256 / cols;
+    const int k0 = tid % cols, pp = tid / cols;
+    const int T = Ho * Wo, t0 = blockIdx.x * P, t1 = min(T, t0 + P);
+    const int groups = a.gn_out_groups, cpg = a.gn_out_cpg;
+    for (int i = tid; i < 2 * groups; i += 256) bins[i] = 0.0;
+    __syncthreads();
+    if (pp < ppi) {
+        for (int k = k0; k < nq; k += 256) {
+            const int c = k * 4;
+            const float4 bq = *reinterpret_cast<const float4*>(a.bias + c);
+            float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int t = t0 + pp; t < t1; t += ppi) {
+                const int oy = t / Wo, ox = t - oy * Wo;
+                const float* w = a.ws + (((int64_t)b * Ho + oy) * Wo + ox) * a.N + c;
+                float4 s = bq;
+                for (int sp = 0; sp < nsplit; ++sp) {
+                    const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)sp * a.ws_split);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                float v[4] = {s.x, s.y, s.z, s.w};
+                const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
+                const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)ox * a.rj;
+                epilogue_store_v(a, v, yo, ro, c, a.y_lo != nullptr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s4[e] += v[e]; q4[e] += v[e] * v[e]; }
+            }
+            int g_cur = c / cpg;
+            double as = 0.0, aq = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int g = (c + e) / cpg;
+                if (g != g_cur) {
+                    atomicAdd(&bins[2 * g_cur], as); atomicAdd(&bins[2 * g_cur + 1], aq);
+                    g_cur = g; as = 0.0; aq = 0.0;
+                }
+                as += (double)s4[e]; aq += (double)q4[e];
+            }
+            atomicAdd(&bins[2 * g_cur], as); atomicAdd(&bins[2 * g_cur + 1], aq);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * groups; i += 256) atomicAdd(&a.gn_out[2 * ((size_t)b * groups) + i], bins[i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1111,8 +1217,33 @@ int mf_conv_launch_gn(ConvPlan* p, const ActView& in, const ActView& out, const 
     return rc;
 }
 
+static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, hipStream_t stream, int tokens, bool* stats_done);
+
+// split-K combine that also leaves the consumer GroupNorm's statistics (k_splitk_epilogue_stats); false = not applicable, run the plain combine
+static bool launch_combine_stats(const ConvPlan* p, ConvArgs e, int nsplit, int Ho, int Wo, int batch, hipStream_t stream) {
+    static const bool on = [] { const char* v = getenv("MF_GN_EPI_SPLITK"); return !v || atoi(v) != 0; }();
+    if (!on || !p->out_stats || p->d.act == 5 || p->d.cout % 4 || p->d.cout % p->out_stats_groups || p->out_stats_groups > 64) return false;
+    e.gn_out = p->out_stats; e.gn_out_groups = p->out_stats_groups; e.gn_out_cpg = p->d.cout / p->out_stats_groups;
+    const int nq = p->d.cout / 4, cols = std::min(256, nq), ppi = 256 / cols, T = Ho * Wo;
+    static const int target = [] { const char* v = getenv("MF_COMBINE_BLOCKS"); return v ? std::max(1, atoi(v)) : 1024; }();   // workgroups aimed for (each issues 2 * groups fp64 atomics)
+    const int P = std::max(ppi, std::min(64 * ppi, (int)(((int64_t)T * batch + target - 1) / target)));
+    hipLaunchKernelGGL(k_splitk_epilogue_stats, dim3((unsigned)((T + P - 1) / P), batch), dim3(256), 0, stream, e, nsplit, Ho, Wo, P);
+    return true;
+}
+
+// ConvPlan::out_stats (set by the network builder when the layer's consumer is a GroupNorm of exactly this output): every launch leaves the
+// (sum, sum of squares) per (sample, group) of the stored values ADDED to out_stats -- from the kernel's epilogue or the split-K combine where
+// the chosen configuration can, else from a k_gn_stats pass behind the conv.  The consumer then skips its own statistics pass.
 int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
                    int batch, hipStream_t stream, int tokens) {
+    bool stats_done = false;
+    const int rc = conv_launch_impl(p, in, out, res, batch, stream, tokens, &stats_done);
+    if (rc || !p->out_stats || stats_done) return rc;
+    return mf_groupnorm_stats(out, p->out_stats_groups, p->out_stats, batch, stream);
+}
+
+static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
+                            int batch, hipStream_t stream, int tokens, bool* stats_done) {
     const ActBuf& ib = *in.buf;
     const ActBuf& ob = *out.buf;
     MF_REQUIRE(tokens >= 0 && (tokens == 0 || (!p->halo && !p->up_hi && p->Hq == 1 && p->nphase == 1 && p->out_step == 1 && tokens <= p->Wq)),
@@ -1162,9 +1293,10 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
             // 313 / 370 / 290 us for bf16x3 on its best tiles); MF_Q_TILE=12822: 4 waves of 128 px x 64 ch, one workgroup per CU (359 / 418 / 331 us)
             if (p->out_stats) {
                 const int cpg = p->d.cout / p->out_stats_groups;
-                MF_REQUIRE(p->d.cout % p->out_stats_groups == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && out.coff == 0 && !ha.ws,
-                           "conv (f16q): fused GroupNorm statistics need 4, 8 or 16 channels per group (cout %d, groups %d)", p->d.cout, p->out_stats_groups);
-                ha.gn_out = p->out_stats; ha.gn_out_cpg = cpg; ha.gn_out_groups = p->out_stats_groups;
+                if (p->d.cout % p->out_stats_groups == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && !ha.ws) {   // (other group widths: k_gn_stats behind the conv)
+                    ha.gn_out = p->out_stats; ha.gn_out_cpg = cpg; ha.gn_out_groups = p->out_stats_groups;
+                    *stats_done = true;
+                }
             }
             static const int qt = [] { const char* e = getenv("MF_Q_TILE"); return e ? atoi(e) : 12842; }();
             return mf_halo_w_launch(ha, qt == 12822 ? HaloTile{16, 128, 2, 2} : HaloTile{16, 128, 4, 2}, true, stream);
@@ -1201,14 +1333,16 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
                     e.rb = rb.per_batch(); e.ri = rb.Wp() * rb.C; e.rj = rb.C;
                 }
                 const int64_t total = (int64_t)batch * p->out_h * p->out_w * (p->d.cout / 4);
-                hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e, ns, p->out_h, p->out_w, total);
+                if (launch_combine_stats(p, e, ns, p->out_h, p->out_w, batch, stream)) *stats_done = true;
+                else hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e, ns, p->out_h, p->out_w, total);
                 MF_HIP(hipGetLastError());
                 return MF_OK;
             }
         }
         if (p->alt) {                          // wide layer, too few patches for the fat tiles at this batch: implicit GEMM
             p->alt->prof_mid = p->prof_mid;
-            const int rc = mf_conv_launch(p->alt, in, out, res, batch, stream);
+            p->alt->out_stats = p->out_stats; p->alt->out_stats_groups = p->out_stats_groups;
+            const int rc = conv_launch_impl(p->alt, in, out, res, batch, stream, 0, stats_done);
             p->alt->prof_mid = nullptr;
             return rc;
         }
@@ -1332,6 +1466,11 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
             a.tile_cnt = p->tile_cnt;
         }
     }
+    if (p->out_stats && p->d.act != 5 && p->d.cout % p->out_stats_groups == 0 && p->out_stats_groups <= 64 && tokens == 0) {
+        a.gn_out_cpg = p->d.cout / p->out_stats_groups; a.gn_out_groups = p->out_stats_groups;
+        // in the epilogue: 4-wave tiles (k_conv_igemm's ST) whose pixel tile lies inside one sample; split-K layers: in the combine pass below
+        if (tc.nsplit == 1 && tc.wgm * tc.wgn == 4 && tc.bm * tc.bn < 128 * 128 && a.HqWq % tc.bm == 0) { a.gn_out = p->out_stats; *stats_done = true; }
+    }
     int rc = MF_ERR_INVALID;
 #define MF_CASE(BM, BN, WGM, WGN)                                                          \
     if (tc.bm == BM && tc.bn == BN) rc = launch_prec<BM, BN, WGM, WGN>(a, p->nphase, tc.nsplit, goff_max, x3, stream);
@@ -1374,8 +1513,9 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
         ConvArgs e = a;   // unit-grid strides for the combine pass
         e.yi = ob.Wp() * ob.C; e.yj = ob.C;
         const int64_t total = (int64_t)batch * p->out_h * out_w_eff * ((a.act == 5 ? a.N / 2 : a.N) / 4);
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e,
-                           tc.nsplit, p->out_h, out_w_eff, total);
+        if (tokens == 0 && launch_combine_stats(p, e, tc.nsplit, p->out_h, out_w_eff, batch, stream)) *stats_done = true;
+        else hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e,
+                                tc.nsplit, p->out_h, out_w_eff, total);
         MF_HIP(hipGetLastError());
     }
     return MF_OK;
@@ -1526,7 +1666,7 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
     snprintf(keybuf, sizeof(keybuf), "g950:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d", p->precision, batch, p->d.cin, p->d.cout, p->d.kh, p->d.kw, p->d.stride_h, p->d.stride_w,
              p->d.pad_h, p->d.pad_w, p->d.transposed, p->d.output_padding, p->d.residual, p->d.act, p->d.in_h, p->d.in_w, p->d.upsample, p->d.pad_hi,
              in.buf ? in.buf->C : 0);
-    const std::string key(keybuf);
+    const std::string key = std::string(keybuf) + (p->out_stats ? ":s" : "");     // a layer that also leaves GroupNorm statistics times (and may pick) differently
     {
         auto it = tune_cache().find(key);
         if (it != tune_cache().end()) {

@@ -73,6 +73,18 @@ extern "C" int mf_conv2d_forward(mf_conv2d* h, const float* x, float* y, int bat
     return mf_act_to_nchw(out, y, batch, s);
 }
 
+// Test seam of ConvPlan::out_stats: the layer as the producer of a GroupNorm(groups) -- the launch also leaves the (sum, sum of squares) of
+// the stored output per (sample, group) in stats[batch][groups][2] (device fp64), whichever way the chosen kernel configuration provides them.
+extern "C" int mf_conv2d_forward_stats(mf_conv2d* h, const float* x, float* y, int groups, double* stats, int batch, void* stream) {
+    MF_REQUIRE(h && stats && groups > 0 && groups <= 64 && h->plan.d.act != 5 && h->plan.d.cout % groups == 0 && h->plan.d.cout % 8 == 0,
+               "conv2d_forward_stats: needs cout %% groups == 0, cout %% 8 == 0, groups <= 64, no GEGLU");
+    MF_HIP(hipMemsetAsync(stats, 0, (size_t)batch * groups * 2 * sizeof(double), (hipStream_t)stream));
+    h->plan.out_stats = stats; h->plan.out_stats_groups = groups;
+    const int rc = mf_conv2d_forward(h, x, y, batch, stream);
+    h->plan.out_stats = nullptr; h->plan.out_stats_groups = 0;
+    return rc;
+}
+
 extern "C" int mf_conv2d_time(mf_conv2d* h, int batch, int iters, float* ms, void* stream) {
     MF_REQUIRE(h && ms, "conv2d_time: null argument");
     MF_REQUIRE(batch > 0 && batch <= h->cap && iters > 0, "conv2d_time: run mf_conv2d_forward at this batch first");

@@ -12,6 +12,7 @@
 //   * GroupNorm(+SiLU) = fp64 statistics pass + one apply pass.
 #include "mf_nn.h"
 #include "mf_aux.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -50,9 +51,20 @@ struct Net {
     struct Tunable { ConvPlan* p; ActView in, out, res; int op; };
     std::vector<Tunable> tunables;
     bool autotune = false;
-    // the last f16 + FP6 conv and the buffer it filled: a GroupNorm that reads exactly that buffer next takes its statistics from the conv's
-    // epilogue (ConvPlan::out_stats) instead of a pass over the tensor.  Cleared by any other op that writes the buffer.
-    ConvPlan* stats_src = nullptr; const ActBuf* stats_buf = nullptr;
+    // the last conv and the view it filled: a GroupNorm that reads exactly that view next takes its statistics from the conv's launch
+    // (ConvPlan::out_stats: epilogue, split-K combine, or a statistics pass behind the conv) instead of running its own pass over the tensor.
+    // Cleared by any other op that writes the buffer.
+    // (A few recent producers are remembered: a resnet's shortcut conv runs between conv1 and the norm2 that reads conv1's output.)
+    struct StatsSrc { ConvPlan* p; ActView v; };
+    std::vector<StatsSrc> stats_srcs;
+    void stats_forget(const ActBuf* b) {
+        stats_srcs.erase(std::remove_if(stats_srcs.begin(), stats_srcs.end(), [b](const StatsSrc& e) { return e.v.buf == b; }), stats_srcs.end());
+    }
+    void stats_remember(ConvPlan* p, const ActView& v) {
+        stats_forget(v.buf);
+        stats_srcs.push_back(StatsSrc{p, v});
+        if (stats_srcs.size() > 4) stats_srcs.erase(stats_srcs.begin());
+    }
     bool q_allowed = false;     // the f16 + FP6 conv format: the VAE decoder's resnets (set by the builder of a network whose parity was established with it)
     int next_pad_hi = 0;        // consumed by the next conv(): extra zero rows / columns bottom-right (the VAE encoder's Downsample2D)
     std::string err;
@@ -145,7 +157,7 @@ struct Net {
         d.cin = cin; d.cout = cout; d.kh = d.kw = k; d.stride_h = d.stride_w = stride; d.pad_h = d.pad_w = pad;
         d.act = act; d.residual = res.buf ? 1 : 0; d.in_h = in.buf->H; d.in_w = in.buf->W; d.upsample = upsample;
         d.pad_hi = next_pad_hi; next_pad_hi = 0;
-        if (stats_buf == out.buf) { stats_src = nullptr; stats_buf = nullptr; }
+        stats_forget(out.buf);
         ConvPlan* p = new_plan();
         int rc = mf_conv_plan_create(p, d, w, bb.data(), nullptr, nullptr, nullptr, nullptr, precision);
         if (rc) return rc;
@@ -155,6 +167,7 @@ struct Net {
         mf_conv_kernel_name(p, cap, kn, sizeof(kn));
         push(name, kn, mf_conv_flops(p, 1), [p, in, out, res](int B, hipStream_t s) { return mf_conv_launch(p, in, out, res, B, s); });
         tunables.push_back(Tunable{p, in, out, res, (int)ops.size() - 1});
+        if (act != 5) stats_remember(p, out);
         return MF_OK;
     }
     // GroupNorm(+SiLU) `gname` of x followed by the 3x3 conv `cname`.  Where the conv runs on the LDS-weights halo kernel's fat tiles at the
@@ -165,12 +178,16 @@ struct Net {
     // statistics for GroupNorm(groups) of `x` come from its producer's epilogue?  (MF_GN_EPI=0: off)
     bool take_stats(const ActView& x, int groups, double* st) {
         static const bool on = [] { const char* e = getenv("MF_GN_EPI"); return !e || atoi(e) != 0; }();
-        if (!on || !stats_src || stats_buf != x.buf || x.coff != 0 || x.C != x.buf->C || stats_src->d.cout != x.C || stats_src->out_stats) return false;
-        const int cpg = x.C / groups;
-        if (x.C % groups || (cpg != 4 && cpg != 8 && cpg != 16)) return false;
-        stats_src->out_stats = st; stats_src->out_stats_groups = groups;
-        stats_src = nullptr; stats_buf = nullptr;
-        return true;
+        if (!on || x.C % groups || groups > 64 || x.C % 8 || x.coff % 8) return false;
+        static const bool q_only = [] { const char* e = getenv("MF_GN_EPI"); return e && atoi(e) == 2; }();   // A/B: 2 = only the f16 + FP6 producers (the r02a state)
+        for (size_t i = 0; i < stats_srcs.size(); ++i) {
+            const StatsSrc& e = stats_srcs[i];
+            if (e.v.buf != x.buf || e.v.coff != x.coff || e.v.C != x.C || e.p->d.cout != x.C || e.p->out_stats || (q_only && !e.p->q)) continue;
+            e.p->out_stats = st; e.p->out_stats_groups = groups;
+            stats_srcs.erase(stats_srcs.begin() + i);
+            return true;
+        }
+        return false;
     }
     int gn_conv(const std::string& gname, const std::string& cname, ActView x, ActBuf* t, ActView out, int cin, int cout, int groups, float eps,
                 ActView res, const std::vector<float>* extra_bias = nullptr) {
@@ -213,8 +230,7 @@ struct Net {
             char kn[96];
             mf_conv_kernel_name(p, cap, kn, sizeof(kn));
             push(cname, kn, mf_conv_flops(p, 1), [=](int B, hipStream_t s) { return mf_conv_launch(p, tv, out, res, B, s); });
-            if (stats_buf == out.buf) { stats_src = nullptr; stats_buf = nullptr; }
-            if (out.coff == 0 && out.C == out.buf->C) { stats_src = p; stats_buf = out.buf; }
+            stats_remember(p, out);
             return MF_OK;
         }
         static const bool on = [] { const char* e = getenv("MF_GN_FUSE"); return e && atoi(e) != 0; }();
@@ -267,7 +283,7 @@ struct Net {
         if (gn_count >= GN_MAX_OPS) { err = "more GroupNorm layers than GN_MAX_OPS"; return MF_ERR_INVALID; }
         double* st = gn_stats + (size_t)(gn_count++) * gn_slice;
         const bool epi = take_stats(in, groups, st);
-        if (stats_buf == out.buf) { stats_src = nullptr; stats_buf = nullptr; }
+        stats_forget(out.buf);
         push(name, epi ? "k_gn_apply (statistics from the producer's epilogue)" : "k_gn_stats+k_gn_apply", 0.0,
              [=](int B, hipStream_t s) { return mf_groupnorm(in, out, dg, db, groups, eps, silu, st, B, s, epi); });
         return MF_OK;

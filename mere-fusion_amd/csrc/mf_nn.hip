@@ -584,6 +584,19 @@ int mf_groupnorm_affine(const ActView& x, const float* gamma, const float* beta,
     return MF_OK;
 }
 
+// the statistics pass alone: (sum, sum of squares) per (sample, group) ADDED to `stats` (mf_conv_launch behind a conv whose kernel
+// configuration cannot accumulate them in its epilogue, ConvPlan::out_stats)
+int mf_groupnorm_stats(const ActView& x, int groups, double* stats, int batch, hipStream_t s) {
+    MF_REQUIRE(x.C % groups == 0 && x.C % 8 == 0 && x.coff % 8 == 0, "groupnorm: C=%d groups=%d", x.C, groups);
+    MF_REQUIRE(groups <= 64 && x.C <= 8 * 256 * GN_MAXCOL, "groupnorm: groups=%d / C=%d beyond the kernel's limits", groups, x.C);
+    const Rows xr = rows_of(x);
+    const int cols = std::min(256, x.C / 8), ppi = 256 / cols;
+    const int P = std::max(ppi, std::min(64 * ppi, (xr.T * batch + 1023) / 1024));
+    hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, x.C / groups, x.C, P, stats);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
 int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, int groups, float eps,
                  bool silu, double* stats, int batch, hipStream_t s, bool have_stats) {
     MF_REQUIRE(x.C == y.C && x.C % groups == 0 && x.C % 8 == 0 && x.coff % 8 == 0 && y.coff % 8 == 0, "groupnorm: C=%d groups=%d", x.C, groups);

@@ -90,3 +90,50 @@ def test_f16q_experimental_format_vs_fp64(lib_built, cin, cout, hw):
     h = C.c_void_p()
     w1 = torch.zeros(64, 64, 1, 1)
     assert l.mf_conv2d_create(C.byref(d), C.c_void_p(w1.data_ptr()), None, None, None, None, None, _lib.PRECISIONS["f16q"], C.byref(h)) != 0
+
+
+# A conv as the producer of a GroupNorm (ConvPlan::out_stats): (cin, cout, k, H, W, batch, residual, upsample, groups) chosen so that every way
+# the statistics can come out runs at least once -- the 4-wave implicit-GEMM epilogue (wide Linears on 32 x 32 maps), the split-K combine (small
+# maps, deep K), the 8-wave / 128 x 128 tiles and the halo kernels with a statistics pass behind them, the split halo tiles (512 channels at
+# 32 x 32), the 4-phase upsample conv, channels-per-group 10 / 20 / 40 (the UNet) and 4 / 8 / 16 (the VAE).
+STATS_CASES = [(320, 320, 1, 32, 32, 8, 0, 0, 32), (320, 320, 3, 32, 32, 8, 1, 0, 32), (640, 640, 3, 16, 16, 8, 0, 0, 32),
+               (1280, 1280, 3, 8, 8, 8, 1, 0, 32), (1280, 640, 1, 16, 16, 3, 0, 0, 32), (512, 512, 3, 32, 32, 8, 0, 0, 32),
+               (256, 256, 3, 64, 64, 8, 0, 0, 32), (256, 256, 3, 24, 40, 2, 0, 1, 32), (640, 320, 3, 32, 32, 8, 0, 0, 32),
+               (320, 320, 3, 64, 64, 1, 0, 0, 32)]
+
+
+@pytest.mark.parametrize("cin,cout,k,H,W,B,res,up,groups", STATS_CASES)
+def test_conv_leaves_groupnorm_statistics_of_its_output(lib_built, cin, cout, k, H, W, B, res, up, groups):
+    from mere_fusion_amd import _lib
+    l = _lib.lib()
+    _lib.init_device(0)
+    g = torch.Generator().manual_seed(cin + 3 * H + k)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.3
+    d = _lib.MfConv2dDesc(cin=cin, cout=cout, kh=k, kw=k, stride_h=1, stride_w=1, pad_h=k // 2, pad_w=k // 2, transposed=0, output_padding=0,
+                          residual=res, act=0, in_h=H, in_w=W, upsample=up)
+    h = C.c_void_p()
+    _lib.check(l.mf_conv2d_create(C.byref(d), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), None, None, None, None,
+                                  _lib.PRECISIONS["bf16x3"], C.byref(h)))
+    try:
+        oh, ow = C.c_int(), C.c_int()
+        l.mf_conv2d_out_shape(h, C.byref(oh), C.byref(ow))
+        x = torch.randn(B, cin, H, W, generator=g).cuda() + 0.25
+        for nb in (B, max(1, B // 2)):                     # the smaller batch usually lands on another tile / split
+            y = torch.empty(nb, cout, oh.value, ow.value, device="cuda")
+            st = torch.full((nb, groups, 2), 7.0, dtype=torch.float64, device="cuda")
+            _lib.check(l.mf_conv2d_forward_stats(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), groups, C.c_void_p(st.data_ptr()), nb, None))
+            torch.cuda.synchronize()
+            yg = y.double().reshape(nb, groups, -1)
+            want = torch.stack([yg.sum(-1), (yg * yg).sum(-1)], dim=-1)
+            # the kernels sum the fp32 values they store as (hi, lo) pairs; y is those values back in fp32: agreement to fp32 summation noise
+            scale = want.abs().amax(dim=(0, 1)) + 1e-30
+            err = float(((st - want).abs() / scale).max())
+            assert err <= 2e-6, (nb, err)
+            # and the output itself is what the plain launch writes
+            y2 = torch.empty_like(y)
+            _lib.check(l.mf_conv2d_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y2.data_ptr()), nb, None))
+            torch.cuda.synchronize()
+            assert torch.equal(y, y2)
+    finally:
+        l.mf_conv2d_destroy(h)
