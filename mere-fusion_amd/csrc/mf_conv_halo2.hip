@@ -39,6 +39,13 @@ __device__ __forceinline__ int hswz(int hx) {
     return CK == 32 ? (((hx >> 2) & 1) << 1) : (((hx >> 1) & 3) << 1);
 }
 
+// Slot permutation of the FP6 plane (f16 + FP6 format): a row holds two 32-byte blocks, and lane group fk reads block fk & 1 as two
+// ds_read_b128.  With the f16 plane's XOR (0 / 2) every such read touches only the even or only the odd 16-byte slots of its rows -- half
+// the banks, a 2-way conflict on half of the kernel's LDS traffic (SQ_LDS_BANK_CONFLICT = 34 % of SQ_LDS_IDX_ACTIVE).  ds_read_b128 serves
+// lanes {0-3, 12-15, 20-27} etc. together: of the four rows r, r+4, r+8, r+12 that share a 256-byte bank window, two read block 0 and two
+// block 1; XOR 3 on every other group of four rows sends them to four different slots, for every tap shift.
+__device__ __forceinline__ int qswz(int r) { return ((r >> 2) & 1) * 3; }
+
 __device__ __forceinline__ float hbf2f(uint32_t h16) { return __uint_as_float(h16 << 16); }
 __device__ __forceinline__ uint32_t hf2bf(float f) {
     uint32_t u = __float_as_uint(f);
@@ -116,11 +123,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     // padded coordinate (y0 + hy + halo - 1, ...).  Rows/cols past the buffer are clamped: they only
     // feed output pixels that are masked below.
     const bf16_t* hp[NHC];
+    int hq[Q ? NHC : 1];                       // f16 + FP6 format: element offset of the FP6 plane's source slot relative to the f16 plane's (qswz)
     const int64_t x_delta = X3 ? (a.x_lo - a.x_hi) : 0;
 #pragma unroll
     for (int i = 0; i < NHC; ++i) {
         int hr = (wave + NW * i) * RPC + lane / KG;
         const int kg = (lane % KG) ^ hswz<CK>(hr % HW);
+        if (Q) hq[i] = (((lane % KG) ^ qswz(hr % HW)) - kg) * 8;
         hr = hr < HROWS ? hr : HROWS - 1;
         const int hy = hr / HW, hx = hr - hy * HW;
         int iy = y0 + hy + a.in_halo - 1, ix = x0 + hx + a.in_halo - 1;
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             if (HCH % NW == 0 || c < HCH) {
                 const bf16_t* src = hp[i] + slice * CK;
                 hglds16(src, base + c * 1024);
-                if (X3) hglds16(src + x_delta, base + H_BYTES + c * 1024);
+                if (X3) hglds16(src + x_delta + (Q ? hq[i] : 0), base + H_BYTES + c * 1024);
             }
         }
     };
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         const int c = wave + NW * i;
         const int t3 = c / (NP * WCH), rem = c - t3 * (NP * WCH), pl = rem / WCH, q = rem - pl * WCH;
         const int r = q * RPC + lane / KG;
-        const int kg = (lane % KG) ^ hswz<CK>(r);
+        const int kg = (lane % KG) ^ ((Q && pl) ? qswz(r) : hswz<CK>(r));
         int nrow = n0 + r;
         nrow = nrow < a.Npad ? nrow : a.Npad - 1;
         wsrc[i] = a.w_hi + (pl ? w_delta : 0) + ((int64_t)nrow * CK + kg * 8);
@@ -254,8 +263,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
                     for (int i = 0; i < FN; ++i) {
                         const int r = cn0 + i * 16 + fr;
                         wh16[i] = *reinterpret_cast<const f16x8*>(wb + (t3 * NP) * WT_BYTES + wlane[i][kk]);
-                        const char* q = wb + (t3 * NP + 1) * WT_BYTES + r * ROWB + (((2 * blk) ^ hswz<CK>(r)) << 4);
-                        const i32x4 q0 = *reinterpret_cast<const i32x4*>(q), q1 = *reinterpret_cast<const i32x4*>(q + 16);
+                        const char* q = wb + (t3 * NP + 1) * WT_BYTES + r * ROWB;
+                        const i32x4 q0 = *reinterpret_cast<const i32x4*>(q + (((2 * blk) ^ qswz(r)) << 4)), q1 = *reinterpret_cast<const i32x4*>(q + (((2 * blk + 1) ^ qswz(r)) << 4));
                         w6[i] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, -1, -1);
                         wsc[i] = fk < 2 ? q1[2] : 0;
                     }
@@ -264,8 +273,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
                         const int hx = fr + dx;
                         const char* p0 = base + ((row0 + j + dy) * HW + hx) * ROWB;
                         const f16x8 xh16 = *reinterpret_cast<const f16x8*>(p0 + (((kk * 4 + fk) ^ hswz<CK>(hx)) << 4));
-                        const char* q = p0 + H_BYTES + (((2 * blk) ^ hswz<CK>(hx)) << 4);
-                        const i32x4 q0 = *reinterpret_cast<const i32x4*>(q), q1 = *reinterpret_cast<const i32x4*>(q + 16);
+                        const char* q = p0 + H_BYTES;
+                        const i32x4 q0 = *reinterpret_cast<const i32x4*>(q + (((2 * blk) ^ qswz(hx)) << 4)), q1 = *reinterpret_cast<const i32x4*>(q + (((2 * blk + 1) ^ qswz(hx)) << 4));
                         const i32x8 x6 = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, -1, -1);
                         const int xsc = fk < 2 ? q1[2] : 0;
 #pragma unroll
@@ -339,8 +348,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             const int r = cn0 + i * 16 + fr;
             whA[i] = *reinterpret_cast<const f16x8*>(wA + wlane[i][0]);
             if (pairB) whB[i] = *reinterpret_cast<const f16x8*>(wB + wlane[i][0]);
-            const char* q = wq + r * ROWB + (((2 * blk) ^ hswz<CK>(r)) << 4);
-            const i32x4 q0 = *reinterpret_cast<const i32x4*>(q), q1 = *reinterpret_cast<const i32x4*>(q + 16);
+            const char* q = wq + r * ROWB;
+            const i32x4 q0 = *reinterpret_cast<const i32x4*>(q + (((2 * blk) ^ qswz(r)) << 4)), q1 = *reinterpret_cast<const i32x4*>(q + (((2 * blk + 1) ^ qswz(r)) << 4));
             w6[i] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, -1, -1);
             wsc[i] = (second && !pairB) ? 0 : q1[2];
         }
@@ -348,14 +357,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         const int hxq = second ? hxB : hxA, dyq = second ? dyB : dyA;
         const int offA = (dyA * HW + hxA) * ROWB + ((fk ^ hswz<CK>(hxA)) << 4);
         const int offB = (dyB * HW + hxB) * ROWB + ((fk ^ hswz<CK>(hxB)) << 4);
-        const int offq = (dyq * HW + hxq) * ROWB + H_BYTES + (((2 * blk) ^ hswz<CK>(hxq)) << 4);
+        const int offq = (dyq * HW + hxq) * ROWB + H_BYTES + (((2 * blk) ^ qswz(hxq)) << 4);
+        const int offq1 = (dyq * HW + hxq) * ROWB + H_BYTES + (((2 * blk + 1) ^ qswz(hxq)) << 4);
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
             const char* prow = base + (row0 + j) * HW * ROWB;
             const f16x8 xhA = *reinterpret_cast<const f16x8*>(prow + offA);
             f16x8 xhB;
             if (pairB) xhB = *reinterpret_cast<const f16x8*>(prow + offB);
-            const i32x4 q0 = *reinterpret_cast<const i32x4*>(prow + offq), q1 = *reinterpret_cast<const i32x4*>(prow + offq + 16);
+            const i32x4 q0 = *reinterpret_cast<const i32x4*>(prow + offq), q1 = *reinterpret_cast<const i32x4*>(prow + offq1);
             const i32x8 x6 = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, -1, -1);
             const int xsc = (second && !pairB) ? 0 : q1[2];
 #pragma unroll
