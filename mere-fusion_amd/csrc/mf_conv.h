@@ -95,6 +95,7 @@ struct HaloArgs {
     unsigned long long* dbg;                    // MF_DBG_TIMES: 4 s_memtime stamps per workgroup (entry, loop start, loop end, exit), or null
     int q;                                      // operands in the f16 + FP6-residual format (MF_PREC_F16Q): x_lo / w_lo hold [q6 block | q6 block] rows
     double* gn_out; int gn_out_cpg, gn_out_groups;   // f16 + FP6 kernel: (sum, sum of squares) of the OUTPUT per (sample, group) added here for the consumer GroupNorm; null = off
+    int wide_store;                             // f16 + FP6 tiles: the output view starts on an 8-channel group, C % 8 == 0, N % 32 == 0: 16-byte epilogue stores
     int stagger;                                // LDS-weights kernel, 8-wave tiles: the second wave of every SIMD issues its weight DMA mid-tap (filled by the launcher)
 };
 struct HaloTile { int ph, bn, wgm, wgn; };

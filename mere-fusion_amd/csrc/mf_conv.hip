@@ -1263,8 +1263,8 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
     if (p->halo) {
         HaloArgs ha{};
         {
-            static const int qmode = [] { const char* e = getenv("MF_Q_PAIR"); return e ? atoi(e) : 1; }();   // A/B: 0 = one tap per correction instruction
-            ha.q = p->q ? (qmode ? 2 : 1) : 0;
+            static const int qmode = [] { const char* e = getenv("MF_Q_PAIR"); return e ? atoi(e) : 2; }();   // A/B: 0 = one tap per correction instruction, 1 = tap pairs, every wave issues weight DMA
+            ha.q = p->q ? (qmode == 2 ? 3 : (qmode ? 2 : 1)) : 0;                                           // 2: pairs with the weight DMA on the second wave of each SIMD
         }
         ha.x_hi = ib.hi + in.coff; ha.x_lo = x3 ? ib.lo + in.coff : nullptr;
         ha.w_hi = p->w_hi; ha.w_lo = p->w_lo; ha.bias = p->bias;
@@ -1297,6 +1297,10 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
                     ha.gn_out = p->out_stats; ha.gn_out_cpg = cpg; ha.gn_out_groups = p->out_stats_groups;
                     *stats_done = true;
                 }
+            }
+            {
+                static const bool narrow = [] { const char* e = getenv("MF_STORE16"); return e && atoi(e) == 0; }();   // A/B: MF_STORE16=0 keeps 8-byte stores
+                ha.wide_store = !narrow && out.coff % 8 == 0 && ob.C % 8 == 0 && p->d.cout % 32 == 0;
             }
             static const int qt = [] { const char* e = getenv("MF_Q_TILE"); return e ? atoi(e) : 12842; }();
             return mf_halo_w_launch(ha, qt == 12822 ? HaloTile{16, 128, 2, 2} : HaloTile{16, 128, 4, 2}, true, stream);

@@ -58,6 +58,20 @@ __device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// 16-byte epilogue stores (as mf_conv.hip's store_pair16): lanes fk / fk ^ 1 own the two 4-channel halves of one 8-channel group in every
+// fragment; for a fragment PAIR the even lane takes both halves of p0's group, the odd lane both of p1's -- one exchange, one dwordx4 store
+// where two dwordx2 went.  c16 = first channel of p0's 16-channel block; p1's block is 16 channels on.
+__device__ __forceinline__ void hstore_pair16(bf16_t* base, int64_t yo, int c16, int fk, uint2 p0, uint2 p1, int N, bool ok) {
+    const bool odd = fk & 1;
+    const uint2 send = odd ? p0 : p1;
+    uint2 recv;
+    recv.x = (uint32_t)__shfl_xor((int)send.x, 16);
+    recv.y = (uint32_t)__shfl_xor((int)send.y, 16);
+    const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+    const int cw = c16 + (odd ? 16 : 0) + (fk & ~1) * 4;
+    if (ok && cw < N) *reinterpret_cast<uint4*>(base + yo + cw) = out;
+}
+
 }  // namespace
 
 // TR = taps per ring slot: 3 (one kernel row, a barrier per row) or 1 (a barrier per tap: the wide tiles, whose 3-tap slot would not fit)
@@ -71,7 +85,11 @@ __device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
 // ([q6(wh) | q6(wl)] for weights, [q6(xl) | q6(xh)] for pixels: 24 B of e2m3 codes + the block's E8M0 byte).  Per tap and accumulator tile:
 // ONE v_mfma_f32_16x16x32_f16 (wh.xh) + ONE v_mfma_scale_f32_16x16x128_f8f6f4 whose K blocks 0 / 1 are q6(wh).xl / wl.q6(xh) and whose blocks
 // 2 / 3 are switched off by a zero scale -- 32 matrix cycles where bf16x3 spends 48, with the loop, ring and DMA of the bf16x3 kernel unchanged.
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false, int Q = 0>   // Q: 0 off, 1 one tap per correction MFMA, 2 tap pairs
+// Q = 3: tap pairs with the WEIGHT DMA issued by waves NW/2 .. NW-1 only.  Waves w and w + NW/2 share a SIMD; a pair iteration is
+// [DMA issue ~4 x 120 cycles][LDS read burst][768 MFMA cycles] per wave, in lockstep behind the per-pair barrier (s_memtime: 2.6 k cycles per
+// pair against 1.5 k of MFMA).  With all pieces on the second wave of each SIMD the first one starts its reads and MFMAs at once and the
+// second one's run under them.
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false, int Q = 0>   // Q: 0 off, 1 one tap per correction MFMA, 2 tap pairs, 3 pairs + producer waves
 __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_halo_w(const HaloArgs a) {
     constexpr int NW = WGM * WGN;                           // waves per workgroup
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -82,7 +100,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     constexpr int HW = PW + 2, HROWS = (PH + 2) * HW;
     constexpr int HCH = (HROWS + RPC - 1) / RPC;           // 1-KiB DMA chunks of the halo image
     constexpr int H_BYTES = HCH * 1024;
-    constexpr int NHC = (HCH + NW - 1) / NW;
+    constexpr int NHC = (HCH + NW - 1) / NW;                // (halo DMA stays on all waves: moving it to the lower half as well left the loop unchanged and cost 1 k cycles of prologue)
     constexpr int FM = PH / WGM;                            // patch rows (= pixel fragments) per wave
     constexpr int FN = BN / WGN / 16;                       // 16-channel fragment rows per wave
     static_assert(FN >= 1 && FM >= 1, "wave tile must hold a fragment");
@@ -94,7 +112,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     static_assert(PHASE < 0 || TR == 1, "upsample phases use the one-tap ring");
     constexpr int WROW = TR * NP * WT_BYTES;                // one ring slot (TR taps, planes)
     constexpr int WRC = TR * NP * WCH;                      // DMA chunks per slot
-    constexpr int NWR = (WRC + NW - 1) / NW;
+    constexpr bool PROD = Q == 3;                           // weight DMA by the upper half of the waves only
+    constexpr int NWD = PROD ? NW / 2 : NW;                 // waves that issue weight DMA
+    constexpr int NWR = (WRC + NWD - 1) / NWD;
     static_assert(WT_BYTES % 1024 == 0, "weight tile must be whole DMA chunks");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -160,9 +180,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     // chunk c of a tap row = (tap t = c / (NP * WCH), plane, 1-KiB piece q): lane l lands in LDS row q*RPC + l/KG, slot l%KG
     const bf16_t* wsrc[NWR];
     int wtap[NWR];
+    const int dwave = PROD ? wave - NW / 2 : wave;         // index among the DMA-issuing waves (negative: none of this wave's business)
 #pragma unroll
     for (int i = 0; i < NWR; ++i) {
-        const int c = wave + NW * i;
+        const int c = (dwave < 0 ? 0 : dwave) + NWD * i;
         const int t3 = c / (NP * WCH), rem = c - t3 * (NP * WCH), pl = rem / WCH, q = rem - pl * WCH;
         const int r = q * RPC + lane / KG;
         const int kg = (lane % KG) ^ ((Q && pl) ? qswz(r) : hswz<CK>(r));
@@ -173,11 +194,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     }
     // tap row `trow` (0..2) of slice `slice` into ring buffer `buf`
     auto load_wrow = [&](int slice, int trow, int buf) __attribute__((always_inline)) {
+        if (PROD && dwave < 0) return;
         char* base = wring + buf * WROW;
 #pragma unroll
         for (int i = 0; i < NWR; ++i) {
-            const int c = wave + NW * i;
-            if (WRC % NW == 0 || c < WRC) hglds16(wsrc[i] + (int64_t)(slice * NT + trow * TR + wtap[i]) * w_tap, base + c * 1024);
+            const int c = dwave + NWD * i;
+            if (WRC % NWD == 0 || c < WRC) hglds16(wsrc[i] + (int64_t)(slice * NT + trow * TR + wtap[i]) * w_tap, base + c * 1024);
         }
     };
     // A fragment of (tap-in-row t3, channel block i, k-step kk, plane): rows cn0 + i*16 + fr, 16-byte slot kk*4 + fk
@@ -419,7 +441,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     const int s_end = a.nsplit > 1 ? (int)((int64_t)a.n_slices * (blockIdx.y + 1) / a.nsplit) : a.n_slices;
     load_halo(s_begin, 0);
     load_wrow(s_begin, 0, 0);
-    if (Q == 2) load_wrow(s_begin, 1, 1);
+    if (Q >= 2) load_wrow(s_begin, 1, 1);
     __syncthreads();                           // drains the DMA (vmcnt) and publishes halo stage 0 + weight row 0
     if (dbg && threadIdx.x == 0) dbg[1] = __builtin_amdgcn_s_memtime();
     int wbuf = 0;
@@ -432,7 +454,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             __syncthreads();
         }
         if (a.res_from_halo) add_residual(st, slice);
-        if constexpr (Q == 2) {
+        if constexpr (Q >= 2) {
             {
                 // taps in pairs (0,1) (2,3) (4,5) (6,7) (8): four ring slots, the pair being multiplied in slots {2 wbuf, 2 wbuf + 1} while the next pair
                 // lands in the other two (everyone left those at the previous barrier); one barrier per PAIR
@@ -536,6 +558,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             const int oy = y0 + row0 + j;
             const bool row_ok = oy < a.H && ox < a.W;
             const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
+            constexpr bool W16 = Q != 0 && FN % 2 == 0;               // f16 + FP6 tiles: 16-byte stores (a.wide_store)
+            uint2 pk_hi[W16 ? FN : 1], pk_lo[W16 ? FN : 1];
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 const int c = n0 + cn0 + i * 16 + fk * 4;
@@ -555,6 +579,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
                 }
+                if constexpr (W16) {
+                    if (a.wide_store) {                                   // (wave-uniform; every lane takes part in the exchange, the store is masked)
+                        if (row_ok && c < a.N) {
+                            gs[i] += (v[0] + v[1]) + (v[2] + v[3]);
+                            gq[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                        }
+                        uint32_t h[4], l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { h[e] = hf2bf(v[e]); l[e] = hf2bf(v[e] - hbf2f(h[e])); }
+                        pk_hi[i] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                        pk_lo[i] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                        continue;
+                    }
+                }
                 if (!row_ok || c >= a.N) continue;
                 if constexpr (Q != 0) {
                     gs[i] += (v[0] + v[1]) + (v[2] + v[3]);
@@ -569,6 +607,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
 #pragma unroll
                     for (int e = 0; e < 4; ++e) l[e] = hf2bf(v[e] - hbf2f(h[e]));
                     *reinterpret_cast<uint2*>(a.y_lo + yo + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                }
+            }
+            if constexpr (W16) {
+                if (a.wide_store) {
+#pragma unroll
+                    for (int i = 0; i + 1 < FN; i += 2) {
+                        hstore_pair16(a.y_hi, yo, n0 + cn0 + i * 16, fk, pk_hi[i], pk_hi[i + 1], a.N, row_ok);
+                        if (X3) hstore_pair16(a.y_lo, yo, n0 + cn0 + i * 16, fk, pk_lo[i], pk_lo[i + 1], a.N, row_ok);
+                    }
                 }
             }
         }
@@ -693,10 +740,11 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
         if (phase >= 0 || a.nsplit > 1 || a.gn_scale) { mf_set_error("halo conv (f16 + FP6 format): plain unsplit 3x3 layers only"); return MF_ERR_INVALID; }
         // (16 x 16 x 256 as four waves of 128 px x 128 ch -- 64 accumulator tiles per wave -- spills 456 bytes even with 512 registers: not instantiated)
         if (t.ph == 16 && t.bn == 128 && t.wgm == 4)
-            return a.q == 2 ? halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 2>(a, s) : halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 1>(a, s);
+            return a.q == 3 ? halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 3>(a, s)
+                 : a.q == 2 ? halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 2>(a, s) : halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 1>(a, s);
         // 16 x 16 pixels x 128 channels as four waves of 128 px x 64 ch, ONE workgroup per CU (a wave per SIMD, up to 512 registers)
         if (t.ph == 16 && t.bn == 128 && t.wgm == 2 && t.wgn == 2)
-            return a.q == 2 ? halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, false, 2>(a, s) : halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, false, 1>(a, s);
+            return a.q >= 2 ? halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, false, 2>(a, s) : halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, false, 1>(a, s);
         mf_set_error("halo conv (f16 + FP6 format): no kernel for this tile");
         return MF_ERR_INVALID;
     }
