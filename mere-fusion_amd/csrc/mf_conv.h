@@ -197,6 +197,8 @@ struct GroupedGemm {
 };
 int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream);
 
+// channel-slice split the f16 + FP6 kernel runs a layer with at this batch (1 = none): maps with fewer 16 x 16 x 128-channel tiles than CUs
+int mf_q_split_count(const ConvPlan* p, int batch);
 // GroupNorm statistics pass alone (mf_nn.hip): (sum, sum of squares) per (sample, group) of view x ADDED to stats[2 * (b * groups + g)]
 int mf_groupnorm_stats(const ActView& x, int groups, double* stats, int batch, hipStream_t s);
 // Enqueues the layer.  res may have buf == nullptr.

@@ -1198,6 +1198,21 @@ static int mf_halo_split_count(const ConvPlan* p, int batch) {
     return 0;
 }
 
+// Channel-slice split of the f16 + FP6 tile (16 x 16 pixels x 128 channels) for a layer with fewer tiles than CUs at this batch (1 = no split)
+int mf_q_split_count(const ConvPlan* p, int batch) {
+    static const bool on = [] { const char* e = getenv("MF_Q_SPLIT"); return !e || atoi(e) != 0; }();
+    if (!p->q) return 1;
+    const int base = batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * (p->d.cout / 128);
+    if (!on || base >= 256) return 1;
+    int best = 1;
+    for (int cand : {2, 4, 8}) {
+        if (p->n_slices / cand < 2) break;
+        best = cand;
+        if (base * cand >= 256) break;
+    }
+    return best;
+}
+
 namespace { thread_local const float* g_gn_scale = nullptr; thread_local const float* g_gn_shift = nullptr; }
 
 bool mf_conv_can_fuse_gn(const ConvPlan* p, int batch) {
@@ -1303,7 +1318,36 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
                 ha.wide_store = !narrow && out.coff % 8 == 0 && ob.C % 8 == 0 && p->d.cout % 32 == 0;
             }
             static const int qt = [] { const char* e = getenv("MF_Q_TILE"); return e ? atoi(e) : 12842; }();
-            return mf_halo_w_launch(ha, qt == 12822 ? HaloTile{16, 128, 2, 2} : HaloTile{16, 128, 4, 2}, true, stream);
+            const HaloTile qtile = qt == 12822 ? HaloTile{16, 128, 2, 2} : HaloTile{16, 128, 4, 2};
+            // A map too small to give every CU a 16 x 16 patch (the VAE's 512-channel 32 x 32 levels at batch 8: 32 patches x 4 channel tiles): the
+            // channel slices split over blockIdx.y, fp32 partial tiles combined by k_splitk_epilogue[_stats] -- as the bf16x3 256-channel tile does.
+            const int ns = mf_q_split_count(p, batch);
+            if (ns > 1) {
+                const int64_t per_split = (int64_t)batch * p->out_h * p->out_w * p->d.cout;
+                const int64_t need = per_split * ns;
+                if (need > p->ws_cap) {
+                    // (eager launches only; the outgrown buffer is retired, not freed: graphs captured at other batch sizes still hold its address)
+                    if (p->ws) { p->retired.push_back(p->ws); p->ws = nullptr; p->ws_cap = 0; }
+                    MF_HIP(hipMalloc(&p->ws, need * sizeof(float)));
+                    p->ws_cap = need;
+                }
+                HaloArgs hs = ha;
+                hs.ws = p->ws; hs.ws_split = per_split; hs.nsplit = ns;
+                hs.gn_out = nullptr;
+                *stats_done = false;
+                int rc = mf_halo_w_launch(hs, qtile, true, stream);
+                if (rc) return rc;
+                ConvArgs e{};
+                e.ws = p->ws; e.ws_split = per_split; e.bias = p->bias; e.N = p->d.cout; e.act = p->d.act;
+                e.y_hi = ha.y_hi; e.y_lo = ha.y_lo; e.yb = ha.yb; e.yi = ha.yi; e.yj = ha.yj;
+                e.r_hi = ha.r_hi; e.r_lo = ha.r_lo; e.rb = ha.rb; e.ri = ha.ri; e.rj = ha.rj;
+                const int64_t total = (int64_t)batch * p->out_h * p->out_w * (p->d.cout / 4);
+                if (launch_combine_stats(p, e, ns, p->out_h, p->out_w, batch, stream)) *stats_done = true;
+                else hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e, ns, p->out_h, p->out_w, total);
+                MF_HIP(hipGetLastError());
+                return MF_OK;
+            }
+            return mf_halo_w_launch(ha, qtile, true, stream);
         }
         if (tw.ph) return mf_halo_w_launch(ha, tw, x3, stream);
         MF_REQUIRE(!g_gn_scale, "conv: GroupNorm fusion requested but the fat halo tile was not picked");
@@ -1760,7 +1804,12 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
 
 void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision != MF_PREC_BF16 ? "true" : "false";
-    if (p->q) { snprintf(buf, cap, "k_conv3x3_halo_w<16,128,4,2,true,1> f16+fp6"); return; }
+    if (p->q) {
+        const int ns = mf_q_split_count(p, batch);
+        if (ns > 1) snprintf(buf, cap, "k_conv3x3_halo_w<16,128,4,2,true,1> f16+fp6 split %d", ns);
+        else snprintf(buf, cap, "k_conv3x3_halo_w<16,128,4,2,true,1> f16+fp6");
+        return;
+    }
     if (p->halo) {
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         if (!tw.ph && mf_halo_split_count(p, batch)) {

@@ -737,7 +737,7 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
 #define MF_HCASE(PH, BN, WGM, WGN, TR) \
     if (t.ph == PH && t.bn == BN && t.wgm == WGM) return halo_w_launch_prec<PH, BN, WGM, WGN, TR>(a, x3, s);
     if (a.q) {
-        if (phase >= 0 || a.nsplit > 1 || a.gn_scale) { mf_set_error("halo conv (f16 + FP6 format): plain unsplit 3x3 layers only"); return MF_ERR_INVALID; }
+        if (phase >= 0 || a.gn_scale) { mf_set_error("halo conv (f16 + FP6 format): plain 3x3 layers only"); return MF_ERR_INVALID; }
         // (16 x 16 x 256 as four waves of 128 px x 128 ch -- 64 accumulator tiles per wave -- spills 456 bytes even with 512 registers: not instantiated)
         if (t.ph == 16 && t.bn == 128 && t.wgm == 4)
             return a.q == 3 ? halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 3>(a, s)

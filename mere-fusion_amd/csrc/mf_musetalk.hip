@@ -199,8 +199,10 @@ struct Net {
         // f16 + FP6 operand format for the wide 3x3 convs on large maps (MF_CONV_Q=0: bf16x3 everywhere): GroupNorm-apply writes the conv's input in the new
         // format, the conv runs one f16 + half a block-scaled FP6 MFMA per tap where bf16x3 runs three; outputs and residuals stay bf16 (hi, lo).
         static const bool q_on = [] { const char* e = getenv("MF_CONV_Q"); return !e || atoi(e) != 0; }();
-        if (q_on && q_allowed && precision == MF_PREC_BF16X3 && cin % 32 == 0 && cout % 128 == 0 && t->C == cin && t->H * t->W >= 64 * 64 &&
-            (int64_t)cap * ((t->H + 15) / 16) * ((t->W + 15) / 16) * (cout / 128) >= 256) {
+        // (maps below 64 x 64 -- the 512-channel 32 x 32 levels -- run it with the channel slices split over two workgroups per tile, mf_q_split_count; MF_CONV_Q_MINPX=4096: bf16x3 there)
+        static const int q_minpx = [] { const char* e = getenv("MF_CONV_Q_MINPX"); return e ? atoi(e) : 32 * 32; }();
+        if (q_on && q_allowed && precision == MF_PREC_BF16X3 && cin % 32 == 0 && cout % 128 == 0 && t->C == cin && t->H * t->W >= q_minpx && cin >= 128 &&
+            (int64_t)cap * ((t->H + 15) / 16) * ((t->W + 15) / 16) * (cout / 128) >= 64) {
             const float* g = T(gname + ".weight", cin);
             const float* b = T(gname + ".bias", cin);
             const float* w = T(cname + ".weight", (int64_t)cin * cout * 9);
