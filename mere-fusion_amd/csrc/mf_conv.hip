@@ -802,6 +802,59 @@ bool mf_k_tap_major() { static const bool v = [] { const char* e = getenv("MF_K_
 
 }  // namespace
 
+// f16 + FP6 residual format of one weight set: plane 0 = f16(w) rows [slice][tap][Npad][32]; plane 1 = per (slice, tap, row) 64 bytes
+// [q6(f16(w)) | q6(w - f16(w))], each 24 B of e2m3 codes (value t in bits [6t, 6t+6)) + the block's E8M0 byte + pad.  The pixel side stores
+// [q6(x - f16(x)) | q6(f16(x))], so K block 0 of the correction instruction is q6(wh).xl and block 1 is wl.q6(xh).  wfun(n, c, tap) = the fp32 weight.
+template <class W>
+static void pack_q_weights(int n_slices, int ntaps, int Npad, int cout, int cin, W wfun, bf16_t* hi, bf16_t* lo) {
+    auto enc = [](float y) -> uint32_t {
+        const uint32_t sgn = y < 0.f ? 0x20u : 0u;
+        const float a = std::fmin(std::fabs(y), 7.5f);
+        uint32_t code;
+        if (a < 1.f) code = (uint32_t)std::nearbyint(a * 8.f);
+        else {
+            const int e = a < 2.f ? 0 : (a < 4.f ? 1 : 2);
+            const uint32_t m = (uint32_t)std::nearbyint((a * (e == 0 ? 1.f : (e == 1 ? 0.5f : 0.25f)) - 1.f) * 8.f);
+            code = ((uint32_t)(e + 1) << 3) + m;
+            if (code > 0x1fu) code = 0x1fu;
+        }
+        return sgn | code;
+    };
+    std::vector<float> blk_h(32), blk_l(32);
+    for (int sl = 0; sl < n_slices; ++sl)
+        for (int tap = 0; tap < ntaps; ++tap)
+            for (int n = 0; n < cout; ++n) {
+                const int64_t row = (((int64_t)sl * ntaps + tap) * Npad + n) * 32;
+                float mh = 0.f, ml = 0.f;
+                for (int e = 0; e < 32; ++e) {
+                    const int c = sl * 32 + e;
+                    const float wf = c < cin ? wfun(n, c, tap) : 0.f;
+                    const _Float16 h = (_Float16)wf;
+                    blk_h[e] = (float)h; blk_l[e] = wf - blk_h[e];
+                    uint16_t bits; __builtin_memcpy(&bits, &h, 2);
+                    hi[row + e] = bits;
+                    mh = std::fmax(mh, std::fabs(blk_h[e])); ml = std::fmax(ml, std::fabs(blk_l[e]));
+                }
+                uint32_t* dst = reinterpret_cast<uint32_t*>(&lo[row]);     // 64 bytes
+                for (int b = 0; b < 2; ++b) {
+                    const std::vector<float>& v = b == 0 ? blk_h : blk_l;
+                    const float m = b == 0 ? mh : ml;
+                    int ex = 0;
+                    if (m > 0.f) { (void)std::frexp(m, &ex); ex = 3 - ex; }
+                    const float sc = std::ldexp(1.f, ex);
+                    uint32_t w8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int e = 0; e < 32; ++e) {
+                        const uint32_t code = enc(v[e] * sc);
+                        const int bit = 6 * e;
+                        w8[bit >> 5] |= code << (bit & 31);
+                        if ((bit & 31) > 26) w8[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+                    }
+                    w8[6] = (uint32_t)(127 - ex) & 0xffu;
+                    for (int k = 0; k < 8; ++k) dst[8 * b + k] = w8[k];
+                }
+            }
+}
+
 int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weight, const float* bias,
                         const float* bn_gamma, const float* bn_beta, const float* bn_mean,
                         const float* bn_var, int precision) {
@@ -919,6 +972,35 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     p->nphase = (int)p->phase_taps.size();
     MF_REQUIRE(p->nphase <= MF_MAX_PHASE, "conv: too many phases");
     p->Npad = (d.cout + 15) / 16 * 16;
+    if (precision == MF_PREC_F16Q && d.upsample) {
+        // nearest-2x upsample + 3x3 in the f16 + FP6 format: four 2 x 2-tap phases (taps pre-summed), [phase][slice][4 taps][Npad][32] in both planes;
+        // the only kernel of such a plan is the f16 + FP6 halo tile, one launch per phase (mf_conv_launch)
+        MF_REQUIRE(d.cin % 32 == 0 && d.cout % 128 == 0 && !d.residual && d.act <= 2 && d.in_h >= 16 && d.in_w >= 16 && d.cin <= 1024 && d.cout <= 1024,
+                   "conv (f16q): upsample + 3x3 needs cin %% 32 == 0, cout %% 128 == 0, a map of at least 16 x 16, no residual");
+        std::vector<float> scale1(d.cout, 1.f), fb(p->Npad, 0.f);
+        for (int n = 0; n < d.cout; ++n) fb[n] = bias ? bias[n] : 0.f;
+        MF_REQUIRE(!bn_gamma, "conv (f16q): no BatchNorm folding for upsample layers");
+        p->n_slices = d.cin / 32;
+        p->q = true;
+        const int64_t per_phase = (int64_t)p->n_slices * 4 * p->Npad * 32, tot = 4 * per_phase;
+        std::vector<bf16_t> uh(tot, 0), ul(tot, 0);
+        for (int ph = 0; ph < 4; ++ph)
+            pack_q_weights(p->n_slices, 4, p->Npad, d.cout, d.cin,
+                           [&](int n, int c, int ti) {
+                               double w = 0.0;                      // dy = py + ty - 1, dx = px + tx - 1 with ti = 2 * ty + tx: the kernel's tap order
+                               for (const auto& kk : p->phase_taps[ph][ti].src) w += weight[(((int64_t)n * d.cin + c) * 3 + kk.first) * 3 + kk.second];
+                               return (float)w;
+                           }, uh.data() + ph * per_phase, ul.data() + ph * per_phase);
+        MF_HIP(hipMalloc(&p->up_hi, tot * sizeof(bf16_t)));
+        MF_HIP(hipMemcpy(p->up_hi, uh.data(), tot * sizeof(bf16_t), hipMemcpyHostToDevice));
+        MF_HIP(hipMalloc(&p->up_lo, tot * sizeof(bf16_t)));
+        MF_HIP(hipMemcpy(p->up_lo, ul.data(), tot * sizeof(bf16_t), hipMemcpyHostToDevice));
+        MF_HIP(hipMalloc(&p->bias, p->Npad * sizeof(float)));
+        MF_HIP(hipMemcpy(p->bias, fb.data(), p->Npad * sizeof(float), hipMemcpyHostToDevice));
+        p->goff_total = 0;
+        p->bound_in_ld = p->bound_in_wp = -1;
+        return MF_OK;
+    }
 
     // ---- fold BatchNorm (eval mode, eps 1e-5: conv.py:10) into weight scale and bias ---------
     std::vector<float> scale(d.cout, 1.f), fbias(p->Npad, 0.f);
@@ -960,57 +1042,11 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
         const int64_t total = (int64_t)p->n_slices * 9 * p->Npad * HCK;
         std::vector<bf16_t> hi(total, 0), lo(total, 0);
         if (precision == MF_PREC_F16Q) {
-            // f16 + FP6 residual format: plane 0 = f16(w) in the same [slice][tap][Npad][32] order; plane 1 = per (slice, tap, row) 64 bytes
-            // [q6(f16(w)) | q6(w - f16(w))], each 24 B of e2m3 codes (value t in bits [6t, 6t+6)) + the block's E8M0 byte + pad.  The pixel side
-            // stores [q6(x - f16(x)) | q6(f16(x))], so K block 0 of the correction instruction is q6(wh).xl and block 1 is wl.q6(xh).
+            // f16 + FP6 residual format (pack_q_weights)
             MF_REQUIRE(d.cin % 32 == 0 && d.cout % 128 == 0, "conv (f16q): the format serves 3x3 layers with cin %% 32 == 0 and cout %% 128 == 0");
             p->q = true;
-            auto enc = [](float y) -> uint32_t {
-                const uint32_t sgn = y < 0.f ? 0x20u : 0u;
-                const float a = std::fmin(std::fabs(y), 7.5f);
-                uint32_t code;
-                if (a < 1.f) code = (uint32_t)std::nearbyint(a * 8.f);
-                else {
-                    const int e = a < 2.f ? 0 : (a < 4.f ? 1 : 2);
-                    const uint32_t m = (uint32_t)std::nearbyint((a * (e == 0 ? 1.f : (e == 1 ? 0.5f : 0.25f)) - 1.f) * 8.f);
-                    code = ((uint32_t)(e + 1) << 3) + m;
-                    if (code > 0x1fu) code = 0x1fu;
-                }
-                return sgn | code;
-            };
-            std::vector<float> blk_h(32), blk_l(32);
-            for (int sl = 0; sl < p->n_slices; ++sl)
-                for (int tap = 0; tap < 9; ++tap)
-                    for (int n = 0; n < d.cout; ++n) {
-                        const int64_t row = (((int64_t)sl * 9 + tap) * p->Npad + n) * HCK;
-                        float mh = 0.f, ml = 0.f;
-                        for (int e = 0; e < 32; ++e) {
-                            const int c = sl * 32 + e;
-                            const float wf = c < d.cin ? weight[(((int64_t)n * d.cin + c) * 3 + tap / 3) * 3 + tap % 3] * scale[n] : 0.f;
-                            const _Float16 h = (_Float16)wf;
-                            blk_h[e] = (float)h; blk_l[e] = wf - blk_h[e];
-                            uint16_t bits; __builtin_memcpy(&bits, &h, 2);
-                            hi[row + e] = bits;
-                            mh = std::fmax(mh, std::fabs(blk_h[e])); ml = std::fmax(ml, std::fabs(blk_l[e]));
-                        }
-                        uint32_t* dst = reinterpret_cast<uint32_t*>(&lo[row]);     // 64 bytes
-                        for (int b = 0; b < 2; ++b) {
-                            const std::vector<float>& v = b == 0 ? blk_h : blk_l;
-                            const float m = b == 0 ? mh : ml;
-                            int ex = 0;
-                            if (m > 0.f) { (void)std::frexp(m, &ex); ex = 3 - ex; }
-                            const float sc = std::ldexp(1.f, ex);
-                            uint32_t w8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                            for (int e = 0; e < 32; ++e) {
-                                const uint32_t code = enc(v[e] * sc);
-                                const int bit = 6 * e;
-                                w8[bit >> 5] |= code << (bit & 31);
-                                if ((bit & 31) > 26) w8[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
-                            }
-                            w8[6] = (uint32_t)(127 - ex) & 0xffu;
-                            for (int k = 0; k < 8; ++k) dst[8 * b + k] = w8[k];
-                        }
-                    }
+            pack_q_weights(p->n_slices, 9, p->Npad, d.cout, d.cin,
+                           [&](int n, int c, int tap) { return weight[(((int64_t)n * d.cin + c) * 3 + tap / 3) * 3 + tap % 3] * scale[n]; }, hi.data(), lo.data());
         } else
         for (int c = 0; c < d.cin; ++c)
             for (int tap = 0; tap < 9; ++tap)
@@ -1162,7 +1198,7 @@ int mf_conv_bind(ConvPlan* p, const ActBuf& in) {
                p->d.in_h, p->d.in_w, in.H, in.W);
     MF_REQUIRE(in.C % 8 == 0 && in.C >= p->cin_pad, "conv: input buffer has %d channels, need >= %d (multiple of 8)", in.C, p->cin_pad);
     if (p->bound_in_ld == in.C && p->bound_in_wp == in.Wp()) return MF_OK;
-    if (p->halo) {
+    if (p->halo || (p->q && p->up_hi)) {        // halo-tile kernels address the input themselves: nothing to precompute
         p->bound_in_ld = in.C; p->bound_in_wp = in.Wp();
         return p->alt ? mf_conv_bind(p->alt, in) : MF_OK;
     }
@@ -1273,7 +1309,7 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
     MF_REQUIRE(ob.H == p->out_h && ob.W == p->out_w, "conv: output buffer %dx%d != %dx%d", ob.H, ob.W, p->out_h, p->out_w);
     const bool x3 = p->precision != MF_PREC_BF16;                      // two planes per tensor (bf16x3, and the f16 + FP6 format)
     MF_REQUIRE(!x3 || (ib.lo && ob.lo), "conv: BF16X3 needs lo planes");
-    MF_REQUIRE(p->precision != MF_PREC_F16Q || p->halo, "conv (f16q): only wide 3x3 stride-1 layers have a kernel in this format");
+    MF_REQUIRE(p->precision != MF_PREC_F16Q || p->halo || (p->up_hi && p->q), "conv (f16q): only wide 3x3 stride-1 layers (optionally behind a 2x upsample) have a kernel in this format");
 
     if (p->halo) {
         HaloArgs ha{};
@@ -1397,6 +1433,38 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
         return mf_halo_launch(ha, mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin), x3, stream);
     }
 
+    if (p->up_hi && p->q) {
+        // upsample + 3x3 in the f16 + FP6 format: four launches of the 16 x 16 x 128-channel tile, phase (py, px) writes output pixels (2i + py, 2j + px)
+        MF_REQUIRE(ib.halo >= 1 && !res.buf, "conv (f16q): upsample path needs an input halo and no residual");
+        HaloArgs ha{};
+        ha.q = 3;
+        ha.x_hi = ib.hi + in.coff; ha.x_lo = ib.lo + in.coff;
+        ha.bias = p->bias;
+        ha.batch = batch; ha.H = p->d.in_h; ha.W = p->d.in_w; ha.N = p->d.cout; ha.Npad = p->Npad; ha.n_slices = p->n_slices;
+        ha.in_halo = ib.halo; ha.in_hp = ib.Hp(); ha.in_wp = ib.Wp(); ha.x_ld = ib.C; ha.xb = ib.per_batch();
+        ha.yb = ob.per_batch(); ha.yi = 2 * ob.Wp() * ob.C; ha.yj = 2 * ob.C;
+        ha.act = p->d.act;
+        {
+            static const bool narrow = [] { const char* e = getenv("MF_STORE16"); return e && atoi(e) == 0; }();
+            ha.wide_store = !narrow && out.coff % 8 == 0 && ob.C % 8 == 0 && p->d.cout % 32 == 0;
+        }
+        if (p->out_stats) {
+            const int cpg = p->d.cout / p->out_stats_groups;
+            if (p->d.cout % p->out_stats_groups == 0 && (cpg == 4 || cpg == 8 || cpg == 16)) {
+                ha.gn_out = p->out_stats; ha.gn_out_cpg = cpg; ha.gn_out_groups = p->out_stats_groups;    // every phase adds its quarter of the pixels
+                *stats_done = true;
+            }
+        }
+        const int64_t per_phase = (int64_t)p->n_slices * 4 * p->Npad * 32;
+        for (int ph = 0; ph < 4; ++ph) {
+            const int64_t yb0 = ((int64_t)(ob.halo + (ph >> 1)) * ob.Wp() + ob.halo + (ph & 1)) * ob.C + out.coff;
+            ha.y_hi = ob.hi + yb0; ha.y_lo = ob.lo + yb0;
+            ha.w_hi = p->up_hi + ph * per_phase; ha.w_lo = p->up_lo + ph * per_phase;
+            const int rc = mf_halo_w_launch(ha, HaloTile{16, 128, 4, 2}, true, stream, ph);
+            if (rc) return rc;
+        }
+        return MF_OK;
+    }
     if (p->up_hi) {
         // upsample + 3x3 on the fat halo tiles: four launches, phase (py, px) writes output pixels (2i + py, 2j + px)
         const HaloTile tw = mf_halo_w_pick_tile(p->d.in_h, p->d.in_w, p->d.cout, batch, p->d.cin);
@@ -1804,6 +1872,7 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
 
 void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision != MF_PREC_BF16 ? "true" : "false";
+    if (p->q && p->up_hi) { snprintf(buf, cap, "4 x k_conv3x3_halo_w<16,128,4,2,true,1,phase> f16+fp6"); return; }
     if (p->q) {
         const int ns = mf_q_split_count(p, batch);
         if (ns > 1) snprintf(buf, cap, "k_conv3x3_halo_w<16,128,4,2,true,1> f16+fp6 split %d", ns);

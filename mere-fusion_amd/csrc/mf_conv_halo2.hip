@@ -360,7 +360,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         const char* wB = wring + sB * WROW;
         const bool second = fk >= 2, pairB = tB >= 0;
         const int blk = fk & 1;
-        const int dyA = tA / 3, dxA = tA % 3, dyB = pairB ? tB / 3 : dyA, dxB = pairB ? tB % 3 : dxA;
+        // 3x3: tap t sits at halo row t / 3, column t % 3; upsample phase (py, px): its four taps at rows py .. py + 1, columns px .. px + 1
+        const int dyA = PHASE < 0 ? tA / 3 : (PHASE >> 1) + (tA >> 1), dxA = PHASE < 0 ? tA % 3 : (PHASE & 1) + (tA & 1);
+        const int dyB = !pairB ? dyA : (PHASE < 0 ? tB / 3 : (PHASE >> 1) + (tB >> 1)), dxB = !pairB ? dxA : (PHASE < 0 ? tB % 3 : (PHASE & 1) + (tB & 1));
         const char* wq = (second && pairB ? wB : wA) + WT_BYTES;
         f16x8 whA[FN], whB[FN];
         i32x8 w6[FN];
@@ -458,13 +460,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             {
                 // taps in pairs (0,1) (2,3) (4,5) (6,7) (8): four ring slots, the pair being multiplied in slots {2 wbuf, 2 wbuf + 1} while the next pair
                 // lands in the other two (everyone left those at the previous barrier); one barrier per PAIR
+                constexpr int NPAIR = (NT + 1) / 2;                  // 5 for the 3x3 layer (the ninth tap alone), 2 for an upsample phase
 #pragma unroll
-                for (int p = 0; p < 5; ++p) {
+                for (int p = 0; p < NPAIR; ++p) {
                     const int nb = 2 * (wbuf ^ 1);
-                    if (p < 4) { load_wrow(slice, 2 * p + 2, nb); if (2 * p + 3 <= 8) load_wrow(slice, 2 * p + 3, nb + 1); }
+                    if (p < NPAIR - 1) { load_wrow(slice, 2 * p + 2, nb); if (2 * p + 3 < NT) load_wrow(slice, 2 * p + 3, nb + 1); }
                     else if (more) { load_wrow(slice + 1, 0, nb); load_wrow(slice + 1, 1, nb + 1); }
-                    compute_pair(st, 2 * p, p < 4 ? 2 * p + 1 : -1, 2 * wbuf, 2 * wbuf + 1);
-                    if (p < 4 || more) __syncthreads();
+                    compute_pair(st, 2 * p, 2 * p + 1 < NT ? 2 * p + 1 : -1, 2 * wbuf, 2 * wbuf + 1);
+                    if (p < NPAIR - 1 || more) __syncthreads();
                     wbuf ^= 1;
                 }
                 continue;
@@ -737,7 +740,15 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
 #define MF_HCASE(PH, BN, WGM, WGN, TR) \
     if (t.ph == PH && t.bn == BN && t.wgm == WGM) return halo_w_launch_prec<PH, BN, WGM, WGN, TR>(a, x3, s);
     if (a.q) {
-        if (phase >= 0 || a.gn_scale) { mf_set_error("halo conv (f16 + FP6 format): plain 3x3 layers only"); return MF_ERR_INVALID; }
+        if (a.gn_scale || (phase >= 0 && (a.nsplit > 1 || t.wgm != 4))) { mf_set_error("halo conv (f16 + FP6 format): plain 3x3 layers and unsplit upsample phases only"); return MF_ERR_INVALID; }
+        // nearest 2x upsample + 3x3 as four 2 x 2-tap phases: two tap pairs per channel slice on the same four-slot ring
+        switch (phase) {
+            case 0: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 0, 2, false, 3>(a, s);
+            case 1: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 1, 2, false, 3>(a, s);
+            case 2: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 2, 2, false, 3>(a, s);
+            case 3: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 3, 2, false, 3>(a, s);
+            default: break;
+        }
         // (16 x 16 x 256 as four waves of 128 px x 128 ch -- 64 accumulator tiles per wave -- spills 456 bytes even with 512 registers: not instantiated)
         if (t.ph == 16 && t.bn == 128 && t.wgm == 4)
             return a.q == 3 ? halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 3>(a, s)

@@ -456,6 +456,40 @@ struct Net {
         return conv(p + ".proj_out", ActView{hB, 0, C}, y, C, C, 1, 1, 0, 0, x);
     }
 
+    // diffusers Upsample2D (nearest 2x + conv 3x3) in the f16 + FP6 operand format where the layer fills the chip that way: a converter pass writes
+    // the input in the format (identity affine, no SiLU), then four 2 x 2-tap phase launches of the f16 + FP6 halo tile, which also leave the
+    // consumer GroupNorm's statistics.  Elsewhere (small maps, other precisions, MF_CONV_Q=0 / MF_UP_Q=0): the 4-phase implicit GEMM on bf16x3.
+    int upsample_conv(const std::string& name, ActView x, ActView out, int C) {
+        static const bool on = [] { const char* e = getenv("MF_CONV_Q"); const char* u = getenv("MF_UP_Q"); return (!e || atoi(e) != 0) && (!u || atoi(u) != 0); }();
+        const int H = x.buf->H, W = x.buf->W;
+        if (!(on && q_allowed && precision == MF_PREC_BF16X3 && C % 128 == 0 && x.C == C && x.coff % 8 == 0 && H * W >= 64 * 64 &&
+              (int64_t)cap * ((H + 15) / 16) * ((W + 15) / 16) * (C / 128) >= 256))
+            return conv(name, x, out, C, C, 3, 1, 1, 0, ActView{}, 1);
+        const float* w = T(name + ".weight", (int64_t)C * C * 9);
+        const float* b = T(name + ".bias", C);
+        if (!w || !b) return MF_ERR_INVALID;
+        ActBuf* tq = tmp("up.q", C, H, W, 1);
+        if (!tq) return MF_ERR_HIP;
+        std::vector<float> ones((size_t)cap * C, 1.f), zeros((size_t)cap * C, 0.f);
+        float *d1 = upload(ones.data(), ones.size()), *d0 = upload(zeros.data(), zeros.size());
+        if (!d1 || !d0) return MF_ERR_HIP;
+        mf_conv2d_desc d{};
+        d.cin = C; d.cout = C; d.kh = d.kw = 3; d.stride_h = d.stride_w = 1; d.pad_h = d.pad_w = 1; d.in_h = H; d.in_w = W; d.upsample = 1;
+        ConvPlan* p = new_plan();
+        int rc = mf_conv_plan_create(p, d, w, b, nullptr, nullptr, nullptr, nullptr, MF_PREC_F16Q);
+        if (rc) return rc;
+        if ((rc = mf_conv_bind(p, *tq))) return rc;
+        stats_forget(out.buf);
+        const ActBuf* tqc = tq;
+        const ActView tv{tq, 0, C};
+        push(name + " (input -> f16 + FP6)", "k_affine_silu_to_q (identity)", 0.0, [=](int B, hipStream_t s) { return mf_affine_silu_to_act_q(x, d1, d0, 0, *tqc, B, s); });
+        char kn[96];
+        mf_conv_kernel_name(p, cap, kn, sizeof(kn));
+        push(name, kn, mf_conv_flops(p, 1), [=](int B, hipStream_t s) { return mf_conv_launch(p, tv, out, ActView{}, B, s); });
+        stats_remember(p, out);
+        return MF_OK;
+    }
+
     // hoisted cross-attention k | v: reserve the op slot before the blocks are built ...
     int hoist_kv_begin(ActView ctx, int total) {
         static const bool on = [] { const char* e = getenv("MF_KV_HOIST"); return !e || atoi(e) != 0; }();
@@ -879,7 +913,7 @@ extern "C" int mf_vae_create(const mf_vae_config* c, const mf_tensor* weights, i
         if (b < nb - 1) {
             ActBuf* y = net.buf(ch, 2 * s, 2 * s, 1);
             if (!y) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
-            NET_TRY(net.conv("decoder.up_blocks." + std::to_string(b) + ".upsamplers.0.conv", x, ActView{y, 0, ch}, ch, ch, 3, 1, 1, 0, ActView{}, 1));
+            NET_TRY(net.upsample_conv("decoder.up_blocks." + std::to_string(b) + ".upsamplers.0.conv", x, ActView{y, 0, ch}, ch));
             s *= 2;
             x = ActView{y, 0, ch};
         }

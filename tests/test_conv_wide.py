@@ -137,3 +137,34 @@ def test_conv_leaves_groupnorm_statistics_of_its_output(lib_built, cin, cout, k,
             assert torch.equal(y, y2)
     finally:
         l.mf_conv2d_destroy(h)
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B", [(256, 256, 64, 64, 2), (512, 512, 32, 48, 3), (128, 256, 40, 24, 2)])
+def test_f16q_upsample_phases_vs_fp64(lib_built, cin, cout, H, W, B):
+    """nearest 2x upsample + 3x3 in the f16 + FP6 format (the VAE decoder's upsamplers): four 2 x 2-tap phase launches of the halo tile, pre-summed taps
+    quantised per phase; against a float64 convolution of the upsampled input, beside the bf16x3 4-phase implicit GEMM; statistics seam included."""
+    from mere_fusion_amd import _lib
+    l = _lib.lib()
+    _lib.init_device(0)
+    rng = np.random.default_rng(cin + H)
+    w = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x.double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1).float()
+    errs = {}
+    for prec in ("bf16x3", "f16q"):
+        d = _lib.MfConv2dDesc(cin=cin, cout=cout, kh=3, kw=3, stride_h=1, stride_w=1, pad_h=1, pad_w=1, act=0, in_h=H, in_w=W, upsample=1)
+        h = C.c_void_p()
+        _lib.check(l.mf_conv2d_create(C.byref(d), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), None, None, None, None, _lib.PRECISIONS[prec], C.byref(h)))
+        xd, y = x.cuda(), torch.empty(B, cout, 2 * H, 2 * W, device="cuda")
+        st = torch.zeros(B, 32, 2, dtype=torch.float64, device="cuda")
+        _lib.check(l.mf_conv2d_forward_stats(h, C.c_void_p(xd.data_ptr()), C.c_void_p(y.data_ptr()), 32, C.c_void_p(st.data_ptr()), B, None))
+        torch.cuda.synchronize()
+        errs[prec] = float((y.cpu() - ref).abs().max())
+        yg = y.double().reshape(B, 32, -1)
+        want = torch.stack([yg.sum(-1), (yg * yg).sum(-1)], dim=-1)
+        serr = float(((st - want).abs() / (want.abs().amax(dim=(0, 1)) + 1e-30)).max())
+        assert serr <= 2e-6, (prec, serr)
+        l.mf_conv2d_destroy(h)
+    print(f"[f16q upsample {cin}->{cout} @{H}x{W}] L-inf vs fp64: bf16x3 {errs['bf16x3']:.2e}, f16 + FP6 {errs['f16q']:.2e} (max |y| {float(ref.abs().max()):.2f})")
+    assert errs["f16q"] <= 3e-4 and errs["f16q"] <= 6 * errs["bf16x3"] + 1e-5
