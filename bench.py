@@ -227,6 +227,8 @@ def pmc_traffic(kernel, workload, precision, batch_args, want_clock=True):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found", None
     want = "void" + kernel.split(" f16+fp6")[0].replace(" ", "")[:-1]                # "voidk_conv_igemm<256,256,2,4,true,32" (+ ",<ring depth>>" or ">")
+    if "f16+fp6" in kernel:
+        want += ",-1"                                                                # the plain 3x3 instantiation (PHASE = -1), not the four upsample-phase ones
     vals, clock = {}, None
     for ctr in ("FETCH_SIZE", "WRITE_SIZE") + (("GRBM_GUI_ACTIVE",) if want_clock else ()):
         d = tempfile.mkdtemp(prefix="mf_pmc_")
