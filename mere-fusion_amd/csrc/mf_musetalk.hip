@@ -462,7 +462,7 @@ struct Net {
     int upsample_conv(const std::string& name, ActView x, ActView out, int C) {
         static const bool on = [] { const char* e = getenv("MF_CONV_Q"); const char* u = getenv("MF_UP_Q"); return (!e || atoi(e) != 0) && (!u || atoi(u) != 0); }();
         const int H = x.buf->H, W = x.buf->W;
-        if (!(on && q_allowed && precision == MF_PREC_BF16X3 && C % 128 == 0 && x.C == C && x.coff % 8 == 0 && H * W >= 64 * 64 &&
+        if (!(on && q_allowed && precision == MF_PREC_BF16X3 && C % 128 == 0 && x.C == C && x.coff % 8 == 0 && H * W >= 32 * 32 &&
               (int64_t)cap * ((H + 15) / 16) * ((W + 15) / 16) * (C / 128) >= 256))
             return conv(name, x, out, C, C, 3, 1, 1, 0, ActView{}, 1);
         const float* w = T(name + ".weight", (int64_t)C * C * 9);
