@@ -264,7 +264,10 @@ def pmc_traffic(kernel, workload, precision, batch_args, want_clock=True):
             return None, f"{ctr} pass failed: {type(e).__name__}", None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate rocprofv3 --pmc passes, per launch",
+    note = "2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate rocprofv3 --pmc passes, per launch"
+    if "f16+fp6" in kernel:
+        note += "; averaged over every launch of the plain 3x3 instantiation, i.e. including the channel-slice-split launches of the 32 x 32 levels (10 of 28 per step, about a quarter of the bytes each)"
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], note,
             clock)
 
 

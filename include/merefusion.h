@@ -39,7 +39,7 @@ typedef enum mf_status {
  *                  error; meets the north-star parity bound (L-inf <= 1e-3 vs the fp32 CPU
  *                  generator) that plain bf16 cannot. */
 typedef enum mf_precision { MF_PREC_BF16 = 0, MF_PREC_BF16X3 = 1, MF_PREC_F16Q = 2 } mf_precision;
-/* MF_PREC_F16Q (EXPERIMENTAL, mf_conv2d_* test seam only, wide 3x3 layers): operands as f16 + FP6 (e2m3, OCP-MX block scales) residuals --
+/* MF_PREC_F16Q (mf_conv2d_* test seam; inside the VAE decoder it is chosen by the schedule; wide 3x3 stride-1 layers, optionally behind a nearest 2x upsample): operands as f16 + FP6 (e2m3, OCP-MX block scales) residuals --
  * w.x = wh.xh (one f16 MFMA) + q6(wh).xl + wl.q6(xh) (one block-scaled 16x16x128 MFMA at 4x the rate); outputs stay bf16 (hi, lo).  DESIGN.md. */
 
 /* One named fp32 host tensor of a checkpoint (a state_dict item). */
