@@ -9,9 +9,16 @@ that bench.py, the tests and a multi-session harness drive directly:
   MuseBatcher       ONE UNet + VAE pair serving N sessions: every step gathers each active session's latents by mirror index
                     (mf_gather_rows_f32) and its audio chunks into one N * B-frame batch, runs musereal.py:100-108 once, and hands every
                     session its own uint8 frames (optionally already pasted into the full frame, mf_paste_frames)
+  SessionScheduler  the per-GPU serving loop over a MuseBatcher for sessions that arrive on their own clocks (one batch of B frames per
+                    B * 40 ms of audio each, musereal.py:53-58 / basereal's 25 fps pacing): queues every session's batches, picks which
+                    sessions share the next step (oldest first, up to the handle's capacity; a short hold lets a step fill), and stamps
+                    every batch's arrival -> frames-ready latency.  bench.py's `paced_sessions` leg measures BASELINE.json's "max concurrent
+                    >= 25 fps sessions" with it (p99 batch latency <= B * 40 ms) instead of dividing a free-running rate by 25
 
 Cross-session batching is what fills an MI355X: the UNet at 8 frames per step is launch-latency bound, at 64 it is not."""
 import ctypes as C
+import time
+from collections import deque
 
 import numpy as np
 import torch
@@ -92,15 +99,17 @@ class MuseSession:
 class MuseBatcher:
     """N sessions through one UNet / VAE handle per step (BASELINE.json north star: 8 sessions per GPU)."""
 
-    def __init__(self, unet, vae, sessions, batch_size=8, paste=False, device="cuda"):
+    def __init__(self, unet, vae, sessions, batch_size=8, paste=False, device="cuda", max_sessions_per_step=None):
         if not torch.cuda.is_available():
             raise RuntimeError("MuseBatcher needs a HIP device; no CPU path exists here")
         self.unet, self.vae, self.sessions, self.batch_size, self.paste = unet, vae, list(sessions), batch_size, paste
         self.device = torch.device(device)
-        need = len(self.sessions) * batch_size
+        # more sessions than one step holds: step(..., only=[...]) serves a subset (SessionScheduler)
+        self.max_sessions_per_step = len(self.sessions) if max_sessions_per_step is None else int(max_sessions_per_step)
+        need = self.max_sessions_per_step * batch_size
         for h, what in ((unet.model.max_batch, "UNet"), (getattr(vae, "max_batch", need), "VAE")):
             if h < need:
-                raise RuntimeError(f"{what} handle was created with max_batch {h}; {len(self.sessions)} sessions x {batch_size} frames need {need}")
+                raise RuntimeError(f"{what} handle was created with max_batch {h}; {self.max_sessions_per_step} sessions x {batch_size} frames need {need}")
         off = 0
         for s in self.sessions:
             s.pool_offset = off
@@ -112,14 +121,25 @@ class MuseBatcher:
         self.t0 = torch.tensor([0], device=self.device)
 
     @torch.no_grad()
-    def step(self, whisper_chunks):
+    def step(self, whisper_chunks, only=None):
         """whisper_chunks: one entry per session -- a device tensor [B, 50, 384] (MuseASRFrontend.run_step) or None for an all-silent batch
         (musereal.py:82-86: the net is skipped, only the frame indices advance).  Returns one (frames, indices) per session:
         frames = uint8 [B, 256, 256, 3] BGR on the device (`recon`, musereal.py:108), or, with paste=True, the composed full frames
-        [B, H, W, 3] (musereal.py:238-247); None for a silent session."""
+        [B, H, W, 3] (musereal.py:238-247); None for a silent session.
+        only: session numbers that take part in this step; every other session is left untouched (its frame index does not move, its entry
+        of the result is None) -- sessions on their own clocks do not all have a batch at every step."""
         B = self.batch_size
+        take = None if only is None else set(int(k) for k in only)
+        if take is not None and (min(take, default=0) < 0 or max(take, default=0) >= len(self.sessions)):
+            raise RuntimeError(f"only={sorted(take)}: session numbers run from 0 to {len(self.sessions) - 1}")
+        n_act = sum(1 for k, ch in enumerate(whisper_chunks) if ch is not None and (take is None or k in take))
+        if n_act > self.max_sessions_per_step:
+            raise RuntimeError(f"{n_act} active sessions in one step; the handles hold {self.max_sessions_per_step} x {B} frames")
         rows, idx_per, active = [], [], []
         for k, (s, ch) in enumerate(zip(self.sessions, whisper_chunks)):
+            if take is not None and k not in take:
+                idx_per.append(None)
+                continue
             idx = s.next_indices(B)
             idx_per.append(idx)
             if ch is None:
@@ -128,7 +148,7 @@ class MuseBatcher:
                 raise RuntimeError(f"session {k}: expected a device tensor of {B} whisper chunks, got {tuple(ch.shape)} on {ch.device}")
             active.append(k)
             rows.extend(s.pool_offset + i for i in idx)
-        out = [(None, idx) for idx in idx_per]
+        out = [None if idx is None else (None, idx) for idx in idx_per]
         if not active:
             return out
         n = len(rows)
@@ -149,3 +169,72 @@ class MuseBatcher:
                 fr = s.avatar_frames.paste(fr, idx_per[k])
             out[k] = (fr, idx_per[k])
         return out
+
+
+def pick_sessions(pending, now, capacity, hold):
+    """Which sessions share the next step.  pending: {session number: arrival time of its OLDEST queued batch}.  Oldest first (ties: lower
+    session number); a step goes out as soon as `capacity` sessions wait, or once the oldest batch has waited `hold` seconds -- a partly
+    filled step costs almost what a full one does (the UNet is latency-bound at 8 frames), so a short hold buys throughput and
+    its cost is bounded by `hold`.  Returns [] while it is better to wait.  Pure host logic (tests/test_muse_driver.py runs it on the CPU)."""
+    if not pending or capacity < 1:
+        return []
+    order = sorted(pending, key=lambda k: (pending[k], k))
+    if len(order) >= capacity or now - pending[order[0]] >= hold:
+        return order[:capacity]
+    return []
+
+
+class SessionScheduler:
+    """Serving loop of one GPU: N paced sessions over one MuseBatcher.
+
+    submit(k, chunks, t_arrival)   queue one batch of session k (chunks: device tensor [B, 50, 384], or None = silent batch)
+    run_once(now)                  if pick_sessions says so, run ONE batcher step for the picked sessions, wait for its frames and
+                                   return [(k, frames, indices, latency_s)]; [] when nothing is due
+    next_due()                     the time at which run_once would act on what is queued now (None: nothing queued)
+    A session's batches are served in arrival order, one per step (its frame indices are consecutive: musereal.py:92-97)."""
+
+    def __init__(self, batcher, period_s=None, hold_s=None, clock=time.perf_counter, sync=None):
+        self.batcher = batcher
+        self.capacity = batcher.max_sessions_per_step
+        self.period = batcher.batch_size * 0.040 if period_s is None else float(period_s)          # B frames at 25 fps
+        self.hold = self.period / 4 if hold_s is None else float(hold_s)
+        self.clock = clock
+        self.sync = sync if sync is not None else (lambda: torch.cuda.synchronize(batcher.device))
+        self.queues = [deque() for _ in batcher.sessions]
+        self.steps = 0
+        self.sessions_served = 0
+        self.busy_s = 0.0
+
+    def submit(self, k, whisper_chunks, t_arrival=None):
+        self.queues[k].append((self.clock() if t_arrival is None else t_arrival, whisper_chunks))
+
+    def pending(self):
+        return {k: q[0][0] for k, q in enumerate(self.queues) if q}
+
+    def backlog(self):
+        return max((len(q) for q in self.queues), default=0)
+
+    def next_due(self):
+        p = self.pending()
+        if not p:
+            return None
+        t = sorted(p.values())
+        return t[self.capacity - 1] if len(t) >= self.capacity else t[0] + self.hold
+
+    def run_once(self, now=None):
+        now = self.clock() if now is None else now
+        ks = pick_sessions(self.pending(), now, self.capacity, self.hold)
+        if not ks:
+            return []
+        chunks = [None] * len(self.queues)
+        arrival = {}
+        for k in ks:
+            arrival[k], chunks[k] = self.queues[k].popleft()
+        t0 = self.clock()
+        out = self.batcher.step(chunks, only=ks)
+        self.sync()
+        t1 = self.clock()
+        self.steps += 1
+        self.sessions_served += len(ks)
+        self.busy_s += t1 - t0
+        return [(k, out[k][0], out[k][1], t1 - arrival[k]) for k in ks]

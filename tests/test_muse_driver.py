@@ -26,6 +26,55 @@ def test_session_walk_and_errors():
             D.feature_chunks_device(torch.zeros(4, 5, 384), [0])
 
 
+def test_pick_sessions_policy():
+    """Which sessions share a step (host logic of SessionScheduler): oldest first, a full step at once, a partial one after the hold."""
+    assert D.pick_sessions({}, 1.0, 8, 0.08) == []
+    assert D.pick_sessions({3: 1.00}, 1.05, 8, 0.08) == []                               # alone and young: wait for company
+    assert D.pick_sessions({3: 1.00}, 1.08, 8, 0.08) == [3]                              # ... but never longer than the hold
+    assert D.pick_sessions({0: 1.00, 1: 0.50, 2: 0.70}, 1.01, 2, 0.08) == [1, 2]         # capacity reached: no hold, oldest first
+    assert D.pick_sessions({5: 2.0, 1: 2.0, 4: 1.0}, 2.0, 3, 0.5) == [4, 1, 5]           # ties broken by session number
+    assert D.pick_sessions({0: 1.0}, 9.0, 0, 0.0) == []
+
+
+def test_session_scheduler_queues_on_a_fake_clock():
+    """SessionScheduler over a stand-in batcher (no device): per-session FIFO, one batch of a session per step, sessions outside a step
+    untouched, latency = frames-ready time - arrival."""
+    class FakeBatcher:
+        def __init__(self, n, cap):
+            self.sessions, self.batch_size, self.max_sessions_per_step, self.device = [D.MuseSession([torch.zeros(1, 8, 32, 32)] * 5) for _ in range(n)], 8, cap, "cpu"
+            self.calls = []
+
+        def step(self, chunks, only=None):
+            self.calls.append((sorted(only), [c for c in chunks if c is not None]))
+            return [None if k not in only else ("frames%d" % k, self.sessions[k].next_indices(self.batch_size)) for k in range(len(chunks))]
+
+    now = [0.0]
+    fb = FakeBatcher(4, cap=2)
+
+    def sync():
+        now[0] += 0.100                                                                  # a step "takes" 100 ms
+    sch = D.SessionScheduler(fb, clock=lambda: now[0], sync=sync)
+    assert sch.period == pytest.approx(0.320) and sch.hold == pytest.approx(0.080) and sch.capacity == 2
+    assert sch.run_once() == [] and sch.next_due() is None
+    sch.submit(2, "a2", 0.00)
+    sch.submit(2, "b2", 0.01)                                                            # a second batch of the same session queues behind the first
+    assert sch.next_due() == pytest.approx(0.080) and sch.run_once(0.05) == []           # one session waiting, hold not over
+    sch.submit(0, "a0", 0.06)
+    now[0] = 0.06
+    done = sch.run_once()                                                                # two sessions = capacity: goes at once
+    assert [(k, f, round(lat, 3)) for k, f, _, lat in done] == [(2, "frames2", 0.16), (0, "frames0", 0.10)]
+    assert fb.calls[-1] == ([0, 2], ["a0", "a2"]) and done[0][2] == [0, 1, 2, 3, 4, 4, 3, 2]
+    assert sch.backlog() == 1 and sch.pending() == {2: 0.01}
+    sch.submit(1, None, 0.17)                                                            # a silent batch is a batch (indices advance, no frames)
+    sch.submit(3, "a3", 0.18)
+    done = sch.run_once()                                                                # 3 waiting, capacity 2: the two oldest
+    assert [k for k, *_ in done] == [2, 1] and fb.calls[-1] == ([1, 2], ["b2"])
+    assert done[0][2] == [1, 0, 0, 1, 2, 3, 4, 4]                                        # session 2 went on where its first batch stopped
+    assert fb.sessions[3].index == 0                                                     # session 3 was not touched
+    done = sch.run_once(now[0] + 1.0)
+    assert [k for k, *_ in done] == [3] and sch.steps == 3 and sch.sessions_served == 5 and sch.pending() == {}
+
+
 @pytest.mark.gpu
 def test_hip_feature_chunks_vs_oracle(lib_built):
     from oracle import whisper_ref
@@ -111,3 +160,49 @@ def test_hip_batcher_three_sessions_vs_oracle(lib_built):
             pasted = out[s][0].cpu().numpy()
             for k, i in enumerate(want_idx):                                                # byte work: bit-exact on the SAME generated frame
                 assert np.array_equal(pasted[k], blend_ref.muse_paste(frames[i], got_u8[k], boxes[i], masks[i], crops[i])), (step, s, k)
+
+
+@pytest.mark.gpu
+def test_hip_scheduler_serves_paced_sessions_vs_oracle(lib_built):
+    """SessionScheduler over the real batcher: three sessions on their own clocks, two per step at most (handles built for 2 x B frames).
+    Whatever company a session's batch had in its step, its frames are the oracle step on ITS latents / chunks, its indices the mirror walk,
+    and a session without a batch in a step does not move."""
+    from mere_fusion_amd.musetalk.models.unet import UNet
+    from mere_fusion_amd.musetalk.models.vae import VAE
+    from mere_fusion_amd.musetalk.config import unet_config_json, vae_config_json
+    from oracle import musetalk_ref as R
+    cfg = R.MUSETALK_SMALL
+    usd, vsd = W.make_musetalk_unet_state_dict(cfg, 0), W.make_musetalk_vae_state_dict(cfg, 0)
+    B, S, CAP = 2, 3, 2
+    unet = UNet(unet_config_json(cfg["unet"]), usd, max_batch=B * CAP)
+    vae = VAE(config=vae_config_json(cfg["vae"]), state_dict=vsd, max_batch=B * CAP)
+    lat_lists = [[W.make_musetalk_inputs(1, 300 + 10 * s + i)[0] for i in range(3 + s)] for s in range(S)]
+    with pytest.raises(RuntimeError, match="max_batch"):
+        D.MuseBatcher(unet, vae, [D.MuseSession(l) for l in lat_lists], batch_size=B)                      # 3 sessions do not fit one step ...
+    bat = D.MuseBatcher(unet, vae, [D.MuseSession(l) for l in lat_lists], batch_size=B, max_sessions_per_step=CAP)   # ... but two at a time do
+    with pytest.raises(RuntimeError, match="active sessions"):
+        bat.step([torch.zeros(B, 50, 384, device="cuda")] * S)
+    assert [s.index for s in bat.sessions] == [0, 0, 0]                                                 # a refused step moves nothing
+    now = [0.0]
+    sch = D.SessionScheduler(bat, clock=lambda: now[0])
+    chunks = {(s, j): W.make_musetalk_inputs(B, 900 + 10 * s + j)[1] for s in range(S) for j in range(2)}
+    # arrivals: session 1 at 0.00 and 0.05, session 0 at 0.01, session 2 at 0.02 and 0.06
+    for s, j, t in ((1, 0, 0.00), (0, 0, 0.01), (2, 0, 0.02), (1, 1, 0.05), (2, 1, 0.06)):
+        sch.submit(s, chunks[(s, j)].cuda(), t)
+    served, index, seen = [], [0] * S, {s: 0 for s in range(S)}
+    now[0] = 0.03
+    while sch.pending():
+        done = sch.run_once()
+        assert done, "three sessions wait and capacity is two: every call must serve"
+        served.append([k for k, *_ in done])
+        for k, frames, idx, lat in done:
+            want_idx = [glue_ref.mirror_index(len(lat_lists[k]), index[k] + i) for i in range(B)]
+            index[k] += B
+            assert idx == want_idx and lat > 0
+            lat_in = torch.cat([lat_lists[k][i] for i in want_idx], dim=0)
+            want_u8, _ = R.musetalk_step(usd, vsd, cfg, lat_in, chunks[(k, seen[k])])
+            seen[k] += 1
+            d = np.abs(frames.cpu().numpy().astype(int) - want_u8.astype(int))
+            assert d.max() <= 2 and (d > 0).mean() < 0.05, (k, d.max())
+        now[0] += 0.05
+    assert served == [[1, 0], [2, 1], [2]] and sch.steps == 3 and sch.sessions_served == 5
