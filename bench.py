@@ -529,7 +529,6 @@ def muse_paced_sessions(big, args, device, free_fps, periods=12, max_trials=8):
                         f"{periods} batches per session in real time, seeded random phases",
            "scheduler": f"mere_fusion_amd.muse_driver.SessionScheduler: oldest first, <= {S} sessions per step, a partly filled step waits <= {P * 250:.0f} ms",
            "max_sessions_sustained": best["sessions"] if best else None,
-           "per_8gpu_node_if_each_gpu_does_the_same": best["sessions"] * 8 if best else None,
            "at_max": best, "trials": trials, "step_ms_by_sessions_in_step": step_ms, "warmup_s": round(warm_s, 1)}
     if best is None:
         rep["note"] = f"none of N = {cands} held the bound; see trials"
