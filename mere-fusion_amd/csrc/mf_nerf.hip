@@ -11,6 +11,7 @@
 // exactly as written (the CPU restatement the parity tests compare against is built the same way); divisions are the
 // correctly rounded default of hipcc.
 #include "mf_common.h"
+#include "mf_nerf_grid.h"
 #include <cstdlib>
 #include <cstring>
 #include <cfloat>
@@ -302,34 +303,7 @@ __global__ __launch_bounds__(NT) void k_composite_rays_triplane(uint32_t n_alive
 }
 
 // ---- grid encoder -----------------------------------------------------------------------------------------------------
-constexpr int GRID_MAX_L = 32;
-struct GridLevels {                      // per-level constants, computed on the host exactly as gridencoder.cu:122-124 does
-    float scale[GRID_MAX_L];
-    uint32_t resolution[GRID_MAX_L];
-    uint32_t offset[GRID_MAX_L];
-    uint32_t hashmap_size[GRID_MAX_L];
-};
-
-// fast_hash / get_grid_index, gridencoder.cu:35-72
-template <uint32_t D>
-__device__ __forceinline__ uint32_t grid_index(uint32_t C, uint32_t gridtype, bool align_corners, uint32_t hashmap_size,
-                                               uint32_t resolution, const uint32_t (&pos_grid)[D]) {
-    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
-    uint32_t stride = 1, index = 0;
-#pragma unroll
-    for (uint32_t d = 0; d < D; d++) {
-        if (stride <= hashmap_size) {
-            index += pos_grid[d] * stride;
-            stride *= align_corners ? resolution : (resolution + 1);
-        }
-    }
-    if (gridtype == 0 && stride > hashmap_size) {
-        index = 0;
-#pragma unroll
-        for (uint32_t d = 0; d < D; ++d) index ^= pos_grid[d] * primes[d];
-    }
-    return (index % hashmap_size) * C;
-}
+// GridLevels, grid_index<D>: mf_nerf_grid.h
 
 // kernel_grid forward, gridencoder.cu:76-165.  grid (ceil(B/256), L); out_lbc: [L][B][C] as the reference extension writes it
 // (grid.py:42) -- out_blc != 0 writes [B][L*C] directly, the layout grid.py:52 permutes to.

@@ -32,6 +32,12 @@ int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3
                          float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev = nullptr,
                          float sigma_scale = 1.f);
 
+// mf_nerf_torso.hip: the whole torso branch as one fp32 kernel (default); the GEMM chain below stays for A/B (MF_TORSO=gemm)
+int mf_nerf_torso_fused_weight_count();
+int mf_nerf_torso_fused_launch(const float* w, const float* bias_d, const float* bias_t, const float* emb, const int* offsets_host, float log2_pls,
+                               int base_res, const float* density, int G, const float* bg_coords, float shrink, float thresh, const float* bg,
+                               int bg_per_ray, float bg_const, int N, float* out, float* alpha_out, float* deform, hipStream_t s);
+
 namespace {
 
 constexpr int TW = 1024;          // tokens per "image" of the token buffers
@@ -435,6 +441,8 @@ struct mf_nerf_torso : TokenNet {
     ConvPlan *d1, *d2, *d3, *t1, *t2, *t3;
     float *emb = nullptr, *density = nullptr, *xs = nullptr, *coords01 = nullptr, *feat = nullptr;
     std::vector<float> wd_const, wt_const;     // [32][50]: the constant-input columns of the two first layers
+    float* wf = nullptr;                       // fp32 [out][in] tables of the six layers for the fused kernel (mf_nerf_torso.hip)
+    bool fused = true;
 };
 
 extern "C" int mf_nerf_torso_create(const mf_nerf_torso_config* cfg, const mf_tensor* weights, int n_weights, int precision, int max_pixels,
@@ -507,6 +515,27 @@ extern "C" int mf_nerf_torso_create(const mf_nerf_torso_config* cfg, const mf_te
     if ((rc = first_layer("torso_net.net.0.weight", tin, TG + FQ, TH_C, col, w, h->wt_const)) || (rc = h->linear(&h->t1, w, TH_C, 32, 1, h->TH))) return rc;
     if ((rc = plain("torso_net.net.1.weight", 32, 32, w)) || (rc = h->linear(&h->t2, w, 32, 32, 1, h->U1))) return rc;
     if ((rc = plain("torso_net.net.2.weight", 4, 32, w)) || (rc = h->linear(&h->t3, w, 32, 4, 2, h->U2))) return rc;
+    {
+        // the fused kernel's table: the variable-input columns of the two first layers ([freq 34], [grid 32 | freq 34]: the leading columns of
+        // the reference's weight rows, network.py:180-183 / 189-194) and the four other matrices as they are
+        std::vector<float> tab;
+        auto take = [&](const char* name, int cout, int cin_ref, int cols) -> int {
+            const mf_tensor* t = nf_find(sd, name, cout, cin_ref);
+            if (!t) return MF_ERR_INVALID;
+            const float* src = (const float*)t->data;
+            for (int o = 0; o < cout; ++o) tab.insert(tab.end(), src + (size_t)o * cin_ref, src + (size_t)o * cin_ref + cols);
+            return MF_OK;
+        };
+        if ((rc = take("torso_deform_net.net.0.weight", 32, din, FQ)) || (rc = take("torso_deform_net.net.1.weight", 32, 32, 32)) ||
+            (rc = take("torso_deform_net.net.2.weight", 2, 32, 32)) || (rc = take("torso_net.net.0.weight", 32, tin, TG + FQ)) ||
+            (rc = take("torso_net.net.1.weight", 32, 32, 32)) || (rc = take("torso_net.net.2.weight", 4, 32, 32)))
+            return rc;
+        MF_REQUIRE((int)tab.size() == mf_nerf_torso_fused_weight_count(), "nerf_torso_create: fused table has %zu entries", tab.size());
+        if ((rc = dmalloc(&h->wf, tab.size()))) return rc;
+        MF_HIP(hipMemcpy(h->wf, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+        const char* e = std::getenv("MF_TORSO");
+        h->fused = !(e && std::strcmp(e, "gemm") == 0);
+    }
     MF_HIP(hipDeviceSynchronize());
     *out = h.release();
     return MF_OK;
@@ -540,6 +569,10 @@ extern "C" int mf_nerf_torso_forward(mf_nerf_torso* h, const float* bg_coords, c
         }
         bd[o] = (float)a; bt[o] = (float)b;
     }
+    if (h->fused)
+        return mf_nerf_torso_fused_launch(h->wf, bd, bt, h->emb, h->cfg.offsets, h->cfg.log2_per_level_scale, h->cfg.base_resolution, h->density,
+                                          h->cfg.grid_size, bg_coords, h->cfg.torso_shrink, density_thresh, bg_color, bg_per_ray, bg_const, N, bg_out,
+                                          torso_alpha, deform, s);
     hipLaunchKernelGGL(k_torso_bias, dim3(1), dim3(64), 0, s, fb, h->d1->bias, h->t1->bias);   // by value: no staging copy, no host sync
     hipLaunchKernelGGL(k_torso_prep, dim3((unsigned)(((int64_t)N * TX_C + 255) / 256)), dim3(256), 0, s, bg_coords, h->cfg.torso_shrink, N, h->xs,
                        h->TX->hi, h->TX->lo, h->TH->hi, h->TH->lo);
