@@ -511,27 +511,41 @@ def muse_paced_sessions(big, args, device, free_fps, periods=12, max_trials=8):
         wall = time.perf_counter() - t_start
         l = np.sort(np.asarray(lats)) * 1e3
         p99 = float(l[min(len(l) - 1, int(np.ceil(0.99 * len(l))) - 1)])
-        third = np.asarray(lats[-(len(lats) // 3):]) * 1e3                   # served last: a queue that grows shows up here first
-        return {"sessions": N, "batches": int(len(l)), "last_third_mean_ms": round(float(third.mean()), 1), "all_mean_ms": round(float(l.mean()), 1), "p50_ms": round(float(l[len(l) // 2]), 1), "p99_ms": round(p99, 1), "max_ms": round(float(l[-1]), 1),
-                "sustained": bool(p99 <= P * 1e3), "sessions_per_step_mean": round(sch.sessions_served / max(sch.steps, 1), 2),
+        n3 = len(lats) // 3                                                  # served first / last: a queue that grows shows up as a drift between them
+        first, third = np.asarray(lats[:n3]) * 1e3, np.asarray(lats[-n3:]) * 1e3
+        drift = float(third.mean() - first.mean())
+        return {"sessions": N, "batches": int(len(l)), "first_third_mean_ms": round(float(first.mean()), 1), "last_third_mean_ms": round(float(third.mean()), 1),
+                "all_mean_ms": round(float(l.mean()), 1), "p50_ms": round(float(l[len(l) // 2]), 1), "p99_ms": round(p99, 1), "max_ms": round(float(l[-1]), 1),
+                "sustained": bool(p99 <= P * 1e3 and drift <= 0.1 * P * 1e3), "sessions_per_step_mean": round(sch.sessions_served / max(sch.steps, 1), 2),
                 "gpu_busy_frac": round(sch.busy_s / wall, 3), "frames_per_s": round(N * periods * B / wall, 1)}
 
     cap = max(int(free_fps / 25.0), 1)
     trials, best = [], None
-    cands = [n for n in (cap + 1, cap, cap - 1, cap - 2, cap - 3, cap - 4, cap - 6, cap - 8, cap - 11) if n >= 1][:max_trials]
-    for N in cands:
-        r = trial(N)
-        trials.append(r)
-        if r["sustained"]:
+    r = trial(cap + 1)                    # one more session than the free-running rate can feed: expected to fail ...
+    trials.append(r)
+    if r["sustained"]:                    # ... and when it does not (the free-running figure was the low one), walk UP to the first failure
+        best = r
+        for N in range(cap + 2, cap + 5):
+            r = trial(N)
+            trials.append(r)
+            if not r["sustained"]:
+                break
             best = r
-            break
+    else:
+        cands = [n for n in (cap, cap - 1, cap - 2, cap - 3, cap - 4, cap - 6, cap - 8, cap - 11) if n >= 1][:max_trials]
+        for N in cands:
+            r = trial(N)
+            trials.append(r)
+            if r["sustained"]:
+                best = r
+                break
     rep = {"criterion": f"p99 latency of a session's {B}-frame batch (arrival of its Whisper chunks -> uint8 frames complete in HBM) <= {B} x 40 ms = {P * 1e3:.0f} ms, "
-                        f"{periods} batches per session in real time, seeded random phases",
+                        f"and no queue growth (mean latency of the last third of the batches - of the first third <= {P * 100:.0f} ms); {periods} batches per session in real time, seeded random phases",
            "scheduler": f"mere_fusion_amd.muse_driver.SessionScheduler: oldest first, <= {S} sessions per step, a partly filled step waits <= {P * 250:.0f} ms",
            "max_sessions_sustained": best["sessions"] if best else None,
            "at_max": best, "trials": trials, "step_ms_by_sessions_in_step": step_ms, "warmup_s": round(warm_s, 1)}
     if best is None:
-        rep["note"] = f"none of N = {cands} held the bound; see trials"
+        rep["note"] = "no N tried held the bound; see trials"
     return rep
 
 

@@ -760,6 +760,31 @@ def test_hip_torso_full_frame_properties(lib_built):
 
 
 @pytest.mark.gpu
+def test_hip_torso_fused_kernel_matches_gemm_chain(lib_built, monkeypatch):
+    """k_torso_fused (one fp32 kernel, the default) against the twelve-launch bf16x3 GEMM chain it replaces (MF_TORSO=gemm) on a 256 x 256 frame
+    with a [N, 3] background: colours, alpha and the deform field agree to the chain's own precision, and the mask (alpha == 0) is the same set."""
+    from mere_fusion_amd import weights as W
+    from mere_fusion_amd.ernerf.field import grid_geometry
+    from mere_fusion_amd.ernerf.torso import HipTorso
+    offs, _ = grid_geometry(num_levels=16, base_resolution=16, log2_hashmap_size=16, desired_resolution=2048)
+    sd = W.make_ernerf_torso_state_dict(int(offs[-1]), 2)
+    n = 256
+    u = (torch.arange(n, dtype=torch.float32) + 0.5) / n * 2 - 1
+    yy, xx = torch.meshgrid(u, u, indexing="ij")
+    coords = torch.stack([xx, yy], -1).reshape(-1, 2).cuda()
+    bg = torch.rand(n * n, 3, generator=torch.Generator().manual_seed(3)).cuda()
+    pose = torch.eye(4)[None]
+    pose[0, :3, 3] = torch.tensor([0.1, -0.2, 0.3])
+    fused = HipTorso(sd, max_pixels=n * n).run_torso(coords, pose, bg)
+    monkeypatch.setenv("MF_TORSO", "gemm")
+    chain = HipTorso(sd, max_pixels=n * n).run_torso(coords, pose, bg)
+    for k in ("bg_color", "torso_alpha", "deform"):
+        assert (fused[k] - chain[k]).abs().max().item() <= 3e-4, k
+    assert torch.equal(fused["torso_alpha"] == 0, chain["torso_alpha"] == 0)
+    assert 0.05 < (fused["torso_alpha"] > 0).float().mean().item() < 0.95
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("W", [48, 512])
 def test_hip_device_controlled_loop_matches_host_loop(lib_built, W):
     """mf_nerf_head_render (round control on the device, no host sync) against the host-driven loop: every ray sees the same samples,
