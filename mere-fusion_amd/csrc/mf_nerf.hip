@@ -159,6 +159,13 @@ __global__ __launch_bounds__(NT) void k_loop_march(const int* __restrict__ ctl, 
     if (base >= n_alive || n_step == 0) return;
     __shared__ float s_t[LOOP_MAX_STEP][NT], s_dt[LOOP_MAX_STEP][NT], s_o[3][NT], s_d[3][NT];
     __shared__ int s_cnt[NT];
+    // FAST: the Morton code's bit spreading as a 128-entry table (H <= 128: mf_march_rays' bound) -- the march is VALU-bound (a ray crossing the
+    // volume evaluates ~100 positions of ~80 instructions), and 3 LDS reads replace 24 of them
+    __shared__ uint32_t s_spread[128];
+    if (FAST) {
+        if (threadIdx.x < 128) s_spread[threadIdx.x] = expand_bits(threadIdx.x);
+        __syncthreads();
+    }
     const uint32_t n = threadIdx.x + base;
     uint32_t step = 0;
     if (n < n_alive) {
@@ -178,44 +185,66 @@ __global__ __launch_bounds__(NT) void k_loop_march(const int* __restrict__ ctl, 
         const float dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / (float)H;
         const float dt_min = fminf(dt_max, 2 * SQRT3 / (float)max_steps);
         const float mip_bound0 = fminf(1.f, bound), mip_rbound0 = 1 / mip_bound0, halfH = 0.5f * (float)H;
-        while (t < far && step < n_step) {
-            const float x = clampf_(ox + t * dx, -bound, bound);
-            const float y = clampf_(oy + t * dy, -bound, bound);
-            const float z = clampf_(oz + t * dz, -bound, bound);
-            const float dt = clampf_(t * dt_gamma, dt_min, dt_max);
-            float mip_bound, mip_rbound;
-            int nx, ny, nz;
-            uint32_t gi;
+        // voxel of the position at parameter tj: clamped position, cell, occupancy bit index, mip bound -- the reference's operations in its order
+        auto cell = [&](float tj, float dtj, float& x, float& y, float& z, int& nx, int& ny, int& nz, uint32_t& gi, float& mip_bound) __attribute__((always_inline)) {
+            x = clampf_(ox + tj * dx, -bound, bound);
+            y = clampf_(oy + tj * dy, -bound, bound);
+            z = clampf_(oz + tj * dz, -bound, bound);
             if constexpr (FAST) {
-                mip_bound = mip_bound0; mip_rbound = mip_rbound0;
-                nx = (int)clampf_((x * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
-                ny = (int)clampf_((y * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
-                nz = (int)clampf_((z * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
-                gi = morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+                mip_bound = mip_bound0;
+                nx = (int)clampf_((x * mip_rbound0 + 1) * halfH, 0.0f, (float)(H - 1));
+                ny = (int)clampf_((y * mip_rbound0 + 1) * halfH, 0.0f, (float)(H - 1));
+                nz = (int)clampf_((z * mip_rbound0 + 1) * halfH, 0.0f, (float)(H - 1));
+                gi = s_spread[nx] | (s_spread[ny] << 1) | (s_spread[nz] << 2);       // = morton3d(nx, ny, nz)
             } else {
-                const int la = mip_from_pos(x, y, z, (float)C), lb = mip_from_dt(dt, (float)H, (float)C);
+                const int la = mip_from_pos(x, y, z, (float)C), lb = mip_from_dt(dtj, (float)H, (float)C);
                 const int level = la > lb ? la : lb;
                 mip_bound = fminf(scalbnf(1.f, level), bound);
-                mip_rbound = 1 / mip_bound;
+                const float mip_rbound = 1 / mip_bound;
                 nx = (int)clampf_((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
                 ny = (int)clampf_((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
                 nz = (int)clampf_((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
                 gi = (uint32_t)((float)level * H3 + (float)morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
             }
-            const bool occ = grid[gi / 8] & (1 << (gi % 8));
-            if (occ) {
-                s_t[step][threadIdx.x] = t; s_dt[step][threadIdx.x] = dt;
-                t += dt;
-                step++;
-            } else {
-                const float tx = ((((float)nx + 0.5f + 0.5f * signf_(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
-                const float ty = ((((float)ny + 0.5f + 0.5f * signf_(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
-                const float tz = ((((float)nz + 0.5f + 0.5f * signf_(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
-                const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-                do {
-                    t += clampf_(t * dt_gamma, dt_min, dt_max);
-                } while (t < tt);
+        };
+        // The reference's loop (raymarching.cu:862-925) reads one occupancy bit per iteration and the next position depends on it: a ray
+        // crossing empty space is a chain of ~100 dependent loads.  But every parameter it ever visits is a member of ONE sequence that does
+        // not depend on occupancy -- t_{k+1} = t_k + clamp(t_k dt_gamma, dt_min, dt_max): an occupied cell advances by exactly that step, an
+        // empty one by that step repeated until the cell's exit (`do t += ...; while (t < tt)`).  So the bits of the next MB members are fetched
+        // together (MB independent loads, one round trip) and the serial walk over them is pure arithmetic: same float operations in the same
+        // order, same samples, an eighth of the round trips.
+        constexpr int MB = 8;
+        float tt = -FLT_MAX;                         // exit parameter of the empty cell being skipped (the do-while above); none yet
+        bool done = !(t < far && step < n_step);
+        while (!done) {
+            float ts[MB + 1], ds[MB], xs[MB], ys[MB], zs[MB], mbs[MB];
+            int nxs[MB], nys[MB], nzs[MB];
+            uint32_t occ = 0;
+            ts[0] = t;
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                ds[j] = clampf_(ts[j] * dt_gamma, dt_min, dt_max);
+                ts[j + 1] = ts[j] + ds[j];
+                uint32_t gi;
+                cell(ts[j], ds[j], xs[j], ys[j], zs[j], nxs[j], nys[j], nzs[j], gi, mbs[j]);
+                occ |= (uint32_t)((grid[gi / 8] >> (gi % 8)) & 1) << j;
             }
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                if (done || ts[j] < tt) continue;                             // finished, or still inside the skipped cell
+                if (!(ts[j] < far && step < n_step)) { done = true; continue; }   // the while condition, tested where the reference tests it
+                if ((occ >> j) & 1) {
+                    s_t[step][threadIdx.x] = ts[j]; s_dt[step][threadIdx.x] = ds[j];
+                    step++;
+                    tt = -FLT_MAX;
+                } else {
+                    const float tx = ((((float)nxs[j] + 0.5f + 0.5f * signf_(dx)) * rH * 2 - 1) * mbs[j] - xs[j]) * rdx;
+                    const float ty = ((((float)nys[j] + 0.5f + 0.5f * signf_(dy)) * rH * 2 - 1) * mbs[j] - ys[j]) * rdy;
+                    const float tz = ((((float)nzs[j] + 0.5f + 0.5f * signf_(dz)) * rH * 2 - 1) * mbs[j] - zs[j]) * rdz;
+                    tt = ts[j] + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+                }
+            }
+            t = ts[MB];
         }
     }
     s_cnt[threadIdx.x] = (int)step;
@@ -687,7 +716,7 @@ int mf_nerf_loop_round(int* ctl, int N, int max_steps, const int* alive_in, int*
     if (phase == 0)            // march (the round's n_alive / n_step were set by k_loop_init or the previous round's tail)
     {
         const char* e = getenv("MF_NERF_MARCH");                                 // "generic" forces the reference-shaped index arithmetic (tests)
-        const bool fast = cascades == 1 && (grid_size & (grid_size - 1)) == 0 && !(e && !strcmp(e, "generic"));
+        const bool fast = cascades == 1 && (grid_size & (grid_size - 1)) == 0 && grid_size <= 128 && !(e && !strcmp(e, "generic"));   // 128: k_loop_march's spread table
         if (fast)
             hipLaunchKernelGGL(k_loop_march<true>, dim3(blocks(N)), dim3(NT), 0, s, (const int*)ctl, alive_in, rays_t, rays_o, rays_d, bound, dt_gamma,
                                (uint32_t)max_steps, cascades, grid_size, bitfield, fars, xyzs, dirs, deltas);
