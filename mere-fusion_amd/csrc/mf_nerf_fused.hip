@@ -15,7 +15,7 @@
 //   * torch.cat is an ordering of K blocks: sigma_net reads [enc_x | enc_a * aud_ch_att | e * eye_att], colour_net reads
 //     [geo_feat (sigma_net blocks 0..4, its row 0 = log sigma has zero weights) | SH | individual code].
 //   * every weight fragment (63 x 1 KB x planes) sits in LDS, lane-linear, loaded once per workgroup; workgroups are persistent
-//     over 128-sample tiles (8 waves x 16 samples).
+//     over 256-sample tiles (16 waves x 16 samples).
 //   * each lane gathers only the grid features its own B fragments need (channels 4g..4g+3 of each 16-block): 36 bilinear
 //     lookups per sample spread over its 4 lanes, straight from the L2-resident tables.
 #include "mf_nn.h"
@@ -31,7 +31,9 @@ namespace {
 
 constexpr int NLEV = 12;
 constexpr int NSF = 1;          // 16-sample fragments per wave (2 halves the weight reads per MFMA but spills past 256 VGPRs)
-constexpr int TILE = 8 * 16 * NSF;   // samples per workgroup tile
+constexpr int NWAVE = 16;            // waves per workgroup: ONE workgroup fits a CU (126 KB of weight fragments), so its size IS the occupancy --
+                                     // 16 waves = 4 per SIMD hide the gather latency twice as well as 8 did (the kernel needs 120 VGPRs <= 128)
+constexpr int TILE = NWAVE * 16 * NSF;   // samples per workgroup tile
 // fragment table: (first fragment, out blocks, k-steps) per layer, fragment = blk * nks + ks
 enum { L_AUD0, L_AUD1, L_EYE0, L_EYE1, L_SIG0, L_SIG1, L_SIG2, L_COL0, L_COL1, NLAYER };
 constexpr int L_NBLK[NLAYER] = {4, 2, 1, 1, 4, 4, 5, 4, 1};
@@ -61,12 +63,20 @@ __device__ __forceinline__ float bff(uint32_t h) { return __uint_as_float(h << 1
 
 // a B fragment half (4 channels of one 16-block): bf16 (hi, lo) pairs of 4 fp32 values -> 2 + 2 dwords
 struct Half { uint32_t h[2], l[2]; };
+// (hi, lo) split of two values with gfx950's packed converter: v_cvt_pk_bf16_f32 rounds to nearest even exactly as fbf() does, and the whole
+// split is 5 instructions where the integer form needs ~23 -- the kernel packs ~30 of these quads per 16 samples and is VALU-bound
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float v0, float v1, uint32_t& h, uint32_t& l) {
+    const f32x2_t v = {v0, v1};
+    h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    const f32x2_t back = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - back, bf16x2_t));
+}
 __device__ __forceinline__ Half pack4(float v0, float v1, float v2, float v3) {
-    const uint32_t a = fbf(v0), b = fbf(v1), c = fbf(v2), d = fbf(v3);
     Half r;
-    r.h[0] = a | (b << 16); r.h[1] = c | (d << 16);
-    r.l[0] = fbf(v0 - bff(a)) | (fbf(v1 - bff(b)) << 16);
-    r.l[1] = fbf(v2 - bff(c)) | (fbf(v3 - bff(d)) << 16);
+    split2(v0, v1, r.h[0], r.l[0]);
+    split2(v2, v3, r.h[1], r.l[1]);
     return r;
 }
 __device__ __forceinline__ Half zero_half() { Half r; r.h[0] = r.h[1] = r.l[0] = r.l[1] = 0u; return r; }
@@ -79,34 +89,41 @@ __device__ __forceinline__ BFrag join(const Half& p0, const Half& p1) {
 }
 
 // per-level constants in LDS: the level index differs from lane to lane, which kernel-argument arrays cannot serve
-struct LevelTab { float scale[NLEV]; uint32_t resolution[NLEV], offset[NLEV], hashmap_size[NLEV]; };
+struct LevelTab { float scale[NLEV]; uint32_t resolution[NLEV], offset[NLEV], hashmap_size[NLEV], mask[NLEV]; };   // mask: hashmap_size - 1 if that is a power of two, else 0
 
 // one grid feature: level `lv` of plane table `tab` at (u, v) in [0, 1]^2 (gridencoder.cu:76-165 with D = 2, C = 1, hash grid)
 __device__ __forceinline__ float grid_feat(const LevelTab& a, const float* __restrict__ tab, int lv, float u, float v) {
     if (u < 0.f || u > 1.f || v < 0.f || v > 1.f) return 0.f;
     const float scale = a.scale[lv];
-    const uint32_t res = a.resolution[lv], hs = a.hashmap_size[lv];
+    const uint32_t res = a.resolution[lv], hs = a.hashmap_size[lv], msk = a.mask[lv];
     const float* g = tab + a.offset[lv];
     float pu = u * scale + 0.5f, pv = v * scale + 0.5f;
     const float fu = floorf(pu), fv = floorf(pv);
     const uint32_t iu = (uint32_t)fu, iv = (uint32_t)fv;
     pu -= fu; pv -= fv;
-    float r = 0.f;
-#pragma unroll
-    for (int idx = 0; idx < 4; ++idx) {
-        const uint32_t x = iu + (idx & 1), y = iv + (idx >> 1);
-        const float w = ((idx & 1) ? pu : 1.f - pu) * ((idx >> 1) ? pv : 1.f - pv);
-        // get_grid_index: dense while the running stride fits the table, else the 2-prime hash (gridencoder.cu:54-72)
-        uint32_t index = x, stride = res + 1;
-        if (stride <= hs) { index += y * stride; stride *= res + 1; }
-        if (stride > hs) index = x ^ (y * 2654435761u);
-        r += w * g[index % hs];
-    }
+    // get_grid_index (gridencoder.cu:54-72) for the four corners at once.  With s = res + 1: the level is DENSE iff s * s <= hashmap_size (then
+    // index = x + y s, below s * s, so `% hashmap_size` is the identity); otherwise index = x ^ (y * 2654435761) reduced mod hashmap_size -- a
+    // mask when the table is a power of two (2^log2_hashmap_size: grid.py:108-123), the division for any other size.  One multiply per form and
+    // level instead of one of each per corner, and no 32-bit urem (~25 instructions) on the 144 lookups of a sample: the kernel is VALU-bound.
+    const uint32_t s1 = res + 1;
+    const uint32_t d00 = iu + iv * s1;
+    const uint32_t h0 = iv * 2654435761u, h1 = h0 + 2654435761u;
+    uint32_t i00 = iu ^ h0, i10 = (iu + 1) ^ h0, i01 = iu ^ h1, i11 = (iu + 1) ^ h1;
+    if (msk) { i00 &= msk; i10 &= msk; i01 &= msk; i11 &= msk; }
+    else { i00 %= hs; i10 %= hs; i01 %= hs; i11 %= hs; }
+    const bool dense = s1 * s1 <= hs;
+    i00 = dense ? d00 : i00; i10 = dense ? d00 + 1 : i10; i01 = dense ? d00 + s1 : i01; i11 = dense ? d00 + s1 + 1 : i11;
+    const float qu = 1.f - pu, qv = 1.f - pv;
+    float r = 0.f;                     // corner order and arithmetic of the reference's loop: (0,0), (1,0), (0,1), (1,1)
+    r += (qu * qv) * g[i00];
+    r += (pu * qv) * g[i10];
+    r += (qu * pv) * g[i01];
+    r += (pu * pv) * g[i11];
     return r;
 }
 
 template <bool X3>
-__global__ __launch_bounds__(512) void k_nerf_field_fused(const FusedArgs a) {
+__global__ __launch_bounds__(NWAVE * 64) void k_nerf_field_fused(const FusedArgs a) {
     constexpr int NP = X3 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // NFRAG * NP KiB of weight fragments
     const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, g = lane >> 4;
@@ -115,9 +132,9 @@ __global__ __launch_bounds__(512) void k_nerf_field_fused(const FusedArgs a) {
     const int M = a.M_dev ? *a.M_dev : a.M;
     const int ntiles = (M + TILE - 1) / TILE;
     if ((int)blockIdx.x >= ntiles) return;          // also the "round already finished" case of the device-controlled loop (M == 0)
-    for (int i = tid; i < NFRAG * NP * 64; i += 512)
+    for (int i = tid; i < NFRAG * NP * 64; i += NWAVE * 64)
         reinterpret_cast<u32x4*>(smem)[i] = reinterpret_cast<const u32x4*>(a.w)[i];
-    if (tid < NLEV) { lt.scale[tid] = a.scale[tid]; lt.resolution[tid] = a.resolution[tid]; lt.offset[tid] = a.offset[tid]; lt.hashmap_size[tid] = a.hashmap_size[tid]; }
+    if (tid < NLEV) { lt.scale[tid] = a.scale[tid]; lt.resolution[tid] = a.resolution[tid]; lt.offset[tid] = a.offset[tid]; lt.hashmap_size[tid] = a.hashmap_size[tid]; lt.mask[tid] = (a.hashmap_size[tid] & (a.hashmap_size[tid] - 1)) == 0 ? a.hashmap_size[tid] - 1 : 0u; }
     __syncthreads();
     const float* const emb0 = a.emb[0];
     const float* const emb1 = a.emb[1];
@@ -482,8 +499,8 @@ int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3
         attr_done[x3] = true;
     }
     const int grid = std::min(a.ntiles, 256);
-    if (x3) hipLaunchKernelGGL(k_nerf_field_fused<true>, dim3(grid), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL(k_nerf_field_fused<false>, dim3(grid), dim3(512), lds, s, a);
+    if (x3) hipLaunchKernelGGL(k_nerf_field_fused<true>, dim3(grid), dim3(NWAVE * 64), lds, s, a);
+    else hipLaunchKernelGGL(k_nerf_field_fused<false>, dim3(grid), dim3(NWAVE * 64), lds, s, a);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
