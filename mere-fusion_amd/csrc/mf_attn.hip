@@ -38,9 +38,7 @@ struct AttnArgs {
 namespace {
 
 __device__ __forceinline__ uint32_t f2bf_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    return (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)f);      // round to nearest even in hardware (v_cvt_pk_bf16_f32)
 }
 __device__ __forceinline__ float bf2f_(uint32_t h16) { return __uint_as_float(h16 << 16); }
 

@@ -45,9 +45,7 @@ constexpr int ENC = 36, AUD = 32, GEO = 64, SHD = 16;
 constexpr int SI_C = 72, CI_C = 96, CI_SH = 72, CI_IND = 88;
 
 __device__ __forceinline__ uint32_t qf2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    return (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)f);      // round to nearest even in hardware (v_cvt_pk_bf16_f32)
 }
 __device__ __forceinline__ float qbf2f(uint32_t h) { return __uint_as_float(h << 16); }
 __device__ __forceinline__ void put(bf16_t* hi, bf16_t* lo, int64_t o, float v) {
