@@ -6,6 +6,7 @@ The reference's own renderer keeps working unchanged on top of the extension shi
 bench.py / smoke() / the tests, and it is what `nerfreal.py:render` amounts to per frame once torso and audio nets are fixed.
 The compaction `rays_alive[rays_alive >= 0]` (renderer.py:266) and its host sync are kept as in the reference."""
 import ctypes as C
+import os
 
 import torch
 
@@ -31,8 +32,8 @@ class HipHeadRenderer:
     def render(self, rays_o, rays_d, auds, bg_coords, poses, eye, bg_color=None, **kw):
         """One frame as `NeRFRenderer.render` -> `run_cuda` does it (renderer.py:657-677, 158-291): audio window -> enc_a (+ the lip
         smoothing EMA of :190-194), fixed individual code 0 (:197-202), head loop, torso / background mix (:272-277).
-        loop="device" runs the head with device-side round control and the torso concurrently on a second stream (the head only needs
-        the torso's colours for the final mix)."""
+        loop="device" runs the head with device-side round control; MF_NERF_TORSO_STREAM=1 puts the torso on a second stream beside it (the
+        head only needs the torso's colours for the final mix)."""
         def audio_part():
             enc_a = self.audio.encode_audio(auds) if self.audio is not None else auds
             if enc_a is not None and self.smooth_lips:
@@ -41,7 +42,9 @@ class HipHeadRenderer:
                 self.enc_a = enc_a
             return enc_a
         device_loop = kw.pop("loop", "host") == "device"
-        if device_loop and self.torso is not None:
+        # torso on a second stream beside the head: paid while the torso was a ~0.3 ms launch chain; as one 71 us kernel the cross-stream
+        # dependency costs more than the overlap returns (0.737 vs 0.711 ms per frame), so it is opt-in now (MF_NERF_TORSO_STREAM=1)
+        if device_loop and self.torso is not None and os.environ.get("MF_NERF_TORSO_STREAM", "0") == "1":
             cur = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream()
