@@ -218,6 +218,13 @@ int mf_wav2lip::ensure_capacity(int batch) {
 }
 
 int mf_wav2lip::run_body(int batch, hipStream_t s) {
+    static const bool fork = [] { const char* e = getenv("MF_W2L_FORK"); return !e || e[0] != '0'; }();   // MF_W2L_FORK=0: one serial chain (A/B)
+    if (!fork) {
+        for (int g = 0; g < 3; ++g)
+            for (auto& st : steps)
+                if (st->group == g) { int rc = mf_conv_launch(&st->plan, st->in, st->out, st->res, batch, s); if (rc) return rc; }
+        return MF_OK;
+    }
     // fork: audio encoder on the side stream beside the face encoder, join before the decoder
     MF_HIP(hipEventRecord(ev_fork, s));
     MF_HIP(hipStreamWaitEvent(side, ev_fork, 0));
