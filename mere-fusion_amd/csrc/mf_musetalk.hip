@@ -51,6 +51,17 @@ struct Net {
     struct Tunable { ConvPlan* p; ActView in, out, res; int op; };
     std::vector<Tunable> tunables;
     bool autotune = false;
+    // Side branches of the schedule: an op whose result is not needed by its successors in the list -- the hoisted k | v GEMM, a resnet's 1x1
+    // shortcut conv -- runs on a second stream beside the chain (a parallel branch of the captured graph) and is joined right before its first
+    // consumer.  The UNet's batch-8 launches leave most CUs idle, so the branch costs the chain nothing (Wav2Lip's forked audio encoder is worth
+    // 11 % of its step the same way).  MF_UNET_FORK=0: everything in line.
+    std::map<int, int> side_ops;                 // op index -> branch number
+    std::multimap<int, int> join_before;         // op index -> branch to wait for before that op
+    std::vector<hipEvent_t> ev_fork, ev_join;
+    hipStream_t side_stream = nullptr;
+    bool fork_on = true;
+    void mark_side(int op) { side_ops[op] = (int)side_ops.size(); }
+    void join_here(int op) { join_before.insert({(int)ops.size(), side_ops.at(op)}); }   // ... before the NEXT op pushed
     // the last conv and the view it filled: a GroupNorm that reads exactly that view next takes its statistics from the conv's launch
     // (ConvPlan::out_stats: epilogue, split-K combine, or a statistics pass behind the conv) instead of running its own pass over the tensor.
     // Cleared by any other op that writes the buffer.
@@ -67,7 +78,7 @@ struct Net {
     }
     // Cross-attention keys / values depend on the audio tokens only: the k | v projections of EVERY transformer block as one GEMM at the head of
     // the schedule (kv_all = [ctx_len][sum of 2 C]) instead of one small launch per block inside the chain (16 x ~14 us in the UNet at batch 8).
-    ActBuf* kv_all = nullptr; int kv_off = 0, kv_op = -1; std::vector<float> kv_w; ActView kv_ctx{};
+    ActBuf* kv_all = nullptr; int kv_off = 0, kv_op = -1; std::vector<float> kv_w; ActView kv_ctx{}; bool kv_joined = false;
     bool q_allowed = false;     // the f16 + FP6 conv format: the VAE decoder's resnets (set by the builder of a network whose parity was established with it)
     int next_pad_hi = 0;        // consumed by the next conv(): extra zero rows / columns bottom-right (the VAE encoder's Downsample2D)
     std::string err;
@@ -78,6 +89,9 @@ struct Net {
         for (auto& b : bufs) { if (b->hi) (void)hipFree(b->hi); if (b->lo) (void)hipFree(b->lo); }
         for (void* d : dev) (void)hipFree(d);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+        for (hipEvent_t e : ev_fork) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_join) (void)hipEventDestroy(e);
         if (ev_in) (void)hipEventDestroy(ev_in);
         if (ev_out) (void)hipEventDestroy(ev_out);
     }
@@ -387,17 +401,22 @@ struct Net {
                 tb[o] = (float)a;
             }
         }
-        if ((rc = gn_conv(p + ".norm1", p + ".conv1", x, t1, ActView{c1, 0, cout}, cin, cout, groups, eps, ActView{}, tb.empty() ? nullptr : &tb))) return rc;
+        // the 1x1 shortcut reads only the block's input: first in the list, on the side branch, joined where conv2 adds it
         ActView res = x;
+        int sc_op = -1;
         if (has(p + ".conv_shortcut.weight")) {
             ActBuf* sc = tmp("rn.sc", cout, H, W, 1);
             if (!sc) return MF_ERR_HIP;
             if ((rc = conv(p + ".conv_shortcut", x, ActView{sc, 0, cout}, cin, cout, 1, 1, 0, 0, ActView{}))) return rc;
             res = ActView{sc, 0, cout};
+            sc_op = (int)ops.size() - 1;
+            mark_side(sc_op);
         } else if (cin != cout) {
             err = p + ": cin != cout but no conv_shortcut in the state dict";
             return MF_ERR_INVALID;
         }
+        if ((rc = gn_conv(p + ".norm1", p + ".conv1", x, t1, ActView{c1, 0, cout}, cin, cout, groups, eps, ActView{}, tb.empty() ? nullptr : &tb))) return rc;
+        if (sc_op >= 0) join_here(sc_op);
         return gn_conv(p + ".norm2", p + ".conv2", ActView{c1, 0, cout}, t2, y, cout, cout, groups, eps, res);
     }
 
@@ -446,6 +465,7 @@ struct Net {
                 if ((rc = linear_raw(w.data(), nullptr, ctx, ActView{kv, 0, 2 * C}, X, 2 * C, ActView{}))) return rc;
             }
         }
+        if (kk.buf == kv_all && kv_op >= 0 && !kv_joined) { join_here(kv_op); kv_joined = true; }
         if ((rc = attention(ActView{qkv, 0, C}, kk, vv, ActView{ao, 0, C}, heads))) return rc;
         if ((rc = conv(t + ".attn2.to_out.0", ActView{ao, 0, C}, ActView{hA, 0, C}, C, C, 1, 1, 0, 0, ActView{hB, 0, C}))) return rc;
         // GEGLU feed-forward
@@ -499,6 +519,8 @@ struct Net {
         kv_ctx = ctx; kv_off = 0; kv_w.clear();
         push("cross-attention k | v of every block", "(placeholder)", 0.0, [](int, hipStream_t) { return MF_OK; });
         kv_op = (int)ops.size() - 1;
+        mark_side(kv_op);                      // depends on the audio tokens only: a side branch until the first cross-attention
+        kv_joined = false;
         return MF_OK;
     }
     // ... and fill it once every block has handed in its rows
@@ -563,7 +585,37 @@ struct Net {
 
     // ---- execution ----------------------------------------------------------------------------------------
     int run_body(int B, hipStream_t s) {
-        for (auto& op : ops) { int rc = op(B, s); if (rc) return rc; }
+        if (!fork_on || side_ops.empty()) {
+            for (auto& op : ops) { int rc = op(B, s); if (rc) return rc; }
+            return MF_OK;
+        }
+        while (ev_fork.size() < side_ops.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            MF_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            MF_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            ev_fork.push_back(a); ev_join.push_back(b);
+        }
+        std::vector<char> open(side_ops.size(), 0);
+        for (size_t i = 0; i < ops.size(); ++i) {
+            auto jr = join_before.equal_range((int)i);
+            for (auto it = jr.first; it != jr.second; ++it)
+                if (open[it->second]) { MF_HIP(hipStreamWaitEvent(s, ev_join[it->second], 0)); open[it->second] = 0; }
+            auto so = side_ops.find((int)i);
+            if (so == side_ops.end()) {
+                int rc = ops[i](B, s);
+                if (rc) return rc;
+                continue;
+            }
+            const int k = so->second;
+            MF_HIP(hipEventRecord(ev_fork[k], s));
+            MF_HIP(hipStreamWaitEvent(side_stream, ev_fork[k], 0));
+            int rc = ops[i](B, side_stream);
+            if (rc) return rc;
+            MF_HIP(hipEventRecord(ev_join[k], side_stream));
+            open[k] = 1;
+        }
+        for (size_t k = 0; k < open.size(); ++k)                       // a branch nobody consumed inside the list still ends inside it
+            if (open[k]) MF_HIP(hipStreamWaitEvent(s, ev_join[k], 0));
         return MF_OK;
     }
     int run(int B, hipStream_t s) {
@@ -624,6 +676,9 @@ struct Net {
         MF_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
         MF_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
         MF_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+        MF_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+        const char* fk = std::getenv("MF_UNET_FORK");
+        fork_on = !(fk && fk[0] == '0');
         const char* ng = std::getenv("MF_NO_GRAPH");
         use_graph = !(ng && ng[0] == '1');
         const char* at = std::getenv("MF_AUTOTUNE");                 // read per handle (tests switch it per case); default on
