@@ -97,6 +97,14 @@ int mf_wav2lip_launch_info(const mf_wav2lip* h, int index, int batch, char* name
 int mf_wav2lip_profile(mf_wav2lip* h, const float* mel, const float* face, float* out, int batch,
                        int iters, float* ms_per_launch, void* stream);
 
+/* Launch configurations.  A forward never measures: at the first forward of a batch size every implicit-GEMM layer looks its signature up in the
+ * tuning table -- the file MF_TUNE_CACHE names, else `tune/gfx950.txt` beside the library (measured on an MI355X for the BASELINE.json shapes) --
+ * and a signature that is not there runs the cost model's pick.  mf_*_tune is the explicit warm-up a server calls at start-up for every batch size its
+ * loop can emit: it times each layer's tile x split-K x operand-path candidates on the buffers the last forward at `batch` filled (one forward at
+ * that batch must have run), records the winners in the table (appended to MF_TUNE_CACHE when set) and drops the hipGraph captured with the old
+ * ones.  Seconds per full-size network; results differ from the un-tuned ones by fp32 summation order only.  (ABI version 4) */
+int mf_wav2lip_tune(mf_wav2lip* h, int batch, void* stream);
+
 void mf_wav2lip_destroy(mf_wav2lip* h);
 
 /* ---- single fused convolution layer (building block, also the per-geometry test seam) ---- */
@@ -229,6 +237,7 @@ int mf_unet_forward(mf_unet* h, const float* latents, const float* audio, int ad
 int mf_unet_num_ops(const mf_unet* h);
 int mf_unet_op_info(const mf_unet* h, int i, char* name, int ncap, char* kernel, int kcap, double* flops_per_frame);
 int mf_unet_profile(mf_unet* h, int batch, int iters, float* ms_per_op, void* stream);
+int mf_unet_tune(mf_unet* h, int batch, void* stream);                       /* explicit launch-configuration warm-up: see mf_wav2lip_tune */
 void mf_unet_destroy(mf_unet* h);
 
 /* Replaces `AutoencoderKL.from_pretrained` for the DECODER half (musetalk/models/vae.py:24,96-108). */
@@ -240,6 +249,7 @@ int mf_vae_decode_latents(mf_vae* h, const float* latents, uint8_t* frames, floa
 int mf_vae_num_ops(const mf_vae* h);
 int mf_vae_op_info(const mf_vae* h, int i, char* name, int ncap, char* kernel, int kcap, double* flops_per_frame);
 int mf_vae_profile(mf_vae* h, int batch, int iters, float* ms_per_op, void* stream);
+int mf_vae_tune(mf_vae* h, int batch, void* stream);                         /* explicit launch-configuration warm-up: see mf_wav2lip_tune */
 void mf_vae_destroy(mf_vae* h);
 
 /* ---- ER-NeRF inference kernels (H6): the functions of the reference's four torch extensions ------------------
@@ -485,6 +495,7 @@ int mf_net_num_ops(const mf_net* h);
 double mf_net_flops_per_item(const mf_net* h);                                                           /* 2 x MACs of the convolutions, one batch item */
 int mf_net_set_input(mf_net* h, int buf, const float* nchw, int C, int batch, void* stream);             /* device fp32 [batch][C][H][W] */
 int mf_net_run(mf_net* h, int batch, void* stream);
+int mf_net_tune(mf_net* h, int batch, void* stream);                                                     /* explicit launch-configuration warm-up: see mf_wav2lip_tune */
 int mf_net_get_output(mf_net* h, int buf, int coff, int C, float* nchw, int batch, void* stream);        /* device fp32 [batch][C][H][W] */
 /* F.interpolate(x, (H, W), mode='bilinear', align_corners=True) of a channel slice -> device fp32 [batch][C][H][W] (model.py:257-259) */
 int mf_net_get_output_bilinear(mf_net* h, int buf, int coff, int C, float* nchw, int H, int W, int batch, void* stream);

@@ -87,6 +87,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_double)]),
     "mf_wav2lip_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.POINTER(C.c_float), C.c_void_p]),
+    "mf_wav2lip_tune": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mf_wav2lip_destroy": (None, [C.c_void_p]),
     "mf_conv2d_create": (C.c_int, [C.POINTER(MfConv2dDesc)] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(C.c_void_p)]),
     "mf_conv2d_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     "mf_net_flops_per_item": (C.c_double, [C.c_void_p]),
     "mf_net_set_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mf_net_run": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mf_net_tune": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mf_net_get_output": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_net_get_output_bilinear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mf_s3fd_maxout_bg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -128,12 +130,14 @@ SIGNATURES = {
     "mf_unet_num_ops": (C.c_int, [C.c_void_p]),
     "mf_unet_op_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double)]),
     "mf_unet_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "mf_unet_tune": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mf_unet_destroy": (None, [C.c_void_p]),
     "mf_vae_create": (C.c_int, [C.POINTER(MfVaeConfig), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mf_vae_decode_latents": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mf_vae_num_ops": (C.c_int, [C.c_void_p]),
     "mf_vae_op_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double)]),
     "mf_vae_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "mf_vae_tune": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mf_vae_destroy": (None, [C.c_void_p]),
     "mf_vae_encoder_create": (C.c_int, [C.POINTER(MfVaeConfig), C.POINTER(MfTensor), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mf_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

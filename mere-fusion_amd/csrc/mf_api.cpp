@@ -13,7 +13,7 @@ void mf_set_error(const char* fmt, ...) {
 
 extern "C" const char* mf_last_error(void) { return g_err; }
 
-extern "C" int mf_abi_version(void) { return 3; }
+extern "C" int mf_abi_version(void) { return 4; }
 
 extern "C" int mf_init(int device) {
     int n = 0;

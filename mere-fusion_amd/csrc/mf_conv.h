@@ -181,7 +181,11 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch);
 // fastest in p->tuned (layers that run on the halo kernels are left alone).  Eager only: call between two uncaptured forwards.  The cost model
 // behind mf_conv_pick_tile was fitted to one kernel generation; on the UNet's small GEMMs its pick is 0-15 % off per layer in either direction.
 int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, hipStream_t stream);
-// MF_AUTOTUNE=0 turns the measured configurations off (the cost model alone decides); default on
+// The table lookup alone (no launch, no timing): applies the configuration recorded for this layer's signature at this batch -- from MF_TUNE_CACHE, from the
+// table shipped beside the library (tune/gfx950.txt), or from an mf_conv_tune earlier in this process.  Returns 1 if the signature was found.  This is all a
+// forward ever does; measuring is explicit (mf_unet_tune / mf_vae_tune / mf_wav2lip_tune / mf_net_tune).
+int mf_conv_tune_lookup(ConvPlan* p, const ActView& in, int batch);
+// MF_AUTOTUNE=1 (development only): measure on the first forward at a batch size, as rounds 1-2 did; default off
 bool mf_autotune_enabled();
 // Algorithmic FLOPs of the layer (2 x MACs of the convolution itself; BN/ReLU/residual excluded).
 double mf_conv_flops(const ConvPlan* p, int batch);

@@ -21,6 +21,7 @@
 // main loop is predicated.  Layers with few output pixels and a long contraction are split along K
 // over blockIdx.y; their fp32 partial tiles are combined by k_splitk_epilogue.
 #include "mf_conv.h"
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1736,21 +1737,34 @@ __global__ __launch_bounds__(256) void k_tune_touch(const uint4* __restrict__ p,
 }  // namespace
 
 namespace {
-// Measured configurations by layer signature: layers of one shape share a measurement (the UNet's 188 GEMMs are ~60 distinct shapes), and
-// MF_TUNE_CACHE=<file> persists them across processes (a restarted server, or a profiled run that must not contain tuning launches).
+// Measured configurations by layer signature: layers of one shape share a measurement (the UNet's 188 GEMMs are ~60 distinct shapes).
+// Where they come from, in this order:
+//   MF_TUNE_CACHE=<file>   read at first use; every new measurement (mf_*_tune) is appended to it
+//   <library dir>/tune/gfx950.txt   the table shipped with the library for the BASELINE.json shapes (tools/make_tune_cache.py on an MI355X): with it a
+//                          process launches the same configurations -- hence the same fp32 summation order, the same output bits -- on every box
+// A forward NEVER measures (tuning inside run() stalled a serving loop for seconds at every new session count): it only looks its
+// layers up here; a shape that is not in the table runs the cost model's pick.  Measuring is an explicit call (mf_unet_tune, mf_vae_tune,
+// mf_wav2lip_tune, mf_net_tune), or, for development, MF_AUTOTUNE=1 (measure on the first forward at a batch size, as rounds 1-2 did).
 // bm == 0 records "the cost model's pick stays".
+std::string shipped_tune_table() {
+    Dl_info info{};
+    if (!dladdr(reinterpret_cast<const void*>(&mf_conv_tune), &info) || !info.dli_fname) return "";
+    std::string path = info.dli_fname;
+    const size_t slash = path.rfind('/');
+    return (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/tune/gfx950.txt";
+}
 std::map<std::string, ConvTuned>& tune_cache() {
     static std::map<std::string, ConvTuned> cache;
     static bool loaded = false;
     if (!loaded) {
         loaded = true;
-        if (const char* path = getenv("MF_TUNE_CACHE")) {
-            if (FILE* f = fopen(path, "r")) {
-                char key[256];
-                ConvTuned c{};
-                while (fscanf(f, "%255s %d %d %d %d %d %d", key, &c.tile.bm, &c.tile.bn, &c.tile.wgm, &c.tile.wgn, &c.tile.nsplit, &c.ld) == 7) cache[key] = c;
-                fclose(f);
-            }
+        const char* env = getenv("MF_TUNE_CACHE");
+        const std::string path = env ? std::string(env) : shipped_tune_table();
+        if (FILE* f = path.empty() ? nullptr : fopen(path.c_str(), "r")) {
+            char key[256];
+            ConvTuned c{};
+            while (fscanf(f, "%255s %d %d %d %d %d %d", key, &c.tile.bm, &c.tile.bn, &c.tile.wgm, &c.tile.wgn, &c.tile.nsplit, &c.ld) == 7) cache[key] = c;
+            fclose(f);
         }
     }
     return cache;
@@ -1764,31 +1778,40 @@ void tune_cache_store(const std::string& key, const ConvTuned& c) {
         }
     }
 }
-}  // namespace
-
-bool mf_autotune_enabled() {
-    static const bool on = [] { const char* e = getenv("MF_AUTOTUNE"); return !e || atoi(e) != 0; }();
-    return on;
-}
-
-int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, hipStream_t stream) {
+bool tunable_layer(const ConvPlan* p, int batch) {
     static const bool forced = getenv("MF_FORCE_TILE") || getenv("MF_FORCE_SPLIT");
-    if (p->halo || p->up_hi || forced) return MF_OK;                                 // halo-kernel layers keep their own tile choice
+    if (p->halo || p->up_hi || forced) return false;                                 // halo-kernel layers keep their own tile choice
     const int M = batch * p->Hq * p->Wq, N = p->d.cout;
-    if (N <= 32 || (M <= 16 && p->d.act != 5)) return MF_OK;                          // the narrow special tiles have no alternatives
-    p->tuned.erase(batch);
+    return !(N <= 32 || (M <= 16 && p->d.act != 5));                                  // the narrow special tiles have no alternatives
+}
+std::string tune_key(const ConvPlan* p, const ActView& in, int batch) {
     char keybuf[256];
     snprintf(keybuf, sizeof(keybuf), "g950:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d", p->precision, batch, p->d.cin, p->d.cout, p->d.kh, p->d.kw, p->d.stride_h, p->d.stride_w,
              p->d.pad_h, p->d.pad_w, p->d.transposed, p->d.output_padding, p->d.residual, p->d.act, p->d.in_h, p->d.in_w, p->d.upsample, p->d.pad_hi,
              in.buf ? in.buf->C : 0);
-    const std::string key = std::string(keybuf) + (p->out_stats ? ":s" : "");     // a layer that also leaves GroupNorm statistics times (and may pick) differently
-    {
-        auto it = tune_cache().find(key);
-        if (it != tune_cache().end()) {
-            if (it->second.tile.bm > 0) p->tuned[batch] = it->second;
-            return MF_OK;
-        }
-    }
+    return std::string(keybuf) + (p->out_stats ? ":s" : "");     // a layer that also leaves GroupNorm statistics times (and may pick) differently
+}
+}  // namespace
+
+bool mf_autotune_enabled() {
+    const char* e = getenv("MF_AUTOTUNE");         // (read at every use: tests switch it per case)
+    return e && atoi(e) != 0;
+}
+
+int mf_conv_tune_lookup(ConvPlan* p, const ActView& in, int batch) {
+    if (!tunable_layer(p, batch)) return 0;
+    auto it = tune_cache().find(tune_key(p, in, batch));
+    if (it == tune_cache().end()) return 0;
+    if (it->second.tile.bm > 0) p->tuned[batch] = it->second; else p->tuned.erase(batch);
+    return 1;
+}
+
+int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, hipStream_t stream) {
+    if (!tunable_layer(p, batch)) return MF_OK;
+    const std::string key = tune_key(p, in, batch);
+    if (mf_conv_tune_lookup(p, in, batch)) return MF_OK;                              // measured before (this process, MF_TUNE_CACHE, or the shipped table)
+    p->tuned.erase(batch);
+    const int M = batch * p->Hq * p->Wq, N = p->d.cout;
     const ConvTile base = mf_conv_pick_tile(p, batch);                                // what the cost model would launch
     int kt_min = p->ph[0].KT;
     for (int ph = 0; ph < p->nphase; ++ph) kt_min = std::min(kt_min, p->ph[ph].KT);

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <tuple>
@@ -50,7 +51,7 @@ struct Net {
     // implicit-GEMM layers with their bound views: measured launch configurations (mf_conv_tune) on the first forward at a batch size
     struct Tunable { ConvPlan* p; ActView in, out, res; int op; };
     std::vector<Tunable> tunables;
-    bool autotune = false;
+    std::set<int> looked_up;                     // (graph-less mode: batch sizes whose table lookup is done)
     // Side branches of the schedule: an op whose result is not needed by its successors in the list -- the hoisted k | v GEMM, a resnet's 1x1
     // shortcut conv -- runs on a second stream beside the chain (a parallel branch of the captured graph) and is joined right before its first
     // consumer.  The UNet's batch-8 launches leave most CUs idle, so the branch costs the chain nothing (Wav2Lip's forked audio encoder is worth
@@ -618,21 +619,53 @@ struct Net {
             if (open[k]) MF_HIP(hipStreamWaitEvent(s, ev_join[k], 0));
         return MF_OK;
     }
+    void name_kernel(const Tunable& t, int B) {
+        char kn[96];
+        mf_conv_kernel_name(t.p, B, kn, sizeof(kn));               // the measurement seam names the kernel that actually runs
+        info[t.op].kernel = kn;
+    }
+    // every buffer holds real data (a forward at this batch size has run): time each implicit-GEMM layer's launch configurations in place
+    int measure(int B, hipStream_t s) {
+        for (auto& t : tunables) {
+            int rc = mf_conv_tune(t.p, t.in, t.out, t.res, B, s);
+            if (rc) return rc;
+            name_kernel(t, B);
+        }
+        return MF_OK;
+    }
+    // The explicit warm-up behind mf_unet_tune / mf_vae_tune: measure at batch B on the data the last forward at B left in the buffers, then drop
+    // the graph captured with the old configurations (the next forward re-captures).  Seconds per full-size network: call it at start-up for every
+    // batch size the serving loop can emit, or ship MF_TUNE_CACHE.
+    int tune(int B, hipStream_t s) {
+        auto it = graphs.find(B);
+        if (use_graph && it == graphs.end()) { mf_set_error("tune: run one forward at batch %d first (the layers are timed on its buffers)", B); return MF_ERR_INVALID; }
+        MF_HIP(hipStreamSynchronize(cap_stream));
+        MF_HIP(hipStreamSynchronize(s));
+        int rc = measure(B, s);
+        if (rc) return rc;
+        MF_HIP(hipStreamSynchronize(s));
+        if (use_graph && it->second) { (void)hipGraphExecDestroy(it->second); it->second = nullptr; }
+        return MF_OK;
+    }
     int run(int B, hipStream_t s) {
-        if (!use_graph) return run_body(B, s);
+        if (!use_graph) {
+            if (!looked_up.count(B)) {
+                looked_up.insert(B);
+                for (auto& t : tunables)
+                    if (mf_conv_tune_lookup(t.p, t.in, B)) name_kernel(t, B);
+            }
+            return run_body(B, s);
+        }
         auto it = graphs.find(B);
         if (it == graphs.end()) {                                                        // first call eager
             graphs.emplace(B, nullptr);
+            // launch configurations: a table lookup per implicit-GEMM layer (MF_TUNE_CACHE / the shipped table), never a measurement -- a serving loop
+            // that meets a new batch size pays one eager forward and one capture, nothing more.  (MF_AUTOTUNE=1, development: measure here.)
+            for (auto& t : tunables)
+                if (mf_conv_tune_lookup(t.p, t.in, B)) name_kernel(t, B);
             int rc = run_body(B, s);
-            if (rc || !autotune) return rc;
-            // every buffer now holds real data: measure each implicit-GEMM layer's launch configurations in place, then run once more so that
-            // the outputs are those of the configurations the graph will capture
-            for (auto& t : tunables) {
-                if ((rc = mf_conv_tune(t.p, t.in, t.out, t.res, B, s))) return rc;
-                char kn[96];
-                mf_conv_kernel_name(t.p, B, kn, sizeof(kn));               // the measurement seam names the kernel that actually runs
-                info[t.op].kernel = kn;
-            }
+            if (rc || !mf_autotune_enabled()) return rc;
+            if ((rc = measure(B, s))) return rc;
             return run_body(B, s);
         }
         if (!it->second) {
@@ -681,8 +714,6 @@ struct Net {
         fork_on = !(fk && fk[0] == '0');
         const char* ng = std::getenv("MF_NO_GRAPH");
         use_graph = !(ng && ng[0] == '1');
-        const char* at = std::getenv("MF_AUTOTUNE");                 // read per handle (tests switch it per case); default on
-        autotune = !at || at[0] != '0';
         return MF_OK;
     }
 };
@@ -907,6 +938,10 @@ extern "C" int mf_unet_profile(mf_unet* h, int batch, int iters, float* ms_per_o
     MF_REQUIRE(h && ms_per_op && batch > 0 && batch <= h->net.cap && iters > 0, "unet_profile: bad argument");
     return h->net.profile(batch, iters, ms_per_op, (hipStream_t)stream);
 }
+extern "C" int mf_unet_tune(mf_unet* h, int batch, void* stream) {
+    MF_REQUIRE(h && batch >= 1 && batch <= h->net.cap, "unet_tune: batch %d exceeds the capacity %d", batch, h ? h->net.cap : 0);
+    return h->net.tune(batch, (hipStream_t)stream);
+}
 extern "C" void mf_unet_destroy(mf_unet* h) { delete h; }
 
 // ==========================================================================================================
@@ -1003,6 +1038,10 @@ extern "C" int mf_vae_op_info(const mf_vae* h, int i, char* name, int ncap, char
 extern "C" int mf_vae_profile(mf_vae* h, int batch, int iters, float* ms_per_op, void* stream) {
     MF_REQUIRE(h && ms_per_op && batch > 0 && batch <= h->net.cap && iters > 0, "vae_profile: bad argument");
     return h->net.profile(batch, iters, ms_per_op, (hipStream_t)stream);
+}
+extern "C" int mf_vae_tune(mf_vae* h, int batch, void* stream) {
+    MF_REQUIRE(h && batch >= 1 && batch <= h->net.cap, "vae_tune: batch %d exceeds the capacity %d", batch, h ? h->net.cap : 0);
+    return h->net.tune(batch, (hipStream_t)stream);
 }
 extern "C" void mf_vae_destroy(mf_vae* h) { delete h; }
 

@@ -327,17 +327,37 @@ extern "C" int mf_net_set_input(mf_net* h, int buf, const float* nchw, int C, in
     return mf_nchw_to_act(nchw, C, *b, batch, (hipStream_t)stream);
 }
 
+// the explicit warm-up: time every conv's launch configurations on the buffers the last run at this batch size filled, drop the graph captured with the old ones
+extern "C" int mf_net_tune(mf_net* h, int batch, void* stream) {
+    MF_REQUIRE(h && batch >= 1 && batch <= h->cap, "net_tune: batch %d exceeds the capacity %d", batch, h ? h->cap : 0);
+    hipStream_t s = (hipStream_t)stream;
+    auto it = h->graphs.find(batch);
+    MF_REQUIRE(!h->use_graph || it != h->graphs.end(), "net_tune: run the net once at batch %d first (the layers are timed on its buffers)", batch);
+    MF_HIP(hipStreamSynchronize(h->cap_stream));
+    MF_HIP(hipStreamSynchronize(s));
+    for (auto& t : h->tunables) {
+        int rc = mf_conv_tune(t.p, t.in, t.out, t.res, batch, s);
+        if (rc) return rc;
+    }
+    MF_HIP(hipStreamSynchronize(s));
+    if (h->use_graph && it->second) { (void)hipGraphExecDestroy(it->second); it->second = nullptr; }
+    return MF_OK;
+}
+
 extern "C" int mf_net_run(mf_net* h, int batch, void* stream) {
     MF_REQUIRE(h && batch >= 1 && batch <= h->cap, "net_run: batch %d exceeds the capacity %d", batch, h ? h->cap : 0);
     hipStream_t s = (hipStream_t)stream;
-    if (!h->use_graph) return h->run_body(batch, s);
+    if (!h->use_graph) {
+        for (auto& t : h->tunables) mf_conv_tune_lookup(t.p, t.in, batch);
+        return h->run_body(batch, s);
+    }
     auto it = h->graphs.find(batch);
     if (it == h->graphs.end()) {                                                                        // first call eager (split-K workspaces grow here)
         h->graphs.emplace(batch, nullptr);
+        for (auto& t : h->tunables) mf_conv_tune_lookup(t.p, t.in, batch);                              // launch configurations: a table lookup, never a measurement
         int rc = h->run_body(batch, s);
-        const char* at = getenv("MF_AUTOTUNE");
-        if (rc || (at && at[0] == '0')) return rc;
-        for (auto& t : h->tunables)                                                                     // measured launch configurations, then the real outputs again
+        if (rc || !mf_autotune_enabled()) return rc;
+        for (auto& t : h->tunables)                                                                     // MF_AUTOTUNE=1 (development): measure here, then the real outputs again
             if ((rc = mf_conv_tune(t.p, t.in, t.out, t.res, batch, s))) return rc;
         return h->run_body(batch, s);
     }

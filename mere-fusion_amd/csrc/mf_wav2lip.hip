@@ -147,6 +147,8 @@ struct mf_wav2lip {
     int ensure_capacity(int batch);
     int run_body(int batch, hipStream_t s);
     int run(int batch, hipStream_t s);
+    int measure(int batch, hipStream_t s);
+    int tune(int batch, hipStream_t s);
 };
 
 namespace {
@@ -239,21 +241,46 @@ int mf_wav2lip::run_body(int batch, hipStream_t s) {
     return MF_OK;
 }
 
+int mf_wav2lip::measure(int batch, hipStream_t s) {
+    MF_HIP(hipStreamSynchronize(side));
+    for (auto& st : steps) {
+        int rc = mf_conv_tune(&st->plan, st->in, st->out, st->res, batch, s);
+        if (rc) return rc;
+    }
+    return MF_OK;
+}
+
+// mf_wav2lip_tune: the explicit warm-up -- time every layer's launch configurations on the buffers the last forward at this batch size filled, drop the
+// graph captured with the old ones
+int mf_wav2lip::tune(int batch, hipStream_t s) {
+    auto it = graphs.find(batch);
+    if (use_graph && it == graphs.end()) { mf_set_error("wav2lip_tune: run one forward at batch %d first (the layers are timed on its buffers)", batch); return MF_ERR_INVALID; }
+    MF_HIP(hipStreamSynchronize(cap_stream));
+    MF_HIP(hipStreamSynchronize(s));
+    int rc = measure(batch, s);
+    if (rc) return rc;
+    MF_HIP(hipStreamSynchronize(s));
+    if (use_graph && it->second) { (void)hipGraphExecDestroy(it->second); it->second = nullptr; }
+    return MF_OK;
+}
+
 int mf_wav2lip::run(int batch, hipStream_t s) {
-    if (!use_graph) return run_body(batch, s);
+    if (!use_graph) {
+        for (auto& st : steps) mf_conv_tune_lookup(&st->plan, st->in, batch);
+        return run_body(batch, s);
+    }
     auto it = graphs.find(batch);
     if (it == graphs.end()) {
         // first forward at this batch size runs eagerly (it also sets the kernels' LDS attributes,
         // which must not happen inside a capture); the second one captures
         graphs.emplace(batch, nullptr);
+        // launch configurations: a table lookup per layer (MF_TUNE_CACHE / the table shipped beside the library), never a measurement
+        for (auto& st : steps) mf_conv_tune_lookup(&st->plan, st->in, batch);
         int rc = run_body(batch, s);
-        const char* at = std::getenv("MF_AUTOTUNE");
-        if (rc || (at && at[0] == '0')) return rc;
-        // the buffers hold real data now: measure every implicit-GEMM layer's launch configurations in place (mf_conv_tune), then run once more
-        // so that the outputs belong to the configurations the graph will capture
-        MF_HIP(hipStreamSynchronize(side));
-        for (auto& st : steps)
-            if ((rc = mf_conv_tune(&st->plan, st->in, st->out, st->res, batch, s))) return rc;
+        if (rc || !mf_autotune_enabled()) return rc;
+        // MF_AUTOTUNE=1 (development): the buffers hold real data now -- measure every implicit-GEMM layer in place, then run once more so that the
+        // outputs belong to the configurations the graph will capture
+        if ((rc = measure(batch, s))) return rc;
         return run_body(batch, s);
     }
     if (it->second == nullptr) {
@@ -370,6 +397,11 @@ extern "C" int mf_wav2lip_create(const mf_tensor* weights, int n_weights, int pr
     MF_HIP(hipMemcpy(h->head_b, hb_, 3 * sizeof(float), hipMemcpyHostToDevice));
     *out = h.release();
     return MF_OK;
+}
+
+extern "C" int mf_wav2lip_tune(mf_wav2lip* h, int batch, void* stream) {
+    MF_REQUIRE(h && batch >= 1, "wav2lip_tune: bad argument");
+    return h->tune(batch, (hipStream_t)stream);
 }
 
 extern "C" int mf_wav2lip_forward(mf_wav2lip* h, const float* mel, const float* face, float* out, int batch,

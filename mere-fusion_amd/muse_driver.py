@@ -121,6 +121,25 @@ class MuseBatcher:
         self.t0 = torch.tensor([0], device=self.device)
 
     @torch.no_grad()
+    def prewarm(self, tune=False):
+        """Everything a step size costs the FIRST time -- the eager forward that sizes the split-K workspaces, the hipGraph capture, and (tune=True)
+        the explicit launch-configuration measurement (mf_unet_tune / mf_vae_tune, seconds per size) -- for every number of sessions a step can hold,
+        so that the serving loop never meets a new batch size.  Session state (frame indices) is left untouched.  Call once at start-up."""
+        B = self.batch_size
+        zeros = torch.zeros((self.max_sessions_per_step * B, 50, self.unet.model.config["cross_attention_dim"]), dtype=torch.float32, device=self.device)
+        lat = torch.zeros((self.max_sessions_per_step * B,) + self.lat_shape, dtype=torch.float32, device=self.device)
+        lat.copy_(self.pool[:1].reshape((1,) + self.lat_shape).expand_as(lat))
+        for k in range(1, self.max_sessions_per_step + 1):
+            n = k * B
+            for it in range(3 if tune else 2):                         # eager (+ table lookup), [tune + eager], capture
+                pred = self.unet.model(lat[:n], self.t0, encoder_hidden_states=self.unet.pe(zeros[:n])).sample
+                self.vae.decode_latents_device(pred)
+                if tune and it == 0:
+                    self.unet.model.tune(n)
+                    self.vae.tune(n)
+        torch.cuda.synchronize(self.device)
+
+    @torch.no_grad()
     def step(self, whisper_chunks, only=None):
         """whisper_chunks: one entry per session -- a device tensor [B, 50, 384] (MuseASRFrontend.run_step) or None for an all-silent batch
         (musereal.py:82-86: the net is skipped, only the frame indices advance).  Returns one (frames, indices) per session:
@@ -135,6 +154,9 @@ class MuseBatcher:
         n_act = sum(1 for k, ch in enumerate(whisper_chunks) if ch is not None and (take is None or k in take))
         if n_act > self.max_sessions_per_step:
             raise RuntimeError(f"{n_act} active sessions in one step; the handles hold {self.max_sessions_per_step} x {B} frames")
+        for k, ch in enumerate(whisper_chunks):                          # every input is checked BEFORE any session's frame index moves
+            if ch is not None and (take is None or k in take) and (ch.shape[0] != B or not ch.is_cuda):
+                raise RuntimeError(f"session {k}: expected a device tensor of {B} whisper chunks, got {tuple(ch.shape)} on {ch.device}")
         rows, idx_per, active = [], [], []
         for k, (s, ch) in enumerate(zip(self.sessions, whisper_chunks)):
             if take is not None and k not in take:
@@ -144,8 +166,6 @@ class MuseBatcher:
             idx_per.append(idx)
             if ch is None:
                 continue
-            if ch.shape[0] != B or not ch.is_cuda:
-                raise RuntimeError(f"session {k}: expected a device tensor of {B} whisper chunks, got {tuple(ch.shape)} on {ch.device}")
             active.append(k)
             rows.extend(s.pool_offset + i for i in idx)
         out = [None if idx is None else (None, idx) for idx in idx_per]

@@ -91,6 +91,13 @@ class HipUNetModel:
         except Exception:
             pass
 
+    def tune(self, batch):
+        """Explicit launch-configuration warm-up (mf_unet_tune): times every implicit-GEMM layer at this batch size on the buffers of the last
+        forward at that size and keeps the fastest; a server calls it at start-up for every batch size its loop emits, or ships MF_TUNE_CACHE.
+        A forward itself never measures."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mf_unet_tune(self._h, int(batch), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "unet_tune")
+
     def half(self):   # musereal.py:62; arithmetic mode is fixed at create time, dtype only labels the I/O tensors
         self.dtype = torch.float16
         return self

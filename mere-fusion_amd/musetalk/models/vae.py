@@ -37,6 +37,15 @@ def remap_legacy_attention_keys(state_dict):
     return out
 
 
+def load_diffusers_weights(model_dir, stem="diffusion_pytorch_model"):
+    """The weight file `from_pretrained(model_dir)` would read (vae.py:24): `<stem>.safetensors` when present, else `<stem>.bin`."""
+    st = os.path.join(model_dir, stem + ".safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        return load_file(st, device="cpu")
+    return torch.load(os.path.join(model_dir, stem + ".bin"), map_location="cpu")
+
+
 def vae_config_struct(cfg):
     boc = list(cfg["block_out_channels"])
     c = _lib.MfVaeConfig()
@@ -70,8 +79,7 @@ class VAE:
         if state_dict is None:
             with open(os.path.join(model_path, "config.json")) as f:
                 config = json.load(f)
-            wpath = os.path.join(model_path, "diffusion_pytorch_model.bin")
-            state_dict = torch.load(wpath, map_location="cpu")
+            state_dict = load_diffusers_weights(model_path)
         if not torch.cuda.is_available():
             raise RuntimeError("the MuseTalk VAE decoder needs a HIP device; no CPU path exists here")
         self.model_path = model_path
@@ -199,3 +207,7 @@ class VAE:
 
     def decode_latents(self, latents):
         return self.decode_latents_device(latents).cpu().numpy()
+
+    def tune(self, batch):
+        """Explicit launch-configuration warm-up of the decoder at this batch size (mf_vae_tune; see HipUNetModel.tune)."""
+        _lib.check(_lib.lib().mf_vae_tune(self._h, int(batch), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "vae_tune")

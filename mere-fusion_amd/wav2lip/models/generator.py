@@ -135,6 +135,16 @@ class Wav2Lip(nn.Module):
         h = self._ensure_handle(faces_u8.device)
         return ops.wav2lip_forward_u8(h, mel_batch, faces_u8)
 
+    def tune(self, batch):
+        """Explicit launch-configuration warm-up (mf_wav2lip_tune): times every implicit-GEMM layer at this batch size on the buffers of the last
+        forward at that size and keeps the fastest.  A forward itself never measures: it uses the tuning table (MF_TUNE_CACHE or the one shipped
+        beside the library) or the cost model."""
+        if self._handle is None:
+            raise RuntimeError("Wav2Lip.tune: run one forward first")
+        dev = self._handle_device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mf_wav2lip_tune(self._handle, int(batch), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "wav2lip_tune")
+
     def read_tap(self, name, batch):
         """Intermediate activation of the last forward as fp32 NCHW (parity tests)."""
         shapes = {"audio_embedding": (512, 1, 1)}

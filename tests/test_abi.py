@@ -24,7 +24,7 @@ def test_header_symbols_exported(lib_built):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in merefusion.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert _lib.lib().mf_abi_version() == 3
+    assert _lib.lib().mf_abi_version() == 4
 
 
 def test_errors_without_device(lib_built):

@@ -86,6 +86,33 @@ def test_ring_put_batch_host_frames():
     ring.close()
 
 
+def test_ring_failed_puts_leave_the_ring_intact():
+    """an oversized frame, a batch larger than the ring, or a time-out part-way through a batch must neither leak slots nor move the
+    cursor onto a slot whose frame is still unread."""
+    ring = FrameRing(slots=4, frame_shape=(8, 8, 3))
+    ok = np.arange(8 * 8 * 3, dtype=np.uint8).reshape(8, 8, 3)
+    big = np.zeros((9, 8, 3), np.uint8)
+    audio = [(np.zeros(320, np.float32), 0)] * 16
+    ring.put((ok, 0, []))
+    with pytest.raises(ValueError, match="does not fit"):
+        ring.put((big, 1, []))
+    with pytest.raises(ValueError, match="does not fit"):
+        ring.put_batch(np.stack([big, big]), [1, 2], audio[:4])
+    with pytest.raises(ValueError, match="never fit"):
+        ring.put_batch(np.stack([ok] * 5), list(range(5)), audio[:10])           # B > slots would block for ever
+    with pytest.raises(queue.Full):
+        ring.put_batch(np.stack([ok] * 4), [1, 2, 3, 4], audio[:8], timeout=0.05)  # 3 free slots, 4 wanted: all-or-nothing
+    ring.put_batch(np.stack([ok + 1, ok + 2, ok + 3]), [1, 2, 3], audio[:6], timeout=5)   # ... and the 3 are all still there, in order behind frame 0
+    for want in range(4):
+        f, idx, _ = ring.get(timeout=5)
+        assert idx == want and np.array_equal(f, ok + want)
+    with pytest.raises(queue.Empty):
+        ring.get(block=True, timeout=0.05)
+    ring.put_batch(np.stack([ok] * 4), [4, 5, 6, 7], audio[:8], timeout=5)       # the full ring is usable again
+    assert [ring.get(timeout=5)[1] for _ in range(4)] == [4, 5, 6, 7]
+    ring.close()
+
+
 @pytest.mark.gpu
 def test_ring_takes_device_frames_by_dma(lib_built):
     """uint8 frames straight from HBM into the page-locked ring (single put and put_batch incl. the wrap-around split into two DMAs)."""
