@@ -28,10 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# The library measures its GEMM launch configurations on the first forward at a batch size (mf_conv_tune).  One cache file per bench run keeps the child
-# processes of the PMC passes (and a profiled re-run that names the same file) on the parent's configurations, with no tuning launches of their own.
-import tempfile  # noqa: E402
-os.environ.setdefault("MF_TUNE_CACHE", os.path.join(tempfile.gettempdir(), f"mf_tune_cache_{os.getpid()}.txt"))
+# Launch configurations come from the tuning table shipped beside the library (mere-fusion_amd/tune/gfx950.txt): the bench, its PMC child processes and a
+# deployment all launch the same kernels.  Nothing in this script measures configurations (MF_AUTOTUNE is left unset).
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -216,8 +214,11 @@ def roofline(rows, precision, only_mfma=False):
     for r in rows:
         if only_mfma and not r["kernel"].startswith("k_conv"):
             continue
-        k = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, launches=0))
+        name, _, grid = r["kernel"].partition(" grid ")              # (" grid N": the launch's thread count, mf_conv_kernel_name)
+        k = by.setdefault(name, dict(ms=0.0, flops=0.0, launches=0, grids=[]))
         k["ms"] += r["ms"]; k["flops"] += r["flops"]; k["launches"] += 1
+        if grid:
+            k["grids"].append(int(grid))
     dom = max(by, key=lambda k: by[k]["ms"])
     d = by[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -236,6 +237,7 @@ def roofline(rows, precision, only_mfma=False):
         "operand_format": "f16 + FP6 (e2m3, MX block scales) correction terms" if "f16+fp6" in dom else precision,
         "kernel_share_of_step": round(d["ms"] / total_ms, 3),
         "sum_of_launches_ms": round(total_ms, 4),
+        "launch_grids": sorted(set(d["grids"])),
     }, by
 
 
@@ -254,7 +256,7 @@ def mfma_only_ceiling(precision):
     return out
 
 
-def pmc_traffic(kernel, workload, precision, batch_args, want_clock=True):
+def pmc_traffic(kernel, workload, precision, batch_args, want_clock=True, grids=None):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC counters, collected as MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE
     and WRITE_SIZE in SEPARATE passes (they do not fit one), --kernel-trace only beside --pmc, values in KiB; on gfx950 FETCH_SIZE
     tallies 128-byte requests of wide coalesced reads at 64 bytes, so the read side is doubled.  WRITE_SIZE is uncalibrated (guide).
@@ -280,6 +282,8 @@ def pmc_traffic(kernel, workload, precision, batch_args, want_clock=True):
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     kn = r.get("Kernel_Name", "").replace(" ", "")
+                    if grids and int(float(r.get("Grid_Size", 0))) not in grids:
+                        continue                                     # (the same kernel symbol also runs the channel-slice-split launches: other grids)
                     if r.get("Counter_Name") == ctr and kn.startswith(want) and kn[len(want):len(want) + 1] in (",", ">"):
                         tot += float(r["Counter_Value"]); n += 1
                         if r.get("Start_Timestamp") and r.get("End_Timestamp"):
@@ -303,8 +307,8 @@ def pmc_traffic(kernel, workload, precision, batch_args, want_clock=True):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     note = "2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate rocprofv3 --pmc passes, per launch"
-    if "f16+fp6" in kernel:
-        note += "; averaged over every launch of the plain 3x3 instantiation, i.e. including the channel-slice-split launches of the 32 x 32 levels (10 of 28 per step, about a quarter of the bytes each)"
+    if grids:
+        note += f"; averaged over the launches `avg_launch_us` averages (grids {sorted(grids)})"
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], note,
             clock)
 
@@ -447,7 +451,7 @@ def muse_multi_session(args, device):
             rep["fps_per_session"] = round(B * 5 / el, 1)
     if getattr(args, "paced", 1):
         _stage("paced sessions")
-        rep["paced_sessions"] = muse_paced_sessions(big, args, device, rep["value"])
+        rep["paced_sessions"] = muse_paced_sessions(big, args, device, rep["value"], full=True)
     rows_b = big.profile(2)
     cb = [r for r in rows_b if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
     tb, fb = sum(r["ms"] for r in cb), sum(r["flops"] for r in cb)
@@ -458,94 +462,243 @@ def muse_multi_session(args, device):
     return rep
 
 
-def muse_paced_sessions(big, args, device, free_fps, periods=12, max_trials=8):
-    """BASELINE.json's second metric -- "max concurrent >= 25 fps sessions" -- measured instead of extrapolated (SURVEY 8d: a session is
-    sustained when the p99 latency of its B-frame batches is <= B x 40 ms).  N sessions run on their own clocks in real time: each hands the
-    scheduler (mere_fusion_amd.muse_driver.SessionScheduler) one batch of Whisper chunks every B x 40 ms at a seeded random phase; the
-    scheduler packs whoever waits into steps of up to `--sessions` sessions on the one UNet / VAE pair (musereal.py:91-108 for all of them) and a
-    batch's latency runs from its arrival to its uint8 frames being complete in HBM.  N walks down from (free-running rate / 25) + 1 -- one more
-    session than the free-running rate can feed, which must fail -- until p99 holds."""
-    from mere_fusion_amd import muse_driver as D
-    S, B = args.sessions, args.batch
-    P = B * 0.040
-    lat25 = W.make_musetalk_inputs(25, 4242)[0]
-    chunk = W.make_musetalk_inputs(B, 4243)[1].to(device)
-    sync = lambda: torch.cuda.synchronize(device)
-    # every step size the scheduler can issue: eager (+ launch-configuration measurements), graph capture, replay -- outside the paced runs
-    t_w = time.perf_counter()
-    warm = D.MuseBatcher(big.unet, big.vae, [D.MuseSession(lat25) for _ in range(S)], batch_size=B, device=device)
-    step_ms = {}
-    for k in range(1, S + 1):
-        for _ in range(3):
-            warm.step([chunk] * S, only=range(k))
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            warm.step([chunk] * S, only=range(k))
-        sync()
-        step_ms[str(k)] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
-    warm_s = time.perf_counter() - t_w
+class PacedRig:
+    """What the real-time legs share: the warmed-up UNet / VAE pair, one Whisper encoder, and per session an avatar (25 cached latents + 25 cached
+    720p frames with paste geometry on the device), an endless 16 kHz PCM stream cut into 20 ms chunks, a MuseASRFrontend and a FrameRing of 2B slots
+    (musereal.py:153) -- built once for the largest N a search can reach and reused by every trial."""
 
-    def trial(N):
-        bat = D.MuseBatcher(big.unet, big.vae, [D.MuseSession(lat25) for _ in range(N)], batch_size=B, device=device, max_sessions_per_step=S)
-        sch = D.SessionScheduler(bat, period_s=P)
+    def __init__(self, big, args, device, n_max):
+        from mere_fusion_amd import muse_driver as D
+        from mere_fusion_amd.paste import AvatarFrames
+        from mere_fusion_amd.transport import FrameRing
+        from mere_fusion_amd.musetalk.whisper.audio2feature import Audio2Feature
+        self.D, self.big, self.device, self.S, self.B, self.n_max = D, big, device, args.sessions, args.batch, n_max
+        self.P = self.B * 0.040
+        self.lat25 = W.make_musetalk_inputs(25, 4242)[0]
+        self.chunk = W.make_musetalk_inputs(self.B, 4243)[1].to(device)
+        self.a2f = Audio2Feature(state_dict=W.make_whisper_encoder_state_dict(0), n_head=6, precision=args.precision, device=device)
+        rng = np.random.default_rng(0)
+        H_, W_, n = 720, 1280, 25
+        boxes = [(500 + i, 200 + i, 500 + i + 260, 200 + i + 270) for i in range(n)]
+        crops = [(b[0] - 26, b[1] - 27, b[2] + 26, b[3] + 27) for b in boxes]
+        masks = [np.repeat(rng.integers(0, 256, (c[3] - c[1], c[2] - c[0], 1), dtype=np.uint8), 3, axis=2) for c in crops]
+        self.avatars = [AvatarFrames(torch.randint(0, 256, (n, H_, W_, 3), dtype=torch.uint8, device=device), boxes, masks, crops, device=device)
+                        for _ in range(n_max)]
+        self.pcm = [W.make_speech_like_wav(2 * self.B * 320 * 32, 1000 + k) for k in range(min(n_max, 8))]       # 32 batches of audio per stream, looped
+        self.rings_full = [FrameRing(2 * self.B, (H_, W_, 3)) for _ in range(n_max)]
+        self.rings_face = None
+        self.FrameRing = FrameRing
+        # every step size the schedulers can issue: eager forward, graph capture (MuseBatcher.prewarm), and the Whisper encoder at every window count
+        t_w = time.perf_counter()
+        warm = D.MuseBatcher(big.unet, big.vae, [D.MuseSession(self.lat25) for _ in range(self.S)], batch_size=self.B, device=device)
+        warm.prewarm()
+        nwin = (2 * self.B + 20) * 320
+        for k in range(self.S, 0, -1):
+            self.a2f.audio2feat_windows_device(torch.zeros((k, nwin), device=device))
+        self.step_ms = {}
+        for k in range(1, self.S + 1):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                warm.step([self.chunk] * self.S, only=range(k))
+            torch.cuda.synchronize(device)
+            self.step_ms[str(k)] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+        self.warm_s = time.perf_counter() - t_w
+
+    def chunks_of(self, k, j):
+        """the 2B 20 ms chunks of session k's j-th batch"""
+        wav = self.pcm[k % len(self.pcm)]
+        n = 2 * self.B * 320
+        o = (j * n) % (len(wav) - n + 1)
+        return [wav[o + i * 320:o + (i + 1) * 320] for i in range(2 * self.B)]
+
+    def close(self):
+        for r in self.rings_full + (self.rings_face or []):
+            r.close()
+
+    def trial(self, N, seconds, stages=("whisper", "paste", "ring")):
+        """N sessions in real time for `seconds`: every session completes one batch of 2B PCM chunks per B x 40 ms at a seeded random phase.
+        stages: () = the round-2 measurement (precomputed Whisper chunks in HBM -> UNet -> VAE, frames complete in HBM); "whisper": the chunks
+        come from each session's PCM through its front-end and ONE encoder call per step; "paste": 720p paste-back on the device; "ring": the
+        frames leave through the session's FrameRing and the latency ends when the consumer thread HOLDS the batch's last tuple."""
+        import threading
+        D, B, P, dev = self.D, self.B, self.P, self.device
+        periods = max(int(round(seconds / P)), 4)
+        use_w, use_p, use_r = "whisper" in stages, "paste" in stages, "ring" in stages
+        sessions = [D.MuseSession(self.lat25, avatar_frames=self.avatars[k] if use_p else None) for k in range(N)]
+        bat = D.MuseBatcher(self.big.unet, self.big.vae, sessions, batch_size=B, paste=use_p, device=dev, max_sessions_per_step=self.S)
+        rings = None
+        if use_r:
+            if use_p:
+                rings = self.rings_full[:N]
+            else:
+                if self.rings_face is None or len(self.rings_face) < N:
+                    for r in self.rings_face or []:
+                        r.close()
+                    self.rings_face = [self.FrameRing(2 * B, (256, 256, 3)) for _ in range(self.n_max)]
+                rings = self.rings_face[:N]
+        if use_w or use_r:
+            fes = [D.MuseASRFrontend(self.a2f, B) for _ in range(N)]
+            for fe in fes:
+                fe.warm_up()
+            sch = D.EndToEndScheduler(bat, fes, self.a2f, rings=rings, period_s=P, fixed_chunks=None if use_w else self.chunk)
+        else:
+            sch = D.SessionScheduler(bat, period_s=P)
+        # the consumer (`process_frames`, lipreal.py:195): one thread draining every session's ring; a batch is delivered when its last tuple is held
+        got_t = [[] for _ in range(N)]
+        stop = threading.Event()
+
+        def drain():
+            import queue as _q
+            cnt = [0] * N
+            while not stop.is_set():
+                idle = True
+                for k in range(N):
+                    try:
+                        while True:
+                            f, idx, au = rings[k].get(block=False, copy=False)
+                            if f is not None:
+                                rings[k].release()
+                            cnt[k] += 1
+                            if cnt[k] % B == 0:
+                                got_t[k].append(time.perf_counter())
+                            idle = False
+                    except _q.Empty:
+                        pass
+                if idle:
+                    time.sleep(0.0005)
+        th = None
+        if use_r:
+            th = threading.Thread(target=drain, daemon=True)
+            th.start()
         phase = np.random.default_rng(N).uniform(0.0, P, N)
         t_start = time.perf_counter() + 0.01
         nxt = [t_start + float(ph) for ph in phase]
-        issued, lats, total = [0] * N, [], N * periods
-        while len(lats) < total:
+        issued, arrivals, lats, total = [0] * N, [[] for _ in range(N)], [], N * periods
+        n_done = 0
+        while n_done < total:
             now = time.perf_counter()
             for k in range(N):
                 while issued[k] < periods and nxt[k] <= now:
-                    sch.submit(k, chunk, nxt[k])
+                    if use_w or use_r:
+                        sch.submit(k, self.chunks_of(k, issued[k]), nxt[k])
+                    else:
+                        sch.submit(k, self.chunk, nxt[k])
+                    arrivals[k].append(nxt[k])
                     nxt[k] += P
                     issued[k] += 1
             done = sch.run_once(now)
             if done:
-                lats.extend(d[3] for d in done)
+                n_done += len(done)
+                if not use_r:
+                    lats.extend(d[3] for d in done)
                 continue
             due = [t for t in ([nxt[k] for k in range(N) if issued[k] < periods] + [sch.next_due()]) if t is not None]
             dt = (min(due) if due else now) - time.perf_counter()
             if dt > 1e-3:
                 time.sleep(dt - 5e-4)
+            elif dt > 1e-4:
+                time.sleep(1e-4)                                            # (a step is in flight: yield the GIL to the consumer thread between polls)
         wall = time.perf_counter() - t_start
+        if use_r:
+            t_end = time.perf_counter() + 2.0
+            while any(len(got_t[k]) < periods for k in range(N)) and time.perf_counter() < t_end:
+                time.sleep(0.001)
+            stop.set()
+            th.join(2.0)
+            # by arrival order over all sessions, so that first / last thirds mean what they mean in the other legs
+            pairs = sorted((arrivals[k][j], got_t[k][j] - arrivals[k][j]) for k in range(N) for j in range(min(len(got_t[k]), periods)))
+            lats = [l for _, l in pairs]
         l = np.sort(np.asarray(lats)) * 1e3
         p99 = float(l[min(len(l) - 1, int(np.ceil(0.99 * len(l))) - 1)])
-        n3 = len(lats) // 3                                                  # served first / last: a queue that grows shows up as a drift between them
+        n3 = max(len(lats) // 3, 1)                                          # served first / last: a queue that grows shows up as a drift between them
         first, third = np.asarray(lats[:n3]) * 1e3, np.asarray(lats[-n3:]) * 1e3
         drift = float(third.mean() - first.mean())
-        return {"sessions": N, "batches": int(len(l)), "first_third_mean_ms": round(float(first.mean()), 1), "last_third_mean_ms": round(float(third.mean()), 1),
-                "all_mean_ms": round(float(l.mean()), 1), "p50_ms": round(float(l[len(l) // 2]), 1), "p99_ms": round(p99, 1), "max_ms": round(float(l[-1]), 1),
-                "sustained": bool(p99 <= P * 1e3 and drift <= 0.1 * P * 1e3), "sessions_per_step_mean": round(sch.sessions_served / max(sch.steps, 1), 2),
+        return {"sessions": N, "stages": list(stages), "seconds": round(wall, 1), "batches": int(len(l)), "first_third_mean_ms": round(float(first.mean()), 1),
+                "last_third_mean_ms": round(float(third.mean()), 1), "all_mean_ms": round(float(l.mean()), 1), "p50_ms": round(float(l[len(l) // 2]), 1),
+                "p99_ms": round(p99, 1), "max_ms": round(float(l[-1]), 1),
+                "sustained": bool(len(l) == total and p99 <= P * 1e3 and drift <= 0.1 * P * 1e3),
+                "sessions_per_step_mean": round(sch.sessions_served / max(sch.steps, 1), 2),
                 "gpu_busy_frac": round(sch.busy_s / wall, 3), "frames_per_s": round(N * periods * B / wall, 1)}
 
-    cap = max(int(free_fps / 25.0), 1)
-    trials, best = [], None
-    r = trial(cap + 1)                    # one more session than the free-running rate can feed: expected to fail ...
-    trials.append(r)
-    if r["sustained"]:                    # ... and when it does not (the free-running figure was the low one), walk UP to the first failure
-        best = r
-        for N in range(cap + 2, cap + 5):
-            r = trial(N)
-            trials.append(r)
-            if not r["sustained"]:
-                break
-            best = r
-    else:
-        cands = [n for n in (cap, cap - 1, cap - 2, cap - 3, cap - 4, cap - 6, cap - 8, cap - 11) if n >= 1][:max_trials]
-        for N in cands:
-            r = trial(N)
-            trials.append(r)
+    def search(self, cap, stages, screen_s, confirm_s, fail_s):
+        """Largest N whose trial holds the bound: short screening trials walk from cap + 1 (which should fail) to the first N that holds, then ONE long
+        trial confirms it (and steps down if the long run disagrees) and a medium one shows N + 1 failing."""
+        trials, best = [], None
+        N = cap + 1
+        r = self.trial(N, screen_s, stages); trials.append(r)
+        if r["sustained"]:
+            while r["sustained"] and N < self.n_max:
+                N += 1
+                r = self.trial(N, screen_s, stages); trials.append(r)
+            N = N - 1 if not r["sustained"] else N
+        else:
+            while not r["sustained"] and N > 1:
+                N -= 1
+                r = self.trial(N, screen_s, stages); trials.append(r)
+        while N >= 1:
+            r = self.trial(N, confirm_s, stages); trials.append(r)
             if r["sustained"]:
                 best = r
                 break
-    rep = {"criterion": f"p99 latency of a session's {B}-frame batch (arrival of its Whisper chunks -> uint8 frames complete in HBM) <= {B} x 40 ms = {P * 1e3:.0f} ms, "
-                        f"and no queue growth (mean latency of the last third of the batches - of the first third <= {P * 100:.0f} ms); {periods} batches per session in real time, seeded random phases",
-           "scheduler": f"mere_fusion_amd.muse_driver.SessionScheduler: oldest first, <= {S} sessions per step, a partly filled step waits <= {P * 250:.0f} ms",
-           "max_sessions_sustained": best["sessions"] if best else None,
-           "at_max": best, "trials": trials, "step_ms_by_sessions_in_step": step_ms, "warmup_s": round(warm_s, 1)}
-    if best is None:
-        rep["note"] = "no N tried held the bound; see trials"
+            N -= 1
+        if best is not None and N + 1 <= self.n_max and fail_s > 0:
+            trials.append(self.trial(N + 1, fail_s, stages))
+        return best, trials
+
+
+def muse_paced_sessions(big, args, device, free_fps, full=True):
+    """BASELINE.json's second metric -- "max concurrent >= 25 fps sessions" -- measured instead of extrapolated (SURVEY 8d: a session is
+    sustained when the p99 latency of its B-frame batches is <= B x 40 ms).  N sessions run on their own clocks in real time; the per-GPU
+    scheduler (mere_fusion_amd.muse_driver) packs whoever waits into steps of up to `--sessions` sessions on the one UNet / VAE pair.
+    `end_to_end`: the whole session loop inside the measurement -- each session's 20 ms PCM chunks -> its ASR front-end, the
+    Whisper encoder once per step for all picked sessions, UNet + VAE, 720p paste-back on the device, frames out through the session's FrameRing;
+    latency = arrival of the batch's last audio chunk -> the consumer thread holds the batch's last (res_frame, idx, audio_frames) tuple.
+    `unet_vae_only`: the round-2 measurement (precomputed Whisper chunks resident in HBM, frames complete in HBM).  `stages`: what each stage costs,
+    at the N the end-to-end loop sustains and one above."""
+    S, B = args.sessions, args.batch
+    P = B * 0.040
+    cap = max(int(free_fps / 25.0), 1)
+    rig = PacedRig(big, args, device, n_max=cap + 4)
+    try:
+        e2e, e2e_trials = rig.search(cap, ("whisper", "paste", "ring"), screen_s=4.0, confirm_s=60.0, fail_s=20.0)
+        rep = {"criterion": f"p99 latency of a session's {B}-frame batch <= {B} x 40 ms = {P * 1e3:.0f} ms, every batch delivered, and no queue growth (mean latency of the "
+                            f"last third of the batches - of the first third <= {P * 100:.0f} ms); real time, seeded random phases, one batch per session per {P * 1e3:.0f} ms",
+               "scheduler": f"mere_fusion_amd.muse_driver.EndToEndScheduler / SessionScheduler: oldest first, <= {S} sessions per step, a partly filled step waits <= {P * 250:.0f} ms; "
+                            "frames copied out on a second stream behind the step",
+               "end_to_end": {"latency": "arrival of the batch's last 20 ms PCM chunk -> the consumer thread holds the batch's last (res_frame, idx, audio_frames) tuple",
+                              "stages": "museasr.py:15-29 front-end + one Whisper encoder call per step, musereal.py:91-108 UNet + VAE, :238-247 paste-back into 720p frames on the device, "
+                                        ":116,153 FrameRing hand-off (D2H of the 720p frames)",
+                              "max_sessions_sustained": e2e["sessions"] if e2e else None, "at_max": e2e, "trials": e2e_trials},
+               "max_sessions_sustained": e2e["sessions"] if e2e else None,
+               "step_ms_by_sessions_in_step": rig.step_ms, "warmup_s": round(rig.warm_s, 1)}
+        if full:
+            uv, uv_trials = rig.search(cap, (), screen_s=4.0, confirm_s=30.0, fail_s=0.0)
+            rep["unet_vae_only"] = {"latency": "arrival of the batch's Whisper chunks (already in HBM) -> uint8 256 x 256 frames complete in HBM (the round-2 measurement)",
+                                    "max_sessions_sustained": uv["sessions"] if uv else None, "at_max": uv, "trials": uv_trials}
+            if e2e:
+                n0 = e2e["sessions"]
+                rep["stages"] = {"note": f"12 s trials at N = {n0} (what the end-to-end loop sustains) and N = {n0 + 1}: which stage costs the next session",
+                                 "rows": [rig.trial(n, 12.0, st) for st in ((), ("whisper",), ("whisper", "paste"), ("whisper", "ring")) for n in (n0, n0 + 1) if n <= rig.n_max]}
+    finally:
+        rig.close()
+    return rep
+
+
+def muse_node_rank_leg(args, device):
+    """One rank's share of the node metric at --gpus N > 1: the 8-sessions-per-step handles, the free-running 8 x 8 rate (where the search starts), then the
+    end-to-end paced search -- every rank runs this at the same time on its own GPU (host cores and PCIe are shared, as on a serving node)."""
+    from mere_fusion_amd import muse_driver as D
+    S, B = args.sessions, args.batch
+    big = MuseTalkRunner(args.precision, S * B, device)
+    bat = D.MuseBatcher(big.unet, big.vae, [D.MuseSession(W.make_musetalk_inputs(25, 500 + s)[0]) for s in range(S)], batch_size=B, device=device)
+    chunks = [W.make_musetalk_inputs(B, 700 + s)[1].to(device) for s in range(S)]
+    bat.prewarm()
+    el = harness.timed_steps(lambda: bat.step(chunks), 5, 2, sync_fn=lambda: torch.cuda.synchronize(device), device=device)
+    rep = muse_paced_sessions(big, args, device, S * B * 5 / el, full=False)
+    rep["free_running_8x8_frames_per_s"] = round(S * B * 5 / el, 1)
+    del big
+    torch.cuda.empty_cache()
     return rep
 
 
@@ -605,6 +758,25 @@ def transport_report(args, device):
     for _ in range(50):
         frames.cpu().numpy()                                          # vae.py:105
     rep["device_batch_cpu_numpy_ms"] = round((time.perf_counter() - t0) / 50 * 1e3, 3)
+    # the reference's hand-off of the same batch, like for like: vae.py:105 `.cpu().numpy()`, then one pickled tuple per frame through mp.Queue
+    # (musereal.py:116-119) and the consumer's get() (musereal.py:226)
+    q = ctx.Queue(2 * args.batch)
+
+    def ref_one():
+        host = frames.cpu().numpy()
+        for i in range(args.batch):
+            q.put((host[i], i, audio[2 * i:2 * i + 2]))
+        for _ in range(args.batch):
+            q.get(timeout=5)
+    for _ in range(3):
+        ref_one()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        ref_one()
+    rep["device_batch_reference_handoff_ms"] = round((time.perf_counter() - t0) / 50 * 1e3, 3)
+    rep["note"] = ("device_batch_*: one batch of B uint8 256 x 256 frames from HBM to the consumer's hands in this process: FrameRing.put_batch (one DMA into page-locked "
+                   "slots, one descriptor message) + B get()s, against the reference's `.cpu().numpy()` + B pickled mp.Queue puts + B gets; "
+                   "device_batch_cpu_numpy_ms is the bare copy with no hand-off at all")
     ring.close()
     return rep
 
@@ -909,11 +1081,14 @@ def main():
         elapsed = harness.timed_steps(run.step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=device)
         _stage("per-op profile")
         value = harness.aggregate_value(args.batch, args.steps, elapsed, world)
+        solo = world == 1
+        q_on = args.precision == "bf16x3" and os.environ.get("MF_CONV_Q", "1") != "0"
+        line = None
         if rank == 0:
             gf_frame = run.gflop_per_frame()      # summed over the handles' own op lists (tests/test_musetalk_full.py holds it to SURVEY Appendix C)
             line = {"metric": "lip-sync frames/sec @256x256", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
                     "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3+f16q" if q_on else args.precision, "data": "synthetic",
                     "config": {"workload": "MuseTalk step 256x256: pe(audio) + UNet(t=0) + VAE decode to uint8 frames, batch=8 latents + "
                                            "Whisper chunks per GPU, inputs resident in HBM (BASELINE.json configs[2]); assumed MuseTalk-v1 / "
                                            "sd-vae-ft-mse architecture, seeded random-init weights",
@@ -921,9 +1096,9 @@ def main():
                                "algorithmic_gflop_per_frame": round(gf_frame, 1),
                                "parallelism": f"{world} independent replicas, sessions sharded by GPU, no collective"},
                     "net_tflops": round(value / world * gf_frame / 1e3, 1)}
-            if args.precision == "bf16x3" and os.environ.get("MF_CONV_Q", "1") != "0":
-                line["dtype_note"] = ("bf16x3 (hi, lo bf16 pairs, three MFMAs per product) everywhere except the VAE decoder's 3x3 resnet convs on maps >= 64 x 64: "
-                                      "f16 + FP6 (e2m3, MX block scales) correction terms, 1.5 pass-equivalents per product, outputs bf16 (hi, lo); "
+            if q_on:
+                line["dtype_note"] = ("bf16x3 (hi, lo bf16 pairs, three MFMAs per product) everywhere except the VAE decoder's 3x3 resnet convs and upsamplers on maps >= 32 x 32 "
+                                      "(28 % of the step's time): f16 + FP6 (e2m3, MX block scales) correction terms, 1.5 pass-equivalents per product, outputs bf16 (hi, lo); "
                                       "parity bound unchanged (tests/test_musetalk_full.py)")
             if args.profile_iters <= 0:          # child of a PMC pass: the timed steps above are all it needs to run
                 print(json.dumps(line), flush=True)
@@ -932,7 +1107,7 @@ def main():
             rf, by = roofline(rows, args.precision, only_mfma=True)
             if extras and args.pmc_traffic:
                 _stage("musetalk PMC traffic passes")
-                rf["traffic"], rf["traffic_note"], clk = pmc_traffic(rf["kernel"], "musetalk", args.precision, ["--batch", str(args.batch)])
+                rf["traffic"], rf["traffic_note"], clk = pmc_traffic(rf["kernel"], "musetalk", args.precision, ["--batch", str(args.batch)], grids=set(rf["launch_grids"]))
                 if rf["traffic"]:
                     rf["traffic"] = round(rf["traffic"])
                     rf["traffic_gbytes_per_s"] = round(rf["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9, 1)
@@ -942,7 +1117,7 @@ def main():
                     rf["peak_at_effective_clock"] = round(rf["peak"] * clk / 2.4, 1)
                     rf["frac_of_peak_at_effective_clock"] = round(rf["achieved"] / (rf["peak"] * clk / 2.4), 4)
                     rf["clock_note"] = "GRBM_GUI_ACTIVE / dispatch wall time under rocprofv3 (profiled passes clock ~3 % lower than un-profiled ones)"
-            if extras:
+            if bool(args.extras):
                 # the ceiling a kernel of pure matrix instructions reaches on this device, next to the nominal peak
                 ceil = mfma_only_ceiling(args.precision)
                 rf["mfma_only_ceiling_tflops"] = ceil
@@ -950,7 +1125,8 @@ def main():
                 rf["frac_of_mfma_only_ceiling"] = round(rf["achieved"] / ref, 4)
                 rf["ceiling_note"] = ("mf_probe_mfma_ceiling: TFLOP/s of the convolution's own arithmetic from a loop of nothing but MFMAs (8 waves per CU, random "
                                       "operand bits) for the instruction mix of one product: 3 bf16 MFMAs as shipped; f16 + two block-scaled FP8 / FP6 correction terms "
-                                      "(the FP6 form is what the VAE decoder's resnet convs run; numerics in tools/numerics_split_study.py, layouts in tools/mx_cross_probe.hip)")
+                                      "(the FP6 form is what the VAE decoder's resnet convs run; numerics in tools/numerics_split_study.py, layouts in tools/mx_cross_probe.hip); "
+                                      "profiles/r03_halo_q_loop_study.md: this kernel's own matrix-instruction floor, LDS floor and DMA share by ablation")
             line["roofline"] = rf
             conv_rows = [r for r in rows if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
             if conv_rows:
@@ -960,7 +1136,7 @@ def main():
             _stage("parity vs oracle")
             line["parity"] = run.parity()
             # the same step bracketed as the reference brackets it (musereal.py:99-115): uint8 frames copied to the host inside the timed region
-            el_h = harness.timed_steps(run.step_d2h, max(args.steps // 2, 1), 2, sync_fn=torch.cuda.synchronize)
+            el_h = harness.timed_steps(run.step_d2h, max(args.steps // 2, 1), 2, sync_fn=lambda: torch.cuda.synchronize(device), collective=False)
             line["with_d2h"] = {"value": round(args.batch * max(args.steps // 2, 1) / el_h, 1), "unit": "frames/s",
                                 "ms_per_step": round(el_h / max(args.steps // 2, 1) * 1e3, 3),
                                 "note": "step + vae.py:105's `.cpu().numpy()` of the uint8 frames (pageable host memory, one sync per step)"}
@@ -972,12 +1148,12 @@ def main():
             if args.dump_layers:
                 with open(args.dump_layers, "w") as f_:
                     json.dump({"musetalk_rows": rows, "by_kernel": by}, f_, indent=1)
+            if bool(args.extras) and args.cpu_seconds > 0:
+                _stage("cpu baseline")
+                line["cpu_baseline"] = run.cpu_baseline(args.cpu_seconds, args.cpu_threads)
             if extras:
-                if args.cpu_seconds > 0:
-                    _stage("cpu baseline")
-                    line["cpu_baseline"] = run.cpu_baseline(args.cpu_seconds, args.cpu_threads)
-                usd, vsd = run.usd, run.vsd
                 del run
+                run = None
                 torch.cuda.empty_cache()
                 other = "bf16" if args.precision == "bf16x3" else "bf16x3"
                 _stage("alt precision")
@@ -988,18 +1164,50 @@ def main():
                                "latent_linf_vs_oracle": par["latent_linf_vs_oracle"], "u8_max_diff": par["u8_max_diff"]}
                 del alt
                 torch.cuda.empty_cache()
-                # cross-session batching: the north star's 8 sessions per GPU x 8 frames in one step (what a node does with 64 sessions on
-                # 8 GPUs); the UNet's GEMMs get 8x the pixels per launch
-                if args.sessions > 0:
-                    _stage("multi session")
-                    line["multi_session"] = muse_multi_session(args, device)
-                dl = args.dump_layers
-                args.dump_layers = dl + ".wav2lip.json" if dl else None
-                _stage("wav2lip leg")
-                line["wav2lip"] = wav2lip_report(args, device, world, rank)
-                _stage("ernerf leg")
-                line["ernerf"] = ernerf_report(args, device, world, rank)
-                _stage("done")
+        # ---- BASELINE.json's second metric, on EVERY rank at once: max concurrent >= 25 fps sessions per GPU -> per node --------------------------
+        if bool(args.extras) and args.sessions > 0 and args.profile_iters > 0:
+            del run
+            torch.cuda.empty_cache()
+            if solo:
+                _stage("multi session")
+                ms_rep = muse_multi_session(args, device)       # cross-session batching (8 sessions x 8 frames per step) + the paced legs
+                mine = ms_rep.get("paced_sessions")
+                line["multi_session"] = ms_rep
+            else:
+                _stage("paced sessions on every rank")
+                mine = muse_node_rank_leg(args, device)
+            # each rank's measured capacity -> the node's admission cap and placement (harness.SessionPlacer; no data-path exchange)
+            caps = None
+            if mine is not None:
+                my_cap = int(mine.get("max_sessions_sustained") or 0)
+                placer = harness.SessionPlacer.from_measured(my_cap)
+                caps = placer.capacity
+                rows_n = [None] * world
+                row = {"rank": rank, "gpu": local_rank, "max_sessions_sustained": my_cap,
+                       "p99_ms_at_max": (mine["end_to_end"]["at_max"] or {}).get("p99_ms"), "frames_per_s_at_max": (mine["end_to_end"]["at_max"] or {}).get("frames_per_s")}
+                if world > 1:
+                    torch.distributed.all_gather_object(rows_n, row)
+                else:
+                    rows_n = [row]
+                if rank == 0:
+                    p99s = [r["p99_ms_at_max"] for r in rows_n if r["p99_ms_at_max"] is not None]
+                    line["node"] = {"gpus": world, "sessions_per_node": int(sum(caps)), "unit": "concurrent MuseTalk sessions at >= 25 fps, end to end "
+                                    "(PCM chunks -> Whisper -> UNet -> VAE -> 720p paste-back -> FrameRing), every rank measured at the same time",
+                                    "worst_rank_p99_ms": max(p99s) if p99s else None, "latency_bound_ms": args.batch * 40, "per_rank": rows_n,
+                                    "admission": "harness.SessionPlacer: cap = sum of the measured per-GPU capacities (app.py:42,79-80,705), a new session goes to "
+                                                 "the GPU with the lowest load fraction",
+                                    "north_star_target": ">= 64 sessions on 8 GPUs = 8 per GPU"}
+                    if not solo:
+                        line["paced_sessions_rank0"] = mine
+        if rank == 0 and extras:
+            dl = args.dump_layers
+            args.dump_layers = dl + ".wav2lip.json" if dl else None
+            _stage("wav2lip leg")
+            line["wav2lip"] = wav2lip_report(args, device, world, rank)
+            _stage("ernerf leg")
+            line["ernerf"] = ernerf_report(args, device, world, rank)
+        if rank == 0:
+            _stage("done")
             print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

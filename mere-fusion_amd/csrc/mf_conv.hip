@@ -1896,9 +1896,12 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision != MF_PREC_BF16 ? "true" : "false";
     if (p->q && p->up_hi) { snprintf(buf, cap, "4 x k_conv3x3_halo_w<16,128,4,2,true,1,phase> f16+fp6"); return; }
     if (p->q) {
+        // (" grid N": the launch's thread count as rocprofv3 reports it, so that a counter pass can be matched to exactly these launches -- the split
+        // and unsplit launches share one kernel symbol)
         const int ns = mf_q_split_count(p, batch);
-        if (ns > 1) snprintf(buf, cap, "k_conv3x3_halo_w<16,128,4,2,true,1> f16+fp6 split %d", ns);
-        else snprintf(buf, cap, "k_conv3x3_halo_w<16,128,4,2,true,1> f16+fp6");
+        const long grid = (long)batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * (p->d.cout / 128) * ns * 512;
+        if (ns > 1) snprintf(buf, cap, "k_conv3x3_halo_w<16,128,4,2,true,1> f16+fp6 split %d grid %ld", ns, grid);
+        else snprintf(buf, cap, "k_conv3x3_halo_w<16,128,4,2,true,1> f16+fp6 grid %ld", grid);
         return;
     }
     if (p->halo) {

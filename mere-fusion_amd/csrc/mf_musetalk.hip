@@ -644,7 +644,8 @@ struct Net {
         int rc = measure(B, s);
         if (rc) return rc;
         MF_HIP(hipStreamSynchronize(s));
-        if (use_graph && it->second) { (void)hipGraphExecDestroy(it->second); it->second = nullptr; }
+        // the next forward at B runs eagerly again (layers that share a measured signature size their split-K workspaces there), then re-captures
+        if (use_graph) { if (it->second) (void)hipGraphExecDestroy(it->second); graphs.erase(it); }
         return MF_OK;
     }
     int run(int B, hipStream_t s) {

@@ -340,7 +340,7 @@ extern "C" int mf_net_tune(mf_net* h, int batch, void* stream) {
         if (rc) return rc;
     }
     MF_HIP(hipStreamSynchronize(s));
-    if (h->use_graph && it->second) { (void)hipGraphExecDestroy(it->second); it->second = nullptr; }
+    if (h->use_graph) { if (it->second) (void)hipGraphExecDestroy(it->second); h->graphs.erase(it); }   // next run: eager (workspaces), then re-capture
     return MF_OK;
 }
 

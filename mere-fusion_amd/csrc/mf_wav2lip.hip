@@ -260,7 +260,8 @@ int mf_wav2lip::tune(int batch, hipStream_t s) {
     int rc = measure(batch, s);
     if (rc) return rc;
     MF_HIP(hipStreamSynchronize(s));
-    if (use_graph && it->second) { (void)hipGraphExecDestroy(it->second); it->second = nullptr; }
+    // the next forward at this batch runs eagerly again (split-K workspaces of the new configurations), then re-captures
+    if (use_graph) { if (it->second) (void)hipGraphExecDestroy(it->second); graphs.erase(it); }
     return MF_OK;
 }
 

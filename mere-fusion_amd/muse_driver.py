@@ -66,14 +66,25 @@ class MuseASRFrontend:
         """baseasr.py:53-59: prime the context with l + r silent chunks."""
         self.frames = [np.zeros(chunk, dtype=np.float32) for _ in range(self.l + self.r)]
 
-    def run_step(self, new_chunks, out=None):
+    def window(self, new_chunks):
+        """museasr.py:17-29 up to the encoder call: take the 2B new 20 ms chunks, return the (l + 2B + r) x 320-sample window the encoder sees
+        (None while the context is still filling, museasr.py:22-23) and keep the last l + r chunks as the next window's context."""
         self.frames.extend(new_chunks)
         if len(self.frames) <= self.l + self.r:                       # museasr.py:22-23
             return None
-        feat = self.audio_processor.audio2feat_device(np.concatenate(self.frames))          # museasr.py:25-26
-        chunks = feature_chunks_device(feat, chunk_left_rows(self.batch_size, self.fps / 2, self.l / 2), out=out)   # museasr.py:27
+        win = np.concatenate(self.frames)                             # museasr.py:25
         self.frames = self.frames[-(self.l + self.r):]                # museasr.py:29
-        return chunks
+        return win
+
+    def chunks_from_features(self, feat, out=None):
+        """museasr.py:27: the B (50, 384) chunks of this step from the window's features [T, 5, 384] (device)."""
+        return feature_chunks_device(feat, chunk_left_rows(self.batch_size, self.fps / 2, self.l / 2), out=out)
+
+    def run_step(self, new_chunks, out=None):
+        win = self.window(new_chunks)
+        if win is None:
+            return None
+        return self.chunks_from_features(self.audio_processor.audio2feat_device(win), out=out)   # museasr.py:25-27
 
 
 class MuseSession:
@@ -258,3 +269,112 @@ class SessionScheduler:
         self.sessions_served += len(ks)
         self.busy_s += t1 - t0
         return [(k, out[k][0], out[k][1], t1 - arrival[k]) for k in ks]
+
+
+class EndToEndScheduler(SessionScheduler):
+    """The whole per-GPU session loop in one place: what reaches a session's `process_frames` thread, from what its ASR thread saw.
+
+      museasr.py:15-29    every session's 2B new 20 ms PCM chunks -> its sliding window; the windows of ALL sessions picked for a step go through the
+                          Whisper encoder in ONE call (mf_whisper_encode_windows), then `feature2chunks` per session on the device
+      musereal.py:91-108  MuseBatcher.step for the picked sessions (gather -> UNet -> VAE -> uint8 frames)
+      musereal.py:238-247 paste-back into the cached full frames on the device (`paste` stage; the batcher must have been built with paste=True)
+      musereal.py:116,153 each session's frames leave through ITS FrameRing as (res_frame, idx, audio_frames) tuples: the D2H runs on a copy stream
+                          behind the step (the next step's kernels do not wait for it) and the descriptors are published when its event is done
+
+    submit(k, pcm_chunks, t_arrival)  the 2B chunks of session k that completed a batch at t_arrival (audio_frames = [(chunk, 0)] * 2B)
+    run_once(now) -> finished batches [(k, frames_or_None, indices, latency_s)]: latency = arrival -> descriptors published (ring stage on) or frames
+    complete in HBM (ring stage off).  Stages can be switched off individually to price them (bench.py `paced_sessions.stages`)."""
+
+    def __init__(self, batcher, frontends, audio_processor, rings=None, period_s=None, hold_s=None, clock=time.perf_counter, depth=2, fixed_chunks=None):
+        super().__init__(batcher, period_s=period_s, hold_s=hold_s, clock=clock)
+        self.fixed_chunks = fixed_chunks                             # (measurement only: this [B, 50, 384] tensor instead of the Whisper stage)
+        if len(frontends) != len(batcher.sessions):
+            raise RuntimeError("one MuseASRFrontend per session is required")
+        self.frontends, self.audio_processor, self.rings = list(frontends), audio_processor, rings
+        self.depth = max(int(depth), 1)                              # steps in flight: the one computing + the one whose frames are being copied
+        self.copy_stream = torch.cuda.Stream(device=batcher.device) if rings is not None else None
+        self.inflight = deque()
+        self.ring_full = 0
+        self._busy_until = 0.0
+
+    def submit(self, k, pcm_chunks, t_arrival=None):
+        t = self.clock() if t_arrival is None else t_arrival
+        win = self.frontends[k].window(pcm_chunks)                    # host side of museasr.py:17-29, at arrival time
+        self.queues[k].append((t, (win, [(c, 0) for c in pcm_chunks])))
+
+    def _retire(self, block=False):
+        done = []
+        while self.inflight:
+            item = self.inflight[0]
+            if block:
+                item["event"].synchronize()
+            elif not item["event"].query():
+                break
+            self.inflight.popleft()
+            t1 = self.clock()
+            for k in item["ks"]:
+                fr, idx = item["out"][k]
+                tok = item["tokens"].get(k)
+                if tok is not None:
+                    self.rings[k].commit_batch(tok, item["audio"][k])
+                    t1 = self.clock()
+                done.append((k, fr, idx, t1 - item["arrival"][k]))
+            self.busy_s += max(t1 - max(item["t0"], self._busy_until), 0.0)      # union of the steps' [launch, done] intervals
+            self._busy_until = max(self._busy_until, t1)
+        return done
+
+    def next_due(self):
+        if self.inflight:
+            return self.clock() + 2e-4                                # something to retire: poll again shortly
+        return super().next_due()
+
+    def run_once(self, now=None):
+        now = self.clock() if now is None else now
+        done = self._retire()
+        if len(self.inflight) >= self.depth:
+            return done
+        ks = pick_sessions(self.pending(), now, self.capacity, self.hold)
+        if not ks:
+            return done
+        dev = self.batcher.device
+        arrival, audio, wins = {}, {}, {}
+        for k in ks:
+            arrival[k], (wins[k], audio[k]) = self.queues[k].popleft()
+        t0 = self.clock()
+        chunks = [None] * len(self.queues)
+        speaking = [k for k in ks if wins[k] is not None]
+        if speaking and self.fixed_chunks is not None:
+            for k in speaking:
+                chunks[k] = self.fixed_chunks
+        elif speaking:
+            wav = torch.from_numpy(np.stack([wins[k] for k in speaking])).to(dev, non_blocking=True)
+            feats = self.audio_processor.audio2feat_windows_device(wav)            # every picked session's window in one encoder call
+            for i, k in enumerate(speaking):
+                chunks[k] = self.frontends[k].chunks_from_features(feats[i])
+        out = self.batcher.step(chunks, only=ks)
+        tokens = {}
+        ev = torch.cuda.Event()
+        if self.rings is not None:
+            cur = torch.cuda.current_stream(dev)
+            self.copy_stream.wait_stream(cur)
+            for k in ks:
+                fr, idx = out[k]
+                if fr is None:
+                    continue
+                try:
+                    tokens[k] = self.rings[k].begin_batch(fr, idx, stream=self.copy_stream, block=True, timeout=self.period)
+                except Exception:
+                    self.ring_full += 1
+                    raise
+                fr.record_stream(self.copy_stream)
+            ev.record(self.copy_stream)
+        else:
+            ev.record(torch.cuda.current_stream(dev))
+        self.inflight.append({"ks": ks, "out": out, "tokens": tokens, "audio": audio, "arrival": arrival, "event": ev, "t0": t0})
+        self.steps += 1
+        self.sessions_served += len(ks)
+        return done
+
+    def drain(self):
+        """Waits for everything in flight (end of a run)."""
+        return self._retire(block=True)

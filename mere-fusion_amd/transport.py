@@ -132,9 +132,25 @@ class FrameRing:
         or the host, idxs the B frame indices, audio_frames the 2B (pcm, type) pairs (two per frame).  A device batch travels as ONE DMA per run
         of consecutive slots (the ring wraps at most once per batch) behind ONE stream fence, and its B descriptors as ONE queue message --
         the per-frame pickle + pipe round trip was what the ring's device path cost in round 2 (0.39 ms per batch of 8 against 0.05 ms of DMA)."""
+        tok = self.begin_batch(frames, idxs, block=block, timeout=timeout)
+        if tok is None:
+            return
+        if tok["stream"] is not None:
+            from . import _lib
+            try:
+                _lib.check(_lib.lib().mf_stream_synchronize(tok["stream"]), "stream_synchronize")   # one fence per batch, then the slots are published
+            except BaseException:
+                self.abort_batch(tok)
+                raise
+        self.commit_batch(tok, audio_frames, _single_audio=_single_audio)
+
+    def begin_batch(self, frames, idxs, stream=None, block=True, timeout=None):
+        """First half of put_batch, for a producer that overlaps the copy with its next step: takes the slots and ENQUEUES the DMA on `stream`
+        (a torch stream; default: the current one) without waiting.  Once the caller knows the copy is complete (an event recorded behind it on
+        that stream) it calls commit_batch(token, audio_frames); abort_batch(token) hands the slots back instead.  Returns None for an empty batch."""
         B = len(idxs)
         if B == 0:
-            return
+            return None
         is_dev = self._is_device(frames)
         if is_dev:
             import torch
@@ -148,34 +164,45 @@ class FrameRing:
         if len(frames) != B:
             raise ValueError(f"{len(frames)} frames for {B} indices")
         slots = self._acquire(B, block, timeout)
+        tok = {"slots": slots, "shape": shape, "dtype": dtype.str, "idxs": list(idxs), "stream": None, "keep": None}
         try:
             if is_dev:
                 from . import _lib
                 lib = _lib.lib()
                 self.register_pinned()
-                stream = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+                st = torch.cuda.current_stream(t.device) if stream is None else stream
+                cs = C.c_void_p(st.cuda_stream)
                 with torch.cuda.device(t.device):
                     i = 0
                     while i < B:
                         j = i + 1
                         while j < B and slots[j] == slots[j - 1] + 1:
                             j += 1
-                        _lib.check(self._dma(t, i, slots[i:j], stream, lib), "copy_d2h_async")
+                        _lib.check(self._dma(t, i, slots[i:j], cs, lib), "copy_d2h_async")
                         i = j
-                    _lib.check(lib.mf_stream_synchronize(stream), "stream_synchronize")   # one fence per batch, then the slots are published
+                tok["stream"], tok["keep"] = cs, t                   # (the source tensor must outlive the copy)
             else:
                 for i, sl in enumerate(slots):
                     self._slot_view(sl, shape, dtype)[...] = a[i]
         except BaseException:
-            # nothing was published: give the slots back and rewind the cursor (single producer: nobody else moved it)
-            self._head = slots[0]
-            for _ in slots:
-                self._free.release()
+            self.abort_batch(tok)
             raise
+        return tok
+
+    def abort_batch(self, tok):
+        """nothing of this batch was published: give the slots back and rewind the cursor (single producer: nobody else moved it)"""
+        self._head = tok["slots"][0]
+        for _ in tok["slots"]:
+            self._free.release()
+
+    def commit_batch(self, tok, audio_frames, _single_audio=None):
+        """Second half of put_batch: publishes the batch's descriptors as one message.  The copy must be complete."""
+        sl, shape, dt, idxs = tok["slots"], tok["shape"], tok["dtype"], tok["idxs"]
+        tok["keep"] = None
         if _single_audio is not None:
-            self._desc.put([(slots[0], shape, dtype.str, idxs[0], _single_audio)])
+            self._desc.put([(sl[0], shape, dt, idxs[0], _single_audio)])
         else:
-            self._desc.put([(sl, shape, dtype.str, idxs[i], audio_frames[2 * i:2 * i + 2]) for i, sl in enumerate(slots)])
+            self._desc.put([(s_, shape, dt, idxs[i], audio_frames[2 * i:2 * i + 2]) for i, s_ in enumerate(sl)])
 
     # ---- consumer -----------------------------------------------------------------------------------------------------------
     def get(self, block=True, timeout=None, copy=True):

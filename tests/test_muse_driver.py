@@ -75,6 +75,20 @@ def test_session_scheduler_queues_on_a_fake_clock():
     assert [k for k, *_ in done] == [3] and sch.steps == 3 and sch.sessions_served == 5 and sch.pending() == {}
 
 
+def test_frontend_window_is_the_host_side_of_run_step():
+    """museasr.py:17-29 without the encoder call: the window is context + new chunks, the context kept for the next step is the last l + r chunks."""
+    fe = D.MuseASRFrontend(None, batch_size=8)
+    new = [np.full(320, i, np.float32) for i in range(16)]
+    assert fe.window(new) is None and len(fe.frames) == 16                      # 16 <= l + r = 20: museasr.py:22-23 returns before the encoder
+    win = fe.window([np.full(320, 16 + i, np.float32) for i in range(16)])
+    assert win.shape == (32 * 320,) and win[0] == 0 and win[-1] == 31 and [float(f[0]) for f in fe.frames] == list(range(12, 32))
+    fe2 = D.MuseASRFrontend(None, batch_size=8)
+    fe2.warm_up()                                                               # baseasr.py:53-59: l + r silent chunks
+    win = fe2.window(new)
+    assert win.shape == ((20 + 16) * 320,) and not win[:20 * 320].any() and win[20 * 320] == 0 and win[-1] == 15
+    assert len(fe2.frames) == 20 and float(fe2.frames[0][0]) == 0.0 and float(fe2.frames[4][0]) == 0.0 and float(fe2.frames[-1][0]) == 15.0
+
+
 @pytest.mark.gpu
 def test_hip_feature_chunks_vs_oracle(lib_built):
     from oracle import whisper_ref
@@ -206,3 +220,84 @@ def test_hip_scheduler_serves_paced_sessions_vs_oracle(lib_built):
             assert d.max() <= 2 and (d > 0).mean() < 0.05, (k, d.max())
         now[0] += 0.05
     assert served == [[1, 0], [2, 1], [2]] and sch.steps == 3 and sch.sessions_served == 5
+
+
+@pytest.mark.gpu
+def test_hip_end_to_end_scheduler_delivers_the_session_loop_through_rings(lib_built):
+    """EndToEndScheduler: PCM chunks in, (res_frame, idx, audio_frames) tuples out of each session's FrameRing.  Every delivered frame equals what the
+    step-by-step path of this library (MuseASRFrontend.run_step -> MuseBatcher.step with paste) produces for that session alone -- up to the fp32
+    summation order of a Whisper call that holds two windows instead of one -- the indices are the mirror walk, the audio pairs are the session's own
+    chunks, and a session's batches come out in order whatever company they had."""
+    from mere_fusion_amd.musetalk.models.unet import UNet
+    from mere_fusion_amd.musetalk.models.vae import VAE
+    from mere_fusion_amd.musetalk.whisper.audio2feature import Audio2Feature
+    from mere_fusion_amd.musetalk.config import unet_config_json, vae_config_json
+    from mere_fusion_amd.paste import AvatarFrames
+    from mere_fusion_amd.transport import FrameRing
+    from oracle import musetalk_ref as R
+    cfg = R.MUSETALK_SMALL
+    usd, vsd = W.make_musetalk_unet_state_dict(cfg, 0), W.make_musetalk_vae_state_dict(cfg, 0)
+    B, S, CAP, NB = 2, 3, 2, 3
+    unet = UNet(unet_config_json(cfg["unet"]), usd, max_batch=B * CAP)
+    vae = VAE(config=vae_config_json(cfg["vae"]), state_dict=vsd, max_batch=B * CAP)
+    a2f = Audio2Feature(state_dict=W.make_whisper_encoder_state_dict(0), n_head=6)
+    rng = np.random.default_rng(3)
+    H_, W_ = 300, 320
+    lat_lists, avatars = [], []
+    for s in range(S):
+        n = 3 + s
+        lat_lists.append([W.make_musetalk_inputs(1, 700 + 10 * s + i)[0] for i in range(n)])
+        boxes = [(40 + 3 * i, 30 + 2 * i, 40 + 3 * i + 200, 30 + 2 * i + 220) for i in range(n)]
+        crops = [(b[0] - 10, b[1] - 12, b[2] + 10, b[3] + 12) for b in boxes]
+        masks = [np.repeat(rng.integers(0, 256, (c[3] - c[1], c[2] - c[0], 1), dtype=np.uint8), 3, axis=2) for c in crops]
+        avatars.append(AvatarFrames(rng.integers(0, 256, (n, H_, W_, 3), dtype=np.uint8), boxes, masks, crops))
+    pcm = [[[W.make_speech_like_wav(320, 50 * s + 7 * j + i) for i in range(2 * B)] for j in range(NB)] for s in range(S)]
+
+    # the step-by-step path, one session at a time
+    want = []
+    for s in range(S):
+        fe = D.MuseASRFrontend(a2f, B)
+        fe.warm_up()
+        bat1 = D.MuseBatcher(unet, vae, [D.MuseSession(lat_lists[s], avatar_frames=avatars[s])], batch_size=B, paste=True, max_sessions_per_step=1)
+        rows = []
+        for j in range(NB):
+            fr, idx = bat1.step([fe.run_step(pcm[s][j])])[0]
+            rows.append((fr.cpu().numpy(), idx))
+        want.append(rows)
+
+    fes = [D.MuseASRFrontend(a2f, B) for _ in range(S)]
+    for fe in fes:
+        fe.warm_up()
+    rings = [FrameRing(2 * B, (H_, W_, 3)) for _ in range(S)]
+    bat = D.MuseBatcher(unet, vae, [D.MuseSession(lat_lists[s], avatar_frames=avatars[s]) for s in range(S)], batch_size=B, paste=True, max_sessions_per_step=CAP)
+    now = [0.0]
+    sch = D.EndToEndScheduler(bat, fes, a2f, rings=rings, clock=lambda: now[0], hold_s=0.0)
+    for j in range(NB):
+        for s in range(S):
+            sch.submit(s, pcm[s][j], 0.01 * (S * j + s))
+    got = [[] for _ in range(S)]
+    served = []
+    for _ in range(200):
+        now[0] += 0.05
+        done = sch.run_once()
+        done += sch.drain()                                                                   # (a test has no other work to overlap the copy with)
+        served.extend(k for k, *_ in done)
+        for k, fr, idx, lat in done:
+            assert lat > 0
+            for i in range(B):                                                                # the consumer side: process_frames' get()
+                f, fidx, audio = rings[k].get(timeout=5)
+                j = len(got[k]) // B
+                assert fidx == idx[i] and len(audio) == 2 and audio[0][1] == 0 and np.array_equal(audio[0][0], pcm[k][j][2 * i]) and np.array_equal(audio[1][0], pcm[k][j][2 * i + 1])
+                got[k].append(f)
+        if not sch.pending() and not sch.inflight:
+            break
+    assert sorted(served) == sorted(list(range(S)) * NB) and sch.steps >= -(-S * NB // CAP)
+    for s in range(S):
+        assert len(got[s]) == NB * B
+        for j in range(NB):
+            wfr, widx = want[s][j]
+            for i in range(B):
+                d = np.abs(got[s][j * B + i].astype(int) - wfr[i].astype(int))
+                assert d.max() <= 1 and (d > 0).mean() < 0.01, (s, j, i, d.max(), (d > 0).mean())
+    for r in rings:
+        r.close()
