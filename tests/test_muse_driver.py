@@ -169,7 +169,8 @@ def test_hip_batcher_three_sessions_vs_oracle(lib_built):
             want_u8, _ = R.musetalk_step(usd, vsd, cfg, lat, chunks[s])
             got_u8 = raw[s][0].cpu().numpy()
             d = np.abs(got_u8.astype(int) - want_u8.astype(int))
-            assert d.max() <= 2 and (d > 0).mean() < 0.05, (step, s, d.max())
+            print(f"batcher step {step} session {s}: uint8 max diff {d.max()}, differing pixels {100 * (d > 0).mean():.3f} %")
+            assert d.max() <= 1 and (d > 0).mean() < 0.01, (step, s, d.max(), (d > 0).mean())
             frames, boxes, masks, crops = avatars[s]
             pasted = out[s][0].cpu().numpy()
             for k, i in enumerate(want_idx):                                                # byte work: bit-exact on the SAME generated frame
@@ -217,7 +218,8 @@ def test_hip_scheduler_serves_paced_sessions_vs_oracle(lib_built):
             want_u8, _ = R.musetalk_step(usd, vsd, cfg, lat_in, chunks[(k, seen[k])])
             seen[k] += 1
             d = np.abs(frames.cpu().numpy().astype(int) - want_u8.astype(int))
-            assert d.max() <= 2 and (d > 0).mean() < 0.05, (k, d.max())
+            print(f"scheduler session {k}: uint8 max diff {d.max()}, differing pixels {100 * (d > 0).mean():.3f} %")
+            assert d.max() <= 1 and (d > 0).mean() < 0.01, (k, d.max(), (d > 0).mean())
         now[0] += 0.05
     assert served == [[1, 0], [2, 1], [2]] and sch.steps == 3 and sch.sessions_served == 5
 

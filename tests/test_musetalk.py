@@ -66,8 +66,8 @@ def test_oracle_small_step_shapes(small):
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------
-TOL_LATENT = 2e-3     # bf16x3 through ~60 convs / 16 attention blocks; latents are O(1)
-TOL_IMAGE = 4e-3      # decoder output before clamp, values in about [-4, 4]
+TOL_LATENT = 1e-4     # bf16x3 through ~60 convs / 16 attention blocks; latents are O(1); measured ~3e-5 (bound 1e-3): gate at ~3 x
+TOL_IMAGE = 6e-4      # decoder output before clamp, values in about [-4, 4]; measured ~2e-4
 
 
 def _cfg_json(c):
@@ -114,7 +114,8 @@ def test_hip_vae_vs_oracle(hip_small, small):
     got = frames.cpu().numpy()
     assert got.shape == want_u8.shape == (2, 256, 256, 3) and got.dtype == np.uint8
     diff = np.abs(got.astype(int) - want_u8.astype(int))
-    assert diff.max() <= 1 and (diff > 0).mean() < 0.02        # rounding boundaries only
+    print(f"small VAE: uint8 max diff {diff.max()}, differing pixels {100 * (diff > 0).mean():.3f} %")
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01        # rounding boundaries only (gate ~3 x measured)
     assert np.array_equal(vae.decode_latents(lat.cuda()), got)  # the reference-shaped call: numpy uint8 BGR
 
 
@@ -135,7 +136,8 @@ def test_hip_musetalk_step_and_replay(hip_small, small):
           "u8 vs oracle", [int(np.abs(o.astype(int) - want.astype(int)).max()) for o in outs])
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
     diff = np.abs(outs[0].astype(int) - want.astype(int))
-    assert diff.max() <= 2 and (diff > 0).mean() < 0.05
+    print(f"small step: uint8 max diff {diff.max()}, differing pixels {100 * (diff > 0).mean():.3f} %")
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01
 
 
 @pytest.mark.gpu

@@ -14,8 +14,12 @@ from mere_fusion_amd.musetalk.config import MUSETALK_V1, unet_config_json, vae_c
 pytestmark = pytest.mark.gpu
 
 B = 8
-TOL_LATENT = 1e-3          # north_star bound
-TOL_IMAGE = 4e-3           # decoder output before the clamp, values in about [-4, 4]: 1e-3 relative
+# The parity BOUND is the north star's (fp32 L-inf <= 1e-3; frames within one grey level).  The GATES below sit at about 3 x what the product measures
+# on an MI355X (profiles/r02_full_size_parity.txt: latents 2.8e-5, image 1.8e-4, 0.19-0.24 % of uint8 pixels off by one), so that a 10 x regression
+# that still meets the bound does not pass unnoticed.
+TOL_LATENT = 1e-4          # measured 2.8e-5 (bound 1e-3)
+TOL_IMAGE = 6e-4           # decoder output before the clamp, values in about [-4, 4]; measured 1.8e-4 (bound 1e-3 relative = 4e-3)
+TOL_U8_FRACTION = 0.007    # fraction of uint8 pixels off by one level (round-half ties); measured 0.0019 - 0.0024
 
 
 @pytest.fixture(scope="module")
@@ -25,22 +29,12 @@ def full_sd():
 
 @pytest.fixture(scope="module")
 def hip_full(lib_built, full_sd):
-    """The handles of this module run as production does: launch configurations measured on the first forward (MF_AUTOTUNE default, which the
-    rest of the suite switches off for speed)."""
-    import os
+    """The handles of this module run as a deployment does: launch configurations from the tuning table shipped beside the library."""
     from mere_fusion_amd.musetalk.models.unet import UNet
     from mere_fusion_amd.musetalk.models.vae import VAE
     usd, vsd = full_sd
-    old = os.environ.get("MF_AUTOTUNE")
-    os.environ["MF_AUTOTUNE"] = "1"
-    try:
-        unet = UNet(unet_config_json(MUSETALK_V1["unet"]), usd, max_batch=B)
-        vae = VAE(config=vae_config_json(MUSETALK_V1["vae"]), state_dict=vsd, max_batch=B)
-    finally:
-        if old is None:
-            os.environ.pop("MF_AUTOTUNE", None)
-        else:
-            os.environ["MF_AUTOTUNE"] = old
+    unet = UNet(unet_config_json(MUSETALK_V1["unet"]), usd, max_batch=B)
+    vae = VAE(config=vae_config_json(MUSETALK_V1["vae"]), state_dict=vsd, max_batch=B)
     return unet, vae
 
 
@@ -74,7 +68,9 @@ def test_full_unet_batch8_vs_oracle(hip_full, oracle_full):
     assert err <= TOL_LATENT, err
     # batch-composition invariance at full size: frames 2 and 5 alone (other tile / split choices) agree with the batch-8 result
     sub = unet.model(o["lat"][[2, 5]].cuda(), torch.tensor([0]).cuda(), encoder_hidden_states=unet.pe(o["aud"][[2, 5]].cuda())).sample.cpu()
-    assert (sub - got[[2, 5]]).abs().max().item() <= 2e-4
+    sub_err = (sub - got[[2, 5]]).abs().max().item()
+    print(f"batch-composition: frames 2, 5 alone vs inside the batch of 8: {sub_err:.3e}")
+    assert sub_err <= 1e-4
 
 
 def test_full_vae_batch8_vs_oracle(hip_full, oracle_full):
@@ -89,7 +85,7 @@ def test_full_vae_batch8_vs_oracle(hip_full, oracle_full):
     print(f"sd-vae-ft-mse decoder, batch {B}: image L-inf {ierr:.3e} (bound {TOL_IMAGE}); uint8 max diff {d.max()}, "
           f"differing pixels {100 * (d > 0).mean():.3f} %")
     assert ierr <= TOL_IMAGE, ierr
-    assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
+    assert d.max() <= 1 and (d > 0).mean() < TOL_U8_FRACTION, (d.max(), (d > 0).mean())
     assert o["u8"].std() > 10                                 # the frames are not flat
 
 
@@ -102,7 +98,7 @@ def test_full_step_graph_replay_vs_oracle(hip_full, oracle_full):
         assert np.array_equal(x, outs[0])
     d = np.abs(outs[0].astype(int) - o["u8"].astype(int))
     print(f"full step, batch {B}, graph replay: uint8 max diff vs oracle {d.max()}, differing pixels {100 * (d > 0).mean():.3f} %")
-    assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
+    assert d.max() <= 1 and (d > 0).mean() < TOL_U8_FRACTION, (d.max(), (d > 0).mean())
 
 
 def test_full_graphs_survive_other_batch_sizes(hip_full, oracle_full):
@@ -129,7 +125,8 @@ def test_full_vae_batch8_matches_batch1(hip_full):
     for i in (0, 3, 7):
         f1 = vae.decode_latents_device(lat[i:i + 1])
         d = (f1[0].int() - f8[i].int()).abs()
-        assert int(d.max()) <= 2 and float((d > 0).float().mean()) < 0.02, (i, int(d.max()), float((d > 0).float().mean()))
+        print(f"VAE batch 1 vs batch 8, frame {i}: uint8 max diff {int(d.max())}, differing pixels {100 * float((d > 0).float().mean()):.3f} %")
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 0.01, (i, int(d.max()), float((d > 0).float().mean()))
 
 
 def test_full_vae_large_batch_handle_vs_oracle(full_sd, oracle_full):
@@ -147,10 +144,10 @@ def test_full_vae_large_batch_handle_vs_oracle(full_sd, oracle_full):
     d = np.abs(got[:B].astype(int) - o["u8"].astype(int))
     print(f"sd-vae-ft-mse decoder, handle for 24 frames: image L-inf {ierr:.3e}; uint8 max diff {d.max()}, differing pixels {100 * (d > 0).mean():.3f} %")
     assert ierr <= TOL_IMAGE, ierr
-    assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
+    assert d.max() <= 1 and (d > 0).mean() < TOL_U8_FRACTION, (d.max(), (d > 0).mean())
     for k in (1, 2):
         dk = np.abs(got[k * B:(k + 1) * B].astype(int) - got[:B].astype(int))
-        assert dk.max() <= 1 and (dk > 0).mean() < 0.01
+        assert dk.max() <= 1 and (dk > 0).mean() < TOL_U8_FRACTION
 
 
 def test_algorithmic_flops_match_the_oracle_count(hip_full):
