@@ -304,8 +304,7 @@ template <int DH, int KT>
 int launch_qb(AttnArgs& a, int groups, bool x3, hipStream_t s) {
     // 32 queries per wave halve the K / V^T fragment reads per MFMA; take them when the chip still gets >= 2 waves of
     // workgroups, otherwise spread the queries over more workgroups
-    static const int force = [] { const char* e = getenv("MF_ATTN_QB"); return e ? atoi(e) : 0; }();
-    const bool wide = force ? force == 2 : (int64_t)groups * ((a.Tq + 127) / 128) >= 512;
+    const bool wide = (int64_t)groups * ((a.Tq + 127) / 128) >= 512;
     if (DH <= 80 && wide) {
         a.qtiles = (a.Tq + 127) / 128;
         a.total = groups * a.qtiles;

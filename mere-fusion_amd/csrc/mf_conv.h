@@ -66,7 +66,6 @@ struct ConvArgs {
     int64_t zx_b, zx_h, zw, zy_b, zy_h;
     float* ws;                // split-K fp32 partials [split][B][Ho][Wo][N], or null
     int64_t ws_split, wsb; int wsi, wsj;
-    int* tile_cnt;            // fused split-K combine: arrivals per (phase, tile); the last workgroup reduces and resets it (null: k_splitk_epilogue)
     // GroupNorm statistics of the OUTPUT for the layer's consumer: (sum, sum of squares) per (sample, group) added to gn_out[2 * (b * groups + g)]
     // by the epilogue (4-wave tiles whose pixel tile lies in one sample) or by the split-K combine; null = off
     double* gn_out; int gn_out_cpg, gn_out_groups;
@@ -90,13 +89,10 @@ struct HaloArgs {
     int patches_x, patches_per_img, n_patches, tiles_n;   // filled by mf_halo_launch
     // LDS-weights kernel only: channel slices split over blockIdx.y, fp32 partial tiles [split][B][H][W][N] combined by k_splitk_epilogue
     float* ws; int64_t ws_split; int nsplit;
-    // LDS-weights kernel only: GroupNorm + SiLU of the INPUT applied to the halo image in LDS, v = silu(x * gn_scale[b][c] + gn_shift[b][c]); null = none
-    const float* gn_scale; const float* gn_shift; int gn_C;
     unsigned long long* dbg;                    // MF_DBG_TIMES: 4 s_memtime stamps per workgroup (entry, loop start, loop end, exit), or null
     int q;                                      // operands in the f16 + FP6-residual format (MF_PREC_F16Q): x_lo / w_lo hold [q6 block | q6 block] rows
     double* gn_out; int gn_out_cpg, gn_out_groups;   // f16 + FP6 kernel: (sum, sum of squares) of the OUTPUT per (sample, group) added here for the consumer GroupNorm; null = off
     int wide_store;                             // f16 + FP6 tiles: the output view starts on an 8-channel group, C % 8 == 0, N % 32 == 0: 16-byte epilogue stores
-    int stagger;                                // LDS-weights kernel, 8-wave tiles: the second wave of every SIMD issues its weight DMA mid-tap (filled by the launcher)
 };
 struct HaloTile { int ph, bn, wgm, wgn; };
 HaloTile mf_halo_pick_tile(int H, int W, int N, int batch, int cin = 0);
@@ -104,12 +100,6 @@ int mf_halo_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s)
 // second generation (mf_conv_halo2.hip): weights shared through an LDS ring; pick_tile returns ph == 0 to decline
 HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch, int cin = 0);
 int mf_halo_w_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s, int phase = -1);
-// mf_conv_launch with GroupNorm + SiLU of the input folded in (scale / shift [batch][cin] from mf_groupnorm_affine); only valid when
-// mf_conv_can_fuse_gn(p, batch) (a plain 3x3 layer that runs on the LDS-weights halo kernel's fat tiles at this batch)
-bool mf_conv_can_fuse_gn(const struct ConvPlan* p, int batch);
-int mf_conv_launch_gn(struct ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, const float* gn_scale,
-                      const float* gn_shift, hipStream_t stream);   // phase 0..3: one phase of upsample + 3x3
-
 struct ConvTile { int bm, bn, wgm, wgn, nsplit; };
 struct ConvTuned { ConvTile tile; int ld; };   // a measured launch configuration (mf_conv_tune)
 
@@ -140,8 +130,6 @@ struct ConvPlan {
     hipEvent_t prof_mid = nullptr;   // measurement only: recorded between the MFMA kernel and its split-K combine
     float* ws = nullptr;  // split-K workspace, grown on the first (eager) launch that needs it
     int64_t ws_cap = 0;
-    int* tile_cnt = nullptr;  // arrival counters of the fused split-K combine (zeroed once; self-resetting)
-    int tile_cnt_cap = 0;
     // Outgrown workspaces / counters.  A hipGraph captured at one batch size keeps the pointer it was captured with; the split count comes
     // from a batch-dependent cost model, so a SMALLER batch can need a LARGER workspace later.  Outgrown buffers are therefore never freed
     // while the plan lives (a replayed graph may still write them): they are parked here until mf_conv_plan_destroy.

@@ -404,45 +404,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
                 *reinterpret_cast<float4*>(wo + c) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             }
         }
-        if (!a.tile_cnt) {
-            if (dbg && threadIdx.x == 0) dbg[3] = __builtin_amdgcn_s_memtime();
-            return;
-        }
-        // Fused combine (small tiles): the last workgroup of a tile to arrive sums the partials -- its own included, in split order, so
-        // the result does not depend on arrival order -- back into its accumulator registers and runs the ordinary epilogue below.
-        // Saves the k_splitk_epilogue launch and its pass over the output.
-        __threadfence();
-        __syncthreads();
-        int* s_flag = reinterpret_cast<int*>(smem);          // the ring is drained: its first word is free
-        if (threadIdx.x == 0) {
-            int* cnt = a.tile_cnt + (int)blockIdx.z * nt + t;
-            const int last = atomicAdd(cnt, 1) == (int)gridDim.y - 1;
-            if (last) *cnt = 0;
-            *s_flag = last;
-        }
-        __syncthreads();
-        if (!*s_flag) return;
-        __threadfence();
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            const int m = m0 + pm0 + j * 16 + fr;
-            if (m >= a.M) continue;
-            const int b = m / a.HqWq;
-            const int rem = m - b * a.HqWq;
-            const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
-            const float* wo = a.ws + (int64_t)b * a.wsb + (int64_t)qi * a.wsi + (int64_t)qj * a.wsj + ph.ws_off;
-#pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const int c = n0 + cn0 + i * 16 + fk * 4;
-                if (c >= a.N) continue;
-                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int k = 0; k < (int)gridDim.y; ++k) {
-                    const float4 v = *reinterpret_cast<const float4*>(wo + (int64_t)k * a.ws_split + c);
-                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-                }
-                acc[i][j][0] = sum.x; acc[i][j][1] = sum.y; acc[i][j][2] = sum.z; acc[i][j][3] = sum.w;
-            }
-        }
+        // (the combine -- bias, residual, activation, the (hi, lo) store -- is k_splitk_epilogue's: doing it here, in the last workgroup of a tile to
+        // arrive, measured slower: one workgroup re-reading nsplit tiles behind two fences and an atomic is a longer tail than a 5 us pass over every CU)
+        if (dbg && threadIdx.x == 0) dbg[3] = __builtin_amdgcn_s_memtime();
+        return;
     }
     // Bias quads of this lane, fetched once and with clamped (never branched-around) addresses; the activation is a
     // compile-time parameter of the body below.  Both keep the per-fragment code straight-line, so the residual loads of a
@@ -737,15 +702,6 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const ConvArgs a,
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int BM, int BN, int WGM, int WGN, bool X3, int BK>
-struct RingDepth {
-    static constexpr int stage_bytes = (BM + BN) * BK * 2 * (X3 ? 2 : 1);
-    static constexpr int RPC = 1024 / (BK * 2);
-    static constexpr bool countable = (BM / RPC) % (WGM * WGN) == 0 && (BN / RPC) % (WGM * WGN) == 0;
-    // deepest ring (<= 4) that leaves room for two workgroups per CU when a stage is small, one otherwise
-    static constexpr int value = !countable ? 2 : (4 * stage_bytes <= 72 * 1024 ? 4 : (3 * stage_bytes <= 76 * 1024 ? 3 : (4 * stage_bytes <= 150 * 1024 ? 4 : (3 * stage_bytes <= 150 * 1024 ? 3 : 2))));
-};
-
 template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST, int LD = 0>
 int launch_cfg_n(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStream_t s) {
     static bool attr_done = false;
@@ -764,19 +720,13 @@ int launch_cfg_n(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStr
 
 template <int BM, int BN, int WGM, int WGN, bool X3, int BK>
 int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStream_t s) {
-    // Measured on MI355X (profiles/r01_ring_ab.md): the double buffer wins on the MuseTalk / Wav2Lip shapes because the
-    // deeper ring halves the workgroups per CU; MF_RING=deep keeps the 3/4-stage ring reachable for A/B runs.
-    static const bool deep = [] { const char* e = getenv("MF_RING"); return e && !strcmp(e, "deep"); }();
-    constexpr int NST = RingDepth<BM, BN, WGM, WGN, X3, BK>::value;
-    if (deep && NST != 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, NST>(a, nphase, nsplit, goff_max, s);
-    // 4-wave tiles: operands through registers into ONE LDS stage, so that 64-deep bf16x3 tiles (128-byte operand rows) still leave 2-3 workgroups
-    // per CU (MF_IGEMM_LD=0 keeps the LDS-DMA ring, 1 the two-stage register path, for A/B); the 8-wave 256-wide tiles have no VGPRs to spare.
-    // Per-op A/B at batch 8 (tools/igemm_ld_ab.sh): UNet 11.05 -> 10.62 ms, Wav2Lip 14.6 k -> 15.1 k frames/s; every variant within +-15 % per layer.
-    // Choosing DMA for the weight-heavy layers only (a.m_fastest) measured 1.4 % slower over the UNet than registers everywhere (10.80 vs 10.64 ms).
-    static const int regs_default = [] { const char* e = getenv("MF_IGEMM_LD"); return e ? atoi(e) : 2; }();
-    const int regs = a.ld >= 0 ? a.ld : regs_default;
+    // Two operand paths, a measured choice per layer (ConvArgs::ld, mf_conv_tune):
+    //   ld 0  both tiles by LDS-DMA into a 2-stage ring (deeper rings halve the workgroups per CU: measured slower, profiles/r01_ring_ab.md)
+    //   ld 2  (4-wave tiles only, their default) operands through registers into ONE LDS stage, so that 64-deep bf16x3 tiles (128-byte operand rows)
+    //         still leave 2-3 workgroups per CU; the 8-wave 256-wide tiles have no VGPRs to spare
+    // Per-op A/B at batch 8: UNet 11.05 -> 10.62 ms, Wav2Lip 14.6 k -> 15.1 k frames/s with ld 2 as the default; every variant within +-15 % per layer.
+    const int regs = a.ld >= 0 ? a.ld : 2;
     if constexpr (WGM * WGN == 4) {
-        if (regs == 1 && 2 * RingDepth<BM, BN, WGM, WGN, X3, BK>::stage_bytes <= 150 * 1024) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 1>(a, nphase, nsplit, goff_max, s);
         if (regs == 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 2>(a, nphase, nsplit, goff_max, s);
     }
     return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2>(a, nphase, nsplit, goff_max, s);
@@ -787,10 +737,9 @@ int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3
     // bf16x3 doubles the LDS image: 64-deep tiles only where two stages of (hi, lo) still leave >= 2
     // workgroups per CU (the small tiles of the long-K layers), 32-deep otherwise
     constexpr bool deep = (BM + BN) <= 128;
-    // 64-deep bf16x3 tiles (128-byte operand rows: every request a full line) on every 4-wave tile; MF_IGEMM_BK=32 restores the 32-deep ones
-    static const bool bk64 = [] { const char* e = getenv("MF_IGEMM_BK"); return !e || atoi(e) == 64; }();
+    // 64-deep bf16x3 tiles (128-byte operand rows: every request a full line) on every 4-wave tile
     if constexpr (WGM * WGN == 4 && !deep) {
-        if (x3 && bk64) return launch_cfg<BM, BN, WGM, WGN, true, 64>(a, nphase, nsplit, goff_max, s);
+        if (x3) return launch_cfg<BM, BN, WGM, WGN, true, 64>(a, nphase, nsplit, goff_max, s);
     }
     return x3 ? launch_cfg<BM, BN, WGM, WGN, true, deep ? 64 : 32>(a, nphase, nsplit, goff_max, s)
               : launch_cfg<BM, BN, WGM, WGN, false, 64>(a, nphase, nsplit, goff_max, s);
@@ -798,7 +747,6 @@ int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3
 
 int cdiv(int a, int b) { return (a + b - 1) / b; }
 bool g_no_halo_wide = false;   // set while mf_conv_plan_create builds the implicit-GEMM twin of a wide halo plan
-bool mf_k_tap_major() { static const bool v = [] { const char* e = getenv("MF_K_ORDER"); return e && !strcmp(e, "tap"); }(); return v; }
 
 }  // namespace
 
@@ -1020,20 +968,13 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     p->BK = BK;
     // up to 256 channels: the register-weights halo kernel (mf_conv_halo.hip) or the LDS-weights one (mf_conv_halo2.hip);
     // wider (<= 1024, cout a multiple of 128, maps >= 64 x 64): only the LDS-weights kernel's fat tiles, with an implicit-GEMM twin
-    // (p->alt) for launches too small to fill the chip with 16 x 16-pixel patches.  MF_HALO_WIDE=0 keeps wide layers on implicit GEMM.
-    static const bool halo_wide = [] { const char* e = getenv("MF_HALO_WIDE"); return !e || atoi(e) != 0; }();
-    static const int halo_wide_minpx = [] { const char* e = getenv("MF_HALO_WIDE_MINPX"); return e ? atoi(e) : 64 * 64; }();
+    // (p->alt) for launches too small to fill the chip with 16 x 16-pixel patches.
     const bool narrow = d.cin <= 256 && d.cout <= 256;
-    const bool wide_ok = halo_wide && !g_no_halo_wide && d.cin <= 1024 && d.cout <= 1024 && d.cout % 128 == 0 && d.cin % 32 == 0 &&
-                         (d.in_h * d.in_w >= halo_wide_minpx || (d.cout % 256 == 0 && d.cin >= 512));   // small maps: only the 256-channel tile pays
+    const bool wide_ok = !g_no_halo_wide && d.cin <= 1024 && d.cout <= 1024 && d.cout % 128 == 0 && d.cin % 32 == 0 &&
+                         (d.in_h * d.in_w >= 64 * 64 || (d.cout % 256 == 0 && d.cin >= 512));   // small maps: only the 256-channel tile pays
     p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
               d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16 && d.residual != 2 && d.act <= 2 && !d.upsample &&
               (narrow || wide_ok) && d.cout % 4 == 0;
-    {
-        // MF_HALO_MAXC=n: halo kernel only up to n input channels (A/B against the 8-wave implicit-GEMM tiles)
-        static const int maxc = [] { const char* e = getenv("MF_HALO_MAXC"); return e ? atoi(e) : 256; }();
-        if (d.cin > maxc && narrow) p->halo = false;
-    }
     const bool want_alt = p->halo && !narrow;
     if (p->halo) {
         // ---- pack for the halo-tile kernel: [slice][tap][Npad][CK], channels past cin are zero --------
@@ -1080,9 +1021,7 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     // between: by then the lines have left L2 (64 workgroups per XCD x 0.5 MB), so a 3x3 layer pulled its input ~9x from HBM / MALL
     // (PMC: 510-627 MB per launch against 153 MB of tensors on the VAE's 512-channel layers).  Channel-slice-major (for each 64-channel
     // slice: its taps back to back) keeps the taps' overlapping rows within nine consecutive K-tiles -- about 50 KB per workgroup.
-    // MF_K_ORDER=tap restores the old order (A/B).
-    const bool k_tap_major = mf_k_tap_major();
-    auto kgroup = [&](int ntaps, int ti, int cg) { return (!k_tap_major && cpg % 8 == 0) ? ((cg / 8) * ntaps + ti) * 8 + cg % 8 : ti * cpg + cg; };
+    auto kgroup = [&](int ntaps, int ti, int cg) { return (cpg % 8 == 0) ? ((cg / 8) * ntaps + ti) * 8 + cg % 8 : ti * cpg + cg; };
     int64_t total = 0;
     int goff_total = 0;
     for (int ph = 0; ph < p->nphase; ++ph) {
@@ -1140,37 +1079,6 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     MF_HIP(hipMemcpy(p->bias, fbias.data(), p->Npad * sizeof(float), hipMemcpyHostToDevice));
     MF_HIP(hipMalloc(&p->goff, goff_total * sizeof(int)));
     p->bound_in_ld = p->bound_in_wp = -1;
-    // nearest-2x upsample + 3x3 with wide channels (the VAE's upsamplers): a second pack for the LDS-weights halo kernel's fat tiles, one
-    // 2 x 2-tap phase per launch (mf_conv_launch picks it when the input grid gives >= 256 workgroups).  Opt-in (MF_HALO_UP=1): correct
-    // (checked against torch on five shapes) but only 1-5 % ahead of the 4-phase implicit GEMM per layer and nothing in the net -- a halo image
-    // amortised over 4 taps instead of 9, four launches.
-    static const bool halo_up = [] { const char* e = getenv("MF_HALO_UP"); return e && atoi(e) != 0; }();
-    if (halo_up && d.upsample && p->nphase == 4 && d.cout % 128 == 0 && d.cin % 32 == 0 && d.cin <= 1024 && d.cout <= 1024 && d.act <= 2 &&
-        !d.residual && d.in_h >= 16 && d.in_w >= 16) {
-        p->n_slices = cdiv(d.cin, HCK);
-        const int64_t per_phase = (int64_t)p->n_slices * 4 * p->Npad * HCK, tot = 4 * per_phase;
-        std::vector<bf16_t> uh(tot, 0), ul(tot, 0);
-        for (int ph = 0; ph < 4; ++ph)
-            for (int ti = 0; ti < 4; ++ti) {
-                const auto& tp = p->phase_taps[ph][ti];      // dy = py + ty - 1, dx = px + tx - 1 with ti = 2 * ty + tx: the kernel's tap order
-                for (int n = 0; n < d.cout; ++n)
-                    for (int c = 0; c < d.cin; ++c) {
-                        double w = 0.0;
-                        for (const auto& kk : tp.src) w += weight[(((int64_t)n * d.cin + c) * 3 + kk.first) * 3 + kk.second];
-                        const float wf = (float)(w * (double)scale[n]);
-                        const int64_t idx = ph * per_phase + (((int64_t)(c / HCK) * 4 + ti) * p->Npad + n) * HCK + c % HCK;
-                        const bf16_t h = mf_f2bf(wf);
-                        uh[idx] = h;
-                        ul[idx] = mf_f2bf(wf - mf_bf2f(h));
-                    }
-            }
-        MF_HIP(hipMalloc(&p->up_hi, tot * sizeof(bf16_t)));
-        MF_HIP(hipMemcpy(p->up_hi, uh.data(), tot * sizeof(bf16_t), hipMemcpyHostToDevice));
-        if (precision == MF_PREC_BF16X3) {
-            MF_HIP(hipMalloc(&p->up_lo, tot * sizeof(bf16_t)));
-            MF_HIP(hipMemcpy(p->up_lo, ul.data(), tot * sizeof(bf16_t), hipMemcpyHostToDevice));
-        }
-    }
     return MF_OK;
 }
 
@@ -1182,13 +1090,11 @@ void mf_conv_plan_destroy(ConvPlan* p) {
     if (p->bias) (void)hipFree(p->bias);
     if (p->goff) (void)hipFree(p->goff);
     if (p->ws) (void)hipFree(p->ws);
-    if (p->tile_cnt) (void)hipFree(p->tile_cnt);
     if (p->up_hi) (void)hipFree(p->up_hi);
     if (p->up_lo) (void)hipFree(p->up_lo);
     for (void* r : p->retired) (void)hipFree(r);
     p->retired.clear();
     p->up_hi = p->up_lo = nullptr;
-    p->tile_cnt = nullptr; p->tile_cnt_cap = 0;
     p->w_hi = p->w_lo = nullptr; p->bias = nullptr; p->goff = nullptr; p->ws = nullptr; p->ws_cap = 0;
 }
 
@@ -1210,7 +1116,7 @@ int mf_conv_bind(ConvPlan* p, const ActBuf& in) {
         for (int g = 0; g < p->ph[ph].ngroups; ++g) {
             const int gg = g < real ? g : 0;   // padding groups re-read group 0 against zero weights
             int ti = gg / cpg, cg = gg % cpg;
-            if (!mf_k_tap_major() && cpg % 8 == 0) {           // inverse of kgroup() in mf_conv_plan_create
+            if (cpg % 8 == 0) {                                // inverse of kgroup() in mf_conv_plan_create
                 const int nt = (int)taps.size(), s8 = gg / (nt * 8), rem = gg % (nt * 8);
                 ti = rem / 8; cg = s8 * 8 + rem % 8;
             }
@@ -1225,8 +1131,7 @@ int mf_conv_bind(ConvPlan* p, const ActBuf& in) {
 
 // Channel-slice split of the fat 256-channel halo tile for a wide layer whose map gives too few patches at this batch (0 = no split).
 static int mf_halo_split_count(const ConvPlan* p, int batch) {
-    static const bool halo_split = [] { const char* e = getenv("MF_HALO_SPLIT"); return !e || atoi(e) != 0; }();
-    if (!halo_split || !p->halo || !p->alt || p->d.cout % 256 || p->d.cin < 512) return 0;
+    if (!p->halo || !p->alt || p->d.cout % 256 || p->d.cin < 512) return 0;
     const int base = batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * (p->d.cout / 256);
     if (base < 64) return 0;          // (at 32 patches x tiles the split measured +5 % / -2 % on two shapes: not worth the second pass)
     for (int cand : {2, 4, 8})
@@ -1236,10 +1141,9 @@ static int mf_halo_split_count(const ConvPlan* p, int batch) {
 
 // Channel-slice split of the f16 + FP6 tile (16 x 16 pixels x 128 channels) for a layer with fewer tiles than CUs at this batch (1 = no split)
 int mf_q_split_count(const ConvPlan* p, int batch) {
-    static const bool on = [] { const char* e = getenv("MF_Q_SPLIT"); return !e || atoi(e) != 0; }();
     if (!p->q) return 1;
     const int base = batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * (p->d.cout / 128);
-    if (!on || base >= 256) return 1;
+    if (base >= 256) return 1;
     int best = 1;
     for (int cand : {2, 4, 8}) {
         if (p->n_slices / cand < 2) break;
@@ -1249,34 +1153,14 @@ int mf_q_split_count(const ConvPlan* p, int batch) {
     return best;
 }
 
-namespace { thread_local const float* g_gn_scale = nullptr; thread_local const float* g_gn_shift = nullptr; }
-
-bool mf_conv_can_fuse_gn(const ConvPlan* p, int batch) {
-    static const bool on = [] { const char* e = getenv("MF_GN_FUSE"); return e && atoi(e) != 0; }();
-    if (!on || !p->halo || p->up_hi) return false;
-    const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
-    return tw.ph == 16 && (tw.bn == 256 || tw.bn == 128) && !(tw.bn == 128 && tw.wgm == 2 && tw.wgn == 4);
-}
-
-int mf_conv_launch_gn(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, const float* gn_scale, const float* gn_shift,
-                      hipStream_t stream) {
-    MF_REQUIRE(mf_conv_can_fuse_gn(p, batch) && gn_scale && gn_shift, "conv: GroupNorm fusion not available for this layer / batch");
-    MF_REQUIRE(!(res.buf == in.buf && res.coff == in.coff), "conv: GroupNorm fusion with the input as residual is not supported");
-    g_gn_scale = gn_scale; g_gn_shift = gn_shift;
-    const int rc = mf_conv_launch(p, in, out, res, batch, stream);
-    g_gn_scale = g_gn_shift = nullptr;
-    return rc;
-}
-
 static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, hipStream_t stream, int tokens, bool* stats_done);
 
 // split-K combine that also leaves the consumer GroupNorm's statistics (k_splitk_epilogue_stats); false = not applicable, run the plain combine
 static bool launch_combine_stats(const ConvPlan* p, ConvArgs e, int nsplit, int Ho, int Wo, int batch, hipStream_t stream) {
-    static const bool on = [] { const char* v = getenv("MF_GN_EPI_SPLITK"); return !v || atoi(v) != 0; }();
-    if (!on || !p->out_stats || p->d.act == 5 || p->d.cout % 4 || p->d.cout % p->out_stats_groups || p->out_stats_groups > 64) return false;
+    if (!p->out_stats || p->d.act == 5 || p->d.cout % 4 || p->d.cout % p->out_stats_groups || p->out_stats_groups > 64) return false;
     e.gn_out = p->out_stats; e.gn_out_groups = p->out_stats_groups; e.gn_out_cpg = p->d.cout / p->out_stats_groups;
     const int nq = p->d.cout / 4, cols = std::min(256, nq), ppi = 256 / cols, T = Ho * Wo;
-    static const int target = [] { const char* v = getenv("MF_COMBINE_BLOCKS"); return v ? std::max(1, atoi(v)) : 1024; }();   // workgroups aimed for (each issues 2 * groups fp64 atomics)
+    const int target = 1024;                                         // workgroups aimed for (each issues 2 * groups fp64 atomics): 128 / 256 and 2048 / 4096 all measured slower
     const int P = std::max(ppi, std::min(64 * ppi, (int)(((int64_t)T * batch + target - 1) / target)));
     hipLaunchKernelGGL(k_splitk_epilogue_stats, dim3((unsigned)((T + P - 1) / P), batch), dim3(256), 0, stream, e, nsplit, Ho, Wo, P);
     return true;
@@ -1313,10 +1197,7 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
 
     if (p->halo) {
         HaloArgs ha{};
-        {
-            static const int qmode = [] { const char* e = getenv("MF_Q_PAIR"); return e ? atoi(e) : 2; }();   // A/B: 0 = one tap per correction instruction, 1 = tap pairs, every wave issues weight DMA
-            ha.q = p->q ? (qmode == 2 ? 3 : (qmode ? 2 : 1)) : 0;                                           // 2: pairs with the weight DMA on the second wave of each SIMD
-        }
+        ha.q = p->q ? 1 : 0;
         ha.x_hi = ib.hi + in.coff; ha.x_lo = x3 ? ib.lo + in.coff : nullptr;
         ha.w_hi = p->w_hi; ha.w_lo = p->w_lo; ha.bias = p->bias;
         ha.batch = batch; ha.H = p->out_h; ha.W = p->out_w; ha.N = p->d.cout; ha.Npad = p->Npad; ha.n_slices = p->n_slices;
@@ -1337,11 +1218,8 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
         }
         ha.act = p->d.act;
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
-        ha.gn_scale = g_gn_scale; ha.gn_shift = g_gn_shift; ha.gn_C = p->d.cin;
         if (p->q) {                             // the f16 + FP6 format has one kernel: the 8-wave 16 x 16 x 128-channel tile
-            MF_REQUIRE(!ha.res_from_halo && !g_gn_scale, "conv (f16q): residual-from-input / GroupNorm fusion are not built for this format");
-            // 8 waves of 64 px x 64 ch (default; measured 338 / 396 / 316 us on 256->256 @128^2, 128->128 @256^2, 512->512 @64^2 at batch 8 against
-            // 313 / 370 / 290 us for bf16x3 on its best tiles); MF_Q_TILE=12822: 4 waves of 128 px x 64 ch, one workgroup per CU (359 / 418 / 331 us)
+            MF_REQUIRE(!ha.res_from_halo, "conv (f16q): residual-from-input is not built for this format");
             if (p->out_stats) {
                 const int cpg = p->d.cout / p->out_stats_groups;
                 if (p->d.cout % p->out_stats_groups == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && !ha.ws) {   // (other group widths: k_gn_stats behind the conv)
@@ -1349,12 +1227,8 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
                     *stats_done = true;
                 }
             }
-            {
-                static const bool narrow = [] { const char* e = getenv("MF_STORE16"); return e && atoi(e) == 0; }();   // A/B: MF_STORE16=0 keeps 8-byte stores
-                ha.wide_store = !narrow && out.coff % 8 == 0 && ob.C % 8 == 0 && p->d.cout % 32 == 0;
-            }
-            static const int qt = [] { const char* e = getenv("MF_Q_TILE"); return e ? atoi(e) : 12842; }();
-            const HaloTile qtile = qt == 12822 ? HaloTile{16, 128, 2, 2} : HaloTile{16, 128, 4, 2};
+            ha.wide_store = out.coff % 8 == 0 && ob.C % 8 == 0 && p->d.cout % 32 == 0;   // 16-byte epilogue stores (lane pairs exchange halves)
+            const HaloTile qtile{16, 128, 4, 2};
             // A map too small to give every CU a 16 x 16 patch (the VAE's 512-channel 32 x 32 levels at batch 8: 32 patches x 4 channel tiles): the
             // channel slices split over blockIdx.y, fp32 partial tiles combined by k_splitk_epilogue[_stats] -- as the bf16x3 256-channel tile does.
             const int ns = mf_q_split_count(p, batch);
@@ -1386,7 +1260,6 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
             return mf_halo_w_launch(ha, qtile, true, stream);
         }
         if (tw.ph) return mf_halo_w_launch(ha, tw, x3, stream);
-        MF_REQUIRE(!g_gn_scale, "conv: GroupNorm fusion requested but the fat halo tile was not picked");
         // Wide layer on a map too small to give every CU a 16 x 16 patch (the VAE's 512-channel 32 x 32 levels at batch 8: 64 patches x
         // channel tiles): the 256-channel tile with the channel slices split over blockIdx.y, fp32 partials combined by
         // k_splitk_epilogue -- the same two-pass scheme as the implicit GEMM's split-K, with half its L2 -> LDS bytes.  MF_HALO_SPLIT=0: off.
@@ -1437,17 +1310,14 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
         // upsample + 3x3 in the f16 + FP6 format: four launches of the 16 x 16 x 128-channel tile, phase (py, px) writes output pixels (2i + py, 2j + px)
         MF_REQUIRE(ib.halo >= 1 && !res.buf, "conv (f16q): upsample path needs an input halo and no residual");
         HaloArgs ha{};
-        ha.q = 3;
+        ha.q = 1;
         ha.x_hi = ib.hi + in.coff; ha.x_lo = ib.lo + in.coff;
         ha.bias = p->bias;
         ha.batch = batch; ha.H = p->d.in_h; ha.W = p->d.in_w; ha.N = p->d.cout; ha.Npad = p->Npad; ha.n_slices = p->n_slices;
         ha.in_halo = ib.halo; ha.in_hp = ib.Hp(); ha.in_wp = ib.Wp(); ha.x_ld = ib.C; ha.xb = ib.per_batch();
         ha.yb = ob.per_batch(); ha.yi = 2 * ob.Wp() * ob.C; ha.yj = 2 * ob.C;
         ha.act = p->d.act;
-        {
-            static const bool narrow = [] { const char* e = getenv("MF_STORE16"); return e && atoi(e) == 0; }();
-            ha.wide_store = !narrow && out.coff % 8 == 0 && ob.C % 8 == 0 && p->d.cout % 32 == 0;
-        }
+        ha.wide_store = out.coff % 8 == 0 && ob.C % 8 == 0 && p->d.cout % 32 == 0;
         if (p->out_stats) {
             const int cpg = p->d.cout / p->out_stats_groups;
             if (p->d.cout % p->out_stats_groups == 0 && (cpg == 4 || cpg == 8 || cpg == 16)) {
@@ -1465,31 +1335,6 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
         }
         return MF_OK;
     }
-    if (p->up_hi) {
-        // upsample + 3x3 on the fat halo tiles: four launches, phase (py, px) writes output pixels (2i + py, 2j + px)
-        const HaloTile tw = mf_halo_w_pick_tile(p->d.in_h, p->d.in_w, p->d.cout, batch, p->d.cin);
-        if (tw.ph == 16 && (tw.bn == 256 || (tw.bn == 128 && tw.wgm == 4))) {
-            MF_REQUIRE(ib.halo >= 1 && !res.buf, "conv: upsample halo path needs an input halo and no residual");
-            HaloArgs ha{};
-            ha.x_hi = ib.hi + in.coff; ha.x_lo = x3 ? ib.lo + in.coff : nullptr;
-            ha.bias = p->bias;
-            ha.batch = batch; ha.H = p->d.in_h; ha.W = p->d.in_w; ha.N = p->d.cout; ha.Npad = p->Npad; ha.n_slices = p->n_slices;
-            ha.in_halo = ib.halo; ha.in_hp = ib.Hp(); ha.in_wp = ib.Wp(); ha.x_ld = ib.C; ha.xb = ib.per_batch();
-            ha.yb = ob.per_batch(); ha.yi = 2 * ob.Wp() * ob.C; ha.yj = 2 * ob.C;
-            ha.act = p->d.act;
-            const int HCKl = x3 ? 32 : 64;
-            const int64_t per_phase = (int64_t)p->n_slices * 4 * p->Npad * HCKl;
-            for (int ph = 0; ph < 4; ++ph) {
-                const int64_t yb0 = ((int64_t)(ob.halo + (ph >> 1)) * ob.Wp() + ob.halo + (ph & 1)) * ob.C + out.coff;
-                ha.y_hi = ob.hi + yb0; ha.y_lo = x3 ? ob.lo + yb0 : nullptr;
-                ha.w_hi = p->up_hi + ph * per_phase; ha.w_lo = x3 ? p->up_lo + ph * per_phase : nullptr;
-                const int rc = mf_halo_w_launch(ha, tw, x3, stream, ph);
-                if (rc) return rc;
-            }
-            return MF_OK;
-        }
-    }
-
     ConvArgs a{};
     a.x_hi = ib.hi + in.coff; a.x_lo = x3 ? ib.lo + in.coff : nullptr;
     a.w_hi = p->w_hi; a.w_lo = p->w_lo; a.bias = p->bias; a.goff = p->goff;
@@ -1510,9 +1355,8 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
     a.act = p->d.act;
     a.res_after_act = p->d.residual == 2;
     {
-        static const bool narrow = [] { const char* e = getenv("MF_STORE16"); return e && atoi(e) == 0; }();   // A/B: MF_STORE16=0 keeps 8-byte stores
         const int n_out = p->d.act == 5 ? p->d.cout / 2 : p->d.cout;
-        a.wide_store = !narrow && out.coff % 8 == 0 && ob.C % 8 == 0 && n_out % 8 == 0 && p->d.cout % 16 == 0;
+        a.wide_store = out.coff % 8 == 0 && ob.C % 8 == 0 && n_out % 8 == 0 && p->d.cout % 16 == 0;
     }
     a.goff_total = p->goff_total;
     int goff_max = 0;
@@ -1540,10 +1384,9 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
     a.tiles_m = cdiv(a.M, tc.bm); a.tiles_n = cdiv(a.N, tc.bn);
     {
         // XCD tile order by which operand is heavier: weights N x K vs the input tensor M x Cin (both x planes)
-        static const int order = [] { const char* e = getenv("MF_TILE_ORDER"); return !e ? 0 : (e[0] == 'm' ? 1 : 2); }();
         const int64_t w_elems = (int64_t)a.Npad * p->ph[0].KT * 64 * p->nphase;
         const int64_t x_elems = (int64_t)batch * ib.H * ib.W * in.C;
-        a.m_fastest = order ? order == 1 : w_elems > x_elems;
+        a.m_fastest = w_elems > x_elems;
         static const bool dbg_times = getenv("MF_DBG_TIMES") != nullptr;
         if (dbg_times) {
             static unsigned long long* dbg_buf = nullptr;
@@ -1551,7 +1394,6 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
             a.dbg = (int64_t)a.tiles_m * a.tiles_n * tc.nsplit * p->nphase <= 65536 ? dbg_buf : nullptr;
         }
     }
-    bool fused = false;
     if (tc.nsplit > 1) {
         // fp32 partial tiles [split][B][Ho][Wo][N]; combined by k_splitk_epilogue below
         const int64_t per_split = (int64_t)batch * p->out_h * out_w_eff * a.N;
@@ -1566,21 +1408,6 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
         a.ws = p->ws; a.ws_split = per_split;
         a.wsb = (int64_t)p->out_h * out_w_eff * a.N;
         a.wsi = p->out_step * out_w_eff * a.N; a.wsj = p->out_step * a.N;
-        // MF_SPLITK_FUSE=1: combine inside the conv kernel (the last workgroup of a tile re-reads the nsplit partial tiles).  Measured
-        // SLOWER than the separate chip-wide pass (Wav2Lip 14.2 k -> 11.2 k frames/s, MuseTalk 322 -> 316: one workgroup re-reading
-        // nsplit tiles after two fences and an atomic is a longer tail than a 5 us launch spread over every CU), so it stays opt-in.
-        static const int fuse_mode = [] { const char* e = getenv("MF_SPLITK_FUSE"); return e ? atoi(e) : 0; }();
-        fused = fuse_mode > 0 && (int64_t)tc.bm * tc.bn * 4 * tc.nsplit <= 160 * 1024;
-        if (fused) {
-            const int need_cnt = a.tiles_m * a.tiles_n * std::max(1, p->nphase);
-            if (need_cnt > p->tile_cnt_cap) {
-                if (p->tile_cnt) { p->retired.push_back(p->tile_cnt); p->tile_cnt = nullptr; p->tile_cnt_cap = 0; }
-                MF_HIP(hipMalloc(&p->tile_cnt, need_cnt * sizeof(int)));
-                MF_HIP(hipMemset(p->tile_cnt, 0, need_cnt * sizeof(int)));
-                p->tile_cnt_cap = need_cnt;
-            }
-            a.tile_cnt = p->tile_cnt;
-        }
     }
     if (p->out_stats && p->d.act != 5 && p->d.cout % p->out_stats_groups == 0 && p->out_stats_groups <= 64 && tokens == 0) {
         a.gn_out_cpg = p->d.cout / p->out_stats_groups; a.gn_out_groups = p->out_stats_groups;
@@ -1624,8 +1451,8 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
                     nwg, tc.bm, tc.bn, tc.nsplit, hi - lo, med(d[0]), mx(d[0]), med(d[1]), mx(d[1]), med(d[2]), mx(d[2]), med(start), mx(start), med(end));
         }
     }
-    if (tc.nsplit > 1 && p->prof_mid) MF_HIP(hipEventRecord(p->prof_mid, stream));   // (fused combine: the second row of the launch table reads ~0)
-    if (tc.nsplit > 1 && !fused) {
+    if (tc.nsplit > 1 && p->prof_mid) MF_HIP(hipEventRecord(p->prof_mid, stream));
+    if (tc.nsplit > 1) {
         ConvArgs e = a;   // unit-grid strides for the combine pass
         e.yi = ob.Wp() * ob.C; e.yj = ob.C;
         const int64_t total = (int64_t)batch * p->out_h * out_w_eff * ((a.act == 5 ? a.N / 2 : a.N) / 4);
@@ -1821,9 +1648,9 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
     hipEvent_t e0, e1;
     MF_HIP(hipEventCreate(&e0)); MF_HIP(hipEventCreate(&e1));
     // In the network a layer finds its INPUT in the Infinity Cache (the previous layer just wrote it) and its WEIGHTS in HBM (3.4 GB of them
-    // cycle through per step); timed back to back it would find both warm.  MF_TUNE_COLD=1 (default): before every timed launch a 384 MB
+    // cycle through per step); timed back to back it would find both warm.  So before every timed launch a 384 MB
     // memset evicts the caches and a read pass brings the input (and residual) planes back.
-    static const bool cold = [] { const char* e = getenv("MF_TUNE_COLD"); return !e || atoi(e) != 0; }();
+    const bool cold = true;
     static void* scratch = nullptr;
     static unsigned* sink = nullptr;
     const size_t scratch_bytes = (size_t)384 << 20;
@@ -1914,16 +1741,11 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
         const HaloTile t = tw.ph ? tw : mf_halo_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         // last template argument: halo stages (register-weights kernel) / taps per weight-ring slot (LDS-weights kernel)
         snprintf(buf, cap, "k_conv3x3_halo%s<%d,%d,%d,%d,%s,%d>", tw.ph ? "_w" : "", t.ph, t.bn, t.wgm, t.wgn, x3, tw.ph ? (t.bn >= 128 ? 1 : 3) : 2);
-    } else if (p->up_hi && [&] { const HaloTile tw = mf_halo_w_pick_tile(p->d.in_h, p->d.in_w, p->d.cout, batch, p->d.cin);
-                                 return tw.ph == 16 && (tw.bn == 256 || (tw.bn == 128 && tw.wgm == 4)); }()) {
-        const HaloTile tw = mf_halo_w_pick_tile(p->d.in_h, p->d.in_w, p->d.cout, batch, p->d.cin);
-        snprintf(buf, cap, "4 x k_conv3x3_halo_w<%d,%d,%d,%d,%s,1,phase>", tw.ph, tw.bn, tw.wgm, tw.wgn, x3);
     } else {
         const ConvTile t = mf_conv_pick_tile(p, batch);
-        // tile depth as launch_prec picks it: 64 everywhere except the 8-wave bf16x3 tiles (and the 4-wave ones under MF_IGEMM_BK=32)
-        static const bool bk64 = [] { const char* e = getenv("MF_IGEMM_BK"); return !e || atoi(e) == 64; }();
+        // tile depth as launch_prec picks it: 64 everywhere except the 8-wave bf16x3 tiles
         const bool x3b = p->precision == MF_PREC_BF16X3;
-        const int bk = (x3b && t.bm + t.bn > 128 && !(t.wgm * t.wgn == 4 && bk64)) ? 32 : 64;
+        const int bk = (x3b && t.bm + t.bn > 128 && t.wgm * t.wgn != 4) ? 32 : 64;
         snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s,%d>", t.bm, t.bn, t.wgm, t.wgn, x3, bk);
     }
 }

@@ -365,9 +365,6 @@ int halo_launch_cfg(const HaloArgs& a, hipStream_t s) {
 
 template <int PH, int BN, int WGM, int WGN>
 int halo_launch_prec(const HaloArgs& a, bool x3, hipStream_t s) {
-    static const bool one_stage = [] { const char* e = getenv("MF_HALO_STAGES"); return e && e[0] == '1'; }();
-    if (one_stage)
-        return x3 ? halo_launch_cfg<PH, BN, WGM, WGN, true, 1>(a, s) : halo_launch_cfg<PH, BN, WGM, WGN, false, 1>(a, s);
     return x3 ? halo_launch_cfg<PH, BN, WGM, WGN, true, 2>(a, s) : halo_launch_cfg<PH, BN, WGM, WGN, false, 2>(a, s);
 }
 
@@ -378,17 +375,7 @@ int halo_launch_prec(const HaloArgs& a, bool x3, hipStream_t s) {
 HaloTile mf_halo_pick_tile(int H, int W, int N, int batch, int cin) {
     auto wgs = [&](int ph, int bn) { return batch * ((H + ph - 1) / ph) * ((W + PW - 1) / PW) * ((N + bn - 1) / bn); };
     if (N <= 32) return wgs(8, 32) >= 256 ? HaloTile{8, 32, 2, 2} : HaloTile{4, 32, 2, 2};
-    // 16 x 16 patch, 8 waves (the weight stream shared by twice the pixels): measured 4 % SLOWER than the 8-row patch on
-    // the VAE's 128 / 256-channel layers and on Wav2Lip's 96^2 layers, so it stays opt-in (MF_HALO_PH16=1)
-    static const int big = [] { const char* e = getenv("MF_HALO_PH16"); return e ? atoi(e) : 0; }();
-    if (big && wgs(16, 64) >= 512) return HaloTile{16, 64, 4, 2};
-    // Fat wave tiles, 2 x 2 waves (MF_HALO_TILE=8x128 | 16x64 | 16x128, A/B only): a wave's weight fragment (L1 -> VGPR) and pixel fragment
-    // (LDS -> VGPR) each feed more MFMAs -- per CU and clock the 8x64 tile moves 85 B from LDS and 43 B through L1, 16x128 (wave = 128
-    // pixels x 64 channels, one wave per SIMD) 43 and 21.  Alone the VAE's 256-channel layers gain 6-8 % with 16x128 and the 128-channel
-    // ones 3 % with 8x128, but inside the decoder (residual epilogues, GroupNorm neighbours) the step time does not move, so the default
-    // stays 8x64: neither L1 nor LDS bandwidth is what holds this kernel at ~45 % MFMA issue.
-    static const int fat = [] { const char* e = getenv("MF_HALO_TILE"); int a = 0, b = 0; return e && sscanf(e, "%dx%d", &a, &b) == 2 ? a * 1000 + b : 0; }();
-    if (fat && N >= fat % 1000 && wgs(fat / 1000, fat % 1000) >= 256) return HaloTile{fat / 1000, fat % 1000, 2, 2};
+    // (16 x 16 patches and fat 2 x 2-wave tiles measured 4 % slower / no faster inside the networks than the 8-row patch: not instantiated)
     (void)cin;
     if (wgs(8, 64) >= 256) return HaloTile{8, 64, 2, 2};
     if (wgs(4, 64) >= 256) return HaloTile{4, 64, 2, 2};
@@ -404,10 +391,6 @@ int mf_halo_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t s
     a.tiles_n = (a.N + t.bn - 1) / t.bn;
 #define MF_HCASE(PH, BN, WGM, WGN) \
     if (t.ph == PH && t.bn == BN && t.wgm == WGM) return halo_launch_prec<PH, BN, WGM, WGN>(a, x3, s);
-    MF_HCASE(16, 128, 2, 2)
-    MF_HCASE(16, 64, 2, 2)
-    MF_HCASE(8, 128, 2, 2)
-    MF_HCASE(16, 64, 4, 2)
     MF_HCASE(8, 64, 2, 2)
     MF_HCASE(4, 64, 2, 2)
     MF_HCASE(4, 32, 2, 2)

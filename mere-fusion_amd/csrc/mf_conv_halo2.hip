@@ -79,16 +79,15 @@ __device__ __forceinline__ void hstore_pair16(bf16_t* base, int64_t yo, int c16,
 // launcher passes doubled output strides and the phase's weight block.
 // HS = halo images in LDS: 2 (the next slice's image lands under this slice's MFMAs) or 1 (half the LDS: two 4-wave workgroups per CU, each
 // other's DMA waits and epilogues hidden by the neighbour's MFMAs)
-// GN: GroupNorm + SiLU of the input folded in (a separate instantiation: its extra live registers must not touch the plain kernel)
 // Q: operands in the f16 + FP6-residual format (MF_PREC_F16Q).  Plane 0 rows are 32 f16 channels, plane 1 rows two 32-byte FP6 blocks
-// ([q6(wh) | q6(wl)] for weights, [q6(xl) | q6(xh)] for pixels: 24 B of e2m3 codes + the block's E8M0 byte).  Per tap and accumulator tile:
-// ONE v_mfma_f32_16x16x32_f16 (wh.xh) + ONE v_mfma_scale_f32_16x16x128_f8f6f4 whose K blocks 0 / 1 are q6(wh).xl / wl.q6(xh) and whose blocks
-// 2 / 3 are switched off by a zero scale -- 32 matrix cycles where bf16x3 spends 48, with the loop, ring and DMA of the bf16x3 kernel unchanged.
-// Q = 3: tap pairs with the WEIGHT DMA issued by waves NW/2 .. NW-1 only.  Waves w and w + NW/2 share a SIMD; a pair iteration is
-// [DMA issue ~4 x 120 cycles][LDS read burst][768 MFMA cycles] per wave, in lockstep behind the per-pair barrier (s_memtime: 2.6 k cycles per
-// pair against 1.5 k of MFMA).  With all pieces on the second wave of each SIMD the first one starts its reads and MFMAs at once and the
-// second one's run under them.
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false, int Q = 0>   // Q: 0 off, 1 one tap per correction MFMA, 2 tap pairs, 3 pairs + producer waves
+// ([q6(wh) | q6(wl)] for weights, [q6(xl) | q6(xh)] for pixels: 24 B of e2m3 codes + the block's E8M0 byte).  TWO taps share one correction
+// instruction (compute_pair): per tap pair and accumulator tile two v_mfma_f32_16x16x32_f16 (wh.xh) + ONE v_mfma_scale_f32_16x16x128_f8f6f4 whose K
+// blocks 0 / 1 carry tap A's q6(wh).xl / wl.q6(xh) and blocks 2 / 3 tap B's -- 48 matrix cycles where bf16x3 spends 96, with the ring, DMA and LDS
+// swizzle of the bf16x3 kernel unchanged.  The WEIGHT DMA is issued by waves NW/2 .. NW-1 only: waves w and w + NW/2 share a SIMD, and with all
+// pieces on the second one the first starts its reads and MFMAs at once (s_memtime: 13.0 k -> 12.3 k cycles per slice).
+// Where this kernel's time goes, by ablation (matrix floor 7.7 k cycles per slice, LDS floor 6.3 k, overlapped by half; DMA 10 %), and the
+// restructurings that did NOT move it (two workgroups per CU, skewed halves, software pipelining): profiles/r03_halo_q_loop_study.md.
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool Q = false>
 __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_halo_w(const HaloArgs a) {
     constexpr int NW = WGM * WGN;                           // waves per workgroup
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     static_assert(PHASE < 0 || TR == 1, "upsample phases use the one-tap ring");
     constexpr int WROW = TR * NP * WT_BYTES;                // one ring slot (TR taps, planes)
     constexpr int WRC = TR * NP * WCH;                      // DMA chunks per slot
-    constexpr bool PROD = Q == 3;                           // weight DMA by the upper half of the waves only
+    constexpr bool PROD = Q;                                // f16 + FP6 tiles: weight DMA by the upper half of the waves only
     constexpr int NWD = PROD ? NW / 2 : NW;                 // waves that issue weight DMA
     constexpr int NWR = (WRC + NWD - 1) / NWD;
     static_assert(WT_BYTES % 1024 == 0, "weight tile must be whole DMA chunks");
@@ -257,12 +256,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         if (step < NSTEP - 1) load_wrow(slice, step + 1, buf ^ 1);
         else if (more) load_wrow(slice + 1, 0, buf ^ 1);
     };
-    // Two waves share a SIMD in the 8-wave tiles and run the same program: both would spend the first few hundred cycles of every tap
-    // issuing their LDS-DMA pieces (100-185 cycles each inside a loaded phase, MI355X_MICROARCH.md) with the matrix pipe idle.  The second
-    // wave of each SIMD (waves NW/2 ...) issues its pieces in the MIDDLE of the tap instead, under its partner's MFMAs.  MEASURED (VAE, batch 8):
-    // halo_w convs 7.78 -> 8.00 ms -- moving issue slots between the two waves of a SIMD is negative-sum here too, as the guide warns; opt-in only
-    // (MF_HALO_STAGGER=1).
-    const bool late_dma = NW == 8 && TR == 1 && a.stagger && wave >= NW / 2;
     auto compute_row = [&](int stage, int step, int buf, int slice, bool more) __attribute__((always_inline)) {
         const char* base = smem + stage * STAGE;
         const char* wb = wring + buf * WROW;
@@ -272,39 +265,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             const int dy = PHASE < 0 ? tap / 3 : (PHASE >> 1) + (tap >> 1), dx = PHASE < 0 ? tap % 3 : (PHASE & 1) + (tap & 1);
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
-                if constexpr (Q == 1) {
-                    static_assert(!Q || (X3 && KK == 1 && TR == 1 && PHASE < 0 && !GN), "f16 + FP6 format: the plain 3x3 bf16x3-shaped tile only");
-                    // lane (fr, fk): f16 fragments as the bf16 ones; the FP6 fragment of its row is the 32-byte block fk & 1 of the plane-1 row, and
-                    // lane groups 2, 3 (K blocks that carry nothing) read the same bytes with their scale forced to 2^-127
-                    const int blk = fk & 1;
-                    f16x8 wh16[FN];
-                    i32x8 w6[FN];
-                    int wsc[FN];
-#pragma unroll
-                    for (int i = 0; i < FN; ++i) {
-                        const int r = cn0 + i * 16 + fr;
-                        wh16[i] = *reinterpret_cast<const f16x8*>(wb + (t3 * NP) * WT_BYTES + wlane[i][kk]);
-                        const char* q = wb + (t3 * NP + 1) * WT_BYTES + r * ROWB;
-                        const i32x4 q0 = *reinterpret_cast<const i32x4*>(q + (((2 * blk) ^ qswz(r)) << 4)), q1 = *reinterpret_cast<const i32x4*>(q + (((2 * blk + 1) ^ qswz(r)) << 4));
-                        w6[i] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, -1, -1);
-                        wsc[i] = fk < 2 ? q1[2] : 0;
-                    }
-#pragma unroll
-                    for (int j = 0; j < FM; ++j) {
-                        const int hx = fr + dx;
-                        const char* p0 = base + ((row0 + j + dy) * HW + hx) * ROWB;
-                        const f16x8 xh16 = *reinterpret_cast<const f16x8*>(p0 + (((kk * 4 + fk) ^ hswz<CK>(hx)) << 4));
-                        const char* q = p0 + H_BYTES;
-                        const i32x4 q0 = *reinterpret_cast<const i32x4*>(q + (((2 * blk) ^ qswz(hx)) << 4)), q1 = *reinterpret_cast<const i32x4*>(q + (((2 * blk + 1) ^ qswz(hx)) << 4));
-                        const i32x8 x6 = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, -1, -1);
-                        const int xsc = fk < 2 ? q1[2] : 0;
-#pragma unroll
-                        for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w6[i], x6, acc[i][j], 2, 2, 0, wsc[i], 0, xsc);
-#pragma unroll
-                        for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh16[i], xh16, acc[i][j], 0, 0, 0);
-                    }
-                    continue;
-                }
                 bf16x8 whi[FN], wlo[FN];
 #pragma unroll
                 for (int i = 0; i < FN; ++i) {
@@ -322,7 +282,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
                 }
 #pragma unroll
                 for (int j = 0; j < FM; ++j) {
-                    if (NW == 8 && TR == 1 && j == FM / 2 && late_dma) issue_next(slice, step, more, buf);
                     if (PF) {
                         if (j + 1 < FM) {
                             const char* p = base + lane_off[dx][kk] + (j + 1 + dy) * HW * ROWB;
@@ -343,7 +302,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
                     }
 #pragma unroll
                     for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[i], c_hi, acc[i][j], 0, 0, 0);
-                    if (PF) { c_hi = n_hi; c_lo = n_lo; }
+                    if (PF) { c_hi = n_hi; if (X3) c_lo = n_lo; }
                 }
             }
         }
@@ -402,47 +361,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         }
     };
 
-    // GroupNorm + SiLU of the input, folded in: once a halo image has landed, every 16-byte slot of it (8 channels of one pixel, hi and lo
-    // planes) is rewritten in place as silu(x * scale[b][c] + shift[b][c]).  Pixels outside the image stay zero: the convolution pads the
-    // NORMALISED tensor.  ~3 slots per thread and slice, against ~27 k MFMA cycles per slice.
-    auto gn_transform = [&](int slice, int stage) __attribute__((always_inline)) {
-        char* base = smem + stage * STAGE;
-        for (int q = tid; q < HROWS * KG; q += NW * 64) {
-            const int r = q / KG, slot = q - r * KG;
-            const int hy = r / HW, hx = r - hy * HW;
-            const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-            if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.W) continue;
-            const int kg = slot ^ hswz<CK>(hx);                                  // logical channel group held by this slot
-            const int c0 = slice * CK + kg * 8;
-            if (c0 >= a.gn_C) continue;
-            const float* sc = a.gn_scale + (int64_t)b * a.gn_C + c0;
-            const float* sh = a.gn_shift + (int64_t)b * a.gn_C + c0;
-            const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
-            const float4 t0 = *reinterpret_cast<const float4*>(sh), t1 = *reinterpret_cast<const float4*>(sh + 4);
-            const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, shv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-            char* ph = base + r * ROWB + (slot << 4);
-            uint4 vh = *reinterpret_cast<uint4*>(ph);
-            uint4 vl = X3 ? *reinterpret_cast<uint4*>(ph + H_BYTES) : make_uint4(0, 0, 0, 0);
-            uint32_t hh[4] = {vh.x, vh.y, vh.z, vh.w}, ll[4] = {vl.x, vl.y, vl.z, vl.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v0 = hbf2f(hh[e] & 0xffffu) + hbf2f(ll[e] & 0xffffu), v1 = hbf2f(hh[e] >> 16) + hbf2f(ll[e] >> 16);
-                v0 = v0 * scv[2 * e] + shv[2 * e]; v1 = v1 * scv[2 * e + 1] + shv[2 * e + 1];
-                v0 = v0 / (1.f + __expf(-v0)); v1 = v1 / (1.f + __expf(-v1));
-                const uint32_t h0 = hf2bf(v0), h1 = hf2bf(v1);
-                hh[e] = h0 | (h1 << 16);
-                ll[e] = hf2bf(v0 - hbf2f(h0)) | (hf2bf(v1 - hbf2f(h1)) << 16);
-            }
-            *reinterpret_cast<uint4*>(ph) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-            if (X3) *reinterpret_cast<uint4*>(ph + H_BYTES) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
-        }
-    };
     // channel slices of this workgroup: all of them, or the blockIdx.y-th share when the layer is split for lack of patches
     const int s_begin = a.nsplit > 1 ? (int)((int64_t)a.n_slices * blockIdx.y / a.nsplit) : 0;
     const int s_end = a.nsplit > 1 ? (int)((int64_t)a.n_slices * (blockIdx.y + 1) / a.nsplit) : a.n_slices;
     load_halo(s_begin, 0);
     load_wrow(s_begin, 0, 0);
-    if (Q >= 2) load_wrow(s_begin, 1, 1);
+    if (Q) load_wrow(s_begin, 1, 1);
     __syncthreads();                           // drains the DMA (vmcnt) and publishes halo stage 0 + weight row 0
     if (dbg && threadIdx.x == 0) dbg[1] = __builtin_amdgcn_s_memtime();
     int wbuf = 0;
@@ -450,12 +374,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         const bool more = slice + 1 < s_end;
         const int st = HS == 2 ? ((slice - s_begin) & 1) : 0;
         if (HS == 2 && more) load_halo(slice + 1, st ^ 1); // flies under this slice's MFMAs
-        if (GN) {
-            gn_transform(slice, st);
-            __syncthreads();
-        }
         if (a.res_from_halo) add_residual(st, slice);
-        if constexpr (Q >= 2) {
+        if constexpr (Q) {
             {
                 // taps in pairs (0,1) (2,3) (4,5) (6,7) (8): four ring slots, the pair being multiplied in slots {2 wbuf, 2 wbuf + 1} while the next pair
                 // lands in the other two (everyone left those at the previous barrier); one barrier per PAIR
@@ -474,7 +394,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         }
 #pragma unroll
         for (int step = 0; step < NSTEP; ++step) {
-            if (!late_dma) issue_next(slice, step, more, wbuf);
+            issue_next(slice, step, more, wbuf);
             compute_row(st, step, wbuf, slice, more);
             if (step < NSTEP - 1 || more) __syncthreads();   // next slot (and, at the last step, the next halo image) landed; this one is released
             if (HS == 1 && step == NSTEP - 1 && more) {      // single image: reload it now that every wave is done with it
@@ -560,7 +480,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             const int oy = y0 + row0 + j;
             const bool row_ok = oy < a.H && ox < a.W;
             const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
-            constexpr bool W16 = Q != 0 && FN % 2 == 0;               // f16 + FP6 tiles: 16-byte stores (a.wide_store)
+            constexpr bool W16 = Q && FN % 2 == 0;               // f16 + FP6 tiles: 16-byte stores (a.wide_store)
             uint2 pk_hi[W16 ? FN : 1], pk_lo[W16 ? FN : 1];
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
@@ -596,7 +516,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
                     }
                 }
                 if (!row_ok || c >= a.N) continue;
-                if constexpr (Q != 0) {
+                if constexpr (Q) {
                     gs[i] += (v[0] + v[1]) + (v[2] + v[3]);
                     gq[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                 }
@@ -622,7 +542,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
             }
         }
     }
-    if constexpr (Q != 0) {
+    if constexpr (Q) {
         // The consumer's GroupNorm statistics from the accumulators instead of a second pass over the tensor (k_gn_stats re-reads 4 bytes per
         // value: 268 MB on the 256^2 maps).  A thread's quad lies in one group (channels per group 4, 8 or 16); sum over the wave's 16 pixel
         // columns, park per (wave, quad) in LDS, then one fp64 atomic per (workgroup, group, moment) -- the granularity k_gn_stats has.
@@ -662,10 +582,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool GN = false, int Q = 0>
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool Q = false>
 int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE, HS, GN, Q>;
+    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE, HS, Q>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (Q ? 158 : 160) * 1024));   // Q: 1-2 KiB of static LDS (s_gn) beside the dynamic block
@@ -676,8 +596,6 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     const size_t lds = (size_t)HS * NP * HCH * 1024 + (size_t)(Q ? 4 : 2) * TR * NP * BN * CK * 2;   // (the two-taps-per-instruction loop of the f16 + FP6 format: four ring slots)
     static const bool dbg_times = getenv("MF_DBG_TIMES") != nullptr;
     HaloArgs aa = a;
-    static const bool stagger = [] { const char* e = getenv("MF_HALO_STAGGER"); return e && atoi(e) != 0; }();   // opt-in: measured 2.7 % SLOWER
-    aa.stagger = stagger ? 1 : 0;
     const size_t nwg = (size_t)a.n_patches * a.tiles_n * (a.nsplit > 1 ? a.nsplit : 1);
     if (dbg_times && nwg <= 65536) {
         static unsigned long long* dbg_buf = nullptr;
@@ -715,17 +633,6 @@ template <int PH, int BN, int WGM, int WGN, int TR, int PHASE = -1>
 int halo_w_launch_prec(const HaloArgs& a, bool x3, hipStream_t s) {
     return x3 ? halo_w_launch_cfg<PH, BN, WGM, WGN, true, TR, PHASE>(a, s) : halo_w_launch_cfg<PH, BN, WGM, WGN, false, TR, PHASE>(a, s);
 }
-template <int PH, int BN, int WGM, int WGN>
-int halo_w_launch_phase(const HaloArgs& a, bool x3, int phase, hipStream_t s) {
-    switch (phase) {
-        case 0: return halo_w_launch_prec<PH, BN, WGM, WGN, 1, 0>(a, x3, s);
-        case 1: return halo_w_launch_prec<PH, BN, WGM, WGN, 1, 1>(a, x3, s);
-        case 2: return halo_w_launch_prec<PH, BN, WGM, WGN, 1, 2>(a, x3, s);
-        case 3: return halo_w_launch_prec<PH, BN, WGM, WGN, 1, 3>(a, x3, s);
-        default: return halo_w_launch_prec<PH, BN, WGM, WGN, 1, -1>(a, x3, s);
-    }
-}
-
 }  // namespace
 
 // Same contract as mf_halo_launch; `t` comes from mf_halo_w_pick_tile.
@@ -736,51 +643,25 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
     a.patches_per_img = a.patches_x * patches_y;
     a.n_patches = a.batch * a.patches_per_img;
     a.tiles_n = (a.N + t.bn - 1) / t.bn;
-#define MF_HCASE(PH, BN, WGM, WGN, TR) \
-    if (t.ph == PH && t.bn == BN && t.wgm == WGM) return halo_w_launch_prec<PH, BN, WGM, WGN, TR>(a, x3, s);
     if (a.q) {
-        if (a.gn_scale || (phase >= 0 && (a.nsplit > 1 || t.wgm != 4))) { mf_set_error("halo conv (f16 + FP6 format): plain 3x3 layers and unsplit upsample phases only"); return MF_ERR_INVALID; }
-        // nearest 2x upsample + 3x3 as four 2 x 2-tap phases: two tap pairs per channel slice on the same four-slot ring
+        // the f16 + FP6 format has ONE tile: 16 x 16 pixels x 128 channels, 8 waves of 64 px x 64 ch (the 256-channel tile does not fit its registers,
+        // four waves of 128 px x 64 ch measured 6 % slower); nearest 2x upsample + 3x3 runs it as four 2 x 2-tap phases on the same four-slot ring
+        if (t.ph != 16 || t.bn != 128 || t.wgm != 4 || (phase >= 0 && a.nsplit > 1)) { mf_set_error("halo conv (f16 + FP6 format): plain 3x3 layers and unsplit upsample phases on the 16 x 16 x 128 tile only"); return MF_ERR_INVALID; }
         switch (phase) {
-            case 0: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 0, 2, false, 3>(a, s);
-            case 1: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 1, 2, false, 3>(a, s);
-            case 2: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 2, 2, false, 3>(a, s);
-            case 3: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 3, 2, false, 3>(a, s);
-            default: break;
+            case 0: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 0, 2, true>(a, s);
+            case 1: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 1, 2, true>(a, s);
+            case 2: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 2, 2, true>(a, s);
+            case 3: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 3, 2, true>(a, s);
+            default: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, true>(a, s);
         }
-        // (16 x 16 x 256 as four waves of 128 px x 128 ch -- 64 accumulator tiles per wave -- spills 456 bytes even with 512 registers: not instantiated)
-        if (t.ph == 16 && t.bn == 128 && t.wgm == 4)
-            return a.q == 3 ? halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 3>(a, s)
-                 : a.q == 2 ? halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 2>(a, s) : halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, false, 1>(a, s);
-        // 16 x 16 pixels x 128 channels as four waves of 128 px x 64 ch, ONE workgroup per CU (a wave per SIMD, up to 512 registers)
-        if (t.ph == 16 && t.bn == 128 && t.wgm == 2 && t.wgn == 2)
-            return a.q >= 2 ? halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, false, 2>(a, s) : halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, false, 1>(a, s);
-        mf_set_error("halo conv (f16 + FP6 format): no kernel for this tile");
-        return MF_ERR_INVALID;
     }
-    if (a.gn_scale) {
-        // GroupNorm folded in: the three fat tiles, plain 3x3 only
-        if (phase >= 0 || a.nsplit > 1) { mf_set_error("halo conv (LDS weights): GroupNorm fusion is for plain, unsplit 3x3 layers"); return MF_ERR_INVALID; }
-        if (t.ph == 16 && t.bn == 256 && t.wgm == 2)
-            return x3 ? halo_w_launch_cfg<16, 256, 2, 4, true, 1, -1, 2, true>(a, s) : halo_w_launch_cfg<16, 256, 2, 4, false, 1, -1, 2, true>(a, s);
-        if (t.ph == 16 && t.bn == 128 && t.wgm == 2 && t.wgn == 2)
-            return x3 ? halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 1, true>(a, s) : halo_w_launch_cfg<16, 128, 2, 2, false, 1, -1, 1, true>(a, s);
-        if (t.ph == 16 && t.bn == 128 && t.wgm == 4)
-            return x3 ? halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, true>(a, s) : halo_w_launch_cfg<16, 128, 4, 2, false, 1, -1, 2, true>(a, s);
-        mf_set_error("halo conv (LDS weights): GroupNorm fusion needs a fat tile");
-        return MF_ERR_INVALID;
-    }
-    // the fat tiles, also as upsample phases (phase >= 0)
-    if (t.ph == 16 && t.bn == 256 && t.wgm == 2) return halo_w_launch_phase<16, 256, 2, 4>(a, x3, phase, s);   // wave tile 128 px x 64 ch (FM 8, FN 4)
-    if (t.ph == 16 && t.bn == 128 && t.wgm == 4) return halo_w_launch_phase<16, 128, 4, 2>(a, x3, phase, s);   // 64 px x 64 ch
-    if (phase >= 0) { mf_set_error("halo conv (LDS weights): upsample phases need a fat tile"); return MF_ERR_INVALID; }
+    if (phase >= 0) { mf_set_error("halo conv (LDS weights): upsample phases exist in the f16 + FP6 format only"); return MF_ERR_INVALID; }
+    // the fat tiles
+    if (t.ph == 16 && t.bn == 256 && t.wgm == 2) return halo_w_launch_prec<16, 256, 2, 4, 1>(a, x3, s);   // wave tile 128 px x 64 ch (FM 8, FN 4)
+    if (t.ph == 16 && t.bn == 128 && t.wgm == 4) return halo_w_launch_prec<16, 128, 4, 2, 1>(a, x3, s);   // 64 px x 64 ch
     // two 4-wave workgroups per CU (single halo image): wave tile 128 px x 64 ch like the 256-channel tile
     if (t.ph == 16 && t.bn == 128 && t.wgm == 2 && t.wgn == 2)
         return x3 ? halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 1>(a, s) : halo_w_launch_cfg<16, 128, 2, 2, false, 1, -1, 1>(a, s);
-    MF_HCASE(16, 128, 2, 4, 1)     // 128 pixels x 32 channels (A/B: MF_HALO_W128=24)
-    MF_HCASE(16, 64, 4, 2, 3)
-    MF_HCASE(8, 64, 2, 2, 3)
-#undef MF_HCASE
     mf_set_error("halo conv (LDS weights): no kernel for patch %dx16, BN %d", t.ph, t.bn);
     return MF_ERR_INVALID;
 }
@@ -788,31 +669,16 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
 // The LDS-weights kernel pays off where the weight stream dominates the patch: 64-channel tiles on maps large enough to give every
 // CU a 16 x 16 (or 8 x 16) patch.  Returns ph == 0 when the first-generation kernel should be used.
 HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch, int cin) {
-    // default (unset): the fat tiles wherever they fill the chip; 0: never; 1: also the 64-channel tiles (measured no faster than the
-    // register-weights kernel); 2 / 3 / 5: force 16x64 / 8x64 / the fat tiles whatever the size (tests)
-    static const int mode = [] { const char* e = getenv("MF_HALO_WLDS"); return e ? atoi(e) : -1; }();
     auto wgs = [&](int ph, int bn) { return batch * ((H + ph - 1) / ph) * ((W + PW - 1) / PW) * ((N + bn - 1) / bn); };
-    if (!mode || N < 64) return HaloTile{0, 0, 0, 0};
-    if (mode == 2) return HaloTile{16, 64, 4, 2};
-    if (mode == 3) return HaloTile{8, 64, 2, 2};
-    // fat wave tiles: 16 x 16 pixels x 256 / 128 channels, 2 x 4 waves of 128 pixels x 64 / 32 channels, a ring slot per tap
-    // (maps of at least 64 x 64: on Wav2Lip's 24^2 / 48^2 layers at batch 128 they measured 2 % slower than the register-weights kernel)
-    // 512+ -> 256k-channel layers gain on small maps too once there are 256 patches x channel tiles (512 -> 512 @32^2: 464 -> 521 TF at
-    // batch 64, 459 -> 498 at 32; 374 -> 298 at 16, hence the workgroup floor)
-    static const int big_px = [] { const char* e = getenv("MF_HALO_BIGMAP"); return e ? atoi(e) : 64 * 64; }();   // A/B: map-size floor of the fat tiles
-    const bool big_map = H * W >= big_px;
-    static const bool no256 = [] { const char* e = getenv("MF_HALO_W256"); return e && atoi(e) == 0; }();   // A/B: every wide layer on the 128-channel tile
-    if (!no256 && N % 256 == 0 && (mode == 5 || ((big_map || cin >= 512) && wgs(16, 256) >= 256))) return HaloTile{16, 256, 2, 4};
-    // 128-channel tile: two 4-wave workgroups per CU on one halo image each (wave 128 px x 64 ch) wherever that still gives every CU its
-    // pair -- each other's DMA waits and epilogues are hidden: 128 -> 128 @256^2 401 -> 373 us, VAE 128-channel convs 2.83 -> 2.62 ms;
-    // MF_HALO_W128=42 / 24 select the 8-wave arrangements
-    static const int w128 = [] { const char* e = getenv("MF_HALO_W128"); return e ? atoi(e) : 22; }();
-    if (w128 == 22 && N % 128 == 0 && (mode == 5 || (big_map && wgs(16, 128) >= 512))) return HaloTile{16, 128, 2, 2};
-    const bool w128_42 = w128 != 24;   // 4 x 2 waves (64 px x 64 ch each) measured 0-4 % ahead of 2 x 4 (128 px x 32 ch)
-    if (N % 128 == 0 && (mode == 5 || (big_map && wgs(16, 128) >= 256))) return w128_42 ? HaloTile{16, 128, 4, 2} : HaloTile{16, 128, 2, 4};
-    if (mode == 1) {
-        if (wgs(16, 64) >= 256) return HaloTile{16, 64, 4, 2};
-        if (wgs(8, 64) >= 256) return HaloTile{8, 64, 2, 2};
-    }
+    if (N < 64) return HaloTile{0, 0, 0, 0};
+    // fat wave tiles: 16 x 16 pixels x 256 / 128 channels, a ring slot per tap, on maps of at least 64 x 64 (on Wav2Lip's 24^2 / 48^2 layers at batch
+    // 128 they measured 2 % slower than the register-weights kernel); 512+ -> 256k-channel layers gain on small maps too once there are 256 patches x
+    // channel tiles (512 -> 512 @32^2: 464 -> 521 TF at batch 64, 459 -> 498 at 32; 374 -> 298 at 16, hence the workgroup floor)
+    const bool big_map = H * W >= 64 * 64;
+    if (N % 256 == 0 && (big_map || cin >= 512) && wgs(16, 256) >= 256) return HaloTile{16, 256, 2, 4};
+    // 128-channel tile: two 4-wave workgroups per CU on one halo image each (wave 128 px x 64 ch) wherever that still gives every CU its pair -- each
+    // other's DMA waits and epilogues are hidden (128 -> 128 @256^2 401 -> 373 us) -- else one 8-wave workgroup of 4 x 2 waves (64 px x 64 ch each)
+    if (N % 128 == 0 && big_map && wgs(16, 128) >= 512) return HaloTile{16, 128, 2, 2};
+    if (N % 128 == 0 && big_map && wgs(16, 128) >= 256) return HaloTile{16, 128, 4, 2};
     return HaloTile{0, 0, 0, 0};
 }

@@ -188,19 +188,12 @@ struct Net {
         if (act != 5) stats_remember(p, out);
         return MF_OK;
     }
-    // GroupNorm(+SiLU) `gname` of x followed by the 3x3 conv `cname`.  Where the conv runs on the LDS-weights halo kernel's fat tiles at the
-    // launch's batch (mf_conv_can_fuse_gn) the normalisation is applied to the conv's halo image in LDS -- statistics + a [B][C] affine, no
-    // apply pass, `t` untouched; otherwise GroupNorm writes `t` and the conv reads it, as two launches in one op.  Opt-in (MF_GN_FUSE=1): frames
-    // agree to 1 uint8 level, per-op time of (GroupNorm + conv) drops 3-5 %, but the replayed step does not move (23.9 -> 23.6 ms in one run,
-    // 339 -> 336 frames/s in another): the in-LDS transform costs the conv about what the apply pass cost the memory system.
-    // statistics for GroupNorm(groups) of `x` come from its producer's epilogue?  (MF_GN_EPI=0: off)
+    // statistics for GroupNorm(groups) of `x` come from its producer's epilogue?
     bool take_stats(const ActView& x, int groups, double* st) {
-        static const bool on = [] { const char* e = getenv("MF_GN_EPI"); return !e || atoi(e) != 0; }();
-        if (!on || x.C % groups || groups > 64 || x.C % 8 || x.coff % 8) return false;
-        static const bool q_only = [] { const char* e = getenv("MF_GN_EPI"); return e && atoi(e) == 2; }();   // A/B: 2 = only the f16 + FP6 producers (the r02a state)
+        if (x.C % groups || groups > 64 || x.C % 8 || x.coff % 8) return false;
         for (size_t i = 0; i < stats_srcs.size(); ++i) {
             const StatsSrc& e = stats_srcs[i];
-            if (e.v.buf != x.buf || e.v.coff != x.coff || e.v.C != x.C || e.p->d.cout != x.C || e.p->out_stats || (q_only && !e.p->q)) continue;
+            if (e.v.buf != x.buf || e.v.coff != x.coff || e.v.C != x.C || e.p->d.cout != x.C || e.p->out_stats) continue;
             e.p->out_stats = st; e.p->out_stats_groups = groups;
             stats_srcs.erase(stats_srcs.begin() + i);
             return true;
@@ -210,12 +203,11 @@ struct Net {
     int gn_conv(const std::string& gname, const std::string& cname, ActView x, ActBuf* t, ActView out, int cin, int cout, int groups, float eps,
                 ActView res, const std::vector<float>* extra_bias = nullptr) {
         const ActView tv{t, 0, cin};
-        const bool same_geom = x.coff == 0 && x.buf->C == t->C && x.buf->halo == t->halo && x.buf->H == t->H && x.buf->W == t->W && x.C == cin;
         // f16 + FP6 operand format for the wide 3x3 convs on large maps (MF_CONV_Q=0: bf16x3 everywhere): GroupNorm-apply writes the conv's input in the new
         // format, the conv runs one f16 + half a block-scaled FP6 MFMA per tap where bf16x3 runs three; outputs and residuals stay bf16 (hi, lo).
         static const bool q_on = [] { const char* e = getenv("MF_CONV_Q"); return !e || atoi(e) != 0; }();
-        // (maps below 64 x 64 -- the 512-channel 32 x 32 levels -- run it with the channel slices split over two workgroups per tile, mf_q_split_count; MF_CONV_Q_MINPX=4096: bf16x3 there)
-        static const int q_minpx = [] { const char* e = getenv("MF_CONV_Q_MINPX"); return e ? atoi(e) : 32 * 32; }();
+        // (maps below 64 x 64 -- the 512-channel 32 x 32 levels -- run it with the channel slices split over two workgroups per tile, mf_q_split_count)
+        const int q_minpx = 32 * 32;
         if (q_on && q_allowed && precision == MF_PREC_BF16X3 && cin % 32 == 0 && cout % 128 == 0 && t->C == cin && t->H * t->W >= q_minpx && cin >= 128 &&
             (int64_t)cap * ((t->H + 15) / 16) * ((t->W + 15) / 16) * (cout / 128) >= 64) {
             const float* g = T(gname + ".weight", cin);
@@ -253,45 +245,8 @@ struct Net {
             stats_remember(p, out);
             return MF_OK;
         }
-        static const bool on = [] { const char* e = getenv("MF_GN_FUSE"); return e && atoi(e) != 0; }();
-        if (!on || !same_geom) {
-            int rc = gn(gname, x, tv, groups, eps, true);
-            return rc ? rc : conv(cname, tv, out, cin, cout, 3, 1, 1, 0, res, 0, extra_bias);
-        }
-        const float* g = T(gname + ".weight", cin);
-        const float* b = T(gname + ".bias", cin);
-        if (!g || !b) return MF_ERR_INVALID;
-        float* dg = upload(g, cin);
-        float* db = upload(b, cin);
-        if (!dg || !db) return MF_ERR_HIP;
-        if (gn_count >= GN_MAX_OPS) { err = "more GroupNorm layers than GN_MAX_OPS"; return MF_ERR_INVALID; }
-        double* st = gn_stats + (size_t)(gn_count++) * gn_slice;
-        float* aff = nullptr;
-        if (hipMalloc(&aff, (size_t)2 * cap * cin * sizeof(float)) != hipSuccess) { err = "hipMalloc failed for a GroupNorm affine"; return MF_ERR_HIP; }
-        dev.push_back(aff);
-        float *scale = aff, *shift = aff + (size_t)cap * cin;
-        ConvPlan* p = nullptr;
-        int rc = conv(cname, tv, out, cin, cout, 3, 1, 1, 0, res, 0, extra_bias, 1.f, true, &p);
-        if (rc) return rc;
-        if (!mf_conv_can_fuse_gn(p, cap)) {
-            // never fusable at this handle's capacity: keep GroupNorm and conv as two ops (per-op profiles stay comparable)
-            push(gname, "k_gn_stats+k_gn_apply", 0.0, [=](int B, hipStream_t s) { return mf_groupnorm(x, tv, dg, db, groups, eps, true, st, B, s); });
-            char kn0[96];
-            mf_conv_kernel_name(p, cap, kn0, sizeof(kn0));
-            push(cname, kn0, mf_conv_flops(p, 1), [=](int B, hipStream_t s) { return mf_conv_launch(p, tv, out, res, B, s); });
-            return MF_OK;
-        }
-        char kn[96];
-        mf_conv_kernel_name(p, cap, kn, sizeof(kn));
-        push(cname + " (+" + gname.substr(gname.rfind('.') + 1) + ")", std::string("gn+") + kn, mf_conv_flops(p, 1), [=](int B, hipStream_t s) {
-            if (mf_conv_can_fuse_gn(p, B)) {
-                const int r1 = mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s);
-                return r1 ? r1 : mf_conv_launch_gn(p, x, out, res, B, scale, shift, s);
-            }
-            const int r1 = mf_groupnorm(x, tv, dg, db, groups, eps, true, st, B, s);
-            return r1 ? r1 : mf_conv_launch(p, tv, out, res, B, s);
-        });
-        return MF_OK;
+        int rc = gn(gname, x, tv, groups, eps, true);
+        return rc ? rc : conv(cname, tv, out, cin, cout, 3, 1, 1, 0, res, 0, extra_bias);
     }
     int gn(const std::string& name, ActView in, ActView out, int groups, float eps, bool silu) {
         const float* g = T(name + ".weight", in.C);
@@ -326,9 +281,8 @@ struct Net {
             err = "attention: needs contiguous token buffers and a head dim that is a multiple of 8";
             return MF_ERR_INVALID;
         }
-        // one fused kernel (mf_attn.hip) for the UNet's head dims; MF_ATTN=composite keeps the five-launch path for A/B
-        static const bool composite = [] { const char* e = getenv("MF_ATTN"); return e && !strcmp(e, "composite"); }();
-        if (mf_attention_supported(dh) && !composite) {
+        // one fused kernel (mf_attn.hip) for the UNet's head dims; the five-launch composite below serves the others (the VAE mid-block's dh 512)
+        if (mf_attention_supported(dh)) {
             const int prec = precision;
             push("attention " + std::to_string(Tq) + "x" + std::to_string(Tk) + " heads " + std::to_string(heads) + " dh " + std::to_string(dh),
                  "k_attention", 4.0 * Tq * Tk * C, [=](int B, hipStream_t s) { return mf_attention(q, k, v, out, heads, B, prec, s); });
@@ -479,9 +433,9 @@ struct Net {
 
     // diffusers Upsample2D (nearest 2x + conv 3x3) in the f16 + FP6 operand format where the layer fills the chip that way: a converter pass writes
     // the input in the format (identity affine, no SiLU), then four 2 x 2-tap phase launches of the f16 + FP6 halo tile, which also leave the
-    // consumer GroupNorm's statistics.  Elsewhere (small maps, other precisions, MF_CONV_Q=0 / MF_UP_Q=0): the 4-phase implicit GEMM on bf16x3.
+    // consumer GroupNorm's statistics.  Elsewhere (small maps, other precisions, MF_CONV_Q=0): the 4-phase implicit GEMM on bf16x3.
     int upsample_conv(const std::string& name, ActView x, ActView out, int C) {
-        static const bool on = [] { const char* e = getenv("MF_CONV_Q"); const char* u = getenv("MF_UP_Q"); return (!e || atoi(e) != 0) && (!u || atoi(u) != 0); }();
+        static const bool on = [] { const char* e = getenv("MF_CONV_Q"); return !e || atoi(e) != 0; }();
         const int H = x.buf->H, W = x.buf->W;
         if (!(on && q_allowed && precision == MF_PREC_BF16X3 && C % 128 == 0 && x.C == C && x.coff % 8 == 0 && H * W >= 32 * 32 &&
               (int64_t)cap * ((H + 15) / 16) * ((W + 15) / 16) * (C / 128) >= 256))
@@ -513,8 +467,7 @@ struct Net {
 
     // hoisted cross-attention k | v: reserve the op slot before the blocks are built ...
     int hoist_kv_begin(ActView ctx, int total) {
-        static const bool on = [] { const char* e = getenv("MF_KV_HOIST"); return !e || atoi(e) != 0; }();
-        if (!on || total <= 0) return MF_OK;
+        if (total <= 0) return MF_OK;
         kv_all = buf(total, ctx.buf->H, ctx.buf->W, 0);
         if (!kv_all) return MF_ERR_HIP;
         kv_ctx = ctx; kv_off = 0; kv_w.clear();
@@ -711,8 +664,7 @@ struct Net {
         MF_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
         MF_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
         MF_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-        const char* fk = std::getenv("MF_UNET_FORK");
-        fork_on = !(fk && fk[0] == '0');
+        fork_on = true;
         const char* ng = std::getenv("MF_NO_GRAPH");
         use_graph = !(ng && ng[0] == '1');
         return MF_OK;

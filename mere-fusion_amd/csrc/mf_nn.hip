@@ -420,82 +420,6 @@ __global__ __launch_bounds__(256) void k_vae_post(Rows X, int H, int W, uint8_t*
     }
 }
 
-// GroupNorm(+SiLU) of a SMALL tensor in one launch: a 1024-thread workgroup per (batch item, group) makes two passes over its H*W x cpg values
-// (the second comes out of L2 -- within ONE kernel the lines stay there; across two launches they do not, tools/xcd_affinity_probe.hip), fp32
-// partials per thread, fp64 across the workgroup.  The UNet's 61 GroupNorms at batch 8 are 1-30 k values per (item, group): two launches cost
-// 12-20 us each pair, mostly launch + first-touch latency.  Channels go in pairs (one 32-bit load per plane; cpg is even for every SD channel
-// count) and four pairs per thread are requested together: the loop is a chain of load round trips, so what matters is how few of them it has.
-__global__ __launch_bounds__(1024) void k_gn_small(Rows X, Rows Y, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int cpg, int silu) {
-    __shared__ double s_sum[16], s_sq[16];
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int c0 = g * cpg, half = cpg >> 1, n = X.T * half;
-    const bf16_t* __restrict__ xh = X.hi;
-    const bf16_t* __restrict__ xl = X.lo;
-    bf16_t* __restrict__ yh = const_cast<bf16_t*>(Y.hi);
-    bf16_t* __restrict__ yl = const_cast<bf16_t*>(Y.lo);
-    float s = 0.f, q = 0.f;
-    for (int i0 = tid; i0 < n; i0 += 4096) {
-        uint32_t h[4], l[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 1024;
-            h[u] = l[u] = 0;
-            if (i < n) {
-                const int t = i / half, cp = i - t * half;
-                const int64_t o = X.off(b, t) + c0 + 2 * cp;
-                h[u] = *reinterpret_cast<const uint32_t*>(xh + o);
-                if (xl) l[u] = *reinterpret_cast<const uint32_t*>(xl + o);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float v0 = nbf2f(h[u] & 0xffffu) + nbf2f(l[u] & 0xffffu), v1 = nbf2f(h[u] >> 16) + nbf2f(l[u] >> 16);
-            s += v0 + v1;
-            q += v0 * v0 + v1 * v1;
-        }
-    }
-    double ds = (double)s, dq = (double)q;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
-    if ((tid & 63) == 0) { s_sum[tid >> 6] = ds; s_sq[tid >> 6] = dq; }
-    __syncthreads();
-    ds = 0.0; dq = 0.0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) { ds += s_sum[w]; dq += s_sq[w]; }
-    const double inv_n = 1.0 / ((double)X.T * cpg);
-    const double mean_d = ds * inv_n;
-    const float mean = (float)mean_d, rstd = rsqrtf((float)fmax(dq * inv_n - mean_d * mean_d, 0.0) + eps);
-    for (int i0 = tid; i0 < n; i0 += 4096) {
-        uint32_t h[4], l[4];
-        int64_t yo[4];
-        int cc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 1024;
-            h[u] = l[u] = 0; yo[u] = 0; cc[u] = c0;
-            if (i < n) {
-                const int t = i / half, cp = i - t * half;
-                cc[u] = c0 + 2 * cp;
-                const int64_t o = X.off(b, t) + cc[u];
-                yo[u] = Y.off(b, t) + cc[u];
-                h[u] = *reinterpret_cast<const uint32_t*>(xh + o);
-                if (xl) l[u] = *reinterpret_cast<const uint32_t*>(xl + o);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (i0 + u * 1024 >= n) break;
-            float v0 = nbf2f(h[u] & 0xffffu) + nbf2f(l[u] & 0xffffu), v1 = nbf2f(h[u] >> 16) + nbf2f(l[u] >> 16);
-            v0 = (v0 - mean) * rstd * gamma[cc[u]] + beta[cc[u]];
-            v1 = (v1 - mean) * rstd * gamma[cc[u] + 1] + beta[cc[u] + 1];
-            if (silu) { v0 = v0 / (1.f + __expf(-v0)); v1 = v1 / (1.f + __expf(-v1)); }
-            const uint32_t h0 = nf2bf(v0), h1 = nf2bf(v1);
-            *reinterpret_cast<uint32_t*>(yh + yo[u]) = h0 | (h1 << 16);
-            if (yl) *reinterpret_cast<uint32_t*>(yl + yo[u]) = nf2bf(v0 - nbf2f(h0)) | (nf2bf(v1 - nbf2f(h1)) << 16);
-        }
-    }
-}
-
 Rows rows_of(const ActView& v) {
     const ActBuf& b = *v.buf;
     return Rows{b.hi + v.coff, b.lo ? b.lo + v.coff : nullptr, b.per_batch(), b.W, b.Wp(), b.halo, b.C, b.H * b.W};
@@ -603,17 +527,6 @@ int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const f
     const Rows xr = rows_of(x), yr = rows_of(y);
     const int cpg = x.C / groups;
     MF_REQUIRE(groups <= 64 && x.C <= 8 * 256 * GN_MAXCOL, "groupnorm: groups=%d / C=%d beyond the kernel's limits", groups, x.C);
-    {
-        // small tensors in one launch: OPT-IN (MF_GN_SMALL=<max values per (item, group)>, e.g. 32768).  Measured at batch 8: the UNet's 61
-        // GroupNorms take 1.09 ms this way against 0.91-0.95 ms as two launches -- a workgroup per (item, group) is two chains of load round
-        // trips over 4-byte pieces, the two-launch path spreads the same bytes over the whole chip twice.
-        static const int small_max = [] { const char* e = getenv("MF_GN_SMALL"); return e ? atoi(e) : 0; }();
-        if (!have_stats && cpg % 2 == 0 && (int64_t)xr.T * cpg <= small_max && batch * groups >= 128) {
-            hipLaunchKernelGGL(k_gn_small, dim3(groups, batch), dim3(1024), 0, s, xr, yr, gamma, beta, eps, cpg, silu ? 1 : 0);
-            MF_HIP(hipGetLastError());
-            return MF_OK;
-        }
-    }
     // pixels per workgroup: enough workgroups to fill the chip, at most 64 pixels per thread column
     const int cols = std::min(256, x.C / 8), ppi = 256 / cols;
     int P = std::max(ppi, std::min(64 * ppi, (xr.T * batch + 1023) / 1024));

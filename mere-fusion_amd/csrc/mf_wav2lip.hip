@@ -220,7 +220,7 @@ int mf_wav2lip::ensure_capacity(int batch) {
 }
 
 int mf_wav2lip::run_body(int batch, hipStream_t s) {
-    static const bool fork = [] { const char* e = getenv("MF_W2L_FORK"); return !e || e[0] != '0'; }();   // MF_W2L_FORK=0: one serial chain (A/B)
+    const bool fork = true;                                           // (one serial chain measured 11 % slower: 1.12 vs 1.00 ms at batch 16)
     if (!fork) {
         for (int g = 0; g < 3; ++g)
             for (auto& st : steps)

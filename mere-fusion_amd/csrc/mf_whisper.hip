@@ -341,10 +341,7 @@ extern "C" int mf_whisper_create(const mf_tensor* weights, int n_weights, int n_
     h->n_head = n_head;
     MF_REQUIRE(h->n_mels == W_MELS, "whisper_create: n_mels=%d, only 80 is supported (audio.py:76)", h->n_mels);
     MF_REQUIRE(h->C % n_head == 0 && (h->C / n_head) % 8 == 0, "whisper_create: head dim must be a multiple of 8");
-    {
-        const char* e = getenv("MF_ATTN");
-        h->fused_attn = mf_attention_supported(h->C / n_head) && !(e && !strcmp(e, "composite"));
-    }
+    h->fused_attn = mf_attention_supported(h->C / n_head);
     int L = 0;
     while (sd.count("blocks." + std::to_string(L) + ".attn.query.weight")) ++L;
     MF_REQUIRE(L > 0, "whisper_create: no encoder blocks in the state dict");

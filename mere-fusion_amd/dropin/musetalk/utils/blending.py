@@ -4,7 +4,13 @@ the BiSeNet face parser) are forwarded to the reference's module on first use.""
 from mere_fusion_amd.musetalk.utils.blending import get_image_blending, get_crop_box  # noqa: F401
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=1)
 def _reference_module():
+    """Loaded ONCE: the reference's module builds `FaceParsing()` (the BiSeNet weights) at import time (blending.py:8), and these helpers are called per
+    avatar frame."""
     import importlib.util
     import os
     import sys

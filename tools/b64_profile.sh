@@ -21,4 +21,4 @@ if [ "${PMC:-1}" = 1 ]; then
   done
   python $R/tools/pmc_hbm_summary.py /tmp/pmch_b${B}_FETCH_SIZE /tmp/pmch_b${B}_WRITE_SIZE > $R/gpurun_out/${TAG}_pmc_hbm_musetalk_b$B.md 2>&1
 fi
-head -45 $R/gpurun_out/${TAG}_kernel_stats_musetalk_b$B.md | cut -c1-200
+head -20 $R/gpurun_out/${TAG}_kernel_stats_musetalk_b$B.md | cut -c1-200

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Where the halo conv's time goes: rebuilds the library with MF_HALO_ABLATE bits (wrong results, timing only) into build_ab/ and times
+# Where the (bf16x3) halo conv's time goes: rebuilds the library with MF_HALO_ABLATE bits (wrong results, timing only) into build_ab/ and times
 # one layer with each.  Run the BUILD part here (no GPU): tools/halo_ablate.sh build ; the TIMING part on the GPU box: tools/halo_ablate.sh run
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd $R
