@@ -16,7 +16,10 @@ OBJ = os.path.normpath(os.path.join(HERE, "..", "build", "obj"))
 SOURCES = ["mf_api.cpp", "mf_conv.hip", "mf_conv_halo.hip", "mf_conv_halo2.hip", "mf_aux.hip", "mf_wav2lip.hip", "mf_conv_api.hip", "mf_mel.hip",
            "mf_nn.hip", "mf_attn.hip", "mf_whisper.hip", "mf_musetalk.hip", "mf_nerf.hip", "mf_nerf_net.hip", "mf_nerf_fused.hip", "mf_nerf_torso.hip", "mf_nerf_audio.hip",
            "mf_blend.hip", "mf_session.hip", "mf_wav2vec2.hip", "mf_net.hip", "mf_probe.hip"]
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -pragma-unroll-threshold: the 256 x 256 implicit-GEMM tile's `#pragma unroll` loops (128 accumulator registers, 8 x 4 fragments) exceed LLVM's default
+# cap of 16384 for pragma-driven unrolling; a loop left rolled indexes the accumulator array dynamically, which puts it in scratch (592 bytes per lane,
+# the kernel 5 x slower: found in round 3 when unrelated code left the kernel and the estimate tipped over)
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm", "-pragma-unroll-threshold=262144"]
 
 
 def _headers():
