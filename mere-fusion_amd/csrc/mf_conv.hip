@@ -33,6 +33,9 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 // Swizzled LDS byte offset of the 16-byte slot (row, kg) of a [rows][BK] bf16 tile.  The XOR terms
 // make every 16-lane service group of ds_read_b128 (rows l&15 at one or two kg values) hit 16
@@ -125,23 +128,23 @@ __device__ __forceinline__ void store_pair16(bf16_t* base, int64_t yo, int c16, 
     if (ok && cw < N) *reinterpret_cast<uint4*>(base + yo + cw) = out;
 }
 
-// NST = LDS ring depth.  2: DMA of tile k+1 under the MFMAs of tile k, drained at a __syncthreads().
-// >= 3: NST-1 tiles in flight; each wave waits only for ITS OWN share of the tile it is about to read
-// (counted s_waitcnt vmcnt, every wave issues the same number of DMA instructions per tile) and a raw
-// s_barrier publishes it -- nothing ever drains the queue inside the loop.
-// LD = how the operand tiles reach LDS.  0: LDS-DMA (global_load_lds).  1: through registers -- global_load_dwordx4 of tile k+2 in
-// flight while tile k+1 sits in staging VGPRs / is written to the other LDS stage and tile k is multiplied.  A DMA piece costs its wave
-// 100-185 issue cycles inside a loaded phase (MI355X_MICROARCH.md); with 6 pieces per wave per 32-deep tile and only 24 MFMAs to cover
-// them, the small tiles' loop ran at 1840 cycles per K tile.  A plain load issues in a few cycles and the ds_write_b128 in 13.
-// 2: through registers into ONE LDS stage (two barriers per tile): half the LDS, so a 64-deep bf16x3 tile (128-byte rows: every request
-// a full line) still leaves room for 2-3 workgroups per CU, whose MFMAs cover each other's barriers.
-template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST, int LD = 0>
+// NST = LDS stages of the DMA path (2: the DMA of tile k+1 flies under the MFMAs of tile k, drained at a __syncthreads()).
+// LD = how the operand tiles reach LDS.  0: LDS-DMA (global_load_lds) into the two stages.  2: through registers into ONE LDS stage (two barriers per
+// tile): a DMA piece costs its wave 100-185 issue cycles inside a loaded phase (MI355X_MICROARCH.md), a plain load a few and the ds_write_b128 13; and with
+// half the LDS a 64-deep two-plane tile (128-byte rows: every request a full line) still leaves room for 2-3 workgroups per CU, whose MFMAs cover each
+// other's barriers.
+// Q: operands in the f16 + FP6 format (MF_PREC_F16Q; the two planes are f16 and [q6 | q6] FP6 blocks, see pack_q_block): per 32-deep step ONE
+// v_mfma_f32_16x16x32_f16 (wh.xh) and per 64-deep tile ONE v_mfma_scale_f32_16x16x128_f8f6f4 whose K blocks 0 / 1 carry q6(wh).xl / wl.q6(xh) of channels
+// 0..31 and blocks 2 / 3 those of channels 32..63 -- 48 matrix cycles per tile and accumulator where bf16x3 spends 96.  A 32-deep tile (the 8-wave tiles)
+// leaves blocks 2 / 3 off by a zero scale: 32 cycles against 48.
+template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST, int LD = 0, bool Q = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a) {
+    static_assert(!Q || X3, "the f16 + FP6 format has two planes");
     constexpr int NW = WGM * WGN;         // waves per workgroup
     constexpr int NT = NW * 64;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(BK == 32 || BK == 64, "LDS tile depth");
-    static_assert(NST >= 2 && NST <= 4, "ring depth");
+    static_assert(NST == 2, "two LDS stages (deeper rings halved the workgroups per CU and measured slower)");
     constexpr int KG = BK / 8;            // 16-byte groups per tile row
     constexpr int ROWB = BK * 2;          // bytes per tile row
     constexpr int RPC = 1024 / ROWB;      // tile rows per 1-KiB DMA chunk
@@ -256,6 +259,46 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
 
     auto compute = [&](int s) __attribute__((always_inline)) {
         const char* base = smem + s * STAGE;
+        if constexpr (Q) {
+            // corrections first (small terms), then the f16 products.  A lane's FP6 block: the 32 bytes at 16-byte slots 2g, 2g + 1 of its plane-1 row, g = its
+            // K block (BK 64: lane group fk; BK 32: fk & 1, groups 2 / 3 re-read and are switched off).  The XOR swizzle is even, so the two slots stay adjacent.
+            const int g6 = BK == 64 ? fk : (fk & 1);
+            const bool off = BK == 32 && fk >= 2;
+            i32x8 w6[FN];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const char* q = base + PLANE + P_BYTES + tile_off<BK>(cn0 + i * 16 + fr, 2 * g6);
+                w6[i] = __builtin_shufflevector(*reinterpret_cast<const i32x4*>(q), *reinterpret_cast<const i32x4*>(q + 16), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            constexpr int JH = FM > 4 ? 4 : FM;                   // pixel fragments per batch (the 128-pixel wave tiles have no registers for all eight at once)
+#pragma unroll
+            for (int j0 = 0; j0 < FM; j0 += JH) {
+                i32x8 p6[JH];
+#pragma unroll
+                for (int jj = 0; jj < JH; ++jj) {
+                    const char* q = base + PLANE + tile_off<BK>(pm0 + (j0 + jj) * 16 + fr, 2 * g6);
+                    p6[jj] = __builtin_shufflevector(*reinterpret_cast<const i32x4*>(q), *reinterpret_cast<const i32x4*>(q + 16), 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < JH; ++jj)
+                        acc[i][j0 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w6[i], p6[jj], acc[i][j0 + jj], 2, 2, 0, off ? 0 : w6[i][6], 0, off ? 0 : p6[jj][6]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                f16x8 pf[FM], wf[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) pf[i] = *reinterpret_cast<const f16x8*>(base + tile_off<BK>(pm0 + i * 16 + fr, kk * 4 + fk));
+#pragma unroll
+                for (int i = 0; i < FN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(base + P_BYTES + tile_off<BK>(cn0 + i * 16 + fr, kk * 4 + fk));
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], pf[j], acc[i][j], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 pf[NP][FM], wf[NP][FN];
@@ -286,7 +329,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
     if (dbg && threadIdx.x == 0) dbg[1] = __builtin_amdgcn_s_memtime();
     const int nk = kt_end - kt_begin;
     if constexpr (LD != 0) {
-        static_assert(NST == 2 && (LD == 1 || LD == 2), "register-staged tiles: double buffer (LD 1) or one stage (LD 2)");
+        static_assert(LD == 2, "register-staged tiles: one LDS stage");
         u32x4 rp[NP][NPC], rw[NP][NWC];
         auto gload = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
@@ -327,23 +370,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
                 }
             }
         };
-        if (LD == 1) {
-            if (nk > 0) {
-                gload(kt_begin);
-                lstore(0);
-                if (nk > 1) gload(kt_begin + 1);
-                __syncthreads();
-                for (int kt = kt_begin; kt < kt_end; ++kt) {
-                    const int s = (kt - kt_begin) & 1;
-                    if (kt + 1 < kt_end) {
-                        lstore(s ^ 1);                           // tile kt+1: loaded a whole iteration ago; everyone left that stage at the last barrier
-                        if (kt + 2 < kt_end) gload(kt + 2);      // in flight under this tile's MFMAs and the next iteration's
-                    }
-                    compute(s);
-                    __syncthreads();
-                }
-            }
-        } else {
+        {
             if (nk > 0) gload(kt_begin);
             for (int kt = kt_begin; kt < kt_end; ++kt) {
                 if (kt > kt_begin) __syncthreads();              // everyone is done reading the previous tile
@@ -353,7 +380,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
                 compute(0);
             }
         }
-    } else if (NST == 2) {
+    } else {
         if (nk > 0) {
             stage(kt_begin, 0);
             __syncthreads();   // drains the DMA (vmcnt) and publishes stage 0
@@ -363,24 +390,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
                 compute(s);
                 __syncthreads();
             }
-        }
-    } else {
-        static_assert(NST == 2 || (PCH % NW == 0 && WCH % NW == 0), "counted waits need the same DMA count in every wave");
-        constexpr int L = (NPC + NWC) * NP;          // DMA instructions per wave per tile
-        static_assert(L * (NST - 2) <= 63, "vmcnt field");
-#pragma unroll
-        for (int i = 0; i < NST - 1; ++i)
-            if (i < nk) stage(kt_begin + i, i);
-        int slot = 0;
-        for (int i = 0; i < nk; ++i) {
-            const int newer = nk - 1 - i;            // tiles after i; min(newer, NST-2) of them are in flight
-            if (newer >= NST - 2) wait_vm<L * (NST - 2)>();
-            else if (NST == 4 && newer == 1) wait_vm<L>();
-            else wait_vm<0>();
-            __builtin_amdgcn_s_barrier();            // tile i landed for every wave; slot (i-1)%NST is free
-            if (i + NST - 1 < nk) stage(kt_begin + i + NST - 1, (slot + NST - 1) % NST);
-            compute(slot);
-            slot = slot + 1 == NST ? 0 : slot + 1;
         }
     }
 
@@ -702,10 +711,10 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const ConvArgs a,
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST, int LD = 0>
+template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST, int LD = 0, bool Q = false>
 int launch_cfg_n(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = k_conv_igemm<BM, BN, WGM, WGN, X3, BK, NST, LD>;
+    auto kern = k_conv_igemm<BM, BN, WGM, WGN, X3, BK, NST, LD, Q>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -718,7 +727,7 @@ int launch_cfg_n(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStr
     return MF_OK;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool X3, int BK>
+template <int BM, int BN, int WGM, int WGN, bool X3, int BK, bool Q = false>
 int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStream_t s) {
     // Two operand paths, a measured choice per layer (ConvArgs::ld, mf_conv_tune):
     //   ld 0  both tiles by LDS-DMA into a 2-stage ring (deeper rings halve the workgroups per CU: measured slower, profiles/r01_ring_ab.md)
@@ -727,13 +736,23 @@ int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStrea
     // Per-op A/B at batch 8: UNet 11.05 -> 10.62 ms, Wav2Lip 14.6 k -> 15.1 k frames/s with ld 2 as the default; every variant within +-15 % per layer.
     const int regs = a.ld >= 0 ? a.ld : 2;
     if constexpr (WGM * WGN == 4) {
-        if (regs == 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 2>(a, nphase, nsplit, goff_max, s);
+        if (regs == 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 2, Q>(a, nphase, nsplit, goff_max, s);
     }
-    return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2>(a, nphase, nsplit, goff_max, s);
+    return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 0, Q>(a, nphase, nsplit, goff_max, s);
 }
 
 template <int BM, int BN, int WGM, int WGN>
-int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3, hipStream_t s) {
+int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3, bool q, hipStream_t s) {
+    if (q) {
+        // f16 + FP6 format: 64-deep tiles on the 4-wave tiles (one FP6 instruction covers the tile), 32-deep on the 8-wave ones (two planes of 256 + 256 rows)
+        if constexpr (BN >= 64 && BM >= 64) {
+            if constexpr (WGM * WGN == 4) return launch_cfg<BM, BN, WGM, WGN, true, 64, true>(a, nphase, nsplit, goff_max, s);
+            else return launch_cfg<BM, BN, WGM, WGN, true, 32, true>(a, nphase, nsplit, goff_max, s);
+        } else {
+            mf_set_error("conv (f16q): no implicit-GEMM kernel for the narrow %dx%d tile", BM, BN);
+            return MF_ERR_INVALID;
+        }
+    }
     // bf16x3 doubles the LDS image: 64-deep tiles only where two stages of (hi, lo) still leave >= 2
     // workgroups per CU (the small tiles of the long-K layers), 32-deep otherwise
     constexpr bool deep = (BM + BN) <= 128;
@@ -753,8 +772,8 @@ bool g_no_halo_wide = false;   // set while mf_conv_plan_create builds the impli
 // f16 + FP6 residual format of one weight set: plane 0 = f16(w) rows [slice][tap][Npad][32]; plane 1 = per (slice, tap, row) 64 bytes
 // [q6(f16(w)) | q6(w - f16(w))], each 24 B of e2m3 codes (value t in bits [6t, 6t+6)) + the block's E8M0 byte + pad.  The pixel side stores
 // [q6(x - f16(x)) | q6(f16(x))], so K block 0 of the correction instruction is q6(wh).xl and block 1 is wl.q6(xh).  wfun(n, c, tap) = the fp32 weight.
-template <class W>
-static void pack_q_weights(int n_slices, int ntaps, int Npad, int cout, int cin, W wfun, bf16_t* hi, bf16_t* lo) {
+// one 32-channel block of one weight row: hi32 = the 32 f16 values, lo32 (64 bytes) = [q6(f16(w)) | q6(w - f16(w))]
+static void pack_q_block(const float* w32, bf16_t* hi32, bf16_t* lo32) {
     auto enc = [](float y) -> uint32_t {
         const uint32_t sgn = y < 0.f ? 0x20u : 0u;
         const float a = std::fmin(std::fabs(y), 7.5f);
@@ -768,38 +787,43 @@ static void pack_q_weights(int n_slices, int ntaps, int Npad, int cout, int cin,
         }
         return sgn | code;
     };
-    std::vector<float> blk_h(32), blk_l(32);
+    float blk[2][32], mx[2] = {0.f, 0.f};
+    for (int e = 0; e < 32; ++e) {
+        const _Float16 h = (_Float16)w32[e];
+        blk[0][e] = (float)h; blk[1][e] = w32[e] - blk[0][e];
+        uint16_t bits; __builtin_memcpy(&bits, &h, 2);
+        hi32[e] = bits;
+        mx[0] = std::fmax(mx[0], std::fabs(blk[0][e])); mx[1] = std::fmax(mx[1], std::fabs(blk[1][e]));
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lo32);     // 64 bytes
+    for (int b = 0; b < 2; ++b) {
+        int ex = 0;
+        if (mx[b] > 0.f) { (void)std::frexp(mx[b], &ex); ex = 3 - ex; }
+        const float sc = std::ldexp(1.f, ex);
+        uint32_t w8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int e = 0; e < 32; ++e) {
+            const uint32_t code = enc(blk[b][e] * sc);
+            const int bit = 6 * e;
+            w8[bit >> 5] |= code << (bit & 31);
+            if ((bit & 31) > 26) w8[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+        }
+        w8[6] = (uint32_t)(127 - ex) & 0xffu;
+        for (int k = 0; k < 8; ++k) dst[8 * b + k] = w8[k];
+    }
+}
+
+template <class W>
+static void pack_q_weights(int n_slices, int ntaps, int Npad, int cout, int cin, W wfun, bf16_t* hi, bf16_t* lo) {
+    float w32[32];
     for (int sl = 0; sl < n_slices; ++sl)
         for (int tap = 0; tap < ntaps; ++tap)
             for (int n = 0; n < cout; ++n) {
                 const int64_t row = (((int64_t)sl * ntaps + tap) * Npad + n) * 32;
-                float mh = 0.f, ml = 0.f;
                 for (int e = 0; e < 32; ++e) {
                     const int c = sl * 32 + e;
-                    const float wf = c < cin ? wfun(n, c, tap) : 0.f;
-                    const _Float16 h = (_Float16)wf;
-                    blk_h[e] = (float)h; blk_l[e] = wf - blk_h[e];
-                    uint16_t bits; __builtin_memcpy(&bits, &h, 2);
-                    hi[row + e] = bits;
-                    mh = std::fmax(mh, std::fabs(blk_h[e])); ml = std::fmax(ml, std::fabs(blk_l[e]));
+                    w32[e] = c < cin ? wfun(n, c, tap) : 0.f;
                 }
-                uint32_t* dst = reinterpret_cast<uint32_t*>(&lo[row]);     // 64 bytes
-                for (int b = 0; b < 2; ++b) {
-                    const std::vector<float>& v = b == 0 ? blk_h : blk_l;
-                    const float m = b == 0 ? mh : ml;
-                    int ex = 0;
-                    if (m > 0.f) { (void)std::frexp(m, &ex); ex = 3 - ex; }
-                    const float sc = std::ldexp(1.f, ex);
-                    uint32_t w8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    for (int e = 0; e < 32; ++e) {
-                        const uint32_t code = enc(v[e] * sc);
-                        const int bit = 6 * e;
-                        w8[bit >> 5] |= code << (bit & 31);
-                        if ((bit & 31) > 26) w8[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
-                    }
-                    w8[6] = (uint32_t)(127 - ex) & 0xffu;
-                    for (int k = 0; k < 8; ++k) dst[8 * b + k] = w8[k];
-                }
+                pack_q_block(w32, &hi[row], &lo[row]);
             }
 }
 
@@ -975,6 +999,7 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
               d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16 && d.residual != 2 && d.act <= 2 && !d.upsample &&
               (narrow || wide_ok) && d.cout % 4 == 0;
+    if (precision == MF_PREC_F16Q && !(d.cin % 32 == 0 && d.cout % 128 == 0)) p->halo = false;   // the format's halo tile is 128 channels wide: other shapes take the implicit GEMM
     const bool want_alt = p->halo && !narrow;
     if (p->halo) {
         // ---- pack for the halo-tile kernel: [slice][tap][Npad][CK], channels past cin are zero --------
@@ -1038,6 +1063,14 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     }
     p->goff_total = goff_total;
     std::vector<bf16_t> hi(total, 0), lo(total, 0);
+    std::vector<float> wq;                      // f16 + FP6 format: the fp32 weights in packed order, encoded block by block below
+    if (precision == MF_PREC_F16Q) {
+        // implicit-GEMM layers in the f16 + FP6 format: a 64-deep K tile must be 64 consecutive channels of one tap (two FP6 blocks), and the narrow
+        // special tiles (N <= 32) have no kernel in it
+        MF_REQUIRE(d.cin % 64 == 0 && d.cout > 32, "conv (f16q): implicit-GEMM layers need cin %% 64 == 0 and cout > 32 (got %d -> %d)", d.cin, d.cout);
+        p->q = true;
+        wq.assign(total, 0.f);
+    }
     const int k = d.kh;  // (transposed: square)
     for (int ph = 0; ph < p->nphase; ++ph) {
         auto& taps = p->phase_taps[ph];
@@ -1063,15 +1096,18 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
                     const float wf = (float)(w * (double)scale[n]);
                     const int g = kgroup((int)taps.size(), (int)ti, c / 8);
                     const int64_t idx = p->ph[ph].w_off + ((int64_t)(g / KG) * p->Npad + n) * BK + (g % KG) * 8 + c % 8;
+                    if (p->q) { wq[idx] = wf; continue; }
                     const bf16_t h = mf_f2bf(wf);
                     hi[idx] = h;
                     lo[idx] = mf_f2bf(wf - mf_bf2f(h));
                 }
         }
     }
+    if (p->q)
+        for (int64_t r = 0; r < total; r += 32) pack_q_block(&wq[r], &hi[r], &lo[r]);
     MF_HIP(hipMalloc(&p->w_hi, total * sizeof(bf16_t)));
     MF_HIP(hipMemcpy(p->w_hi, hi.data(), total * sizeof(bf16_t), hipMemcpyHostToDevice));
-    if (precision == MF_PREC_BF16X3) {
+    if (precision != MF_PREC_BF16) {
         MF_HIP(hipMalloc(&p->w_lo, total * sizeof(bf16_t)));
         MF_HIP(hipMemcpy(p->w_lo, lo.data(), total * sizeof(bf16_t), hipMemcpyHostToDevice));
     }
@@ -1141,7 +1177,7 @@ static int mf_halo_split_count(const ConvPlan* p, int batch) {
 
 // Channel-slice split of the f16 + FP6 tile (16 x 16 pixels x 128 channels) for a layer with fewer tiles than CUs at this batch (1 = no split)
 int mf_q_split_count(const ConvPlan* p, int batch) {
-    if (!p->q) return 1;
+    if (!p->q || !p->halo) return 1;
     const int base = batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * (p->d.cout / 128);
     if (base >= 256) return 1;
     int best = 1;
@@ -1193,7 +1229,7 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
     MF_REQUIRE(ob.H == p->out_h && ob.W == p->out_w, "conv: output buffer %dx%d != %dx%d", ob.H, ob.W, p->out_h, p->out_w);
     const bool x3 = p->precision != MF_PREC_BF16;                      // two planes per tensor (bf16x3, and the f16 + FP6 format)
     MF_REQUIRE(!x3 || (ib.lo && ob.lo), "conv: BF16X3 needs lo planes");
-    MF_REQUIRE(p->precision != MF_PREC_F16Q || p->halo || (p->up_hi && p->q), "conv (f16q): only wide 3x3 stride-1 layers (optionally behind a 2x upsample) have a kernel in this format");
+    MF_REQUIRE(p->precision != MF_PREC_F16Q || p->q, "conv (f16q): the plan was not packed in this format");
 
     if (p->halo) {
         HaloArgs ha{};
@@ -1416,7 +1452,7 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
     }
     int rc = MF_ERR_INVALID;
 #define MF_CASE(BM, BN, WGM, WGN)                                                          \
-    if (tc.bm == BM && tc.bn == BN) rc = launch_prec<BM, BN, WGM, WGN>(a, p->nphase, tc.nsplit, goff_max, x3, stream);
+    if (tc.bm == BM && tc.bn == BN) rc = launch_prec<BM, BN, WGM, WGN>(a, p->nphase, tc.nsplit, goff_max, x3, p->q, stream);
     MF_CASE(128, 16, 4, 1)
     MF_CASE(128, 32, 4, 1)
     MF_CASE(16, 64, 1, 4)
@@ -1486,7 +1522,7 @@ int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream
     int rc = MF_ERR_INVALID;
 #define MF_GCASE(BM, BN, WGM, WGN)                                                         \
     { a.tiles_m = cdiv(M, BM); a.tiles_n = cdiv(N, BN);                                    \
-      rc = launch_prec<BM, BN, WGM, WGN>(a, 1, 1, p->ph[0].ngroups, x3, stream); }
+      rc = launch_prec<BM, BN, WGM, WGN>(a, 1, 1, p->ph[0].ngroups, x3, false, stream); }
     if (N <= 16) MF_GCASE(128, 16, 4, 1)
     else if (N <= 32) MF_GCASE(128, 32, 4, 1)
     else if (M <= 16) MF_GCASE(16, 64, 1, 4)
@@ -1515,9 +1551,9 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
     ConvTile t;
     if (N <= 16) t = {128, 16, 4, 1, 1};
     else if (N <= 32) t = {128, 32, 4, 1, 1};
-    else if (M <= 16 && p->d.act != 5) t = {16, 64, 1, 4, 1};   // (its 16-channel wave tile cannot pair GEGLU blocks)
+    else if (M <= 16 && p->d.act != 5 && !p->q) t = {16, 64, 1, 4, 1};   // (its 16-channel wave tile cannot pair GEGLU blocks; no f16 + FP6 form)
     else t = {64, 64, 2, 2, 1};
-    const bool modelled = N > 32 && (M > 16 || p->d.act == 5);
+    const bool modelled = N > 32 && (M > 16 || p->d.act == 5 || p->q);
     // exploration knobs (tools/unet_shape_sweep.py): MF_FORCE_TILE=128x64, MF_FORCE_SPLIT=4
     static const int force_tile = [] { const char* e = getenv("MF_FORCE_TILE"); int a = 0, b = 0; return e && sscanf(e, "%dx%d", &a, &b) == 2 ? a * 1000 + b : 0; }();
     static const int force_split = [] { const char* e = getenv("MF_FORCE_SPLIT"); return e ? atoi(e) : 0; }();
@@ -1525,7 +1561,7 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
     static const Cand cands[] = {{64, 64, 2, 2, 2}, {128, 64, 2, 2, 2}, {128, 128, 2, 2, 2}, {256, 128, 4, 2, 1}, {256, 256, 2, 4, 1}};
     static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
     if (modelled) {
-        const double planes = p->precision == MF_PREC_BF16X3 ? 2.0 : 1.0;
+        const double planes = p->precision != MF_PREC_BF16 ? 2.0 : 1.0;
         const double Kavg = kt_sum / p->nphase * 64.0;
         const double PW = 46e9, CHIP = 10.5e12, EPI_BW = 2.5e12, EPI_FIX = 6e-6, WG_FIX = 2e-6;
         const int fs = force_split ? std::max(1, std::min(std::min(kt_min, force_split), 16)) : 0;
@@ -1609,7 +1645,7 @@ bool tunable_layer(const ConvPlan* p, int batch) {
     static const bool forced = getenv("MF_FORCE_TILE") || getenv("MF_FORCE_SPLIT");
     if (p->halo || p->up_hi || forced) return false;                                 // halo-kernel layers keep their own tile choice
     const int M = batch * p->Hq * p->Wq, N = p->d.cout;
-    return !(N <= 32 || (M <= 16 && p->d.act != 5));                                  // the narrow special tiles have no alternatives
+    return !(N <= 32 || (M <= 16 && p->d.act != 5 && !p->q));                         // the narrow special tiles have no alternatives
 }
 std::string tune_key(const ConvPlan* p, const ActView& in, int batch) {
     char keybuf[256];
@@ -1722,7 +1758,7 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
 void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision != MF_PREC_BF16 ? "true" : "false";
     if (p->q && p->up_hi) { snprintf(buf, cap, "4 x k_conv3x3_halo_w<16,128,4,2,true,1,phase> f16+fp6"); return; }
-    if (p->q) {
+    if (p->q && p->halo) {
         // (" grid N": the launch's thread count as rocprofv3 reports it, so that a counter pass can be matched to exactly these launches -- the split
         // and unsplit launches share one kernel symbol)
         const int ns = mf_q_split_count(p, batch);
@@ -1745,8 +1781,8 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
         const ConvTile t = mf_conv_pick_tile(p, batch);
         // tile depth as launch_prec picks it: 64 everywhere except the 8-wave bf16x3 tiles
         const bool x3b = p->precision == MF_PREC_BF16X3;
-        const int bk = (x3b && t.bm + t.bn > 128 && t.wgm * t.wgn != 4) ? 32 : 64;
-        snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s,%d>", t.bm, t.bn, t.wgm, t.wgn, x3, bk);
+        const int bk = ((x3b && t.bm + t.bn > 128 && t.wgm * t.wgn != 4) || (p->q && t.wgm * t.wgn != 4)) ? 32 : 64;
+        snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s,%d>%s", t.bm, t.bn, t.wgm, t.wgn, x3, bk, p->q ? " f16+fp6" : "");
     }
 }
 
