@@ -49,7 +49,8 @@ def build_model(precision, device):
 
 
 class Runner:
-    """Calls mf_wav2lip_forward (the C ABI the custom op wraps) on resident device buffers."""
+    """lipreal.py:120-121 `pred = model(mel_batch, img_batch)` on resident device tensors, through the drop-in module (`wav2lip.models.Wav2Lip.forward` ->
+    the torch.library op -> mf_wav2lip_forward), as the MuseTalk leg goes through its drop-in objects."""
 
     def __init__(self, precision, batch, device, seed=0):
         self.model = build_model(precision, device)
@@ -62,10 +63,9 @@ class Runner:
         self.stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
     def step(self):
-        rc = self.lib.mf_wav2lip_forward(self.h, self.mel.data_ptr(), self.face.data_ptr(), self.out.data_ptr(),
-                                         self.batch, self.stream)
-        if rc:
-            _lib.check(rc, "wav2lip_forward")
+        with torch.no_grad():
+            self.out = self.model(self.mel, self.face)
+        return self.out
 
     def profile(self, iters):
         n = self.lib.mf_wav2lip_num_launches(self.h, self.batch)

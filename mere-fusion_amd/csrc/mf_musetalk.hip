@@ -87,6 +87,7 @@ struct Net {
     ~Net() {
         for (auto& g : graphs) if (g.second) (void)hipGraphExecDestroy(g.second);
         for (auto& p : plans) mf_conv_plan_destroy(p.get());
+        for (auto& t : tails) mf_tail_conv_destroy(t.get());
         for (auto& b : bufs) { if (b->hi) (void)hipFree(b->hi); if (b->lo) (void)hipFree(b->lo); }
         for (void* d : dev) (void)hipFree(d);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
@@ -261,6 +262,40 @@ struct Net {
         stats_forget(out.buf);
         push(name, epi ? "k_gn_apply (statistics from the producer's epilogue)" : "k_gn_stats+k_gn_apply", 0.0,
              [=](int B, hipStream_t s) { return mf_groupnorm(in, out, dg, db, groups, eps, silu, st, B, s, epi); });
+        return MF_OK;
+    }
+    // `gname` (GroupNorm + SiLU) followed by `cname` (Conv2d 3x3 to <= 16 channels) as ONE pass (mf_conv_tail.hip) where that kernel applies, else the
+    // two-op chain through a scratch buffer.  MF_TAIL_FUSE=0: always the chain (A/B).
+    std::vector<std::unique_ptr<TailConv>> tails;
+    int gn_conv_tail(const std::string& gname, const std::string& cname, ActView x, ActView out, int cin, int cout, int groups, float eps) {
+        static const bool fuse = !(getenv("MF_TAIL_FUSE") && atoi(getenv("MF_TAIL_FUSE")) == 0);
+        // (maps that give a batch of 8 at least 256 patches of 16 x 16: on the UNet's 32 x 32 map the 32 workgroups of the fused kernel measured 63 us against 35)
+        if (!fuse || !mf_tail_conv_supported(cin, cout, precision) || x.buf->H % 16 || x.buf->W % 16 || (x.buf->H / 16) * (x.buf->W / 16) < 32) {
+            ActBuf* t = buf(cin, x.buf->H, x.buf->W, 1);     // the normalised tensor, only materialised on this path
+            if (!t) return MF_ERR_HIP;
+            const ActView tv{t, 0, cin};
+            const int rc = gn(gname, x, tv, groups, eps, true);
+            return rc ? rc : conv(cname, tv, out, cin, cout, 3, 1, 1, 0, ActView{});
+        }
+        const float* g = T(gname + ".weight", cin);
+        const float* b = T(gname + ".bias", cin);
+        const float* w = T(cname + ".weight", (int64_t)cout * cin * 9);
+        const float* cb = T(cname + ".bias", cout);
+        if (!g || !b || !w || !cb) return MF_ERR_INVALID;
+        float* dg = upload(g, cin);
+        float* db = upload(b, cin);
+        if (!dg || !db) return MF_ERR_HIP;
+        if (gn_count >= GN_MAX_OPS) { err = "more GroupNorm layers than GN_MAX_OPS"; return MF_ERR_INVALID; }
+        double* st = gn_stats + (size_t)(gn_count++) * gn_slice;
+        tails.emplace_back(new TailConv());
+        TailConv* tp = tails.back().get();
+        const int rc = mf_tail_conv_create(tp, w, cb, cin, cout);
+        if (rc) return rc;
+        const bool epi = take_stats(x, groups, st);
+        stats_forget(out.buf);
+        push(gname + " + " + cname, epi ? "k_gn_conv3_tail (statistics from the producer's epilogue)" : "k_gn_stats+k_gn_conv3_tail",
+             2.0 * 9 * cin * cout * x.buf->H * x.buf->W,
+             [=](int B, hipStream_t s) { return mf_gn_conv3_tail(*tp, x, dg, db, groups, eps, true, st, epi, out, B, s); });
         return MF_OK;
     }
     int ln(const std::string& name, ActView in, ActView out) {
@@ -861,10 +896,7 @@ extern "C" int mf_unet_create(const mf_unet_config* c, const mf_tensor* weights,
         }
     }
     {
-        ActBuf* t = net.buf(boc[0], S, S, 1);
-        if (!t) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
-        NET_TRY(net.gn("conv_norm_out", last, ActView{t, 0, boc[0]}, G, 1e-5f, true));
-        NET_TRY(net.conv("conv_out", ActView{t, 0, boc[0]}, ActView{h->out_buf, 0, c->out_channels}, boc[0], c->out_channels, 3, 1, 1, 0, ActView{}));
+        NET_TRY(net.gn_conv_tail("conv_norm_out", "conv_out", last, ActView{h->out_buf, 0, c->out_channels}, boc[0], c->out_channels, G, 1e-5f));
     }
     NET_TRY(net.hoist_kv_finish());
     *out = h.release();
@@ -961,11 +993,9 @@ extern "C" int mf_vae_create(const mf_vae_config* c, const mf_tensor* weights, i
             x = ActView{y, 0, ch};
         }
     }
-    ActBuf* t = net.buf(ch, s, s, 1);
     h->out_buf = net.buf(c->out_channels, s, s, 1);
-    if (!t || !h->out_buf) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
-    NET_TRY(net.gn("decoder.conv_norm_out", x, ActView{t, 0, ch}, G, 1e-6f, true));
-    NET_TRY(net.conv("decoder.conv_out", ActView{t, 0, ch}, ActView{h->out_buf, 0, c->out_channels}, ch, c->out_channels, 3, 1, 1, 0, ActView{}));
+    if (!h->out_buf) { mf_set_error("%s", net.err.c_str()); return MF_ERR_HIP; }
+    NET_TRY(net.gn_conv_tail("decoder.conv_norm_out", "decoder.conv_out", x, ActView{h->out_buf, 0, c->out_channels}, ch, c->out_channels, G, 1e-6f));
     *out = h.release();
     return MF_OK;
 }

@@ -43,6 +43,15 @@ int mf_groupnorm_affine(const ActView& x, const float* gamma, const float* beta,
 int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const float* beta, int groups, float eps,
                  bool silu, double* stats, int batch, hipStream_t s, bool have_stats = false);
 
+// GroupNorm [+ SiLU] -> Conv2d 3x3 s1 p1 with <= 16 output channels as ONE pass over x (mf_conv_tail.hip): the `conv_norm_out` -> `conv_act` -> `conv_out`
+// tail of the VAE decoder and of the UNet.  bf16x3 only; cin a multiple of 32.  `stats` as for mf_groupnorm.
+struct TailConv { int cin = 0, cout = 0; bf16_t* w = nullptr; float* bias = nullptr; };
+bool mf_tail_conv_supported(int cin, int cout, int precision);
+int mf_tail_conv_create(TailConv* p, const float* weight, const float* bias, int cin, int cout);
+void mf_tail_conv_destroy(TailConv* p);
+int mf_gn_conv3_tail(const TailConv& p, const ActView& x, const float* gamma, const float* beta, int groups, float eps, bool silu, double* stats,
+                     bool have_stats, const ActView& out, int batch, hipStream_t s);
+
 // GEGLU (diffusers): y[t][c] = x[t][c] * gelu(x[t][C + c]) for c < C = x.C / 2
 int mf_geglu(const ActView& x, const ActView& y, int batch, hipStream_t s);
 

@@ -120,6 +120,37 @@ def test_hip_vae_vs_oracle(hip_small, small):
 
 
 @pytest.mark.gpu
+def test_hip_vae_fused_tail_vs_two_launch_chain(hip_small, small, tmp_path):
+    """`decoder.conv_norm_out` -> SiLU -> `decoder.conv_out` as one pass (k_gn_conv3_tail, the default) against the GroupNorm-apply + conv chain it
+    replaces (MF_TAIL_FUSE=0, latched per process: a child process runs the chain).  Same bf16x3 arithmetic, other summation order."""
+    import subprocess, sys, os
+    _, vae = hip_small
+    torch.manual_seed(1)
+    lat = torch.randn(2, 4, 32, 32) * 0.2
+    _, fused = vae.decode_latents_device(lat.cuda(), want_image=True)
+    np.save(tmp_path / "lat.npy", lat.numpy())
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from mere_fusion_amd import weights as W\n"
+        "from mere_fusion_amd.musetalk.models.vae import VAE\n"
+        "from oracle import musetalk_ref as R\n"
+        "cfg = R.MUSETALK_SMALL\n"
+        "vsd = W.make_musetalk_vae_state_dict(cfg, 0)\n"
+        "vc = dict(cfg['vae']); vc['block_out_channels'] = list(vc['block_out_channels'])\n"
+        "vae = VAE(config=vc, state_dict=vsd, max_batch=4)\n"
+        f"lat = torch.from_numpy(np.load({str(tmp_path / 'lat.npy')!r}))\n"
+        "_, img = vae.decode_latents_device(lat.cuda(), want_image=True)\n"
+        f"np.save({str(tmp_path / 'img.npy')!r}, img.cpu().numpy())\n")
+    env = dict(os.environ, MF_TAIL_FUSE="0")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+    chain = np.load(tmp_path / "img.npy")
+    err = float(np.abs(fused.cpu().numpy() - chain).max())
+    print(f"fused tail vs chain: L-inf {err:.2e}")
+    assert err <= 1e-4, err                     # measured 3.05e-5 = one step of the (hi, lo) output format at |x| in [2, 4): gate ~3 x
+
+
+@pytest.mark.gpu
 def test_hip_musetalk_step_and_replay(hip_small, small):
     """musereal.py:100-108 end to end; call 1 eager, call 2 captures the hipGraphs, call 3 replays."""
     unet, vae = hip_small
