@@ -5,6 +5,6 @@ cd "$(dirname "$0")/.."
 mkdir -p build_ab
 name=$1; src=$2; flags=$3
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=262144 $flags -c mere-fusion_amd/csrc/$src -o build_ab/$name.o
-objs=$(ls build/obj/*.o | grep -v "/$src.o")
+objs=$(ls build/obj/*.o | grep -v "/${REPLACES:-$src}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o build_ab/lib$name.so $objs build_ab/$name.o
 echo build_ab/lib$name.so
