@@ -62,6 +62,9 @@ def make_ops(mode):
             return op(x, w)
         if mode == "f16x1":
             return op(q_f16(x), q_f16(w))
+        if mode == "xf16+w2":                            # x rounded to f16 (one plane), w = f16 + f16: two f16 passes, 2 + 4 operand bytes
+            xh, wh = q_f16(x), q_f16(w)
+            return op(xh, wh) + op(xh, q_f16(w - wh))
         hi = q_bf16 if mode == "bf16x3" else q_f16
         xh, wh = hi(x), hi(w)
         xl, wl = x - xh, w - wh
@@ -88,6 +91,7 @@ def make_ops(mode):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--small", action="store_true", help="reduced-width config (seconds instead of minutes)")
+    ap.add_argument("--modes", default="", help="comma list; U/V = UNet format / VAE format, e.g. fp32,bf16x3/f16+f6,xf16+w2/f16+f6")
     a = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 8)
     cfg = R.MUSETALK_SMALL if a.small else R.MUSETALK_V1
@@ -95,10 +99,14 @@ def main():
     lat, aud = W.make_musetalk_inputs(1, 0)
     conv0, lin0 = R._conv, R._lin
     res = {}
-    for mode in ("fp32", "bf16x3", "f16x3", "f16+f8", "f16+f6", "f16x1"):
-        R._conv, R._lin = (conv0, lin0) if mode == "fp32" else make_ops(mode)
+    modes = a.modes.split(",") if a.modes else ["fp32", "bf16x3", "f16x3", "f16+f8", "f16+f6", "f16x1"]
+    for mode in modes:
+        # "U/V": the UNet in format U, the VAE decoder in format V (what ships is bf16x3/f16+f6)
+        mu, mv = mode.split("/") if "/" in mode else (mode, mode)
         with torch.no_grad():
+            R._conv, R._lin = (conv0, lin0) if mu == "fp32" else make_ops(mu)
             pred = R.unet_forward(usd, cfg["unet"], lat, torch.tensor([0]), R.add_positional_encoding(aud))
+            R._conv, R._lin = (conv0, lin0) if mv == "fp32" else make_ops(mv)
             img = R.vae_decode(vsd, cfg["vae"], pred / cfg["vae"]["scaling_factor"])
         u8 = ((img / 2 + 0.5).clamp(0, 1) * 255).round()
         res[mode] = (pred, img, u8)
