@@ -388,6 +388,10 @@ int mf_audio_encoder_create(const mf_tensor* weights, int n_weights, int use_att
 /* Replaces `NeRFNetwork.encode_audio(a)` (network.py:222-237): auds device fp32 [n_windows, audio_in_dim, 16]
  * (8 windows with the attention net, 1 without) -> enc_a device fp32 [32]. */
 int mf_audio_encoder_forward(mf_audio_encoder* h, const float* auds, int n_windows, float* enc_a, void* stream);
+/* The same followed by the lip-smoothing step of `NeRFRenderer.run_cuda` (ernerf/nerf_triplane/renderer.py:190-194):
+ * enc_a = 0.35 * prev_enc_a + (1 - 0.35) * encode_audio(a), in torch's fp32 evaluation order (bit-identical to the three torch launches it replaces).
+ * prev_enc_a: device fp32 [32], the previous frame's smoothed features (may alias enc_a); null = no smoothing (first frame). */
+int mf_audio_encoder_forward_smooth(mf_audio_encoder* h, const float* auds, int n_windows, const float* prev_enc_a, float* enc_a, void* stream);
 void mf_audio_encoder_destroy(mf_audio_encoder* h);
 
 /* ---- sd-vae encoder: avatar preparation -------------------------------------------------------- */

@@ -168,6 +168,7 @@ SIGNATURES = {
     "mf_nerf_torso_destroy": (None, [C.c_void_p]),
     "mf_audio_encoder_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mf_audio_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mf_audio_encoder_forward_smooth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mf_audio_encoder_destroy": (None, [C.c_void_p]),
     "mf_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p]),
     "mf_whisper_feature_chunks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

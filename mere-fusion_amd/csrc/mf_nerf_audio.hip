@@ -88,8 +88,14 @@ __device__ void linear(const float* in, float* out, const Layer& L, int n, bool 
 
 // One workgroup per window through AudioNet (the windows are independent there, and one CU's issue rate was the bound: ~10 instructions
 // per MAC); the last workgroup to finish pools the 8 feature vectors through AudioAttNet.
+// prev != null: the lip-smoothing EMA of renderer.py:190-194 applied on the way out, enc_a = 0.35 * prev + (1 - 0.35) * enc_a in torch's own fp32 order (two
+// rounded products, one rounded sum; no FMA contraction) -- three torch elementwise launches per frame otherwise.  prev may alias enc_a.
+__device__ __forceinline__ float ema_out(const float* prev, int c, float v) {
+    return prev ? __fadd_rn(__fmul_rn(0.35f, prev[c]), __fmul_rn(0.65f, v)) : v;
+}
+
 __global__ __launch_bounds__(1024) void k_audio_encode(const AudioArgs a, const float* __restrict__ auds_all, int n_win_all, float* enc_a, float* feat_g,
-                                                       int* done) {
+                                                       int* done, const float* prev) {
     const float* auds = auds_all + (size_t)blockIdx.x * a.in_dim * WIN;
     constexpr int n_win = 1;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(1024) void k_audio_encode(const AudioArgs a, const 
     linear(bufB, feat, a.fc[1], n_win, false, wbuf, bbuf);               // [n, 32]
     if (!att) {
         // att == 0: encode_audio returns audio_net's output as is (network.py:230-235); callers pass one window then
-        for (int i = threadIdx.x; i < AUD_DIM; i += blockDim.x) enc_a[i] = feat[i];
+        for (int i = threadIdx.x; i < AUD_DIM; i += blockDim.x) enc_a[i] = ema_out(prev, i, feat[i]);
         return;
     }
     // hand this window's features over; the last workgroup gathers all eight
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(1024) void k_audio_encode(const AudioArgs a, const 
     for (int c = threadIdx.x; c < AUD_DIM; c += blockDim.x) {    // torch.sum(y * x, dim=1), network.py:36
         float acc = 0.f;
         for (int t = 0; t < SEQ; ++t) acc += bufA[t] * feat[t * AUD_DIM + c];
-        enc_a[c] = acc;
+        enc_a[c] = ema_out(prev, c, acc);
     }
 }
 
@@ -218,7 +224,7 @@ extern "C" int mf_audio_encoder_create(const mf_tensor* weights, int n_weights, 
     return MF_OK;
 }
 
-extern "C" int mf_audio_encoder_forward(mf_audio_encoder* h, const float* auds, int n_windows, float* enc_a, void* stream) {
+static int audio_encoder_launch(mf_audio_encoder* h, const float* auds, int n_windows, float* enc_a, const float* prev, void* stream) {
     MF_REQUIRE(h && auds && enc_a, "audio_encoder_forward: null argument");
     MF_REQUIRE(h->a.use_att ? n_windows == SEQ : n_windows == 1,
                "audio_encoder_forward: %d windows (the attention net pools exactly 8, network.py:10; without it one window)", n_windows);
@@ -227,9 +233,17 @@ extern "C" int mf_audio_encoder_forward(mf_audio_encoder* h, const float* auds, 
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_audio_encode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AUDIO_LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_audio_encode, dim3(n_windows), dim3(1024), AUDIO_LDS, (hipStream_t)stream, h->a, auds, n_windows, enc_a, h->feat_g, h->done);
+    hipLaunchKernelGGL(k_audio_encode, dim3(n_windows), dim3(1024), AUDIO_LDS, (hipStream_t)stream, h->a, auds, n_windows, enc_a, h->feat_g, h->done, prev);
     MF_HIP(hipGetLastError());
     return MF_OK;
+}
+
+extern "C" int mf_audio_encoder_forward(mf_audio_encoder* h, const float* auds, int n_windows, float* enc_a, void* stream) {
+    return audio_encoder_launch(h, auds, n_windows, enc_a, nullptr, stream);
+}
+
+extern "C" int mf_audio_encoder_forward_smooth(mf_audio_encoder* h, const float* auds, int n_windows, const float* prev_enc_a, float* enc_a, void* stream) {
+    return audio_encoder_launch(h, auds, n_windows, enc_a, prev_enc_a, stream);
 }
 
 extern "C" void mf_audio_encoder_destroy(mf_audio_encoder* h) { delete h; }

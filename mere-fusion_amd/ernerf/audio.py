@@ -27,6 +27,25 @@ class HipAudioEncoder:
             self._lib.mf_audio_encoder_destroy(h)
             self._h = None
 
+    def encode_audio_smooth(self, a, prev):
+        """`encode_audio(a)` followed by renderer.py:190-194's lip smoothing against the previous frame's features `prev` ([1, 32] CUDA fp32, or None on
+        the first frame): 0.35 * prev + (1 - 0.35) * enc_a, inside the same launch (bit-identical to the torch expression)."""
+        if a is None:
+            return None
+        if not (torch.is_tensor(a) and a.is_cuda):
+            raise RuntimeError("HipAudioEncoder.encode_audio_smooth: the window must be a CUDA tensor (there is no CPU path)")
+        a = a.float().contiguous()
+        out = torch.empty(1, 32, device=a.device)
+        pv = None
+        if prev is not None:
+            pv = prev.float().contiguous()
+            if pv.numel() != 32 or not pv.is_cuda:
+                raise RuntimeError("HipAudioEncoder.encode_audio_smooth: prev must be the previous [1, 32] CUDA feature vector")
+        _lib.check(self._lib.mf_audio_encoder_forward_smooth(self._h, C.c_void_p(a.data_ptr()), int(a.shape[0]),
+                                                             C.c_void_p(pv.data_ptr()) if pv is not None else None, C.c_void_p(out.data_ptr()),
+                                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mf_audio_encoder_forward_smooth")
+        return out
+
     def encode_audio(self, a):
         """a: [8, audio_in_dim, 16] (att > 0) or [1, audio_in_dim, 16] CUDA tensor -> [1, 32]; None passes through (network.py:227)."""
         if a is None:

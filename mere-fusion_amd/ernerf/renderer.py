@@ -35,6 +35,12 @@ class HipHeadRenderer:
         loop="device" runs the head with device-side round control; MF_NERF_TORSO_STREAM=1 puts the torso on a second stream beside it (the
         head only needs the torso's colours for the final mix)."""
         def audio_part():
+            if self.audio is not None and self.smooth_lips and hasattr(self.audio, "encode_audio_smooth"):
+                # the EMA of renderer.py:190-194 inside the encoder's launch (three torch elementwise launches per frame otherwise; same bits)
+                enc_a = self.audio.encode_audio_smooth(auds, self.enc_a)
+                if enc_a is not None:
+                    self.enc_a = enc_a
+                return enc_a
             enc_a = self.audio.encode_audio(auds) if self.audio is not None else auds
             if enc_a is not None and self.smooth_lips:
                 if self.enc_a is not None:

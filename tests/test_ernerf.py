@@ -705,6 +705,16 @@ def test_hip_encode_audio_matches_reference_golden(lib_built, nerf_golden):
     with pytest.raises(RuntimeError, match="windows"):
         enc.encode_audio(torch.zeros(3, 44, 16, device="cuda"))
     assert enc.encode_audio(None) is None
+    # the lip-smoothing EMA of renderer.py:190-194 inside the same launch: bit-identical to the torch expression it replaces, over a few frames
+    a = torch.from_numpy(g["auds"]).cuda()
+    prev_t, prev_k = None, None
+    for f in range(3):
+        af = a * (1.0 + 0.1 * f)
+        raw = enc.encode_audio(af)
+        prev_t = raw if prev_t is None else 0.35 * prev_t + (1 - 0.35) * raw
+        prev_k = enc.encode_audio_smooth(af, prev_k)
+        assert torch.equal(prev_k, prev_t), f
+    assert enc.encode_audio_smooth(None, None) is None
 
 
 # ---- a22: torso branch -----------------------------------------------------------------------------------------------------------
