@@ -994,8 +994,13 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     // wider (<= 1024, cout a multiple of 128, maps >= 64 x 64): only the LDS-weights kernel's fat tiles, with an implicit-GEMM twin
     // (p->alt) for launches too small to fill the chip with 16 x 16-pixel patches.
     const bool narrow = d.cin <= 256 && d.cout <= 256;
-    const bool wide_ok = !g_no_halo_wide && d.cin <= 1024 && d.cout <= 1024 && d.cout % 128 == 0 && d.cin % 32 == 0 &&
-                         (d.in_h * d.in_w >= 64 * 64 || (d.cout % 256 == 0 && d.cin >= 512));   // small maps: only the 256-channel tile pays
+    // ... and the UNet's 320-channel layers on its 32 x 32 maps (cout = 2.5 tiles of 128: the third one half empty): at >= 40 frames per step the 16 x 16 x 128
+    // tile beats the implicit GEMM there by 14-25 % (320 -> 320: 394 -> 305 us at 64 frames, 960 -> 320: 1054 -> 827) -- the input is read once per channel
+    // slice instead of once per tap; smaller steps launch the twin (mf_halo_w_pick_tile).  Whole step, same-box A/B: 112.6 -> 111.8 ms at 64 frames, equal at
+    // 48 and below.  On the 16 x 16 maps (640 channels: one patch per image) it does not pay.
+    const bool odd_wide = d.cout >= 256 && d.cout % 128 != 0 && d.cout % 64 == 0 && d.in_h * d.in_w >= 32 * 32;
+    const bool wide_ok = !g_no_halo_wide && d.cin <= 1024 && d.cout <= 1024 && (d.cout % 128 == 0 || odd_wide) && d.cin % 32 == 0 &&
+                         (d.in_h * d.in_w >= 64 * 64 || (d.cout % 256 == 0 && d.cin >= 512) || odd_wide);   // small maps: only the 256-channel tile pays
     p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
               d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16 && d.residual != 2 && d.act <= 2 && !d.upsample &&
               (narrow || wide_ok) && d.cout % 4 == 0;
@@ -1662,6 +1667,12 @@ bool mf_autotune_enabled() {
 }
 
 int mf_conv_tune_lookup(ConvPlan* p, const ActView& in, int batch) {
+    if (p->halo && p->alt && !p->q) {
+        // a wide halo layer at a batch too small for the fat tiles launches its implicit-GEMM twin: the twin takes the table entry of the layer's signature
+        // (same descriptor; the ':s' suffix follows the statistics request the launch will hand over)
+        p->alt->out_stats = p->out_stats; p->alt->out_stats_groups = p->out_stats_groups;
+        return mf_conv_tune_lookup(p->alt, in, batch);
+    }
     if (!tunable_layer(p, batch)) return 0;
     auto it = tune_cache().find(tune_key(p, in, batch));
     if (it == tune_cache().end()) return 0;
@@ -1670,6 +1681,11 @@ int mf_conv_tune_lookup(ConvPlan* p, const ActView& in, int batch) {
 }
 
 int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res, int batch, hipStream_t stream) {
+    if (p->halo && p->alt && !p->q) {             // (as mf_conv_tune_lookup: the twin is what launches when the fat tiles decline this batch)
+        if (mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin).ph || mf_halo_split_count(p, batch)) return MF_OK;
+        p->alt->out_stats = p->out_stats; p->alt->out_stats_groups = p->out_stats_groups;
+        return mf_conv_tune(p->alt, in, out, res, batch, stream);
+    }
     if (!tunable_layer(p, batch)) return MF_OK;
     const std::string key = tune_key(p, in, batch);
     if (mf_conv_tune_lookup(p, in, batch)) return MF_OK;                              // measured before (this process, MF_TUNE_CACHE, or the shipped table)

@@ -680,5 +680,9 @@ HaloTile mf_halo_w_pick_tile(int H, int W, int N, int batch, int cin) {
     // other's DMA waits and epilogues are hidden (128 -> 128 @256^2 401 -> 373 us) -- else one 8-wave workgroup of 4 x 2 waves (64 px x 64 ch each)
     if (N % 128 == 0 && big_map && wgs(16, 128) >= 512) return HaloTile{16, 128, 2, 2};
     if (N % 128 == 0 && big_map && wgs(16, 128) >= 256) return HaloTile{16, 128, 4, 2};
+    // the UNet's 320-channel layers at 32 x 32 once a step carries >= 40 frames (mf_conv_plan_create's `odd_wide`; 160+ patches x 3 channel tiles).  The conv
+    // alone wins from 24 frames on, but these layers feed GroupNorms with 10 channels per group, whose statistics this epilogue cannot leave (quads straddle
+    // groups): the statistics pass behind the conv eats the gain below ~40 frames (whole step at 32 frames: 59.4 -> 59.7 ms)
+    if (N >= 256 && N % 128 != 0 && N % 64 == 0 && H * W >= 32 * 32 && wgs(16, 128) >= 480) return HaloTile{16, 128, 4, 2};
     return HaloTile{0, 0, 0, 0};
 }

@@ -129,6 +129,23 @@ def test_full_vae_batch8_matches_batch1(hip_full):
         assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 0.01, (i, int(d.max()), float((d > 0).float().mean()))
 
 
+def test_full_unet_large_batch_handle_vs_oracle(full_sd, oracle_full):
+    """A UNet handle at 40 frames per step (five sessions in one MuseBatcher step): the 320-channel 3x3 convs of the 32 x 32 level run on the LDS-weights
+    halo tile there (the implicit GEMM below 40 frames), the 256 x 256 implicit-GEMM tiles appear -- kernel choices the batch-8 handle never makes.  The
+    oracle's 8 inputs, tiled 5 x: same parity bar as batch 8, and the five copies agree."""
+    from mere_fusion_amd.musetalk.models.unet import UNet
+    usd, _ = full_sd
+    o = oracle_full
+    unet = UNet(unet_config_json(MUSETALK_V1["unet"]), usd, max_batch=40)
+    lat, aud = o["lat"].repeat(5, 1, 1, 1).cuda(), o["aud"].repeat(5, 1, 1).cuda()
+    got = unet.model(lat, torch.tensor([0]).cuda(), encoder_hidden_states=unet.pe(aud)).sample.cpu()
+    err = (got[:B] - o["pred"]).abs().max().item()
+    rep = max((got[k * B:(k + 1) * B] - got[:B]).abs().max().item() for k in (1, 2, 3, 4))
+    print(f"MUSETALK_V1 UNet, handle for 40 frames: latents L-inf vs oracle {err:.3e} (gate {TOL_LATENT}); copies of a frame differ by {rep:.3e}")
+    assert err <= TOL_LATENT, err
+    assert rep <= 1e-4, rep
+
+
 def test_full_vae_large_batch_handle_vs_oracle(full_sd, oracle_full):
     """A handle built for 24 frames per step (the cross-session batcher's regime): every resnet conv and all three upsamplers fill the chip in the
     f16 + FP6 format there (no channel-slice split, the 32 x 32 upsampler included) -- kernel choices the batch-8 handle never makes.  The oracle's
