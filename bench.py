@@ -541,7 +541,8 @@ class PacedRig:
             fes = [D.MuseASRFrontend(self.a2f, B) for _ in range(N)]
             for fe in fes:
                 fe.warm_up()
-            sch = D.EndToEndScheduler(bat, fes, self.a2f, rings=rings, period_s=P, fixed_chunks=None if use_w else self.chunk)
+            sch = D.EndToEndScheduler(bat, fes, self.a2f, rings=rings, period_s=P, fixed_chunks=None if use_w else self.chunk,
+                                      asr_stream=os.environ.get("MF_BENCH_ASR_INLINE") != "1")   # (A/B: the Whisper call on the step's own stream)
         else:
             sch = D.SessionScheduler(bat, period_s=P)
         # the consumer (`process_frames`, lipreal.py:195): one thread draining every session's ring; a batch is delivered when its last tuple is held

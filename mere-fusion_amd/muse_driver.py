@@ -285,7 +285,8 @@ class EndToEndScheduler(SessionScheduler):
     run_once(now) -> finished batches [(k, frames_or_None, indices, latency_s)]: latency = arrival -> descriptors published (ring stage on) or frames
     complete in HBM (ring stage off).  Stages can be switched off individually to price them (bench.py `paced_sessions.stages`)."""
 
-    def __init__(self, batcher, frontends, audio_processor, rings=None, period_s=None, hold_s=None, clock=time.perf_counter, depth=2, fixed_chunks=None):
+    def __init__(self, batcher, frontends, audio_processor, rings=None, period_s=None, hold_s=None, clock=time.perf_counter, depth=2, fixed_chunks=None,
+                 asr_stream=True):
         super().__init__(batcher, period_s=period_s, hold_s=hold_s, clock=clock)
         self.fixed_chunks = fixed_chunks                             # (measurement only: this [B, 50, 384] tensor instead of the Whisper stage)
         if len(frontends) != len(batcher.sessions):
@@ -293,6 +294,10 @@ class EndToEndScheduler(SessionScheduler):
         self.frontends, self.audio_processor, self.rings = list(frontends), audio_processor, rings
         self.depth = max(int(depth), 1)                              # steps in flight: the one computing + the one whose frames are being copied
         self.copy_stream = torch.cuda.Stream(device=batcher.device) if rings is not None else None
+        # The Whisper front-end of a step on its OWN stream: with two steps in flight it runs beside the previous step's VAE instead of between that VAE and
+        # this step's UNet.  Its ~25 launches are latency-bound (1.5 ms for seven windows with the GPU mostly idle); beside the VAE's full-chip kernels they cost
+        # the step almost nothing.  asr_stream=False: on the step's stream, as before (A/B, bench `stages`).
+        self.asr_stream = torch.cuda.Stream(device=batcher.device) if asr_stream else None
         self.inflight = deque()
         self.ring_full = 0
         self._busy_until = 0.0
@@ -347,10 +352,17 @@ class EndToEndScheduler(SessionScheduler):
             for k in speaking:
                 chunks[k] = self.fixed_chunks
         elif speaking:
-            wav = torch.from_numpy(np.stack([wins[k] for k in speaking])).to(dev, non_blocking=True)
-            feats = self.audio_processor.audio2feat_windows_device(wav)            # every picked session's window in one encoder call
-            for i, k in enumerate(speaking):
-                chunks[k] = self.frontends[k].chunks_from_features(feats[i])
+            cur = torch.cuda.current_stream(dev)
+            side = self.asr_stream if self.asr_stream is not None else cur
+            with torch.cuda.stream(side):
+                wav = torch.from_numpy(np.stack([wins[k] for k in speaking])).to(dev, non_blocking=True)
+                feats = self.audio_processor.audio2feat_windows_device(wav)        # every picked session's window in one encoder call
+                for i, k in enumerate(speaking):
+                    chunks[k] = self.frontends[k].chunks_from_features(feats[i])
+            if side is not cur:
+                cur.wait_stream(side)                                              # the UNet below reads the chunks
+                for t in [wav, feats] + [chunks[k] for k in speaking]:
+                    t.record_stream(cur)
         out = self.batcher.step(chunks, only=ks)
         tokens = {}
         ev = torch.cuda.Event()
