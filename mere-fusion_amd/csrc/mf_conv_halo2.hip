@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <vector>
 #include <algorithm>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -50,6 +51,16 @@ __device__ __forceinline__ float hbf2f(uint32_t h16) { return __uint_as_float(h1
 __device__ __forceinline__ uint32_t hf2bf(float f) {
     // round to nearest even in hardware: gfx950's v_cvt_pk_bf16_f32 (the compiler pairs neighbouring calls), a quarter of the integer form's instructions
     return (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)f);
+}
+
+// LDS fragment read of the specialised workgroup's compute waves; MF_HALO_ABLATE bit 5 (timing-only build): no read at all, the fragment is made up
+template <typename T>
+__device__ __forceinline__ T ldsr(const char* p) {
+    if (MF_HALO_ABLATE & 32) {
+        const i32x4 v = {0x3C003C00, 0x3C003C00, 127, 0x3C003C00};       // f16 ones; dword 2 doubles as an E8M0 scale of 1
+        return __builtin_bit_cast(T, v);
+    }
+    return *reinterpret_cast<const T*>(p);
 }
 
 __device__ __forceinline__ void hglds16(const void* g, char* lds_wave_base) {
@@ -87,10 +98,15 @@ __device__ __forceinline__ void hstore_pair16(bf16_t* base, int64_t yo, int c16,
 // pieces on the second one the first starts its reads and MFMAs at once (s_memtime: 13.0 k -> 12.3 k cycles per slice).
 // Where this kernel's time goes, by ablation (matrix floor 7.7 k cycles per slice, LDS floor 6.3 k, overlapped by half; DMA 10 %), and the
 // restructurings that did NOT move it (two workgroups per CU, skewed halves, software pipelining): profiles/r03_halo_q_loop_study.md.
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool Q = false>
-__global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_halo_w(const HaloArgs a) {
-    constexpr int NW = WGM * WGN;                           // waves per workgroup
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+// SP: the workgroup is SPECIALISED -- WGM x WGN = 4 compute waves (one per SIMD: 128 px x 64 ch each, the matrix pipe to itself, 25 % fewer LDS
+// fragment reads per MFMA than eight 64 px x 64 ch waves) + 4 producer waves that issue ALL of the LDS-DMA (halo image and weight ring) and
+// otherwise only meet the barriers; every barrier is executed by all eight.
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool Q = false, bool SP = false>
+__global__ __launch_bounds__((WGM * WGN + (SP ? 4 : 0)) * 64, HS == 1 ? 2 : 1) void k_conv3x3_halo_w(const HaloArgs a) {
+    constexpr int NW = WGM * WGN;                           // compute waves per workgroup
+    constexpr int NPW = SP ? 4 : 0;                         // producer waves (SP)
+    static_assert(NW == 4 || NW == 8, "4 or 8 compute waves per workgroup");
+    static_assert(!SP || (Q && NW == 4 && HS == 2), "specialised workgroup: f16 + FP6 format, four compute waves");
     constexpr int CK = X3 ? 32 : 64;
     constexpr int KG = CK / 8, ROWB = CK * 2, RPC = 1024 / ROWB;
     constexpr int NP = X3 ? 2 : 1;
@@ -98,7 +114,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     constexpr int HW = PW + 2, HROWS = (PH + 2) * HW;
     constexpr int HCH = (HROWS + RPC - 1) / RPC;           // 1-KiB DMA chunks of the halo image
     constexpr int H_BYTES = HCH * 1024;
-    constexpr int NHC = (HCH + NW - 1) / NW;                // (halo DMA stays on all waves: moving it to the lower half as well left the loop unchanged and cost 1 k cycles of prologue)
+    constexpr int NHW = SP ? NPW : NW;                      // waves that issue halo DMA (non-SP: all of them -- moving it to the lower half as well left the loop unchanged and cost 1 k cycles of prologue)
+    constexpr int NHC = (HCH + NHW - 1) / NHW;
     constexpr int FM = PH / WGM;                            // patch rows (= pixel fragments) per wave
     constexpr int FN = BN / WGN / 16;                       // 16-channel fragment rows per wave
     static_assert(FN >= 1 && FM >= 1, "wave tile must hold a fragment");
@@ -110,8 +127,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     static_assert(PHASE < 0 || TR == 1, "upsample phases use the one-tap ring");
     constexpr int WROW = TR * NP * WT_BYTES;                // one ring slot (TR taps, planes)
     constexpr int WRC = TR * NP * WCH;                      // DMA chunks per slot
-    constexpr bool PROD = Q;                                // f16 + FP6 tiles: weight DMA by the upper half of the waves only
-    constexpr int NWD = PROD ? NW / 2 : NW;                 // waves that issue weight DMA
+    constexpr bool PROD = Q && !SP;                         // f16 + FP6 tiles: weight DMA by the upper half of the waves only
+    constexpr int NWD = SP ? NPW : (PROD ? NW / 2 : NW);    // waves that issue weight DMA
     constexpr int NWR = (WRC + NWD - 1) / NWD;
     static_assert(WT_BYTES % 1024 == 0, "weight tile must be whole DMA chunks");
 
@@ -143,9 +160,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     const bf16_t* hp[NHC];
     int hq[Q ? NHC : 1];                       // f16 + FP6 format: element offset of the FP6 plane's source slot relative to the f16 plane's (qswz)
     const int64_t x_delta = X3 ? (a.x_lo - a.x_hi) : 0;
+    const int hwave = SP ? wave - NW : wave;               // index among the halo-DMA waves (negative: a compute wave of a specialised workgroup)
+    const bool cons = !SP || wave < NW;                    // this wave multiplies
 #pragma unroll
     for (int i = 0; i < NHC; ++i) {
-        int hr = (wave + NW * i) * RPC + lane / KG;
+        int hr = ((hwave < 0 ? 0 : hwave) + NHW * i) * RPC + lane / KG;
         const int kg = (lane % KG) ^ hswz<CK>(hr % HW);
         if (Q) hq[i] = (((lane % KG) ^ qswz(hr % HW)) - kg) * 8;
         hr = hr < HROWS ? hr : HROWS - 1;
@@ -156,11 +175,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         hp[i] = a.x_hi + ((int64_t)b * a.xb + ((int64_t)iy * a.in_wp + ix) * a.x_ld + kg * 8);
     }
     auto load_halo = [&](int slice, int stage) __attribute__((always_inline)) {
+        if (SP && hwave < 0) return;
         char* base = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < NHC; ++i) {
-            const int c = wave + NW * i;
-            if (HCH % NW == 0 || c < HCH) {
+            const int c = hwave + NHW * i;
+            if (HCH % NHW == 0 || c < HCH) {
                 const bf16_t* src = hp[i] + slice * CK;
                 hglds16(src, base + c * 1024);
                 if (X3) hglds16(src + x_delta + (Q ? hq[i] : 0), base + H_BYTES + c * 1024);
@@ -169,7 +189,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     };
 
     // ---- weights: one tile [BN][CK] per (slice, tap, plane), DMA'd by tap rows into the LDS ring ------------------------
-    const int wave_m = wave % WGM, wave_n = wave / WGM;
+    const int cwave = SP ? wave % NW : wave;               // (a producer wave of a specialised workgroup shares the epilogue of compute wave `wave - NW`)
+    const int wave_m = cwave % WGM, wave_n = cwave / WGM;
     const int row0 = wave_m * FM;
     const int cn0 = wave_n * (FN * 16);
     const int fr = lane & 15, fk = lane >> 4;
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     // chunk c of a tap row = (tap t = c / (NP * WCH), plane, 1-KiB piece q): lane l lands in LDS row q*RPC + l/KG, slot l%KG
     const bf16_t* wsrc[NWR];
     int wtap[NWR];
-    const int dwave = PROD ? wave - NW / 2 : wave;         // index among the DMA-issuing waves (negative: none of this wave's business)
+    const int dwave = SP ? wave - NW : (PROD ? wave - NW / 2 : wave);   // index among the DMA-issuing waves (negative: none of this wave's business)
 #pragma unroll
     for (int i = 0; i < NWR; ++i) {
         const int c = (dwave < 0 ? 0 : dwave) + NWD * i;
@@ -192,7 +213,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     }
     // tap row `trow` (0..2) of slice `slice` into ring buffer `buf`
     auto load_wrow = [&](int slice, int trow, int buf) __attribute__((always_inline)) {
-        if (PROD && dwave < 0) return;
+        if ((PROD || SP) && dwave < 0) return;
         char* base = wring + buf * WROW;
 #pragma unroll
         for (int i = 0; i < NWR; ++i) {
@@ -364,13 +385,192 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     // channel slices of this workgroup: all of them, or the blockIdx.y-th share when the layer is split for lack of patches
     const int s_begin = a.nsplit > 1 ? (int)((int64_t)a.n_slices * blockIdx.y / a.nsplit) : 0;
     const int s_end = a.nsplit > 1 ? (int)((int64_t)a.n_slices * (blockIdx.y + 1) / a.nsplit) : a.n_slices;
-    load_halo(s_begin, 0);
-    load_wrow(s_begin, 0, 0);
-    if (Q) load_wrow(s_begin, 1, 1);
-    __syncthreads();                           // drains the DMA (vmcnt) and publishes halo stage 0 + weight row 0
-    if (dbg && threadIdx.x == 0) dbg[1] = __builtin_amdgcn_s_memtime();
+    if constexpr (SP) {
+        // Two instruction streams with the same barrier sequence (the branch is wave-uniform): the DMA pointers live only in the producers' stream, the
+        // accumulators and fragment addresses only in the compute waves' -- written as one loop, the producers' pointers were spilled around the MFMAs.
+        constexpr int NPAIR = (NT + 1) / 2;
+        if (!cons) {
+            load_halo(s_begin, 0);
+            load_wrow(s_begin, 0, 0);
+            load_wrow(s_begin, 1, 1);
+            __syncthreads();
+            int wb = 0;
+            for (int slice = s_begin; slice < s_end; ++slice) {
+                const bool more = slice + 1 < s_end;
+                if (more && !(MF_HALO_ABLATE & 64)) load_halo(slice + 1, ((slice - s_begin) & 1) ^ 1);
+#pragma unroll
+                for (int p = 0; p < NPAIR; ++p) {
+                    const int nb = 2 * (wb ^ 1);
+                    if (MF_HALO_ABLATE & 64) {}            // (timing-only build: no DMA in the loop)
+                    else if (p < NPAIR - 1) { load_wrow(slice, 2 * p + 2, nb); if (2 * p + 3 < NT) load_wrow(slice, 2 * p + 3, nb + 1); }
+                    else if (more) { load_wrow(slice + 1, 0, nb); load_wrow(slice + 1, 1, nb + 1); }
+                    if (p < NPAIR - 1 || more) __syncthreads();
+                    wb ^= 1;
+                }
+            }
+        } else {
+            // The compute waves' addressing: the lane-dependent part of every fragment address in NINE registers (byte offsets from smem), the halo
+            // stage, ring slot, patch row, tap shift and channel block as instruction immediates -- two slices are unrolled so that stage and ring
+            // parity are compile-time.  (Left to itself hipcc keeps ~40 per-(pair, fragment) addresses live across the loop: 160 B of scratch.)
+            constexpr int RING0 = HS * STAGE;
+            int P16[3], PQx[3], Wh, Wq;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                P16[dx] = (row0 * HW + fr) * ROWB + ((fk ^ hswz<CK>(fr + dx)) << 4);
+                PQx[dx] = (row0 * HW + fr) * ROWB + H_BYTES + (((2 * (fk & 1)) ^ qswz(fr + dx)) << 4);
+                asm volatile("" : "+v"(P16[dx]));
+                asm volatile("" : "+v"(PQx[dx]));
+            }
+            Wh = RING0 + (cn0 + fr) * ROWB + ((fk ^ hswz<CK>(cn0 + fr)) << 4);
+            Wq = RING0 + WT_BYTES + (cn0 + fr) * ROWB + (((2 * (fk & 1)) ^ qswz(cn0 + fr)) << 4) + (fk >= 2 ? WROW : 0);   // lane groups 2, 3: tap B's slot (= tap A's + 1)
+            asm volatile("" : "+v"(Wh));
+            asm volatile("" : "+v"(Wq));
+            const bool second = fk >= 2;
+            // Tap B's f16 products of a pair's LAST DR patch rows are issued behind the pair's barrier, at the head of the next pair: they need only registers
+            // (tap B's weights, the rows' fragments), so they fill the matrix pipe while the next pair's weight fragments are on their way from LDS.
+            constexpr int DR = 3;
+            f16x8 whB[FN], xb[4];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) whB[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xb[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            auto sp_deferred = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = FM - DR; j < FM; ++j)
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whB[i], xb[j % 4], acc[i][j], 0, 0, 0);
+            };
+            auto sp_pair = [&](auto ST_, auto P_, auto WB_) __attribute__((always_inline)) {
+                constexpr int st = decltype(ST_)::value, p = decltype(P_)::value, wb = decltype(WB_)::value;
+                constexpr int tA = 2 * p, tB = 2 * p + 1 < NT ? 2 * p + 1 : -1;
+                constexpr bool pairB = tB >= 0;
+                constexpr int sA = 2 * wb, sB = 2 * wb + 1;
+                constexpr int dyA = PHASE < 0 ? tA / 3 : (PHASE >> 1) + (tA >> 1), dxA = PHASE < 0 ? tA % 3 : (PHASE & 1) + (tA & 1);
+                constexpr int dyB = !pairB ? dyA : (PHASE < 0 ? tB / 3 : (PHASE >> 1) + (tB >> 1)), dxB = !pairB ? dxA : (PHASE < 0 ? tB % 3 : (PHASE & 1) + (tB & 1));
+                // The issue order is pinned (sched_barrier): a compute wave has its SIMD to itself, so nothing hides an operand that is requested late.  Pass 1:
+                // per patch row the correction instruction (both taps) + tap A's f16 product, the next row's fragments requested before the row's MFMAs; pass 2:
+                // tap B's f16 product, fragments two rows ahead.  (All three operand sets at once do not fit beside 128 accumulators.)
+#define MF_SB() __builtin_amdgcn_sched_barrier(0)
+                f16x8 whA[FN];
+                i32x8 w6[FN];
+                int wsc[FN];
+                const int wq1 = Wq ^ 16;
+                constexpr bool defer_in = NT == 9 ? p >= 1 : true;   // the pair before this one (in issue order) left DR rows of its pass 2 behind (3x3: the ninth tap is alone and has none; upsample phases: every pair, the first finds zeros)
+                int pq0 = second ? PQx[dxB] + (dyB * HW + dxB) * ROWB : PQx[dxA] + (dyA * HW + dxA) * ROWB;
+                asm volatile("" : "+v"(pq0));            // (computed here, per pair: two VALU operations instead of a register held across the loop)
+                const int pq1 = pq0 ^ 16;
+                constexpr int IA = st * STAGE + (dyA * HW + dxA) * ROWB, IB = st * STAGE + (dyB * HW + dxB) * ROWB, IQ = st * STAGE;
+                i32x4 wq0r[FN], wq1r[FN];
+                f16x8 xa[2];
+                i32x4 xq0[2], xq1[2];
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    wq0r[i] = ldsr<i32x4>(smem + Wq + (sA * WROW + i * 16 * ROWB));
+                    wq1r[i] = ldsr<i32x4>(smem + wq1 + (sA * WROW + i * 16 * ROWB));
+                }
+                auto ld_q = [&](int j) __attribute__((always_inline)) {
+                    xq0[j & 1] = ldsr<i32x4>(smem + pq0 + (IQ + j * HW * ROWB));
+                    xq1[j & 1] = ldsr<i32x4>(smem + pq1 + (IQ + j * HW * ROWB));
+                };
+                auto ld_a = [&](int j) __attribute__((always_inline)) { xa[j & 1] = ldsr<f16x8>(smem + P16[dxA] + (IA + j * HW * ROWB)); };
+                auto ld_b = [&](int j) __attribute__((always_inline)) { xb[j % 4] = ldsr<f16x8>(smem + P16[dxB] + (IB + j * HW * ROWB)); };
+                ld_q(0);
+                ld_a(0);
+#pragma unroll
+                for (int i = 0; i < FN; ++i) whA[i] = ldsr<f16x8>(smem + Wh + (sA * WROW + i * 16 * ROWB));
+                ld_q(1);
+                ld_a(1);
+                MF_SB();
+                if (defer_in) { sp_deferred(); MF_SB(); }
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    w6[i] = __builtin_shufflevector(wq0r[i], wq1r[i], 0, 1, 2, 3, 4, 5, -1, -1);
+                    wsc[i] = (second && !pairB) ? 0 : wq1r[i][2];
+                }
+                // pass 1, fragments 1.5 rows ahead on two buffers: a row's FP6 fragment is requested as soon as the correction MFMAs of the row two above have
+                // been issued, its f16 fragment behind that row's f16 MFMAs (a request one row = 128 matrix cycles ahead came back late: 10.8 k cycles per slice)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    const int c = j & 1;
+                    const i32x8 x6 = __builtin_shufflevector(xq0[c], xq1[c], 0, 1, 2, 3, 4, 5, -1, -1);
+                    const int xsc = (second && !pairB) ? 0 : xq1[c][2];
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w6[i], x6, acc[i][j], 2, 2, 0, wsc[i], 0, xsc);
+                    MF_SB();
+                    if (j + 2 < FM) ld_q(j + 2);
+                    else if (pairB) {
+                        if (j == FM - 2) {
+                            whB[0] = ldsr<f16x8>(smem + Wh + (sB * WROW + 0 * 16 * ROWB));
+                            whB[1] = ldsr<f16x8>(smem + Wh + (sB * WROW + 1 * 16 * ROWB));
+                        } else { ld_b(0); ld_b(1); }
+                    }
+                    MF_SB();
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whA[i], xa[c], acc[i][j], 0, 0, 0);
+                    MF_SB();
+                    if (j + 2 < FM) ld_a(j + 2);
+                    else if (pairB) {
+                        if (j == FM - 2) {
+                            whB[2] = ldsr<f16x8>(smem + Wh + (sB * WROW + 2 * 16 * ROWB));
+                            whB[3] = ldsr<f16x8>(smem + Wh + (sB * WROW + 3 * 16 * ROWB));
+                        } else ld_b(2);
+                    }
+                    MF_SB();
+                }
+                static_assert(FN == 4, "specialised workgroup: the pass-2 weight loads are written for four channel blocks");
+                if (pairB) {
+                    // pass 2: tap B's f16 product, fragments three rows ahead; the last DR rows are left to the head of the next pair (sp_deferred)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) {
+                        if (j + 3 < FM) ld_b(j + 3);
+                        MF_SB();
+                        if (j < FM - DR) {
+#pragma unroll
+                            for (int i = 0; i < FN; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whB[i], xb[j % 4], acc[i][j], 0, 0, 0);
+                        }
+                        MF_SB();
+                    }
+                }
+#undef MF_SB
+            };
+#define MF_IC(x) std::integral_constant<int, (x)>{}
+            // one channel slice: NPAIR tap pairs from ring parity WB0 on, a barrier behind every pair but the very last of the workgroup
+            auto sp_slice = [&](auto ST_, auto WB0_, bool more) __attribute__((always_inline)) {
+                constexpr int st = decltype(ST_)::value, wb0 = decltype(WB0_)::value;
+                sp_pair(MF_IC(st), MF_IC(0), MF_IC(wb0));
+                __syncthreads();
+                sp_pair(MF_IC(st), MF_IC(1), MF_IC(wb0 ^ 1));
+                if (NPAIR > 2 || more) __syncthreads();
+                if constexpr (NPAIR == 5) {
+                    sp_pair(MF_IC(st), MF_IC(2), MF_IC(wb0));
+                    __syncthreads();
+                    sp_pair(MF_IC(st), MF_IC(3), MF_IC(wb0 ^ 1));
+                    __syncthreads();
+                    sp_pair(MF_IC(st), MF_IC(4), MF_IC(wb0));
+                    if (more) __syncthreads();
+                }
+            };
+            __syncthreads();
+            if (dbg && threadIdx.x == 0) dbg[1] = __builtin_amdgcn_s_memtime();
+            int slice = s_begin;
+            for (; slice + 1 < s_end; slice += 2) {
+                sp_slice(MF_IC(0), MF_IC(0), true);
+                sp_slice(MF_IC(1), MF_IC(NPAIR & 1), slice + 2 < s_end);
+            }
+            if (slice < s_end) sp_slice(MF_IC(0), MF_IC(0), false);
+            if (NT != 9) sp_deferred();                              // (3x3: the last pair is the lone ninth tap)
+#undef MF_IC
+        }
+    }
+    if (!SP) {
+        load_halo(s_begin, 0);
+        load_wrow(s_begin, 0, 0);
+        if (Q) load_wrow(s_begin, 1, 1);
+        __syncthreads();                           // drains the DMA (vmcnt) and publishes halo stage 0 + weight row 0
+    }
+    if (dbg && threadIdx.x == 0 && !SP) dbg[1] = __builtin_amdgcn_s_memtime();
     int wbuf = 0;
-    for (int slice = s_begin; slice < s_end; ++slice) {
+    for (int slice = s_begin; slice < (SP ? s_begin : s_end); ++slice) {
         const bool more = slice + 1 < s_end;
         const int st = HS == 2 ? ((slice - s_begin) & 1) : 0;
         if (HS == 2 && more) load_halo(slice + 1, st ^ 1); // flies under this slice's MFMAs
@@ -385,7 +585,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
                     const int nb = 2 * (wbuf ^ 1);
                     if (p < NPAIR - 1) { load_wrow(slice, 2 * p + 2, nb); if (2 * p + 3 < NT) load_wrow(slice, 2 * p + 3, nb + 1); }
                     else if (more) { load_wrow(slice + 1, 0, nb); load_wrow(slice + 1, 1, nb + 1); }
-                    compute_pair(st, 2 * p, 2 * p + 1 < NT ? 2 * p + 1 : -1, 2 * wbuf, 2 * wbuf + 1);
+                    if (cons) compute_pair(st, 2 * p, 2 * p + 1 < NT ? 2 * p + 1 : -1, 2 * wbuf, 2 * wbuf + 1);
                     if (p < NPAIR - 1 || more) __syncthreads();
                     wbuf ^= 1;
                 }
@@ -416,12 +616,37 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         if (keep == 1234.5f) a.y_hi[0] = 1;
         return;
     }
+    // GroupNorm statistics of the OUTPUT for the layer's consumer (a.gn_out): per-thread fp32 (sum, sum of squares) of its channel quads
+    float gs[Q ? FN : 1], gq[Q ? FN : 1];
+#pragma unroll
+    for (int i = 0; i < (Q ? FN : 1); ++i) { gs[i] = 0.f; gq[i] = 0.f; }
+    // Specialised workgroup: the compute waves hand the lower half of their patch rows to the producer waves through LDS (free now), so that all
+    // eight waves issue the epilogue's loads and stores -- with four, the epilogue took 29 k cycles instead of 11 k (store issue is per wave).
+    constexpr int FME = SP ? FM / 2 : FM;       // patch rows per wave in the epilogue
+    const int erow0 = row0 + (SP && !cons ? FM / 2 : 0);
+    if constexpr (SP) {
+        f32x4* xch = reinterpret_cast<f32x4*>(smem);
+        __syncthreads();                        // every compute wave is done with the halo images and the ring
+        if (cons) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int jj = 0; jj < FME; ++jj) xch[((wave * FN + i) * FME + jj) * 64 + lane] = acc[i][FME + jj];
+        }
+        __syncthreads();
+        if (!cons) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int jj = 0; jj < FME; ++jj) acc[i][jj] = xch[(((wave - NW) * FN + i) * FME + jj) * 64 + lane];
+        }
+    }
     if (a.ws) {
         // split over channel slices: fp32 partial tile [split][B][H][W][N]; bias, residual, activation and the (hi, lo) store happen in
         // k_splitk_epilogue (mf_conv.hip)
 #pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            const int oy = y0 + row0 + j, ox = x0 + fr;
+        for (int j = 0; j < FME; ++j) {
+            const int oy = y0 + erow0 + j, ox = x0 + fr;
             if (oy >= a.H || ox >= a.W) continue;
             float* wo = a.ws + (int64_t)blockIdx.y * a.ws_split + (((int64_t)b * a.H + oy) * a.W + ox) * a.N;
 #pragma unroll
@@ -448,20 +673,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
     }
     const bool has_res = a.r_hi != nullptr && !(MF_HALO_ABLATE & 16);
     const int ox = x0 + fr;
-    // GroupNorm statistics of the OUTPUT for the layer's consumer (a.gn_out): per-thread fp32 (sum, sum of squares) of its channel quads
-    float gs[Q ? FN : 1], gq[Q ? FN : 1];
+    constexpr int JG = (FME * FN * NP <= 32) ? FME : (32 / (FN * NP) >= 1 ? 32 / (FN * NP) : 1);   // rows per residual burst
 #pragma unroll
-    for (int i = 0; i < (Q ? FN : 1); ++i) { gs[i] = 0.f; gq[i] = 0.f; }
-    constexpr int JG = (FM * FN * NP <= 32) ? FM : (32 / (FN * NP) >= 1 ? 32 / (FN * NP) : 1);   // rows per residual burst
-#pragma unroll
-    for (int j0 = 0; j0 < FM; j0 += JG) {
+    for (int j0 = 0; j0 < FME; j0 += JG) {
         uint2 rh[JG][FN], rl[JG][FN];
         if (has_res) {
 #pragma unroll
             for (int jj = 0; jj < JG; ++jj) {
                 const int j = j0 + jj;
-                if (j >= FM) break;
-                int oy = y0 + row0 + j, oxc = ox;
+                if (j >= FME) break;
+                int oy = y0 + erow0 + j, oxc = ox;
                 oy = oy < a.H ? oy : a.H - 1; oxc = oxc < a.W ? oxc : a.W - 1;      // clamped, never branched around: the stores are masked
                 const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)oxc * a.rj;
 #pragma unroll
@@ -476,8 +697,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
 #pragma unroll
         for (int jj = 0; jj < JG; ++jj) {
             const int j = j0 + jj;
-            if (j >= FM) break;
-            const int oy = y0 + row0 + j;
+            if (j >= FME) break;
+            const int oy = y0 + erow0 + j;
             const bool row_ok = oy < a.H && ox < a.W;
             const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
             constexpr bool W16 = Q && FN % 2 == 0;               // f16 + FP6 tiles: 16-byte stores (a.wide_store)
@@ -547,7 +768,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
         // value: 268 MB on the 256^2 maps).  A thread's quad lies in one group (channels per group 4, 8 or 16); sum over the wave's 16 pixel
         // columns, park per (wave, quad) in LDS, then one fp64 atomic per (workgroup, group, moment) -- the granularity k_gn_stats has.
         if (a.gn_out) {
-            __shared__ float s_gn[NW][FN * 4][2];
+            __shared__ float s_gn[NW + NPW][FN * 4][2];
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -566,7 +787,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
                     const int qd = gl * qpg + k;                   // quad within the channel tile: wave_n * (FN * 4) + i * 4 + fk
                     const int wn = qd / (FN * 4), sl = qd - wn * (FN * 4);
 #pragma unroll
-                    for (int wm = 0; wm < WGM; ++wm) acc_d += (double)s_gn[wn * WGM + wm][sl][m];
+                    for (int wm = 0; wm < WGM; ++wm) acc_d += (double)s_gn[wn * WGM + wm][sl][m] + (SP ? (double)s_gn[NW + wn * WGM + wm][sl][m] : 0.0);
                 }
                 const int g = n0 / a.gn_out_cpg + gl;
                 if (g < a.gn_out_groups) atomicAdd(a.gn_out + 2 * ((size_t)b * a.gn_out_groups + g) + m, acc_d);
@@ -582,10 +803,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, HS == 1 ? 2 : 1) void k_conv3x3_hal
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool Q = false>
+template <int PH, int BN, int WGM, int WGN, bool X3, int TR, int PHASE = -1, int HS = 2, bool Q = false, bool SP = false>
 int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE, HS, Q>;
+    auto kern = k_conv3x3_halo_w<PH, BN, WGM, WGN, X3, TR, PHASE, HS, Q, SP>;
     if (!attr_done) {
         MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (Q ? 158 : 160) * 1024));   // Q: 1-2 KiB of static LDS (s_gn) beside the dynamic block
@@ -602,7 +823,7 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
         if (!dbg_buf) MF_HIP(hipMalloc(&dbg_buf, (size_t)4 * 65536 * sizeof(unsigned long long)));
         aa.dbg = dbg_buf;
     }
-    hipLaunchKernelGGL(kern, dim3(a.n_patches * a.tiles_n, a.nsplit > 1 ? a.nsplit : 1), dim3(WGM * WGN * 64), lds, s, aa);
+    hipLaunchKernelGGL(kern, dim3(a.n_patches * a.tiles_n, a.nsplit > 1 ? a.nsplit : 1), dim3((WGM * WGN + (SP ? 4 : 0)) * 64), lds, s, aa);
     MF_HIP(hipGetLastError());
     if (aa.dbg) {
         static int reports = 0;
@@ -647,6 +868,14 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
         // the f16 + FP6 format has ONE tile: 16 x 16 pixels x 128 channels, 8 waves of 64 px x 64 ch (the 256-channel tile does not fit its registers,
         // four waves of 128 px x 64 ch measured 6 % slower); nearest 2x upsample + 3x3 runs it as four 2 x 2-tap phases on the same four-slot ring
         if (t.ph != 16 || t.bn != 128 || t.wgm != 4 || (phase >= 0 && a.nsplit > 1)) { mf_set_error("halo conv (f16 + FP6 format): plain 3x3 layers and unsplit upsample phases on the 16 x 16 x 128 tile only"); return MF_ERR_INVALID; }
+        static const bool sp = getenv("MF_HALO_Q_SP") && atoi(getenv("MF_HALO_Q_SP")) != 0;   // specialised workgroup (4 compute + 4 producer waves)
+        if (sp) switch (phase) {
+            case 0: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, 0, 2, true, true>(a, s);
+            case 1: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, 1, 2, true, true>(a, s);
+            case 2: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, 2, 2, true, true>(a, s);
+            case 3: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, 3, 2, true, true>(a, s);
+            default: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, true, true>(a, s);
+        }
         switch (phase) {
             case 0: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 0, 2, true>(a, s);
             case 1: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 1, 2, true>(a, s);
