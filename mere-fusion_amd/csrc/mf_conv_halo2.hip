@@ -868,7 +868,9 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
         // the f16 + FP6 format has ONE tile: 16 x 16 pixels x 128 channels, 8 waves of 64 px x 64 ch (the 256-channel tile does not fit its registers,
         // four waves of 128 px x 64 ch measured 6 % slower); nearest 2x upsample + 3x3 runs it as four 2 x 2-tap phases on the same four-slot ring
         if (t.ph != 16 || t.bn != 128 || t.wgm != 4 || (phase >= 0 && a.nsplit > 1)) { mf_set_error("halo conv (f16 + FP6 format): plain 3x3 layers and unsplit upsample phases on the 16 x 16 x 128 tile only"); return MF_ERR_INVALID; }
-        static const bool sp = getenv("MF_HALO_Q_SP") && atoi(getenv("MF_HALO_Q_SP")) != 0;   // specialised workgroup (4 compute + 4 producer waves)
+        // the specialised workgroup (4 compute + 4 producer waves) is the default: 25 % fewer LDS fragment reads per MFMA, 4-7 % faster on every VAE grid in
+        // same-box A/B (profiles/r04_halo_sp_study.md); MF_HALO_Q_SP=0 selects the eight-compute-wave kernel
+        static const bool sp = !(getenv("MF_HALO_Q_SP") && atoi(getenv("MF_HALO_Q_SP")) == 0);
         if (sp) switch (phase) {
             case 0: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, 0, 2, true, true>(a, s);
             case 1: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, 1, 2, true, true>(a, s);

@@ -26,6 +26,7 @@ ap.add_argument("--transposed", type=int, default=0)
 ap.add_argument("--outpad", type=int, default=0)
 ap.add_argument("--precision", default="bf16x3")
 ap.add_argument("--iters", type=int, default=50)
+ap.add_argument("--alone-iters", type=int, default=0, help="iterations of the kernel-only timing (default: --iters)")
 ap.add_argument("--upsample", type=int, default=0, help="1: nearest 2x upsample in front of the conv")
 ap.add_argument("--check", type=int, default=0, help="1: compare with torch fp32 conv2d (+ReLU, residual) on the GPU")
 a = ap.parse_args()
@@ -67,7 +68,7 @@ taps = a.k * a.k
 sites = a.hw * a.hw if a.transposed else oh.value * ow.value   # (upsample: counted at the output resolution, 9 taps)
 gf = 2.0 * a.batch * sites * a.cin * a.cout * taps / 1e9
 t = C.c_float()
-_lib.check(l.mf_conv2d_time(h, a.batch, a.iters, C.byref(t), None))
+_lib.check(l.mf_conv2d_time(h, a.batch, a.alone_iters or a.iters, C.byref(t), None))
 print(f"   conv launch alone: {t.value * 1e3:.1f} us -> {gf / t.value:.1f} TFLOP/s algorithmic")
 print(f"conv {a.cin}->{a.cout} k{a.k} s{a.stride} @{a.hw}^2 B{a.batch} {a.precision}: {ms * 1e3:.1f} us per forward "
       f"(incl. nchw<->nhwc passes), {gf:.2f} GF")
