@@ -42,6 +42,71 @@ BF16_DENSE_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 MFMA_PASSES = {"bf16": 1, "bf16x3": 3}
 
 
+def cpu_model():
+    """`Model name` of the host CPU (north star: "core count stated" -- and which cores)."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class PowerSampler:
+    """Socket power and shader clock of one GPU while something runs: the amdgpu hwmon files of the device's PCI function (power1_input in uW,
+    freq1_input = sclk in Hz, power1_cap), read by a thread every `period` seconds.  The f16 + FP6 conv kernel runs AT the board's power cap
+    (profiles/r04_halo_sp_study.md): its rate is set by joules per output, and a TFLOP/s figure without the clock and the watts beside it misleads."""
+
+    def __init__(self, device_index=0, period=0.02):
+        import glob
+        self.dir, self.period, self.rows = None, period, []
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            hw = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if hw and os.path.exists(os.path.join(hw[0], "power1_input")):
+                self.dir = hw[0]
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            return float(open(os.path.join(self.dir, name)).read())
+        except (OSError, ValueError):
+            return None
+
+    def __enter__(self):
+        import threading
+        self.rows, self._stop = [], threading.Event()
+        if self.dir is None:
+            return self
+
+        def loop():
+            while not self._stop.is_set():
+                w, f = self._read("power1_input"), self._read("freq1_input")
+                if w is not None and f is not None:
+                    self.rows.append((w * 1e-6, f * 1e-6))
+                time.sleep(self.period)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self.dir is not None:
+            self._th.join(1.0)
+
+    def report(self, skip_frac=0.25):
+        """mean over the samples after the first `skip_frac` of the interval (the firmware needs a moment to settle)"""
+        if self.dir is None or len(self.rows) < 4:
+            return None
+        r = self.rows[int(len(self.rows) * skip_frac):]
+        cap = self._read("power1_cap")
+        return {"socket_w": round(sum(x[0] for x in r) / len(r), 0), "socket_w_max": round(max(x[0] for x in r), 0), "cap_w": round(cap * 1e-6, 0) if cap else None,
+                "sclk_mhz": round(sum(x[1] for x in r) / len(r), 0), "sclk_mhz_min": round(min(x[1] for x in r), 0), "samples": len(r)}
+
+
 def build_model(precision, device):
     m = Wav2Lip(precision=precision)
     m.load_state_dict(W.make_wav2lip_state_dict(0))
@@ -149,7 +214,7 @@ class MuseTalkRunner:
             el = time.perf_counter() - t0
             if el >= seconds and n >= 2:
                 break
-        return {"value": round(n / el, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+        return {"value": round(n / el, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
                 "sample": f"{n} single-frame steps of the fp32 oracle (oracle/musetalk_ref.py: UNet + VAE decode), {el:.1f} s",
                 "gflops": round(n * self.gflop_per_frame() / el, 1)}
 
@@ -233,6 +298,7 @@ def roofline(rows, precision, only_mfma=False):
         "alg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 4),
         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": None,
+        "frac_of_dense_f16_peak": round(achieved / BF16_DENSE_PEAK_TF, 4),      # against the chip's 2.5 PF, whatever the operand format (`peak` = 2.5 PF / passes)
         "mfma_passes_per_product": passes,
         "operand_format": "f16 + FP6 (e2m3, MX block scales) correction terms" if "f16+fp6" in dom else precision,
         "kernel_share_of_step": round(d["ms"] / total_ms, 3),
@@ -254,6 +320,43 @@ def mfma_only_ceiling(precision):
     if precision == "bf16":
         out["bf16_single_pass"] = round(3 * out["bf16x3_12_bf16_mfma_per_128k"], 1)
     return out
+
+
+def roofline_kernel_power(batch, device, seconds=1.5):
+    """The roofline kernel (f16 + FP6 halo conv) under SUSTAINED load: each of its three VAE grids launched back to back for ~`seconds` through the
+    conv2d C ABI (mf_conv2d_time: hipEvents around N launches of the one kernel) while the package power and shader clock are sampled.  Inside a step
+    the kernel alternates with memory-bound ones and sees a warmer power budget; this is the steady state the firmware converges to."""
+    l = _lib.lib()
+    rows = []
+    rng = np.random.default_rng(0)
+    for cin, hw in ((128, 256), (256, 128), (512, 64)):
+        w = torch.from_numpy((rng.standard_normal((cin, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32))
+        b = torch.zeros(cin)
+        d = _lib.MfConv2dDesc(cin=cin, cout=cin, kh=3, kw=3, stride_h=1, stride_w=1, pad_h=1, pad_w=1, transposed=0, output_padding=0, residual=0, act=0,
+                              in_h=hw, in_w=hw, upsample=0)
+        h = C.c_void_p()
+        _lib.check(l.mf_conv2d_create(C.byref(d), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), None, None, None, None, _lib.PRECISIONS["f16q"], C.byref(h)))
+        x = torch.randn(batch, cin, hw, hw, device=device)
+        y = torch.empty(batch, cin, hw, hw, device=device)
+        for _ in range(2):
+            _lib.check(l.mf_conv2d_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), batch, None))
+        t = C.c_float()
+        _lib.check(l.mf_conv2d_time(h, batch, 20, C.byref(t), None))
+        iters = max(int(seconds / max(t.value * 1e-3, 1e-5)), 50)
+        with PowerSampler(torch.device(device).index or 0) as ps:
+            _lib.check(l.mf_conv2d_time(h, batch, iters, C.byref(t), None))
+        gf = 2.0 * batch * hw * hw * cin * cin * 9 / 1e9
+        row = {"layer": f"{cin} -> {cin} @{hw}^2, batch {batch}", "launch_us": round(t.value * 1e3, 1), "algorithmic_tflops": round(gf / t.value, 1), "launches": iters}
+        pw = ps.report()
+        if pw:
+            row.update(pw)
+        rows.append(row)
+        l.mf_conv2d_destroy(h)
+        del x, y
+    torch.cuda.empty_cache()
+    return {"rows": rows, "note": "the kernel alone, launched back to back (steady state); socket power and shader clock from the amdgpu hwmon files, mean over the last 75 % of "
+                                   "the interval.  At the cap the firmware lowers the clock until the package fits: the kernel's rate is joules per output, not issue slots "
+                                   "(profiles/r04_halo_sp_study.md)"}
 
 
 def pmc_traffic(kernel, workload, precision, batch_args, want_clock=True, grids=None):
@@ -361,9 +464,70 @@ def cpu_baseline(batch, seconds, threads):
         el = time.perf_counter() - t0
         if el >= seconds and n >= 2:
             break
-    return {"value": round(n * batch / el, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(n * batch / el, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{n} forwards of the fp32 oracle (oracle/wav2lip_ref.py) at batch {batch}, {el:.1f} s",
             "gflops": round(n * batch * GFLOP_PER_FRAME / el, 1)}
+
+
+def wav2lip_config0(args, device, threads):
+    """BASELINE.json configs[0] / SURVEY 8d cfg 1: ONE session streaming at batch 1 -- one face crop, a 3 s wav, fps 50, l = r = 10 (lipasr.py:14-37 ->
+    lipreal.py:75-141): the context primed with 20 silent chunks, then per video frame two new 20 ms chunks -> the (2 + 20) x 320 = 7040-sample window ->
+    mel (80, 36) -> the one 16-column chunk at column 16 -> generator at B = 1 -> frame x 255 -> uint8.  75 frames.  CPU leg: the oracle (mel_ref, glue_ref,
+    wav2lip_ref).  GPU leg: the same loop through the drop-in objects (mf_melspec -> chunking -> k_faces_u8 -> generator -> k_head), one device sync per frame as a
+    session's loop has (the frame goes to the consumer before the next chunk pair arrives): per-frame latency, not throughput."""
+    from oracle import wav2lip_ref, mel_ref, glue_ref
+    from mere_fusion_amd.lip_driver import LipASRFrontend, LipSession
+    rng = np.random.default_rng(0)
+    face = rng.integers(0, 256, (1, 96, 96, 3), dtype=np.uint8)
+    wav = np.clip(0.1 * rng.standard_normal(48000), -1.0, 1.0).astype(np.float32)
+    chunks = [wav[i * 320:(i + 1) * 320] for i in range(150)]
+    sd = W.make_wav2lip_state_dict(0)
+    n_frames = 75
+    # ---- CPU: the restatement of the reference loop --------------------------------------------------------------------------
+    torch.set_num_threads(threads)
+    ctx = [np.zeros(320, np.float32) for _ in range(20)]
+    cpu_u8, lat_c = [], []
+    for it in range(n_frames + 1):                                    # (first iteration = warm-up, not timed)
+        k = max(it - 1, 0)
+        t0 = time.perf_counter()
+        fr = ctx + chunks[2 * k:2 * k + 2]
+        mel = mel_ref.melspectrogram(np.concatenate(fr))
+        ml, _ = glue_ref.mel_chunks(mel, len(fr), 10, 10, 50)
+        img, melb = glue_ref.face_batch(face, ml)
+        pred = wav2lip_ref.wav2lip_forward(sd, torch.from_numpy(melb), torch.from_numpy(img))
+        u8 = glue_ref.to_uint8(glue_ref.frames_from_pred(pred.numpy()))
+        dt = time.perf_counter() - t0
+        if it > 0:
+            lat_c.append(dt)
+            cpu_u8.append(u8[0])
+            ctx = fr[-20:]
+    # ---- GPU: the same session through the drop-in path -----------------------------------------------------------------------
+    model = build_model(args.precision, device)
+    fe = LipASRFrontend(1, fps=50, stride_left=10, stride_right=10, device=device)
+    sess = LipSession(model, face)
+    lat_g, gpu_u8 = [], []
+    for rep_ in range(2):                                             # (first pass = warm-up: graph capture at B = 1, first-touch)
+        fe.warm_up()
+        sess.index = 0
+        lat_g, gpu_u8 = [], []
+        for k in range(n_frames):
+            t0 = time.perf_counter()
+            mb = fe.run_step(chunks[2 * k:2 * k + 2])
+            frames, _ = sess.step(mb)
+            u8 = frames.to(torch.uint8).cpu().numpy()                 # process_frames' astype(uint8) (truncation, lipreal.py:211) + the copy to the host
+            lat_g.append(time.perf_counter() - t0)
+            gpu_u8.append(u8[0])
+    d = np.abs(np.stack(gpu_u8).astype(int) - np.stack(cpu_u8).astype(int))
+    lc, lg = np.sort(np.asarray(lat_c)) * 1e3, np.sort(np.asarray(lat_g)) * 1e3
+    del model, sess, fe
+    return {"workload": "Wav2Lip 96x96, 1 face crop + 3 s wav, batch=1 streaming, fps 50, l = r = 10, 75 frames (BASELINE.json configs[0]; lipasr.py:14-37 -> lipreal.py:75-141)",
+            "cpu_baseline": {"value": round(n_frames / float(np.sum(lat_c)), 2), "unit": "frames/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
+                             "ms_per_frame_p50": round(float(lc[len(lc) // 2]), 2), "sample": f"{n_frames} frames: mel of the 7040-sample window + chunk + B = 1 forward of the fp32 oracle + uint8"},
+            "gpu": {"value": round(n_frames / float(np.sum(lat_g)), 1), "unit": "frames/s", "ms_per_frame_p50": round(float(lg[len(lg) // 2]), 3),
+                    "ms_per_frame_p99": round(float(lg[min(len(lg) - 1, int(np.ceil(0.99 * len(lg))) - 1)]), 3), "dtype": args.precision,
+                    "note": "host PCM chunks in -> uint8 frame on the host out, one sync per frame (latency of ONE session; a real-time session needs 25 frames/s)"},
+            "parity": {"u8_max_diff_vs_cpu_oracle": int(d.max()), "u8_differing_fraction": float((d > 0).mean()),
+                       "note": "truncating uint8 conversion: a value within 1e-5 of an integer may land on either side"}}
 
 
 def wav2lip_report(args, device, world, rank, value=None, ms_per_step=None, run=None):
@@ -418,6 +582,7 @@ def wav2lip_report(args, device, world, rank, value=None, ms_per_step=None, run=
             del ms_, big
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.w2l_batch, min(args.cpu_seconds, 8.0), args.cpu_threads)
+            out["config0"] = wav2lip_config0(args, device, out["cpu_baseline"]["cores"])
     return out
 
 
@@ -572,7 +737,9 @@ class PacedRig:
         if use_r:
             th = threading.Thread(target=drain, daemon=True)
             th.start()
+        import resource
         phase = np.random.default_rng(N).uniform(0.0, P, N)
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t_start = time.perf_counter() + 0.01
         nxt = [t_start + float(ph) for ph in phase]
         issued, arrivals, lats, total = [0] * N, [[] for _ in range(N)], [], N * periods
@@ -601,6 +768,8 @@ class PacedRig:
             elif dt > 1e-4:
                 time.sleep(1e-4)                                            # (a step is in flight: yield the GIL to the consumer thread between polls)
         wall = time.perf_counter() - t_start
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        host_cpu = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / wall     # scheduler loop + consumer thread + runtime threads of this process
         if use_r:
             t_end = time.perf_counter() + 2.0
             while any(len(got_t[k]) < periods for k in range(N)) and time.perf_counter() < t_end:
@@ -620,7 +789,8 @@ class PacedRig:
                 "p99_ms": round(p99, 1), "max_ms": round(float(l[-1]), 1),
                 "sustained": bool(len(l) == total and p99 <= P * 1e3 and drift <= 0.1 * P * 1e3),
                 "sessions_per_step_mean": round(sch.sessions_served / max(sch.steps, 1), 2),
-                "gpu_busy_frac": round(sch.busy_s / wall, 3), "frames_per_s": round(N * periods * B / wall, 1)}
+                "gpu_busy_frac": round(sch.busy_s / wall, 3), "frames_per_s": round(N * periods * B / wall, 1),
+                "host_cpu_s_per_wall_s": round(host_cpu, 3)}
 
     def search(self, cap, stages, screen_s, confirm_s, fail_s):
         """Largest N whose trial holds the bound: short screening trials walk from cap + 1 (which should fail) to the first N that holds, then ONE long
@@ -679,8 +849,8 @@ def muse_paced_sessions(big, args, device, free_fps, full=True):
                                     "max_sessions_sustained": uv["sessions"] if uv else None, "at_max": uv, "trials": uv_trials}
             if e2e:
                 n0 = e2e["sessions"]
-                rep["stages"] = {"note": f"8 s trials at N = {n0} (what the end-to-end loop sustains) and N = {n0 + 1}: which stage costs the next session",
-                                 "rows": [rig.trial(n, 8.0, st) for st in ((), ("whisper",), ("whisper", "paste"), ("whisper", "ring")) for n in (n0, n0 + 1) if n <= rig.n_max]}
+                rep["stages"] = {"note": f"5 s trials at N = {n0} (what the end-to-end loop sustains) and N = {n0 + 1}: which stage costs the next session",
+                                 "rows": [rig.trial(n, 5.0, st) for st in ((), ("whisper",), ("whisper", "paste"), ("whisper", "ring")) for n in (n0, n0 + 1) if n <= rig.n_max]}
     finally:
         rig.close()
     return rep
@@ -700,6 +870,64 @@ def muse_node_rank_leg(args, device):
     rep["free_running_8x8_frames_per_s"] = round(S * B * 5 / el, 1)
     del big
     torch.cuda.empty_cache()
+    return rep
+
+
+def ranks_on_one_gpu_worker(args, device):
+    """One of R processes sharing GPU 0 (bench.py --ranks-on-one-gpu R spawns them): its own UNet / VAE / Whisper handles, `--sessions` end-to-end sessions in real
+    time for --worker-seconds, started together with the other workers (ready files in --worker-dir).  Prints one JSON line."""
+    import resource
+    S, B = args.sessions, args.batch
+    big = MuseTalkRunner(args.precision, S * B, device)
+    rig = PacedRig(big, args, device, n_max=S)
+    k, R, d = args.worker_rank, args.ranks_on_one_gpu, args.worker_dir
+    open(os.path.join(d, f"ready_{k}"), "w").close()
+    t_wait = time.perf_counter()
+    while len([f for f in os.listdir(d) if f.startswith("ready_")]) < R and time.perf_counter() - t_wait < 600:
+        time.sleep(0.05)
+    try:
+        r = rig.trial(S, args.worker_seconds)
+    finally:
+        rig.close()
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    r.update({"rank": k, "process_cpu_s_total": round(ru.ru_utime + ru.ru_stime, 1), "warmup_s": round(rig.warm_s, 1)})
+    print("WORKER " + json.dumps(r), flush=True)
+
+
+def ranks_on_one_gpu(args, R, sessions_per_rank, seconds):
+    """is the HOST side of an 8-rank node viable?  R processes share THIS GPU (each with its own handles, scheduler, consumer thread and rings,
+    exactly what one rank of `--gpus 8` runs), each driving `sessions_per_rank` end-to-end sessions in real time at the same time; the GPU is time-shared, so the
+    sessions are chosen to fit ONE GPU in total.  Reported: every rank's p99 and its host CPU seconds per wall second (process + threads)."""
+    import subprocess, tempfile, shutil
+    d = tempfile.mkdtemp(prefix="mf_ranks_")
+    cmd = [sys.executable, os.path.abspath(__file__), "--ranks-on-one-gpu", str(R), "--worker-dir", d, "--worker-seconds", str(seconds), "--sessions", str(sessions_per_rank),
+           "--batch", str(args.batch), "--precision", args.precision]
+    procs = [subprocess.Popen(cmd + ["--worker-rank", str(k)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(R)]
+    rows, t0 = [], time.perf_counter()
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out = ""
+        for ln in out.splitlines():
+            if ln.startswith("WORKER "):
+                rows.append(json.loads(ln[7:]))
+    shutil.rmtree(d, ignore_errors=True)
+    rows.sort(key=lambda r: r["rank"])
+    ok = len(rows) == R
+    rep = {"ranks": R, "sessions_per_rank": sessions_per_rank, "seconds": seconds, "wall_s": round(time.perf_counter() - t0, 1), "host_cores_available": host_threads(0),
+           "cpu_model": cpu_model(), "latency_bound_ms": args.batch * 40,
+           "what": "R processes sharing ONE GPU, each the full per-rank stack of --gpus R (own UNet / VAE / Whisper handles, EndToEndScheduler, consumer thread, FrameRings), "
+                   "all trials started together; end-to-end latency as in multi_session.paced_sessions.end_to_end"}
+    if ok:
+        rep.update({"worst_rank_p99_ms": max(r["p99_ms"] for r in rows), "all_sustained": all(r["sustained"] for r in rows),
+                    "host_cpu_s_per_wall_s_per_rank": [r["host_cpu_s_per_wall_s"] for r in rows],
+                    "host_cpu_s_per_wall_s_total": round(sum(r["host_cpu_s_per_wall_s"] for r in rows), 2),
+                    "frames_per_s_total": round(sum(r["frames_per_s"] for r in rows), 1), "per_rank": rows})
+    else:
+        rep["error"] = f"{len(rows)} of {R} workers reported"
+        rep["per_rank"] = rows
     return rep
 
 
@@ -943,7 +1171,7 @@ class ErNeRFRunner:
             n += 1
         dt = (time.perf_counter() - t0) / n
         scale = (self.width * self.width) / (width * width)
-        return {"value": round(1.0 / (dt * scale), 3), "unit": "frames/s", "cores": threads, "kind": "port",
+        return {"value": round(1.0 / (dt * scale), 3), "unit": "frames/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
                 "sample": f"{n} frames of {width}x{width} rays through the C / torch restatement, scaled by ray count to {self.width}x{self.width}"}
 
 
@@ -1025,7 +1253,22 @@ def main():
     ap.add_argument("--paced", type=int, default=1, help="0 skips the real-time paced-sessions measurement of the multi_session leg")
     ap.add_argument("--pmc-traffic", type=int, default=1, help="0 skips the two rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--extras", type=int, default=1, help="0: only the headline workload (no second workload, alt mode, CPU legs)")
+    ap.add_argument("--ranks-on-one-gpu", type=int, default=0, help="R > 0: ONLY the host-readiness leg -- R processes sharing GPU 0, each driving --sessions end-to-end "
+                                                                      "sessions (default 2) in real time; the default line runs it with R = 8")
+    ap.add_argument("--worker-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--worker-dir", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--worker-seconds", type=float, default=20.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.ranks_on_one_gpu > 0:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X; there is no CPU path to measure")
+        if args.worker_rank >= 0:
+            torch.cuda.set_device(0)
+            ranks_on_one_gpu_worker(args, "cuda:0")
+        else:
+            n = args.sessions if any(a.startswith("--sessions") for a in sys.argv) else 2
+            print(json.dumps({"ranks_on_one_gpu": ranks_on_one_gpu(args, args.ranks_on_one_gpu, n, args.worker_seconds)}), flush=True)
+        return
     if args.steps <= 0:
         args.steps = {"musetalk": 40, "ernerf": 30}.get(args.workload, 200)
     if args.warmup <= 0:
@@ -1071,7 +1314,7 @@ def main():
                     "config": {"workload": rep["workload"] + "; seeded random-init weights", "batch_per_gpu": args.w2l_batch,
                                "sessions_at_25fps": round(value / 25.0, 1),
                                "parallelism": f"{world} independent replicas, sessions sharded by GPU, no collective"}}
-            for k in ("roofline", "parity", "alt", "multi_session", "cpu_baseline"):
+            for k in ("roofline", "parity", "alt", "multi_session", "cpu_baseline", "config0"):
                 if k in rep:
                     line[k] = rep[k]
             print(json.dumps(line), flush=True)
@@ -1080,8 +1323,25 @@ def main():
         run = MuseTalkRunner(args.precision, args.batch, device, seed=rank)
         _stage("timed steps")
         elapsed = harness.timed_steps(run.step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=device)
-        _stage("per-op profile")
         value = harness.aggregate_value(args.batch, args.steps, elapsed, world)
+        repeats = None
+        if world == 1 and bool(args.extras) and args.profile_iters > 0:
+            # the headline's own run-to-run spread (the timed region is short: K steps of ~19 ms): five more repeats of the same K steps, with the package power
+            # and shader clock sampled over them
+            _stage("headline repeats")
+            vals = []
+            with PowerSampler(local_rank) as ps:
+                for _ in range(5):
+                    el_r = harness.timed_steps(run.step, args.steps, 1, sync_fn=torch.cuda.synchronize, device=device, collective=False)
+                    vals.append(args.batch * args.steps / el_r)
+            vs = sorted(vals)
+            repeats = {"n": len(vs), "steps_each": args.steps, "median": round(vs[len(vs) // 2], 1), "min": round(vs[0], 1), "max": round(vs[-1], 1),
+                       "spread_pct": round((vs[-1] - vs[0]) / vs[len(vs) // 2] * 100, 2), "unit": "frames/s",
+                       "note": "`value` above is the contract's single timed region; these are five further regions of the same length in the same process"}
+            pw = ps.report(0.1)
+            if pw:
+                repeats["power"] = pw
+        _stage("per-op profile")
         solo = world == 1
         q_on = args.precision == "bf16x3" and os.environ.get("MF_CONV_Q", "1") != "0"
         line = None
@@ -1097,6 +1357,8 @@ def main():
                                "algorithmic_gflop_per_frame": round(gf_frame, 1),
                                "parallelism": f"{world} independent replicas, sessions sharded by GPU, no collective"},
                     "net_tflops": round(value / world * gf_frame / 1e3, 1)}
+            if repeats:
+                line["repeats"] = repeats
             if q_on:
                 line["dtype_note"] = ("bf16x3 (hi, lo bf16 pairs, three MFMAs per product) everywhere except the VAE decoder's 3x3 resnet convs and upsamplers on maps >= 32 x 32 "
                                       "(28 % of the step's time): f16 + FP6 (e2m3, MX block scales) correction terms, 1.5 pass-equivalents per product, outputs bf16 (hi, lo); "
@@ -1128,6 +1390,12 @@ def main():
                                       "operand bits) for the instruction mix of one product: 3 bf16 MFMAs as shipped; f16 + two block-scaled FP8 / FP6 correction terms "
                                       "(the FP6 form is what the VAE decoder's resnet convs run; numerics in tools/numerics_split_study.py, layouts in tools/mx_cross_probe.hip); "
                                       "profiles/r03_halo_q_loop_study.md: this kernel's own matrix-instruction floor, LDS floor and DMA share by ablation")
+            if bool(args.extras) and "f16+fp6" in rf["kernel"]:
+                _stage("roofline kernel under sustained load (power / clock)")
+                try:
+                    rf["power"] = roofline_kernel_power(args.batch, device)
+                except Exception as e:     # measurement leg only
+                    rf["power"] = {"error": f"{type(e).__name__}: {e}"}
             line["roofline"] = rf
             conv_rows = [r for r in rows if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
             if conv_rows:
@@ -1200,6 +1468,10 @@ def main():
                                     "north_star_target": ">= 64 sessions on 8 GPUs = 8 per GPU"}
                     if not solo:
                         line["paced_sessions_rank0"] = mine
+        if rank == 0 and extras and args.sessions > 0 and getattr(args, "paced", 1):
+            _stage("8 ranks on one GPU (host readiness)")
+            torch.cuda.empty_cache()
+            line.setdefault("node", {})["ranks_on_one_gpu"] = ranks_on_one_gpu(args, 8, 2, 20.0)
         if rank == 0 and extras:
             dl = args.dump_layers
             args.dump_layers = dl + ".wav2lip.json" if dl else None
