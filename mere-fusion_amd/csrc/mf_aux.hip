@@ -273,7 +273,8 @@ int mf_nchw_to_act_q(const float* src, int C, const ActBuf& dst, int batch, hipS
 namespace {
 // one thread = one pixel x one 32-channel block (blocks fastest: a wave reads 4 KB of contiguous channels per plane)
 __global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, int xC, int xcoff, int xhalo, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, int C, int silu, int H, int W, bf16_t* yh, bf16_t* yl, int yC, int yhalo, int64_t total) {
+                                                          const float* __restrict__ shift, const float* __restrict__ post, int C, int silu, int H, int W, bf16_t* yh, bf16_t* yl,
+                                                          int yC, int yhalo, int64_t total) {
     // A thread owns one 32-channel block (64 bytes per plane), but a wave moves its 64 blocks as 16-byte pieces with consecutive lanes on consecutive
     // pieces (piece q * 64 + lane belongs to thread (q * 64 + lane) / 4): global requests are whole lines; a wave-private LDS image does the transposition.
     __shared__ uint4 s_img[2][4][256];
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restri
     const int yo = ((b * (H + 2 * yhalo) + y + yhalo) * (W + 2 * yhalo) + x + yhalo) * yC + g * 32;
     const float* sc = scale + b * C + g * 32;
     const float* sh = shift + b * C + g * 32;
+    const float* po = post ? post + g * 32 : nullptr;               // per-CHANNEL power of two applied behind the activation (channel equalisation of the MX blocks), or null
     typedef float v16f __attribute__((ext_vector_type(16)));
     typedef _Float16 v32h __attribute__((ext_vector_type(32)));
     typedef unsigned v6u __attribute__((ext_vector_type(6)));
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restri
     float mh = 0.f, ml = 0.f;
     v16u hbits;
     uint4 av[4], cv[4];
-    float4 scv[8], shv[8];
+    float4 scv[8], shv[8], pov[8];
     const int sub = lane & 3;
     // piece p of the wave's image sits at p ^ ((p >> 4) & 3): 16 consecutive lanes hit 16 different 16-byte bank groups on both the
     // (piece = lane) global side and the (piece = 4 * lane + q) owner side
@@ -323,7 +325,10 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restri
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int pc = lane * 4 + q; av[q] = s_img[0][wv][pc ^ ((pc >> 4) & 3)]; cv[q] = s_img[1][wv][pc ^ ((pc >> 4) & 3)]; }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { scv[q] = *reinterpret_cast<const float4*>(sc + 4 * q); shv[q] = *reinterpret_cast<const float4*>(sh + 4 * q); }
+    for (int q = 0; q < 8; ++q) {
+        scv[q] = *reinterpret_cast<const float4*>(sc + 4 * q); shv[q] = *reinterpret_cast<const float4*>(sh + 4 * q);
+        pov[q] = po ? *reinterpret_cast<const float4*>(po + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t aw[4] = {av[q].x, av[q].y, av[q].z, av[q].w}, cw[4] = {cv[q].x, cv[q].y, cv[q].z, cv[q].w};
@@ -334,9 +339,12 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restri
             const float4 s4 = scv[k >> 2], t4 = shv[k >> 2];
             const float sck = (k & 3) == 0 ? s4.x : ((k & 3) == 1 ? s4.y : ((k & 3) == 2 ? s4.z : s4.w));
             const float shk = (k & 3) == 0 ? t4.x : ((k & 3) == 1 ? t4.y : ((k & 3) == 2 ? t4.z : t4.w));
+            const float4 p4 = pov[k >> 2];
+            const float pok = (k & 3) == 0 ? p4.x : ((k & 3) == 1 ? p4.y : ((k & 3) == 2 ? p4.z : p4.w));
             float v = bf2f_d(hw) + bf2f_d(lw);
             v = v * sck + shk;
             if (silu) v = v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
+            v *= pok;                                               // (a power of two: exact)
             const _Float16 h = (_Float16)v;
             const float vhk = (float)h, vlk = v - vhk;
             mh = fmaxf(mh, fabsf(vhk)); ml = fmaxf(ml, fabsf(vlk));
@@ -371,14 +379,14 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restri
 }
 }  // namespace
 
-int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* shift, int silu, const ActBuf& dst, int batch, hipStream_t s) {
+int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* shift, int silu, const ActBuf& dst, int batch, hipStream_t s, const float* post) {
     const ActBuf& xb = *x.buf;
     MF_REQUIRE(x.C % 32 == 0 && x.coff % 8 == 0 && dst.C == x.C && dst.H == xb.H && dst.W == xb.W && dst.lo && xb.lo && scale && shift,
                "affine_silu_to_act_q: needs 32-channel blocks, matching geometry and a second plane on both sides");
     MF_REQUIRE((int64_t)batch * xb.per_batch() < ((int64_t)1 << 31) && (int64_t)batch * dst.per_batch() < ((int64_t)1 << 31),
                "affine_silu_to_act_q: tensors of 2^31 elements or more are not supported (32-bit offsets)");
     const int64_t total = (int64_t)batch * xb.H * xb.W * (x.C / 32);
-    hipLaunchKernelGGL(k_affine_silu_to_q, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xb.hi, xb.lo, xb.C, x.coff, xb.halo, scale, shift, x.C, silu, xb.H, xb.W, dst.hi,
+    hipLaunchKernelGGL(k_affine_silu_to_q, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xb.hi, xb.lo, xb.C, x.coff, xb.halo, scale, shift, post, x.C, silu, xb.H, xb.W, dst.hi,
                        dst.lo, dst.C, dst.halo, total);
     MF_HIP(hipGetLastError());
     return MF_OK;

@@ -1628,11 +1628,28 @@ std::map<std::string, ConvTuned>& tune_cache() {
         loaded = true;
         const char* env = getenv("MF_TUNE_CACHE");
         const std::string path = env ? std::string(env) : shipped_tune_table();
+        // Entries are validated on load: a stale or hand-edited file must not put a tile the library no longer compiles, an impossible split or an
+        // operand path that was removed into launch selection.  Keys carry the kernel generation ("g950k4": tile list / operand paths of round 4's library).
+        auto valid = [](const std::string& k, const ConvTuned& c) {
+            if (k.rfind("g950k4:", 0) != 0) return false;
+            if (c.tile.bm == 0) return true;                                          // "the cost model's pick stays"
+            static const int tiles[][4] = {{64, 64, 2, 2}, {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 128, 4, 2}, {256, 256, 2, 4}};
+            bool tile_ok = false;
+            for (const auto& t : tiles) tile_ok |= c.tile.bm == t[0] && c.tile.bn == t[1] && c.tile.wgm == t[2] && c.tile.wgn == t[3];
+            return tile_ok && c.tile.nsplit >= 1 && c.tile.nsplit <= 16 && (c.ld == -1 || c.ld == 0 || c.ld == 2);
+        };
+        int dropped = 0;
         if (FILE* f = path.empty() ? nullptr : fopen(path.c_str(), "r")) {
             char key[256];
             ConvTuned c{};
-            while (fscanf(f, "%255s %d %d %d %d %d %d", key, &c.tile.bm, &c.tile.bn, &c.tile.wgm, &c.tile.wgn, &c.tile.nsplit, &c.ld) == 7) cache[key] = c;
+            while (fscanf(f, "%255s %d %d %d %d %d %d", key, &c.tile.bm, &c.tile.bn, &c.tile.wgm, &c.tile.wgn, &c.tile.nsplit, &c.ld) == 7) {
+                if (valid(key, c)) cache[key] = c; else ++dropped;
+            }
             fclose(f);
+            if (dropped) fprintf(stderr, "[mere-fusion_amd] tuning table %s: %d entries ignored (other kernel generation or invalid configuration)\n", path.c_str(), dropped);
+        } else {
+            // said once: without a table every layer runs the cost model's pick, and frames are no longer bit-identical from box to box
+            fprintf(stderr, "[mere-fusion_amd] no tuning table (%s): implicit-GEMM layers use the cost model's launch configurations\n", path.empty() ? "library path unknown" : path.c_str());
         }
     }
     return cache;
@@ -1654,7 +1671,7 @@ bool tunable_layer(const ConvPlan* p, int batch) {
 }
 std::string tune_key(const ConvPlan* p, const ActView& in, int batch) {
     char keybuf[256];
-    snprintf(keybuf, sizeof(keybuf), "g950:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d", p->precision, batch, p->d.cin, p->d.cout, p->d.kh, p->d.kw, p->d.stride_h, p->d.stride_w,
+    snprintf(keybuf, sizeof(keybuf), "g950k4:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d:%d", p->precision, batch, p->d.cin, p->d.cout, p->d.kh, p->d.kw, p->d.stride_h, p->d.stride_w,
              p->d.pad_h, p->d.pad_w, p->d.transposed, p->d.output_padding, p->d.residual, p->d.act, p->d.in_h, p->d.in_w, p->d.upsample, p->d.pad_hi,
              in.buf ? in.buf->C : 0);
     return std::string(keybuf) + (p->out_stats ? ":s" : "");     // a layer that also leaves GroupNorm statistics times (and may pick) differently
@@ -1676,7 +1693,13 @@ int mf_conv_tune_lookup(ConvPlan* p, const ActView& in, int batch) {
     if (!tunable_layer(p, batch)) return 0;
     auto it = tune_cache().find(tune_key(p, in, batch));
     if (it == tune_cache().end()) return 0;
-    if (it->second.tile.bm > 0) p->tuned[batch] = it->second; else p->tuned.erase(batch);
+    if (it->second.tile.bm > 0) {
+        ConvTuned c = it->second;
+        int kt_min = p->ph[0].KT;
+        for (int ph = 0; ph < p->nphase; ++ph) kt_min = std::min(kt_min, p->ph[ph].KT);
+        c.tile.nsplit = std::max(1, std::min(c.tile.nsplit, kt_min));                 // (a split deeper than the layer's K tiles cannot launch)
+        p->tuned[batch] = c;
+    } else p->tuned.erase(batch);
     return 1;
 }
 

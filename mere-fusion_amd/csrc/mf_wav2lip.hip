@@ -9,6 +9,7 @@
 #include "mf_conv.h"
 #include "mf_aux.h"
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <vector>
@@ -111,6 +112,7 @@ struct mf_wav2lip {
     float* head_b = nullptr;
     std::map<std::string, ActView> taps;
     std::map<int, hipGraphExec_t> graphs;
+    std::set<int> looked_up;                     // batch sizes whose launch configurations have been looked up (no-graph path)
     hipStream_t side = nullptr;       // audio-encoder lane
     hipStream_t cap_stream = nullptr; // capture origin
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_gin = nullptr, ev_gout = nullptr;
@@ -267,7 +269,8 @@ int mf_wav2lip::tune(int batch, hipStream_t s) {
 
 int mf_wav2lip::run(int batch, hipStream_t s) {
     if (!use_graph) {
-        for (auto& st : steps) mf_conv_tune_lookup(&st->plan, st->in, batch);
+        if (looked_up.insert(batch).second)                                          // (MF_NO_GRAPH: one table lookup per layer and batch size, not one per forward)
+            for (auto& st : steps) mf_conv_tune_lookup(&st->plan, st->in, batch);
         return run_body(batch, s);
     }
     auto it = graphs.find(batch);
@@ -402,6 +405,7 @@ extern "C" int mf_wav2lip_create(const mf_tensor* weights, int n_weights, int pr
 
 extern "C" int mf_wav2lip_tune(mf_wav2lip* h, int batch, void* stream) {
     MF_REQUIRE(h && batch >= 1, "wav2lip_tune: bad argument");
+    MF_REQUIRE(batch <= h->cap, "wav2lip_tune: batch %d exceeds the handle's workspace (%d frames): run one forward at this batch first", batch, h->cap);
     return h->tune(batch, (hipStream_t)stream);
 }
 

@@ -303,9 +303,15 @@ class EndToEndScheduler(SessionScheduler):
         self._busy_until = 0.0
 
     def submit(self, k, pcm_chunks, t_arrival=None):
+        """pcm_chunks: the batch's 2B 20 ms chunks -- bare arrays (all speech, type 0) or (chunk, type) pairs exactly as `get_audio_frame` hands them out
+        (baseasr.py:33-45; type 1 = silence).  An all-silent batch skips the networks, as musereal.py:82-86 does: its B (None, idx, audio_frames) tuples still
+        reach the session's ring so that `process_frames` keeps audio and idle video in step."""
         t = self.clock() if t_arrival is None else t_arrival
-        win = self.frontends[k].window(pcm_chunks)                    # host side of museasr.py:17-29, at arrival time
-        self.queues[k].append((t, (win, [(c, 0) for c in pcm_chunks])))
+        pairs = [(c if isinstance(c, tuple) else (c, 0)) for c in pcm_chunks]
+        win = self.frontends[k].window([c for c, _ in pairs])         # host side of museasr.py:17-29, at arrival time (the window slides for silent batches too)
+        if all(ty != 0 for _, ty in pairs):
+            win = None
+        self.queues[k].append((t, (win, pairs)))
 
     def _retire(self, block=False):
         done = []
@@ -322,6 +328,13 @@ class EndToEndScheduler(SessionScheduler):
                 tok = item["tokens"].get(k)
                 if tok is not None:
                     self.rings[k].commit_batch(tok, item["audio"][k])
+                    t1 = self.clock()
+                elif self.rings is not None and fr is None:
+                    # a silent batch, or a session whose context is still filling: the reference puts (None, idx, audio_frames[2i:2i+2]) per frame
+                    # (musereal.py:82-86, lipreal.py:104) -- descriptors only, no slot
+                    au = item["audio"][k]
+                    for i, ix in enumerate(idx):
+                        self.rings[k].put((None, ix, au[2 * i:2 * i + 2]))
                     t1 = self.clock()
                 done.append((k, fr, idx, t1 - item["arrival"][k]))
             self.busy_s += max(t1 - max(item["t0"], self._busy_until), 0.0)      # union of the steps' [launch, done] intervals
@@ -342,6 +355,26 @@ class EndToEndScheduler(SessionScheduler):
         if not ks:
             return done
         dev = self.batcher.device
+        # Ring slots for every picked session are taken BEFORE anything irreversible happens (queue entries popped, frame indices and ASR state advanced): a
+        # session whose consumer is behind is DEFERRED -- its batch stays at the head of its queue and is picked again later -- and the other sessions go ahead;
+        # the reference's loop likewise back-pressures only the one session's queue.
+        reserved = {}
+        if self.rings is not None:
+            B = self.batcher.batch_size
+            ok = []
+            for k in ks:
+                if self.queues[k][0][1][0] is None:                   # silent / context still filling: descriptors only
+                    ok.append(k)
+                    continue
+                sl = self.rings[k].try_reserve(B)
+                if sl is None:
+                    self.ring_full += 1
+                    continue
+                reserved[k] = sl
+                ok.append(k)
+            ks = ok
+            if not ks:
+                return done
         arrival, audio, wins = {}, {}, {}
         for k in ks:
             arrival[k], (wins[k], audio[k]) = self.queues[k].popleft()
@@ -363,24 +396,30 @@ class EndToEndScheduler(SessionScheduler):
                 cur.wait_stream(side)                                              # the UNet below reads the chunks
                 for t in [wav, feats] + [chunks[k] for k in speaking]:
                     t.record_stream(cur)
-        out = self.batcher.step(chunks, only=ks)
         tokens = {}
-        ev = torch.cuda.Event()
-        if self.rings is not None:
-            cur = torch.cuda.current_stream(dev)
-            self.copy_stream.wait_stream(cur)
-            for k in ks:
-                fr, idx = out[k]
-                if fr is None:
-                    continue
-                try:
-                    tokens[k] = self.rings[k].begin_batch(fr, idx, stream=self.copy_stream, block=True, timeout=self.period)
-                except Exception:
-                    self.ring_full += 1
-                    raise
-                fr.record_stream(self.copy_stream)
-            ev.record(self.copy_stream)
-        else:
+        try:
+            out = self.batcher.step(chunks, only=ks)
+            ev = torch.cuda.Event()
+            if self.rings is not None:
+                cur = torch.cuda.current_stream(dev)
+                self.copy_stream.wait_stream(cur)
+                for k in ks:
+                    fr, idx = out[k]
+                    if fr is None:
+                        if k in reserved:
+                            self.rings[k].unreserve(reserved.pop(k))
+                        continue
+                    tokens[k] = self.rings[k].begin_batch(fr, idx, stream=self.copy_stream, reserved=reserved.pop(k))
+                    fr.record_stream(self.copy_stream)
+                ev.record(self.copy_stream)
+        except BaseException:
+            # nothing of this step is published: tokens already begun and reservations not yet used go back (newest first: FrameRing.abort_batch's ordering rule)
+            for k in reversed(list(tokens)):
+                self.rings[k].abort_batch(tokens[k])
+            for k in reversed(list(reserved)):
+                self.rings[k].unreserve(reserved[k])
+            raise
+        if self.rings is None:
             ev.record(torch.cuda.current_stream(dev))
         self.inflight.append({"ks": ks, "out": out, "tokens": tokens, "audio": audio, "arrival": arrival, "event": ev, "t0": t0})
         self.steps += 1

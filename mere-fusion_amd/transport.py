@@ -91,6 +91,19 @@ class FrameRing:
         self._head = (self._head + n) % self.slots
         return [(first + i) % self.slots for i in range(n)]
 
+    def try_reserve(self, n):
+        """n consecutive slots if they are free RIGHT NOW, else None -- for a producer that must know every destination has room BEFORE it does work it
+        cannot undo (EndToEndScheduler.run_once reserves for every picked session before the step advances frame indices and ASR state).  Pass the result
+        to begin_batch(..., reserved=slots), or hand it back with unreserve(slots)."""
+        try:
+            return self._acquire(n, False, None)
+        except queue.Full:
+            return None
+
+    def unreserve(self, slots):
+        """hands back slots from try_reserve / a token's slots that were never published (see abort_batch for the ordering rule)"""
+        self.abort_batch({"slots": list(slots)})
+
     def _check_fits(self, nbytes):
         if nbytes > self.slot_bytes:
             raise ValueError(f"frame of {nbytes} bytes does not fit a {self.slot_bytes}-byte slot")
@@ -119,7 +132,7 @@ class FrameRing:
             self._desc.put([(None, None, None, idx, audio)], block, timeout)
             return
         if self._is_device(frame):
-            self.put_batch(frame[None], [idx], audio, block, timeout, _single_audio=audio)
+            self.put_batch(frame[None], [idx], audio, block, timeout, _single_audio=(audio,))     # (wrapped: `audio` itself may be None)
             return
         a = np.asarray(frame)
         self._check_fits(a.nbytes)                                  # everything that can fail, before a slot is taken
@@ -144,10 +157,12 @@ class FrameRing:
                 raise
         self.commit_batch(tok, audio_frames, _single_audio=_single_audio)
 
-    def begin_batch(self, frames, idxs, stream=None, block=True, timeout=None):
+    def begin_batch(self, frames, idxs, stream=None, block=True, timeout=None, reserved=None):
         """First half of put_batch, for a producer that overlaps the copy with its next step: takes the slots and ENQUEUES the DMA on `stream`
         (a torch stream; default: the current one) without waiting.  Once the caller knows the copy is complete (an event recorded behind it on
-        that stream) it calls commit_batch(token, audio_frames); abort_batch(token) hands the slots back instead.  Returns None for an empty batch."""
+        that stream) it calls commit_batch(token, audio_frames); abort_batch(token) hands the slots back instead.  Returns None for an empty batch.
+        reserved: slots from try_reserve(len(idxs)) (then nothing here can block).  Tokens are COMMITTED in the order they were begun (the consumer reads
+        slots in ring order); see abort_batch for aborting."""
         B = len(idxs)
         if B == 0:
             return None
@@ -155,6 +170,9 @@ class FrameRing:
         if is_dev:
             import torch
             t = frames.contiguous()
+            if stream is not None and t is not frames:
+                # the compaction above ran on the CURRENT stream; the DMA below is enqueued on `stream`: order it behind (a silent race otherwise)
+                stream.wait_stream(torch.cuda.current_stream(t.device))
             shape, dtype = tuple(t.shape[1:]), np.dtype(str(t.dtype).replace("torch.", ""))
             self._check_fits(t[0].numel() * t.element_size())
         else:
@@ -163,7 +181,9 @@ class FrameRing:
             self._check_fits(int(np.prod(shape)) * dtype.itemsize)
         if len(frames) != B:
             raise ValueError(f"{len(frames)} frames for {B} indices")
-        slots = self._acquire(B, block, timeout)
+        if reserved is not None and len(reserved) != B:
+            raise ValueError(f"{len(reserved)} reserved slots for {B} frames")
+        slots = list(reserved) if reserved is not None else self._acquire(B, block, timeout)
         tok = {"slots": slots, "shape": shape, "dtype": dtype.str, "idxs": list(idxs), "stream": None, "keep": None}
         try:
             if is_dev:
@@ -190,17 +210,26 @@ class FrameRing:
         return tok
 
     def abort_batch(self, tok):
-        """nothing of this batch was published: give the slots back and rewind the cursor (single producer: nobody else moved it)"""
-        self._head = tok["slots"][0]
-        for _ in tok["slots"]:
-            self._free.release()
+        """Nothing of this batch was published: give the slots back.  If the token is the NEWEST one outstanding (its last slot is the one before the cursor)
+        the cursor is rewound and the slots are simply free again.  With newer tokens outstanding (begin_batch / commit_batch allow several in flight) a rewind
+        would hand out the newer tokens' slots a second time: the slots are then published as a SKIP descriptor instead -- the consumer releases them in ring
+        order without surfacing a frame."""
+        sl = tok["slots"]
+        if not sl:
+            return
+        if (sl[-1] + 1) % self.slots == self._head:
+            self._head = sl[0]
+            for _ in sl:
+                self._free.release()
+        else:
+            self._desc.put([("skip", len(sl), None, None, None)])
 
     def commit_batch(self, tok, audio_frames, _single_audio=None):
         """Second half of put_batch: publishes the batch's descriptors as one message.  The copy must be complete."""
         sl, shape, dt, idxs = tok["slots"], tok["shape"], tok["dtype"], tok["idxs"]
         tok["keep"] = None
         if _single_audio is not None:
-            self._desc.put([(sl[0], shape, dt, idxs[0], _single_audio)])
+            self._desc.put([(sl[0], shape, dt, idxs[0], _single_audio[0])])
         else:
             self._desc.put([(s_, shape, dt, idxs[i], audio_frames[2 * i:2 * i + 2]) for i, s_ in enumerate(sl)])
 
@@ -208,9 +237,15 @@ class FrameRing:
     def get(self, block=True, timeout=None, copy=True):
         """-> (res_frame, idx, audio_frames), the tuple `process_frames` unpacks (lipreal.py:195).  copy=True returns an ndarray the caller
         owns (the slot is free again immediately); copy=False returns a view into the ring and the caller must `release(view)` it."""
-        if not self._inbox:
-            self._inbox.extend(self._desc.get(block, timeout))       # one message = the descriptors of one put / put_batch
-        slot, shape, dtype, idx, audio = self._inbox.popleft()
+        while True:
+            if not self._inbox:
+                self._inbox.extend(self._desc.get(block, timeout))   # one message = the descriptors of one put / put_batch
+            slot, shape, dtype, idx, audio = self._inbox.popleft()
+            if isinstance(slot, str):                                # "skip": slots of an aborted batch, released in ring order (abort_batch)
+                for _ in range(shape):
+                    self._free.release()
+                continue
+            break
         if slot is None:
             return None, idx, audio
         view = self._slot_view(slot, shape, dtype)

@@ -76,7 +76,7 @@ def test_forward_never_measures_and_explicit_tune_does(lib_built, monkeypatch, t
     assert cache.read_text() == ""
     unet.model.tune(B)
     rows = [l for l in cache.read_text().splitlines() if l.strip()]
-    assert len(rows) >= 10 and all(l.startswith("g950:") and f":{B}:" in l for l in rows)
+    assert len(rows) >= 10 and all(l.startswith("g950k4:") and f":{B}:" in l for l in rows)
     after = [run() for _ in range(3)]                        # eager with the measured configurations, capture, replay
     assert torch.equal(after[0], after[1]) and torch.equal(after[1], after[2])
     want = R.unet_forward(usd, cfg["unet"], lat, torch.tensor([0]), R.add_positional_encoding(aud))

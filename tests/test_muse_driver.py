@@ -303,3 +303,58 @@ def test_hip_end_to_end_scheduler_delivers_the_session_loop_through_rings(lib_bu
                 assert d.max() <= 1 and (d > 0).mean() < 0.01, (s, j, i, d.max(), (d > 0).mean())
     for r in rings:
         r.close()
+
+
+@pytest.mark.gpu
+def test_hip_end_to_end_scheduler_stalled_consumer_and_silent_batches(lib_built):
+    """ADVICE r03.  A session whose consumer is behind (its ring is full) is DEFERRED: its batch stays queued, nothing of it is lost, the other sessions of the
+    step are delivered, and it is served once the consumer has caught up.  An all-silent batch (type-1 chunks, baseasr.py:33-45) skips the networks and reaches the
+    ring as B (None, idx, audio_frames) tuples (musereal.py:82-86)."""
+    from mere_fusion_amd.musetalk.models.unet import UNet
+    from mere_fusion_amd.musetalk.models.vae import VAE
+    from mere_fusion_amd.musetalk.whisper.audio2feature import Audio2Feature
+    from mere_fusion_amd.musetalk.config import unet_config_json, vae_config_json
+    from mere_fusion_amd.transport import FrameRing
+    from oracle import musetalk_ref as R
+    cfg = R.MUSETALK_SMALL
+    usd, vsd = W.make_musetalk_unet_state_dict(cfg, 0), W.make_musetalk_vae_state_dict(cfg, 0)
+    B, S = 2, 2
+    unet = UNet(unet_config_json(cfg["unet"]), usd, max_batch=B * S)
+    vae = VAE(config=vae_config_json(cfg["vae"]), state_dict=vsd, max_batch=B * S)
+    a2f = Audio2Feature(state_dict=W.make_whisper_encoder_state_dict(0), n_head=6)
+    lat = [[W.make_musetalk_inputs(1, 900 + 10 * s + i)[0] for i in range(4)] for s in range(S)]
+    fes = [D.MuseASRFrontend(a2f, B) for _ in range(S)]
+    for fe in fes:
+        fe.warm_up()
+    rings = [FrameRing(2 * B, (256, 256, 3)) for _ in range(S)]
+    bat = D.MuseBatcher(unet, vae, [D.MuseSession(lat[s]) for s in range(S)], batch_size=B, max_sessions_per_step=S)
+    now = [0.0]
+    sch = D.EndToEndScheduler(bat, fes, a2f, rings=rings, clock=lambda: now[0], hold_s=0.0)
+    pcm = lambda s, j: [W.make_speech_like_wav(320, 31 * s + 5 * j + i) for i in range(2 * B)]
+    for j in range(3):                                               # three batches each; session 0's consumer is stalled, session 1's drains
+        sch.submit(0, pcm(0, j), 0.01 * j)
+        sch.submit(1, pcm(1, j) if j != 1 else [(c, 1) for c in pcm(1, j)], 0.01 * j + 0.001)     # session 1's second batch is silence
+    got1, served = [], []
+    for _ in range(40):
+        now[0] += 0.05
+        done = sch.run_once() + sch.drain()
+        served += [k for k, *_ in done]
+        for k, fr, idx, _ in done:
+            if k == 1:
+                for i in range(B):
+                    got1.append(rings[1].get(timeout=5))
+    # session 1 got everything, in order, the silent batch as None frames with its type-1 audio; session 0 two batches (its ring holds 2B frames), the third deferred
+    assert served.count(1) == 3 and served.count(0) == 2 and sch.ring_full > 0 and 0 in sch.pending()
+    assert [g[1] for g in got1] == [D.mirror_index(4, i) for i in range(3 * B)]
+    assert all(g[0] is not None for g in got1[:B] + got1[2 * B:]) and all(g[0] is None and g[2][0][1] == 1 and len(g[2]) == 2 for g in got1[B:2 * B])
+    first = [rings[0].get(timeout=5) for _ in range(2 * B)]         # the consumer catches up ...
+    assert [g[1] for g in first] == [D.mirror_index(4, i) for i in range(2 * B)]
+    for _ in range(10):
+        now[0] += 0.05
+        done = sch.run_once() + sch.drain()
+        served += [k for k, *_ in done]
+    assert served.count(0) == 3 and not sch.pending()                # ... and the deferred batch is served, with the indices that follow
+    last = [rings[0].get(timeout=5) for _ in range(B)]
+    assert [g[1] for g in last] == [D.mirror_index(4, 2 * B + i) for i in range(B)] and all(g[0] is not None for g in last)
+    for r in rings:
+        r.close()

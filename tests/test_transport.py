@@ -113,6 +113,52 @@ def test_ring_failed_puts_leave_the_ring_intact():
     ring.close()
 
 
+def test_ring_reservations_and_aborting_an_older_token():
+    """(1) try_reserve is all-or-nothing and non-blocking, and a reservation can be used or handed back; (2) aborting a token while a NEWER one is
+    outstanding must not rewind the cursor onto the newer token's slots: the aborted slots travel as a skip descriptor and come free in ring order."""
+    ring = FrameRing(slots=6, frame_shape=(4, 4, 3))
+    f = lambda v: np.full((2, 4, 4, 3), v, np.uint8)
+    audio = [(np.zeros(320, np.float32), 0)] * 4
+    r = ring.try_reserve(2)
+    assert r == [0, 1]
+    assert ring.try_reserve(5) is None                              # 4 free: nothing taken, cursor unmoved
+    ring.unreserve(r)                                               # newest reservation: plain rewind
+    r = ring.try_reserve(2)
+    assert r == [0, 1]
+    t_old = ring.begin_batch(f(1), [10, 11], reserved=r)
+    t_new = ring.begin_batch(f(2), [20, 21])
+    assert t_new["slots"] == [2, 3]
+    ring.abort_batch(t_old)                                         # an OLDER token: must not hand slots 2, 3 out again
+    t3 = ring.begin_batch(f(3), [30, 31])
+    assert t3["slots"] == [4, 5]
+    assert ring.try_reserve(1) is None                              # slots 0, 1 are not free until the consumer has passed the skip marker
+    ring.commit_batch(t_new, audio)
+    ring.commit_batch(t3, audio)
+    got = [ring.get(timeout=5) for _ in range(4)]
+    assert [g[1] for g in got] == [20, 21, 30, 31] and [int(g[0][0, 0, 0]) for g in got] == [2, 2, 3, 3]
+    assert ring.try_reserve(6) == [0, 1, 2, 3, 4, 5]                # everything came back, in order
+    ring.close()
+
+
+@pytest.mark.gpu
+def test_ring_device_frame_without_audio(lib_built):
+    """put() of a DEVICE frame whose audio_frames is None used to fall into the batch path's slicing (TypeError after the slot was taken)."""
+    ring = FrameRing(slots=2, frame_shape=(16, 16, 3))
+    fr = torch.randint(0, 256, (16, 16, 3), dtype=torch.uint8, device="cuda")
+    ring.put((fr, 5, None))
+    g, idx, au = ring.get(timeout=5)
+    assert idx == 5 and au is None and np.array_equal(g, fr.cpu().numpy())
+    nc = torch.randint(0, 256, (3, 16, 32, 3), dtype=torch.uint8, device="cuda")[:, :, ::2]      # non-contiguous batch + an explicit copy stream
+    st = torch.cuda.Stream()
+    tok = ring.begin_batch(nc[:2], [1, 2], stream=st)
+    st.synchronize()
+    ring.commit_batch(tok, [(np.zeros(320, np.float32), 0)] * 4)
+    for i in range(2):
+        g, idx, _ = ring.get(timeout=5)
+        assert idx == i + 1 and np.array_equal(g, nc[i].cpu().numpy())
+    ring.close()
+
+
 @pytest.mark.gpu
 def test_ring_takes_device_frames_by_dma(lib_built):
     """uint8 frames straight from HBM into the page-locked ring (single put and put_batch incl. the wrap-around split into two DMAs)."""

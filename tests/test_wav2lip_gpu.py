@@ -19,7 +19,7 @@ from oracle import wav2lip_ref as R
 
 pytestmark = pytest.mark.gpu
 
-TOL_X3 = 1e-3
+TOL_X3 = 1.5e-4          # gate at ~4 x the measured 3.5e-5 (bound: 1e-3); VERDICT r03: the gate used to sit at the bound itself
 TOL_BF16_LINF, TOL_BF16_MEAN = 8e-2, 6e-3
 
 
