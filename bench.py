@@ -280,6 +280,7 @@ def roofline(rows, precision, only_mfma=False):
         if only_mfma and not r["kernel"].startswith("k_conv"):
             continue
         name, _, grid = r["kernel"].partition(" grid ")              # (" grid N": the launch's thread count, mf_conv_kernel_name)
+        grid = grid.split()[0] if grid else grid                     # (" +gn" behind it: the GroupNorm-apply runs inside this conv)
         k = by.setdefault(name, dict(ms=0.0, flops=0.0, launches=0, grids=[]))
         k["ms"] += r["ms"]; k["flops"] += r["flops"]; k["launches"] += 1
         if grid:

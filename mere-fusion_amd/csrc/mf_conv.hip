@@ -1140,7 +1140,8 @@ void mf_conv_plan_destroy(ConvPlan* p) {
 }
 
 int mf_conv_bind(ConvPlan* p, const ActBuf& in) {
-    MF_REQUIRE(in.halo >= p->in_halo_need, "conv: input halo %d < required %d", in.halo, p->in_halo_need);
+    // (a plan with the GroupNorm fused into its halo load reads the GroupNorm's INPUT: pixels outside the map are masked by coordinate, no zero ring needed)
+    MF_REQUIRE(p->gn_scale || in.halo >= p->in_halo_need, "conv: input halo %d < required %d", in.halo, p->in_halo_need);
     MF_REQUIRE(in.H == p->d.in_h && in.W == p->d.in_w, "conv: plan built for %dx%d input, bound to %dx%d",
                p->d.in_h, p->d.in_w, in.H, in.W);
     MF_REQUIRE(in.C % 8 == 0 && in.C >= p->cin_pad, "conv: input buffer has %d channels, need >= %d (multiple of 8)", in.C, p->cin_pad);
@@ -1260,7 +1261,17 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
         ha.act = p->d.act;
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         if (p->q) {                             // the f16 + FP6 format has one kernel: the 8-wave 16 x 16 x 128-channel tile
-            MF_REQUIRE(!ha.res_from_halo, "conv (f16q): residual-from-input is not built for this format");
+            MF_REQUIRE(!ha.res_from_halo || p->gn_scale, "conv (f16q): residual-from-input is not built for this format");
+            if (p->gn_scale) {                  // GroupNorm + SiLU fused into the halo load: `in` is the GroupNorm's input (raw bf16 hi / lo planes)
+                ha.gn_scale = p->gn_scale; ha.gn_shift = p->gn_shift; ha.gn_post = p->gn_post; ha.gn_silu = p->gn_silu; ha.gn_C = p->d.cin;
+                if (ha.res_from_halo) {         // (the residual is the RAW tensor, which is what the halo image no longer holds: read it from HBM in the epilogue)
+                    ha.res_from_halo = 0;
+                    const ActBuf& rb = *res.buf;
+                    const int64_t rb0 = ((int64_t)rb.halo * rb.Wp() + rb.halo) * rb.C + res.coff;
+                    ha.r_hi = rb.hi + rb0; ha.r_lo = rb.lo + rb0;
+                    ha.rb = rb.per_batch(); ha.ri = rb.Wp() * rb.C; ha.rj = rb.C;
+                }
+            }
             if (p->out_stats) {
                 const int cpg = p->d.cout / p->out_stats_groups;
                 if (p->d.cout % p->out_stats_groups == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && !ha.ws) {   // (other group widths: k_gn_stats behind the conv)

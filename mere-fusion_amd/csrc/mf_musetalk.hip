@@ -282,9 +282,30 @@ struct Net {
             int rc = mf_conv_plan_create(p, d, w_use, bb.data(), nullptr, nullptr, nullptr, nullptr, MF_PREC_F16Q);
             if (rc) return rc;
             if (!p->q) { err = cname + ": no kernel in the f16 + FP6 format for this layer"; return MF_ERR_INVALID; }
+            // MF_GN_FUSE_Q=1 (opt-in, measured and NOT adopted): GroupNorm-apply + SiLU + the conversion into the operand format INSIDE the conv -- the producer waves
+            // of its specialised workgroup rewrite each landed halo image in LDS, so the normalised tensor is neither written nor re-read (k_affine_silu_to_q: 4 B + 4 B
+            // per value and a launch per layer, 8 % of the step).  Bit-identical frames (tools/gn_fuse_check.py), but the ~700 VALU instructions per 64 pixels and
+            // slice that four producer waves then execute beside the compute waves' MFMAs cost the conv far more than the pass they replace: 128 ch @256^2 295 + 104
+            // -> 490 us, 256 ch @128^2 245 + 60 -> 457, 512 ch @64^2 217 + 25 -> 414 (every one of the 2 / 4 channel tiles converts the same image again);
+            // MuseTalk step 18.75 -> 21.97 ms (profiles/r04_gn_fuse_q.md).
+            static const bool fuse = [] {
+                const char* e = getenv("MF_GN_FUSE_Q"); const char* sp = getenv("MF_HALO_Q_SP");
+                return (e && atoi(e) != 0) && !(sp && atoi(sp) == 0);
+            }();
+            const bool epi = take_stats(x, groups, st);
+            if (fuse && x.buf->lo && x.coff % 8 == 0 && x.buf->H == t->H && x.buf->W == t->W) {
+                p->gn_scale = scale; p->gn_shift = shift; p->gn_post = d_post; p->gn_silu = 1;
+                if ((rc = mf_conv_bind(p, *x.buf))) return rc;
+                push(gname, epi ? "k_gn_affine (statistics from the producer's epilogue; apply + SiLU + f16/FP6 conversion inside the conv)" : "k_gn_stats+k_gn_affine (apply inside the conv)",
+                     0.0, [=](int B, hipStream_t s) { return mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s, epi); });
+                char kn[96];
+                mf_conv_kernel_name(p, cap, kn, sizeof(kn));
+                push(cname, std::string(kn) + " +gn", mf_conv_flops(p, 1), [=](int B, hipStream_t s) { return mf_conv_launch(p, x, out, res, B, s); });
+                stats_remember(p, out);
+                return MF_OK;
+            }
             if ((rc = mf_conv_bind(p, *t))) return rc;
             const ActBuf* tq = t;
-            const bool epi = take_stats(x, groups, st);
             push(gname, epi ? "k_affine_silu_to_q (statistics from the producer's epilogue)" : "k_gn_stats+k_affine_silu_to_q", 0.0, [=](int B, hipStream_t s) {
                 const int r1 = mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s, epi);
                 return r1 ? r1 : mf_affine_silu_to_act_q(x, scale, shift, 1, *tq, B, s, d_post);

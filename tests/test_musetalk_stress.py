@@ -68,3 +68,17 @@ def test_vae_f16_fp6_under_channel_scale_stress(lib_built, seed, one_sided):
           f"on values up to {scale:.2f} (gate {TOL_IMAGE}); uint8 max diff {d.max()}, differing pixels {100 * (d > 0).mean():.3f} %")
     assert np.isfinite(ierr) and ierr <= TOL_IMAGE, (ierr, scale)
     assert d.max() <= 1 and (d > 0).mean() < TOL_U8_FRACTION, (d.max(), (d > 0).mean())
+
+
+def test_gn_fused_into_the_conv_is_bit_identical(lib_built, tmp_path):
+    """MF_GN_FUSE_Q=1 (opt-in, profiles/r04_gn_fuse_q.md): the producer waves of the f16 + FP6 conv convert the raw halo images in LDS.  Same operations on the same
+    values as k_affine_silu_to_q: the frames of the full decoder must be IDENTICAL.  (The switch is read once per process: two child processes.)"""
+    import os, subprocess, sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    a, b = str(tmp_path / "a.npz"), str(tmp_path / "b.npz")
+    for path, env in ((a, {"MF_GN_FUSE_Q": "0"}), (b, {"MF_GN_FUSE_Q": "1"})):
+        subprocess.run([sys.executable, os.path.join(root, "tools", "gn_fuse_check.py"), path], check=True, env=dict(os.environ, **env), timeout=600,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    fa, fb = np.load(a), np.load(b)
+    assert fa["frames"].std() > 10
+    assert np.array_equal(fa["frames"], fb["frames"]) and np.array_equal(fa["image"], fb["image"])
