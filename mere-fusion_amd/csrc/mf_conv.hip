@@ -1807,14 +1807,17 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
 
 void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision != MF_PREC_BF16 ? "true" : "false";
-    if (p->q && p->up_hi) { snprintf(buf, cap, "4 x k_conv3x3_halo_w<16,128,4,2,true,1,phase> f16+fp6"); return; }
+    // (the f16 + FP6 tile: the specialised workgroup <16,128,2,2,...> -- 4 compute + 4 producer waves -- unless MF_HALO_Q_SP=0 selects the eight-compute-wave one)
+    static const bool q_sp = !(getenv("MF_HALO_Q_SP") && atoi(getenv("MF_HALO_Q_SP")) == 0);
+    const char* qt = q_sp ? "2,2" : "4,2";
+    if (p->q && p->up_hi) { snprintf(buf, cap, "4 x k_conv3x3_halo_w<16,128,%s,true,1,phase> f16+fp6", qt); return; }
     if (p->q && p->halo) {
         // (" grid N": the launch's thread count as rocprofv3 reports it, so that a counter pass can be matched to exactly these launches -- the split
         // and unsplit launches share one kernel symbol)
         const int ns = mf_q_split_count(p, batch);
         const long grid = (long)batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * (p->d.cout / 128) * ns * 512;
-        if (ns > 1) snprintf(buf, cap, "k_conv3x3_halo_w<16,128,4,2,true,1> f16+fp6 split %d grid %ld", ns, grid);
-        else snprintf(buf, cap, "k_conv3x3_halo_w<16,128,4,2,true,1> f16+fp6 grid %ld", grid);
+        if (ns > 1) snprintf(buf, cap, "k_conv3x3_halo_w<16,128,%s,true,1> f16+fp6 split %d grid %ld", qt, ns, grid);
+        else snprintf(buf, cap, "k_conv3x3_halo_w<16,128,%s,true,1> f16+fp6 grid %ld", qt, grid);
         return;
     }
     if (p->halo) {
