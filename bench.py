@@ -833,7 +833,7 @@ def muse_paced_sessions(big, args, device, free_fps, full=True):
     cap = max(int(free_fps / 25.0), 1)
     rig = PacedRig(big, args, device, n_max=cap + 4)
     try:
-        e2e, e2e_trials = rig.search(cap, ("whisper", "paste", "ring"), screen_s=4.0, confirm_s=60.0, fail_s=20.0)
+        e2e, e2e_trials = rig.search(cap, ("whisper", "paste", "ring"), screen_s=4.0, confirm_s=40.0, fail_s=20.0)
         rep = {"criterion": f"p99 latency of a session's {B}-frame batch <= {B} x 40 ms = {P * 1e3:.0f} ms, every batch delivered, and no queue growth (mean latency of the "
                             f"last third of the batches - of the first third <= {P * 100:.0f} ms); real time, seeded random phases, one batch per session per {P * 1e3:.0f} ms",
                "scheduler": f"mere_fusion_amd.muse_driver.EndToEndScheduler / SessionScheduler: oldest first, <= {S} sessions per step, a partly filled step waits <= {P * 250:.0f} ms; "
