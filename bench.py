@@ -1472,7 +1472,12 @@ def main():
         if rank == 0 and extras and args.sessions > 0 and getattr(args, "paced", 1):
             _stage("8 ranks on one GPU (host readiness)")
             torch.cuda.empty_cache()
+            # 8 x 2 sessions load ONE GPU to ~85 % from eight time-sharing processes (the ranks' p99 then mostly measures that sharing); 8 x 1 leaves it half idle and
+            # shows the host side by itself
             line.setdefault("node", {})["ranks_on_one_gpu"] = ranks_on_one_gpu(args, 8, 2, 20.0)
+            light = ranks_on_one_gpu(args, 8, 1, 12.0)
+            line["node"]["ranks_on_one_gpu_one_session_each"] = {k: light.get(k) for k in ("ranks", "sessions_per_rank", "seconds", "wall_s", "worst_rank_p99_ms", "all_sustained",
+                                                                                              "host_cpu_s_per_wall_s_per_rank", "host_cpu_s_per_wall_s_total", "frames_per_s_total", "error")}
         if rank == 0 and extras:
             dl = args.dump_layers
             args.dump_layers = dl + ".wav2lip.json" if dl else None
