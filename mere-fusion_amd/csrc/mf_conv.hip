@@ -1004,7 +1004,8 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
               d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16 && d.residual != 2 && d.act <= 2 && !d.upsample &&
               (narrow || wide_ok) && d.cout % 4 == 0;
-    if (precision == MF_PREC_F16Q && !(d.cin % 32 == 0 && d.cout % 128 == 0)) p->halo = false;   // the format's halo tile is 128 channels wide: other shapes take the implicit GEMM
+    // the f16 + FP6 format's halo tile is 128 channels wide (the UNet's 320-channel 32 x 32 layers run it with a half-empty third tile: odd_wide); other shapes take the implicit GEMM
+    if (precision == MF_PREC_F16Q && !(d.cin % 32 == 0 && (d.cout % 128 == 0 || odd_wide))) p->halo = false;
     const bool want_alt = p->halo && !narrow;
     if (p->halo) {
         // ---- pack for the halo-tile kernel: [slice][tap][Npad][CK], channels past cin are zero --------
@@ -1014,7 +1015,7 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
         std::vector<bf16_t> hi(total, 0), lo(total, 0);
         if (precision == MF_PREC_F16Q) {
             // f16 + FP6 residual format (pack_q_weights)
-            MF_REQUIRE(d.cin % 32 == 0 && d.cout % 128 == 0, "conv (f16q): the format serves 3x3 layers with cin %% 32 == 0 and cout %% 128 == 0");
+            MF_REQUIRE(d.cin % 32 == 0 && (d.cout % 128 == 0 || odd_wide), "conv (f16q): the format serves 3x3 layers with cin %% 32 == 0 and cout %% 128 == 0 (or 64-multiples >= 256 on maps >= 32 x 32)");
             p->q = true;
             pack_q_weights(p->n_slices, 9, p->Npad, d.cout, d.cin,
                            [&](int n, int c, int tap) { return weight[(((int64_t)n * d.cin + c) * 3 + tap / 3) * 3 + tap % 3] * scale[n]; }, hi.data(), lo.data());
@@ -1815,7 +1816,7 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
         // (" grid N": the launch's thread count as rocprofv3 reports it, so that a counter pass can be matched to exactly these launches -- the split
         // and unsplit launches share one kernel symbol)
         const int ns = mf_q_split_count(p, batch);
-        const long grid = (long)batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * (p->d.cout / 128) * ns * 512;
+        const long grid = (long)batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * cdiv(p->d.cout, 128) * ns * 512;
         if (ns > 1) snprintf(buf, cap, "k_conv3x3_halo_w<16,128,%s,true,1> f16+fp6 split %d grid %ld", qt, ns, grid);
         else snprintf(buf, cap, "k_conv3x3_halo_w<16,128,%s,true,1> f16+fp6 grid %ld", qt, grid);
         return;

@@ -81,6 +81,8 @@ struct Net {
     // the schedule (kv_all = [ctx_len][sum of 2 C]) instead of one small launch per block inside the chain (16 x ~14 us in the UNet at batch 8).
     ActBuf* kv_all = nullptr; int kv_off = 0, kv_op = -1; std::vector<float> kv_w; ActView kv_ctx{}; bool kv_joined = false;
     bool q_allowed = false;     // the f16 + FP6 conv format: the VAE decoder's resnets (set by the builder of a network whose parity was established with it)
+    bool q_dual_allowed = false;   // ... and, from Q_DUAL_MIN frames per step, the UNet's 320-channel 3x3 convs on its 32 x 32 maps (gn_conv builds both paths, a launch picks by its batch)
+    static constexpr int Q_DUAL_MIN = 40;
     int next_pad_hi = 0;        // consumed by the next conv(): extra zero rows / columns bottom-right (the VAE encoder's Downsample2D)
     std::string err;
 
@@ -209,8 +211,14 @@ struct Net {
         static const bool q_on = [] { const char* e = getenv("MF_CONV_Q"); return !e || atoi(e) != 0; }();
         // (maps below 64 x 64 -- the 512-channel 32 x 32 levels -- run it with the channel slices split over two workgroups per tile, mf_q_split_count)
         const int q_minpx = 32 * 32;
-        if (q_on && q_allowed && precision == MF_PREC_BF16X3 && cin % 32 == 0 && cout % 128 == 0 && t->C == cin && t->H * t->W >= q_minpx && cin >= 128 &&
-            (int64_t)cap * ((t->H + 15) / 16) * ((t->W + 15) / 16) * (cout / 128) >= 64) {
+        // The UNet's 320-channel convs on its 32 x 32 maps (cout = 2.5 tiles of 128): from 40 frames per step the f16 + FP6 tile runs them at 640-730 TF where the
+        // bf16x3 LDS-weights tile reaches 405-440 (conv alone, 64 frames: 320 -> 320 298 -> 222 us, 640 -> 320 570 -> 412, 960 -> 320 824 -> 599).  A handle serves
+        // steps of every size up to its capacity, so BOTH paths are built and a launch picks by its batch (MF_UNET_Q=0: bf16x3 only).
+        static const bool q_unet_on = [] { const char* e = getenv("MF_UNET_Q"); return !e || atoi(e) != 0; }();
+        const bool q_dual = q_on && q_unet_on && q_dual_allowed && precision == MF_PREC_BF16X3 && cout >= 256 && cout % 128 != 0 && cout % 64 == 0 && cin % 32 == 0 &&
+                            t->C == cin && t->H * t->W >= q_minpx && t->H % 16 == 0 && t->W % 16 == 0 && cap >= Q_DUAL_MIN;
+        if (q_dual || (q_on && q_allowed && precision == MF_PREC_BF16X3 && cin % 32 == 0 && cout % 128 == 0 && t->C == cin && t->H * t->W >= q_minpx && cin >= 128 &&
+            (int64_t)cap * ((t->H + 15) / 16) * ((t->W + 15) / 16) * (cout / 128) >= 64)) {
             const float* g = T(gname + ".weight", cin);
             const float* b = T(gname + ".bias", cin);
             const float* w = T(cname + ".weight", (int64_t)cin * cout * 9);
@@ -282,6 +290,31 @@ struct Net {
             int rc = mf_conv_plan_create(p, d, w_use, bb.data(), nullptr, nullptr, nullptr, nullptr, MF_PREC_F16Q);
             if (rc) return rc;
             if (!p->q) { err = cname + ": no kernel in the f16 + FP6 format for this layer"; return MF_ERR_INVALID; }
+            if (q_dual) {
+                // the bf16x3 path of the same layer for steps below Q_DUAL_MIN frames (its own plan, LDS-weights tile / implicit-GEMM twin as before); both
+                // paths read the normalised tensor from `t`, whose second plane holds bf16 lo values or FP6 blocks as the path writes them
+                ConvPlan* p3 = nullptr;
+                if ((rc = conv(cname, tv, out, cin, cout, 3, 1, 1, 0, res, 0, extra_bias, 1.f, true, &p3))) return rc;
+                if ((rc = mf_conv_bind(p, *t))) return rc;
+                const ActBuf* tq = t;
+                const bool epi = take_stats(x, groups, st);
+                push(gname, epi ? "k_gn_apply | k_affine_silu_to_q from 40 frames (statistics from the producer's epilogue)" : "k_gn_stats+k_gn_apply | +k_affine_silu_to_q from 40 frames", 0.0,
+                     [=](int B, hipStream_t s) {
+                         if (B < Q_DUAL_MIN) return mf_groupnorm(x, tv, dg, db, groups, eps, true, st, B, s, epi);
+                         const int r1 = mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s, epi);
+                         return r1 ? r1 : mf_affine_silu_to_act_q(x, scale, shift, 1, *tq, B, s, d_post);
+                     });
+                char kn[96];
+                mf_conv_kernel_name(cap >= Q_DUAL_MIN ? p : p3, cap, kn, sizeof(kn));
+                push(cname, kn, mf_conv_flops(p3, 1), [=](int B, hipStream_t s) {
+                    if (B < Q_DUAL_MIN) return mf_conv_launch(p3, tv, out, res, B, s);
+                    p->out_stats = p3->out_stats; p->out_stats_groups = p3->out_stats_groups;      // (the consumer GroupNorm asked the remembered plan)
+                    return mf_conv_launch(p, tv, out, res, B, s);
+                });
+                tunables.push_back(Tunable{p3, tv, out, res, (int)ops.size() - 1});
+                stats_remember(p3, out);
+                return MF_OK;
+            }
             // MF_GN_FUSE_Q=1 (opt-in, measured and NOT adopted): GroupNorm-apply + SiLU + the conversion into the operand format INSIDE the conv -- the producer waves
             // of its specialised workgroup rewrite each landed halo image in LDS, so the normalised tensor is neither written nor re-read (k_affine_silu_to_q: 4 B + 4 B
             // per value and a launch per layer, 8 % of the step).  Bit-identical frames (tools/gn_fuse_check.py), but the ~700 VALU instructions per 64 pixels and
@@ -813,6 +846,7 @@ extern "C" int mf_unet_create(const mf_unet_config* c, const mf_tensor* weights,
     Net& net = h->net;
     int rc = net.init(weights, n_weights, precision, max_batch, c->norm_num_groups);
     if (rc) return rc;
+    net.q_dual_allowed = true;   // (tests/test_musetalk_full.py holds the 40-frame handle to the batch-8 parity gate with it)
     const int nb = c->n_blocks, L = c->layers_per_block, G = c->norm_num_groups, heads = c->attention_heads;
     const int* boc = c->block_out_channels;
     const int S = c->sample_size, X = c->cross_attention_dim;

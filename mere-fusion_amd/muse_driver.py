@@ -361,8 +361,11 @@ class EndToEndScheduler(SessionScheduler):
         reserved = {}
         if self.rings is not None:
             B = self.batcher.batch_size
+            pend = self.pending()
             ok = []
-            for k in ks:
+            for k in sorted(pend, key=lambda k_: (pend[k_], k_)):     # oldest first; a waiting session takes the place of one that has to be deferred
+                if len(ok) == len(ks):
+                    break
                 if self.queues[k][0][1][0] is None:                   # silent / context still filling: descriptors only
                     ok.append(k)
                     continue
