@@ -126,6 +126,8 @@ struct ConvPlan {
     // f16 + FP6 plans only: GroupNorm-apply (+ SiLU, + channel equalisation) fused into the conv's halo load (set by the network builder; the launch then takes the
     // GroupNorm's INPUT tensor as `in`): per-(sample, channel) scale / shift [cap][cin] written by mf_groupnorm_affine in front of every launch, per-channel post [cin] or null
     const float* gn_scale = nullptr; const float* gn_shift = nullptr; const float* gn_post = nullptr; int gn_silu = 0;
+    bool q_small_maps = false;   // set BEFORE mf_conv_plan_create (MF_PREC_F16Q): take the f16 + FP6 halo tile on maps from 16 x 16 and up to 2048 input channels as well
+                                 // (the UNet's 640-channel 16 x 16 layers at >= 40 frames per step; the caller keeps a bf16x3 plan for smaller steps)
     bool q = false;       // MF_PREC_F16Q: w_hi = f16 [slice][tap][Npad][32], w_lo = [slice][tap][Npad][q6(wh) 32 B | q6(wl) 32 B] (24 B codes + E8M0 byte + pad)
     bool halo = false;    // 3x3 s1 p1 on a >= 16x16 map: LDS halo-tile kernel, weights packed [slice][tap][Npad][CK]
     bf16_t* up_hi = nullptr;  // nearest-2x-upsample + 3x3 layers that qualify for the fat halo tiles: [phase][slice][4 taps][Npad][CK], pre-summed taps

@@ -999,8 +999,11 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     // slice instead of once per tap; smaller steps launch the twin (mf_halo_w_pick_tile).  Whole step, same-box A/B: 112.6 -> 111.8 ms at 64 frames, equal at
     // 48 and below.  On the 16 x 16 maps (640 channels: one patch per image) it does not pay.
     const bool odd_wide = d.cout >= 256 && d.cout % 128 != 0 && d.cout % 64 == 0 && d.in_h * d.in_w >= 32 * 32;
-    const bool wide_ok = !g_no_halo_wide && d.cin <= 1024 && d.cout <= 1024 && (d.cout % 128 == 0 || odd_wide) && d.cin % 32 == 0 &&
-                         (d.in_h * d.in_w >= 64 * 64 || (d.cout % 256 == 0 && d.cin >= 512) || odd_wide);   // small maps: only the 256-channel tile pays
+    static const bool q_small_env = getenv("MF_Q_HALO_SMALL") != nullptr;  // (measurement: tools/conv_probe.py has no plan to set the flag on)
+    const bool q_small = (p->q_small_maps || q_small_env) && precision == MF_PREC_F16Q && d.cin % 32 == 0 && d.cout % 128 == 0 && d.cin <= 2048 && d.cout <= 1024;
+    const bool wide_ok = (!g_no_halo_wide && d.cin <= 1024 && d.cout <= 1024 && (d.cout % 128 == 0 || odd_wide) && d.cin % 32 == 0 &&
+                         (d.in_h * d.in_w >= 64 * 64 || (d.cout % 256 == 0 && d.cin >= 512) || odd_wide)) ||   // small maps: only the 256-channel tile pays
+                         q_small;   // ... and the f16 + FP6 tile where the caller asked for it: 640 -> 640 @16^2 at 64 frames 360 -> 250 us against the bf16x3 implicit GEMM
     p->halo = !d.transposed && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 1 &&
               d.pad_w == 1 && d.in_h >= 16 && d.in_w >= 16 && d.cin >= 16 && d.residual != 2 && d.act <= 2 && !d.upsample &&
               (narrow || wide_ok) && d.cout % 4 == 0;

@@ -215,8 +215,12 @@ struct Net {
         // bf16x3 LDS-weights tile reaches 405-440 (conv alone, 64 frames: 320 -> 320 298 -> 222 us, 640 -> 320 570 -> 412, 960 -> 320 824 -> 599).  A handle serves
         // steps of every size up to its capacity, so BOTH paths are built and a launch picks by its batch (MF_UNET_Q=0: bf16x3 only).
         static const bool q_unet_on = [] { const char* e = getenv("MF_UNET_Q"); return !e || atoi(e) != 0; }();
-        const bool q_dual = q_on && q_unet_on && q_dual_allowed && precision == MF_PREC_BF16X3 && cout >= 256 && cout % 128 != 0 && cout % 64 == 0 && cin % 32 == 0 &&
-                            t->C == cin && t->H * t->W >= q_minpx && t->H % 16 == 0 && t->W % 16 == 0 && cap >= Q_DUAL_MIN;
+        // ... and its 640-channel convs on the 16 x 16 maps (one patch per image, five channel tiles): 640 -> 640 360 -> 250 us, 1280 -> 640 651 -> 455, 1920 -> 640 934 -> 675
+        // at 64 frames against the bf16x3 implicit GEMM (tools/conv_probe.py with MF_Q_HALO_SMALL=1).
+        const bool q_dual32 = cout >= 256 && cout % 128 != 0 && cout % 64 == 0 && t->H * t->W >= q_minpx;
+        const bool q_dual16 = cout >= 512 && cout % 128 == 0 && cin <= 2048 && t->H == 16 && t->W == 16;
+        const bool q_dual = q_on && q_unet_on && q_dual_allowed && precision == MF_PREC_BF16X3 && (q_dual32 || q_dual16) && cin % 32 == 0 &&
+                            t->C == cin && t->H % 16 == 0 && t->W % 16 == 0 && cap >= Q_DUAL_MIN;
         if (q_dual || (q_on && q_allowed && precision == MF_PREC_BF16X3 && cin % 32 == 0 && cout % 128 == 0 && t->C == cin && t->H * t->W >= q_minpx && cin >= 128 &&
             (int64_t)cap * ((t->H + 15) / 16) * ((t->W + 15) / 16) * (cout / 128) >= 64)) {
             const float* g = T(gname + ".weight", cin);
@@ -287,6 +291,7 @@ struct Net {
             mf_conv2d_desc d{};
             d.cin = cin; d.cout = cout; d.kh = d.kw = 3; d.stride_h = d.stride_w = 1; d.pad_h = d.pad_w = 1; d.residual = res.buf ? 1 : 0; d.in_h = t->H; d.in_w = t->W;
             ConvPlan* p = new_plan();
+            p->q_small_maps = q_dual;
             int rc = mf_conv_plan_create(p, d, w_use, bb.data(), nullptr, nullptr, nullptr, nullptr, MF_PREC_F16Q);
             if (rc) return rc;
             if (!p->q) { err = cname + ": no kernel in the f16 + FP6 format for this layer"; return MF_ERR_INVALID; }
