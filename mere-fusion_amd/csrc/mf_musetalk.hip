@@ -49,7 +49,7 @@ struct Net {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     bool use_graph = true;
     // implicit-GEMM layers with their bound views: measured launch configurations (mf_conv_tune) on the first forward at a batch size
-    struct Tunable { ConvPlan* p; ActView in, out, res; int op; };
+    struct Tunable { ConvPlan* p; ActView in, out, res; int op; ConvPlan* pq = nullptr; };   // pq: the f16 + FP6 plan that takes the launches of >= Q_DUAL_MIN frames (gn_conv)
     std::vector<Tunable> tunables;
     std::set<int> looked_up;                     // (graph-less mode: batch sizes whose table lookup is done)
     // Side branches of the schedule: an op whose result is not needed by its successors in the list -- the hoisted k | v GEMM, a resnet's 1x1
@@ -316,7 +316,7 @@ struct Net {
                     p->out_stats = p3->out_stats; p->out_stats_groups = p3->out_stats_groups;      // (the consumer GroupNorm asked the remembered plan)
                     return mf_conv_launch(p, tv, out, res, B, s);
                 });
-                tunables.push_back(Tunable{p3, tv, out, res, (int)ops.size() - 1});
+                tunables.push_back(Tunable{p3, tv, out, res, (int)ops.size() - 1, p});
                 stats_remember(p3, out);
                 return MF_OK;
             }
@@ -717,7 +717,7 @@ struct Net {
     }
     void name_kernel(const Tunable& t, int B) {
         char kn[96];
-        mf_conv_kernel_name(t.p, B, kn, sizeof(kn));               // the measurement seam names the kernel that actually runs
+        mf_conv_kernel_name(t.pq && B >= Q_DUAL_MIN ? t.pq : t.p, B, kn, sizeof(kn));   // the measurement seam names the kernel that actually runs
         info[t.op].kernel = kn;
     }
     // every buffer holds real data (a forward at this batch size has run): time each implicit-GEMM layer's launch configurations in place
