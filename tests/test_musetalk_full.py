@@ -144,6 +144,14 @@ def test_full_unet_large_batch_handle_vs_oracle(full_sd, oracle_full):
     print(f"MUSETALK_V1 UNet, handle for 40 frames: latents L-inf vs oracle {err:.3e} (gate {TOL_LATENT}); copies of a frame differ by {rep:.3e}")
     assert err <= TOL_LATENT, err
     assert rep <= 1e-4, rep
+    # The same handle at 8 frames: its 320- / 640-channel 3x3 convs of the 32 x 32 / 16 x 16 levels are built twice (f16 + FP6 halo tile from 40 frames per step,
+    # bf16x3 below) and a launch picks by its batch -- both sides of that switch against the oracle, and a 40-frame step again afterwards.
+    small = unet.model(lat[:B], torch.tensor([0]).cuda(), encoder_hidden_states=unet.pe(aud[:B])).sample.cpu()
+    err8 = (small - o["pred"]).abs().max().item()
+    again = unet.model(lat, torch.tensor([0]).cuda(), encoder_hidden_states=unet.pe(aud)).sample.cpu()
+    print(f"... the same handle at 8 frames: {err8:.3e}; 40 frames again: identical = {bool(torch.equal(again, got))}")
+    assert err8 <= TOL_LATENT, err8
+    assert torch.equal(again, got)
 
 
 def test_full_vae_large_batch_handle_vs_oracle(full_sd, oracle_full):
