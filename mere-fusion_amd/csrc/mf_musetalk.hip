@@ -49,7 +49,7 @@ struct Net {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     bool use_graph = true;
     // implicit-GEMM layers with their bound views: measured launch configurations (mf_conv_tune) on the first forward at a batch size
-    struct Tunable { ConvPlan* p; ActView in, out, res; int op; ConvPlan* pq = nullptr; };   // pq: the f16 + FP6 plan that takes the launches of >= Q_DUAL_MIN frames (gn_conv)
+    struct Tunable { ConvPlan* p; ActView in, out, res; int op; ConvPlan* pq = nullptr; };   // pq: the f16 + FP6 plan that takes the launches of >= q_dual_min() frames (gn_conv)
     std::vector<Tunable> tunables;
     std::set<int> looked_up;                     // (graph-less mode: batch sizes whose table lookup is done)
     // Side branches of the schedule: an op whose result is not needed by its successors in the list -- the hoisted k | v GEMM, a resnet's 1x1
@@ -81,8 +81,9 @@ struct Net {
     // the schedule (kv_all = [ctx_len][sum of 2 C]) instead of one small launch per block inside the chain (16 x ~14 us in the UNet at batch 8).
     ActBuf* kv_all = nullptr; int kv_off = 0, kv_op = -1; std::vector<float> kv_w; ActView kv_ctx{}; bool kv_joined = false;
     bool q_allowed = false;     // the f16 + FP6 conv format: the VAE decoder's resnets (set by the builder of a network whose parity was established with it)
-    bool q_dual_allowed = false;   // ... and, from Q_DUAL_MIN frames per step, the UNet's 320-channel 3x3 convs on its 32 x 32 maps (gn_conv builds both paths, a launch picks by its batch)
-    static constexpr int Q_DUAL_MIN = 40;
+    bool q_dual_allowed = false;   // ... and, from q_dual_min() frames per step, the UNet's 320-channel 3x3 convs on its 32 x 32 maps (gn_conv builds both paths, a launch picks by its batch)
+    static int q_dual_min() { static const int v = getenv("MF_UNET_Q_MIN") ? atoi(getenv("MF_UNET_Q_MIN")) : 16; return v; }   // frames per step from which the dual-path convs take the f16 + FP6 kernel
+    // (whole step, same box, bf16x3 -> f16 + FP6 on those twenty layers: 8 frames 18.78 -> 18.78 ms, 16: 32.0 -> 31.6, 24: 45.5 -> 44.7, 32: 58.7 -> 57.4, 64: 109.05 -> 107.66)
     int next_pad_hi = 0;        // consumed by the next conv(): extra zero rows / columns bottom-right (the VAE encoder's Downsample2D)
     std::string err;
 
@@ -211,7 +212,7 @@ struct Net {
         static const bool q_on = [] { const char* e = getenv("MF_CONV_Q"); return !e || atoi(e) != 0; }();
         // (maps below 64 x 64 -- the 512-channel 32 x 32 levels -- run it with the channel slices split over two workgroups per tile, mf_q_split_count)
         const int q_minpx = 32 * 32;
-        // The UNet's 320-channel convs on its 32 x 32 maps (cout = 2.5 tiles of 128): from 40 frames per step the f16 + FP6 tile runs them at 640-730 TF where the
+        // The UNet's 320-channel convs on its 32 x 32 maps (cout = 2.5 tiles of 128): from 16 frames per step (q_dual_min) the f16 + FP6 tile runs them at 640-730 TF where the
         // bf16x3 LDS-weights tile reaches 405-440 (conv alone, 64 frames: 320 -> 320 298 -> 222 us, 640 -> 320 570 -> 412, 960 -> 320 824 -> 599).  A handle serves
         // steps of every size up to its capacity, so BOTH paths are built and a launch picks by its batch (MF_UNET_Q=0: bf16x3 only).
         static const bool q_unet_on = [] { const char* e = getenv("MF_UNET_Q"); return !e || atoi(e) != 0; }();
@@ -220,7 +221,7 @@ struct Net {
         const bool q_dual32 = cout >= 256 && cout % 128 != 0 && cout % 64 == 0 && t->H * t->W >= q_minpx;
         const bool q_dual16 = cout >= 512 && cout % 128 == 0 && cin <= 2048 && t->H == 16 && t->W == 16;
         const bool q_dual = q_on && q_unet_on && q_dual_allowed && precision == MF_PREC_BF16X3 && (q_dual32 || q_dual16) && cin % 32 == 0 &&
-                            t->C == cin && t->H % 16 == 0 && t->W % 16 == 0 && cap >= Q_DUAL_MIN;
+                            t->C == cin && t->H % 16 == 0 && t->W % 16 == 0 && cap >= q_dual_min();
         if (q_dual || (q_on && q_allowed && precision == MF_PREC_BF16X3 && cin % 32 == 0 && cout % 128 == 0 && t->C == cin && t->H * t->W >= q_minpx && cin >= 128 &&
             (int64_t)cap * ((t->H + 15) / 16) * ((t->W + 15) / 16) * (cout / 128) >= 64)) {
             const float* g = T(gname + ".weight", cin);
@@ -296,23 +297,23 @@ struct Net {
             if (rc) return rc;
             if (!p->q) { err = cname + ": no kernel in the f16 + FP6 format for this layer"; return MF_ERR_INVALID; }
             if (q_dual) {
-                // the bf16x3 path of the same layer for steps below Q_DUAL_MIN frames (its own plan, LDS-weights tile / implicit-GEMM twin as before); both
+                // the bf16x3 path of the same layer for steps below q_dual_min() frames (its own plan, LDS-weights tile / implicit-GEMM twin as before); both
                 // paths read the normalised tensor from `t`, whose second plane holds bf16 lo values or FP6 blocks as the path writes them
                 ConvPlan* p3 = nullptr;
                 if ((rc = conv(cname, tv, out, cin, cout, 3, 1, 1, 0, res, 0, extra_bias, 1.f, true, &p3))) return rc;
                 if ((rc = mf_conv_bind(p, *t))) return rc;
                 const ActBuf* tq = t;
                 const bool epi = take_stats(x, groups, st);
-                push(gname, epi ? "k_gn_apply | k_affine_silu_to_q from 40 frames (statistics from the producer's epilogue)" : "k_gn_stats+k_gn_apply | +k_affine_silu_to_q from 40 frames", 0.0,
+                push(gname, epi ? "k_gn_apply | k_affine_silu_to_q from q_dual_min frames (statistics from the producer's epilogue)" : "k_gn_stats+k_gn_apply | +k_affine_silu_to_q from q_dual_min frames", 0.0,
                      [=](int B, hipStream_t s) {
-                         if (B < Q_DUAL_MIN) return mf_groupnorm(x, tv, dg, db, groups, eps, true, st, B, s, epi);
+                         if (B < q_dual_min()) return mf_groupnorm(x, tv, dg, db, groups, eps, true, st, B, s, epi);
                          const int r1 = mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s, epi);
                          return r1 ? r1 : mf_affine_silu_to_act_q(x, scale, shift, 1, *tq, B, s, d_post);
                      });
                 char kn[96];
-                mf_conv_kernel_name(cap >= Q_DUAL_MIN ? p : p3, cap, kn, sizeof(kn));
+                mf_conv_kernel_name(cap >= q_dual_min() ? p : p3, cap, kn, sizeof(kn));
                 push(cname, kn, mf_conv_flops(p3, 1), [=](int B, hipStream_t s) {
-                    if (B < Q_DUAL_MIN) return mf_conv_launch(p3, tv, out, res, B, s);
+                    if (B < q_dual_min()) return mf_conv_launch(p3, tv, out, res, B, s);
                     p->out_stats = p3->out_stats; p->out_stats_groups = p3->out_stats_groups;      // (the consumer GroupNorm asked the remembered plan)
                     return mf_conv_launch(p, tv, out, res, B, s);
                 });
@@ -717,7 +718,7 @@ struct Net {
     }
     void name_kernel(const Tunable& t, int B) {
         char kn[96];
-        mf_conv_kernel_name(t.pq && B >= Q_DUAL_MIN ? t.pq : t.p, B, kn, sizeof(kn));   // the measurement seam names the kernel that actually runs
+        mf_conv_kernel_name(t.pq && B >= q_dual_min() ? t.pq : t.p, B, kn, sizeof(kn));   // the measurement seam names the kernel that actually runs
         info[t.op].kernel = kn;
     }
     // every buffer holds real data (a forward at this batch size has run): time each implicit-GEMM layer's launch configurations in place
