@@ -733,7 +733,7 @@ class PacedRig:
                     except _q.Empty:
                         pass
                 if idle:
-                    time.sleep(0.0005)
+                    time.sleep(0.001)
         th = None
         if use_r:
             th = threading.Thread(target=drain, daemon=True)
@@ -766,8 +766,8 @@ class PacedRig:
             dt = (min(due) if due else now) - time.perf_counter()
             if dt > 1e-3:
                 time.sleep(dt - 5e-4)
-            elif dt > 1e-4:
-                time.sleep(1e-4)                                            # (a step is in flight: yield the GIL to the consumer thread between polls)
+            elif dt > 0:
+                time.sleep(dt)                                              # (a step is in flight: the scheduler asks to be polled again in 0.5 ms; the consumer thread runs meanwhile)
         wall = time.perf_counter() - t_start
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
         host_cpu = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / wall     # scheduler loop + consumer thread + runtime threads of this process
@@ -1467,6 +1467,11 @@ def main():
                                     "admission": "harness.SessionPlacer: cap = sum of the measured per-GPU capacities (app.py:42,79-80,705), a new session goes to "
                                                  "the GPU with the lowest load fraction",
                                     "north_star_target": ">= 64 sessions on 8 GPUs = 8 per GPU"}
+                    hc = (mine["end_to_end"]["at_max"] or {}).get("host_cpu_s_per_wall_s")
+                    if hc is not None:
+                        # what the HOST side of a full node needs: every rank carrying its sustained session count (scheduler loop, consumer thread, PCM hand-in, launches)
+                        line["node"]["host_cpu_s_per_wall_s_per_rank_at_capacity"] = hc
+                        line["node"]["host_cores_for_8_ranks_at_capacity"] = round(8 * hc, 1)
                     if not solo:
                         line["paced_sessions_rank0"] = mine
         if rank == 0 and extras and args.sessions > 0 and getattr(args, "paced", 1):

@@ -343,7 +343,7 @@ class EndToEndScheduler(SessionScheduler):
 
     def next_due(self):
         if self.inflight:
-            return self.clock() + 2e-4                                # something to retire: poll again shortly
+            return self.clock() + 5e-4                                # something to retire: poll again shortly (5 kHz polling cost a rank 1.3 - 1.9 host cores at 22 sessions)
         return super().next_due()
 
     def run_once(self, now=None):
