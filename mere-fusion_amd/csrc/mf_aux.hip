@@ -1,5 +1,6 @@
 // Layout-conversion and head kernels (HBM-bound elementwise passes; see mf_aux.h).
 #include "mf_aux.h"
+#include <cstdlib>
 
 namespace {
 
@@ -377,6 +378,106 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restri
         if (ok) { *reinterpret_cast<uint4*>(yh + o) = ph; *reinterpret_cast<uint4*>(yl + o) = pl; }
     }
 }
+
+// The same conversion with the 32-channel block UNIFORM over a wave: wave `wid` owns block g = wid % nblk of 64 consecutive pixels of one image
+// (needs H * W % 64 == 0), so the 96 per-channel parameters are scalar loads into SGPRs instead of 24 vector loads and 96 VGPRs per thread, and the
+// four waves of a workgroup cover four neighbouring blocks of the same pixels (their 64-byte pieces are halves of the same lines).  Thread <-> data
+// ownership, the LDS transposition and the arithmetic are k_affine_silu_to_q's, bit for bit.
+template <bool SILU, bool POST>
+__global__ __launch_bounds__(256) void k_affine_silu_to_q_u(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, int xC, int xcoff, int xhalo, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ post, int C, int H, int W, bf16_t* yh, bf16_t* yl,
+                                                            int yC, int yhalo, int nchunk, int cpb, int nblk, int xcd_order) {
+    __shared__ uint4 s_img[2][4][256];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Workgroup b runs on XCD b % 8.  Each XCD walks its OWN sequence of waves (chunk' = jw / nblk, g = jw % nblk, chunk = 8 * chunk' + xcd): all blocks of a
+    // chunk go through one L2, back to back, and every XCD touches every 256-byte piece of the pixel rows -- with wid = b * 4 + wave and C = 512 an XCD would only
+    // ever see blocks g = 4 * (xcd % 4) + {0..3}, a quarter of the address interleave (measured 4.2 instead of 5.5 TB/s).
+    int chunk, g;
+    if (xcd_order) {
+        const int jw = (blockIdx.x >> 3) * 4 + wv, cl = __builtin_amdgcn_readfirstlane(jw / nblk);
+        g = jw - cl * nblk; chunk = cl * 8 + (blockIdx.x & 7);
+    } else {
+        const int wid = blockIdx.x * 4 + wv;
+        chunk = __builtin_amdgcn_readfirstlane(wid / nblk); g = wid - chunk * nblk;
+    }
+    if (chunk >= nchunk) return;                                    // (a whole wave; the LDS image is wave-private, no barrier in this kernel)
+    const int b = __builtin_amdgcn_readfirstlane(chunk / cpb);
+    const int pix = (chunk - b * cpb) * 64 + lane;
+    const int y = pix / W, x = pix - y * W;
+    const int xo = ((b * (H + 2 * xhalo) + y + xhalo) * (W + 2 * xhalo) + x + xhalo) * xC + xcoff + g * 32;
+    const int yo = ((b * (H + 2 * yhalo) + y + yhalo) * (W + 2 * yhalo) + x + yhalo) * yC + g * 32;
+    const float* __restrict__ sc = scale + b * C + g * 32;          // wave-uniform: scalar loads
+    const float* __restrict__ sh = shift + b * C + g * 32;
+    const float* __restrict__ po = post + g * 32;
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    typedef _Float16 v32h __attribute__((ext_vector_type(32)));
+    typedef unsigned v6u __attribute__((ext_vector_type(6)));
+    typedef unsigned v16u __attribute__((ext_vector_type(16)));
+    v16f le, lod;
+    float mh = 0.f, ml = 0.f;
+    v16u hbits;
+    uint4 av[4], cv[4];
+    const int sub = lane & 3;
+    {
+        uint4 in_h[4], in_l[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = __shfl(xo, (q * 64 + lane) >> 2) + 8 * sub;
+            in_h[q] = *reinterpret_cast<const uint4*>(xh + o);
+            in_l[q] = *reinterpret_cast<const uint4*>(xl + o);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pc = q * 64 + lane;
+            s_img[0][wv][pc ^ ((pc >> 4) & 3)] = in_h[q];
+            s_img[1][wv][pc ^ ((pc >> 4) & 3)] = in_l[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int pc = lane * 4 + q; av[q] = s_img[0][wv][pc ^ ((pc >> 4) & 3)]; cv[q] = s_img[1][wv][pc ^ ((pc >> 4) & 3)]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t aw[4] = {av[q].x, av[q].y, av[q].z, av[q].w}, cw[4] = {cv[q].x, cv[q].y, cv[q].z, cv[q].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // The operation sequence is spelled out (one fused multiply-add, then separately rounded products): left to -ffp-contract=fast the residual below
+            // becomes fma(v, 1 / (1 + e^-v), -f16(v)) in the instantiations without `post`, one rounding less than k_affine_silu_to_q and the GroupNorm-fused
+            // convolution (mf_conv_halo2.hip gn_transform) make -- all three must agree bit for bit (tests/test_musetalk_stress.py).
+#pragma clang fp contract(off)
+            const int k = 8 * q + e;
+            const uint32_t hw = (e & 1) ? aw[e >> 1] >> 16 : aw[e >> 1] & 0xffffu, lw = (e & 1) ? cw[e >> 1] >> 16 : cw[e >> 1] & 0xffffu;
+            float v = bf2f_d(hw) + bf2f_d(lw);
+            v = __builtin_fmaf(v, sc[k], sh[k]);
+            if constexpr (SILU) v = v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
+            if constexpr (POST) v *= po[k];                         // (a power of two: exact)
+            const _Float16 h = (_Float16)v;
+            const float vhk = (float)h, vlk = v - vhk;
+            mh = fmaxf(mh, fabsf(vhk)); ml = fmaxf(ml, fabsf(vlk));
+            if (k & 1) lod[k >> 1] = vlk; else le[k >> 1] = vlk;
+            const uint32_t hb = __builtin_bit_cast(uint16_t, h);
+            if (k & 1) hbits[k >> 1] |= hb << 16; else hbits[k >> 1] = hb;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int pc = lane * 4 + q; s_img[0][wv][pc ^ ((pc >> 4) & 3)] = make_uint4(hbits[4 * q], hbits[4 * q + 1], hbits[4 * q + 2], hbits[4 * q + 3]); }
+    const uint32_t bl = max((__float_as_uint(ml) >> 23) & 0xffu, 2u) - 2u, bh = max((__float_as_uint(mh) >> 23) & 0xffu, 2u) - 2u;
+    const v6u ql = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(le, lod, __uint_as_float(bl << 23));
+    const v6u qh = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(v32h, hbits), __uint_as_float(bh << 23));
+    {
+        const int p0 = lane * 4;
+        s_img[1][wv][(p0 + 0) ^ ((p0 >> 4) & 3)] = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+        s_img[1][wv][(p0 + 1) ^ ((p0 >> 4) & 3)] = make_uint4(ql[4], ql[5], bl, 0u);
+        s_img[1][wv][(p0 + 2) ^ ((p0 >> 4) & 3)] = make_uint4(qh[0], qh[1], qh[2], qh[3]);
+        s_img[1][wv][(p0 + 3) ^ ((p0 >> 4) & 3)] = make_uint4(qh[4], qh[5], bh, 0u);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int pc = q * 64 + lane;
+        const int o = __shfl(yo, pc >> 2) + 8 * sub;
+        const uint4 ph = s_img[0][wv][pc ^ ((pc >> 4) & 3)], pl = s_img[1][wv][pc ^ ((pc >> 4) & 3)];
+        *reinterpret_cast<uint4*>(yh + o) = ph; *reinterpret_cast<uint4*>(yl + o) = pl;
+    }
+}
 }  // namespace
 
 int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* shift, int silu, const ActBuf& dst, int batch, hipStream_t s, const float* post) {
@@ -386,6 +487,24 @@ int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* s
     MF_REQUIRE((int64_t)batch * xb.per_batch() < ((int64_t)1 << 31) && (int64_t)batch * dst.per_batch() < ((int64_t)1 << 31),
                "affine_silu_to_act_q: tensors of 2^31 elements or more are not supported (32-bit offsets)");
     const int64_t total = (int64_t)batch * xb.H * xb.W * (x.C / 32);
+    // MF_AFFQ_VARIANT (measurement, tools/affine_q_probe.hip): 0 = the per-thread-parameter kernel everywhere, 1 = wave-uniform blocks in launch order,
+    // 2 (default) = wave-uniform blocks, XCD-ordered when a pixel row is wider than one workgroup's four blocks
+    static const int variant = getenv("MF_AFFQ_VARIANT") ? atoi(getenv("MF_AFFQ_VARIANT")) : 2;
+    if (variant >= 1 && (xb.H * xb.W) % 64 == 0) {
+        const int cpb = xb.H * xb.W / 64, nchunk = batch * cpb, nblk = x.C / 32;
+        const int64_t waves = (int64_t)nchunk * nblk;
+        const int xcd_order = variant >= 2 && nblk > 4 && waves >= 16384;
+        const int64_t waves_per_xcd = (int64_t)((nchunk + 7) / 8) * nblk;
+        const dim3 grid(xcd_order ? (unsigned)(8 * ((waves_per_xcd + 3) / 4)) : (unsigned)((waves + 3) / 4));
+#define MF_AFFQ_U(S, P)                                                                                                                                                     \
+    hipLaunchKernelGGL((k_affine_silu_to_q_u<S, P>), grid, dim3(256), 0, s, xb.hi, xb.lo, xb.C, x.coff, xb.halo, scale, shift, post, x.C, xb.H, xb.W, dst.hi, dst.lo, dst.C, \
+                       dst.halo, nchunk, cpb, nblk, xcd_order)
+        if (silu) { if (post) MF_AFFQ_U(true, true); else MF_AFFQ_U(true, false); }
+        else      { if (post) MF_AFFQ_U(false, true); else MF_AFFQ_U(false, false); }
+#undef MF_AFFQ_U
+        MF_HIP(hipGetLastError());
+        return MF_OK;
+    }
     hipLaunchKernelGGL(k_affine_silu_to_q, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xb.hi, xb.lo, xb.C, x.coff, xb.halo, scale, shift, post, x.C, silu, xb.H, xb.W, dst.hi,
                        dst.lo, dst.C, dst.halo, total);
     MF_HIP(hipGetLastError());
