@@ -617,7 +617,7 @@ def muse_multi_session(args, device):
             rep["fps_per_session"] = round(B * 5 / el, 1)
     if getattr(args, "paced", 1):
         _stage("paced sessions")
-        rep["paced_sessions"] = muse_paced_sessions(big, args, device, rep["value"], full=True)
+        rep["paced_sessions"] = muse_paced_sessions(big, args, device, rep["value"], full=bool(getattr(args, "full", 0)))
     rows_b = big.profile(2)
     cb = [r for r in rows_b if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
     tb, fb = sum(r["ms"] for r in cb), sum(r["flops"] for r in cb)
@@ -833,7 +833,10 @@ def muse_paced_sessions(big, args, device, free_fps, full=True):
     cap = max(int(free_fps / 25.0), 1)
     rig = PacedRig(big, args, device, n_max=cap + 4)
     try:
-        e2e, e2e_trials = rig.search(cap, ("whisper", "paste", "ring"), screen_s=4.0, confirm_s=40.0, fail_s=20.0)
+        # default run: 3 s screening trials + ONE 15 s confirmation (the whole bench stays under ~4 minutes); --full 1: the 40 s confirmation, N + 1 shown failing
+        # over 20 s, the UNet + VAE only search and the per-stage trials (round 4's measurement, ~150 s)
+        long_ = bool(getattr(args, "full", 0))
+        e2e, e2e_trials = rig.search(cap, ("whisper", "paste", "ring"), screen_s=4.0 if long_ else 3.0, confirm_s=40.0 if long_ else 15.0, fail_s=20.0 if long_ else 0.0)
         rep = {"criterion": f"p99 latency of a session's {B}-frame batch <= {B} x 40 ms = {P * 1e3:.0f} ms, every batch delivered, and no queue growth (mean latency of the "
                             f"last third of the batches - of the first third <= {P * 100:.0f} ms); real time, seeded random phases, one batch per session per {P * 1e3:.0f} ms",
                "scheduler": f"mere_fusion_amd.muse_driver.EndToEndScheduler / SessionScheduler: oldest first, <= {S} sessions per step, a partly filled step waits <= {P * 250:.0f} ms; "
@@ -1231,6 +1234,189 @@ def ernerf_report(args, device, world, rank, value=None, ms_per_step=None, run=N
 
 _T0 = time.perf_counter()
 
+# ---- the ONE stdout line --------------------------------------------------------------------------------------------------------------
+# The driver keeps only the tail of stdout and parses its last line: round 4's line had grown to 24 KB and did not parse (BENCH_r04.json "parsed": null).
+# The stdout line is now a compact object (<= COMPACT_LIMIT bytes: contract keys, `roofline` and `cpu_baseline` as numbers, one summary object per
+# secondary leg); everything else -- trial lists, per-rank rows, notes -- goes to bench_detail.json beside this script (and gpurun_out/ when it exists).
+COMPACT_LIMIT = 6000
+DETAIL_NAME = "bench_detail.json"
+
+
+def _dig(o, *path, default=None):
+    for k in path:
+        if isinstance(o, dict) and k in o:
+            o = o[k]
+        elif isinstance(o, (list, tuple)) and isinstance(k, int) and -len(o) <= k < len(o):
+            o = o[k]
+        else:
+            return default
+    return o
+
+
+def _pick(o, keys, rename=None):
+    """the sub-dict of `o` with `keys` that are present and not None (floats rounded to 6 significant digits)"""
+    out = {}
+    for k in keys:
+        v = _dig(o, k)
+        if v is None:
+            continue
+        if isinstance(v, float):
+            v = float(f"{v:.6g}")
+        out[(rename or {}).get(k, k)] = v
+    return out
+
+
+def _short(sv, n):
+    return sv if not isinstance(sv, str) or len(sv) <= n else sv[:n - 3].rstrip() + "..."
+
+
+_ROOFLINE_KEYS = ("bound", "kernel", "launches_per_step", "launches_per_frame", "avg_launch_us", "alg_gflop_per_launch", "alg_flop_per_sample", "achieved", "peak", "unit", "frac",
+                  "frac_of_dense_f16_peak", "traffic", "traffic_gbytes_per_s", "mfma_passes_per_product", "kernel_share_of_step", "sum_of_launches_ms")
+
+
+def compact_roofline(rf):
+    """`roofline` as numbers only: the contract's fields, the dense-peak fraction whatever the operand format, the package power, cap and
+    shader clock the kernel runs at (back to back, worst = largest-share grid first) and the MFMA-only ceiling of its instruction mix."""
+    if not isinstance(rf, dict):
+        return rf
+    out = _pick(rf, _ROOFLINE_KEYS)
+    out.setdefault("traffic", None)
+    rows = _dig(rf, "power", "rows", default=[]) or []
+    if rows:
+        ws = [r.get("socket_w") for r in rows if r.get("socket_w") is not None]
+        fs = [r.get("sclk_mhz") for r in rows if r.get("sclk_mhz") is not None]
+        if ws:
+            out["socket_w"] = round(sum(ws) / len(ws))
+            out["cap_w"] = next((r.get("cap_w") for r in rows if r.get("cap_w")), None)
+        if fs:
+            out["sclk_mhz"] = round(sum(fs) / len(fs))
+        out["alone_tflops_by_grid"] = [r.get("algorithmic_tflops") for r in rows]
+    ceil = rf.get("mfma_only_ceiling_tflops")
+    if isinstance(ceil, dict):
+        key = "f16_plus_2_mx_fp6" if "f16+fp6" in str(rf.get("kernel")) else ("bf16_single_pass" if "bf16_single_pass" in ceil else "bf16x3_12_bf16_mfma_per_128k")
+        out["mfma_only_ceiling"] = _pick(ceil, (key, key + "_layer_data"), {key: "random_bits", key + "_layer_data": "layer_data"})
+    if rf.get("frac_of_mfma_only_ceiling") is not None:
+        out["frac_of_mfma_only_ceiling"] = rf["frac_of_mfma_only_ceiling"]
+    return out
+
+
+def compact_cpu(cb):
+    if not isinstance(cb, dict):
+        return cb
+    out = _pick(cb, ("value", "unit", "cores", "kind", "cpu_model", "gflops"))
+    out["sample"] = _short(cb.get("sample", ""), 110)
+    return out
+
+
+def compact_line(full):
+    """The line the driver parses: every contract key of the full line, `roofline` / `cpu_baseline` / `parity` / `repeats`, and one summary object per secondary leg."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: full[k] for k in keep if k in full}
+    cfg = dict(full.get("config", {}))
+    cfg["workload"] = _short(cfg.get("workload", ""), 200)
+    cfg["parallelism"] = _short(cfg.get("parallelism", ""), 70)
+    out["config"] = cfg
+    for k in ("net_tflops", "samples_per_frame", "march_iterations", "field_tflops_algorithmic"):
+        if k in full:
+            out[k] = full[k]
+    if "roofline" in full:
+        out["roofline"] = compact_roofline(full["roofline"])
+        pw = _dig(full, "repeats", "power")
+        if pw:                                                             # the timed region's own package power and shader clock
+            out["roofline"].update(_pick(pw, ("socket_w", "cap_w", "sclk_mhz"), {"socket_w": "step_socket_w", "cap_w": "cap_w", "sclk_mhz": "step_sclk_mhz"}))
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = compact_cpu(full["cpu_baseline"])
+    if "parity" in full:
+        out["parity"] = {k: (_short(v, 60) if isinstance(v, str) else v) for k, v in _pick(full["parity"], tuple(full["parity"])).items() if k != "note"}
+    if "repeats" in full:
+        out["repeats"] = _pick(full["repeats"], ("n", "median", "min", "max", "spread_pct"))
+    if "phases" in full:
+        out["phases"] = full["phases"]
+    if "unet_conv_blocks" in full:
+        out["unet_conv_blocks"] = full["unet_conv_blocks"]
+    if "with_d2h" in full:
+        out["with_d2h"] = _pick(full["with_d2h"], ("value", "ms_per_step"))
+    if "alt" in full:
+        out["alt"] = _pick(full["alt"], ("dtype", "value", "latent_linf_vs_oracle", "linf_vs_oracle", "u8_max_diff"))
+    ms_ = full.get("multi_session")
+    if isinstance(ms_, dict):
+        at = _dig(ms_, "paced_sessions", "end_to_end", "at_max", default={}) or {}
+        s_ = _pick(ms_, ("sessions_per_step", "batch_per_session", "value", "ms_per_step", "with_gpu_paste_back_720p"), {"value": "frames_per_s"})
+        s_["sessions_per_gpu_at_25fps_end_to_end"] = _dig(ms_, "paced_sessions", "max_sessions_sustained")
+        s_.update(_pick(at, ("p50_ms", "p99_ms", "seconds", "gpu_busy_frac", "host_cpu_s_per_wall_s")))
+        uv = _dig(ms_, "paced_sessions", "unet_vae_only", "max_sessions_sustained")
+        if uv is not None:
+            s_["unet_vae_only_sessions"] = uv
+        ucb = _dig(ms_, "unet_conv_blocks", "mfma_issue_frac_of_bf16_peak")
+        if ucb is not None:
+            s_["unet_conv_blocks_mfma_issue_frac"] = ucb
+        for k in ("streams", "cross_session_batch"):                        # (the wav2lip headline's multi_session)
+            if _dig(ms_, k, "value") is not None:
+                s_[k + "_frames_per_s"] = ms_[k]["value"]
+        out["sessions"] = s_
+    nd = full.get("node")
+    if isinstance(nd, dict):
+        n_ = _pick(nd, ("gpus", "sessions_per_node", "worst_rank_p99_ms", "latency_bound_ms", "host_cpu_s_per_wall_s_per_rank_at_capacity", "host_cores_for_8_ranks_at_capacity"))
+        r1 = nd.get("ranks_on_one_gpu_one_session_each") or {}
+        if r1:
+            n_["ranks_on_one_gpu_8x1"] = _pick(r1, ("all_sustained", "worst_rank_p99_ms", "host_cpu_s_per_wall_s_total", "frames_per_s_total", "error"))
+        if world_rows := nd.get("per_rank"):
+            if len(world_rows) > 1:
+                n_["sessions_by_rank"] = [r.get("max_sessions_sustained") for r in world_rows]
+        out["node"] = n_
+    w = full.get("wav2lip")
+    if isinstance(w, dict):
+        w_ = _pick(w, ("value", "unit", "ms_per_step", "dtype", "net_tflops"))
+        w_["roofline"] = _pick(w.get("roofline", {}), ("kernel", "launches_per_step", "avg_launch_us", "achieved", "peak", "frac", "frac_of_dense_f16_peak", "traffic"))
+        w_["linf_vs_oracle"] = _dig(w, "parity", "linf_vs_oracle")
+        w_["cpu_baseline"] = _pick(w.get("cpu_baseline", {}), ("value", "unit", "cores", "kind"))
+        w_["cross_session_batch_frames_per_s"] = _dig(w, "multi_session", "cross_session_batch", "value")
+        w_["config0_b1_streaming"] = {"gpu_ms_per_frame_p50": _dig(w, "config0", "gpu", "ms_per_frame_p50"), "cpu_frames_per_s": _dig(w, "config0", "cpu_baseline", "value"),
+                                      "u8_max_diff": _dig(w, "config0", "parity", "u8_max_diff_vs_cpu_oracle")}
+        out["wav2lip"] = w_
+    e = full.get("ernerf")
+    if isinstance(e, dict):
+        e_ = _pick(e, ("value", "unit", "ms_per_step", "dtype", "samples_per_frame"))
+        e_["roofline"] = _pick(e.get("roofline", {}), ("kernel", "avg_launch_us", "achieved", "peak", "frac"))
+        e_["image_linf_vs_oracle"] = _dig(e, "parity", "image_linf_max_vs_oracle")
+        e_["cpu_baseline"] = _pick(e.get("cpu_baseline", {}), ("value", "unit", "cores", "kind"))
+        out["ernerf"] = e_
+    wh = full.get("whisper")
+    if isinstance(wh, dict):
+        out["whisper_ms_per_window"] = _pick(wh, tuple(k for k in wh if k.startswith("exact_") and not k.endswith("linf_vs_full")))
+    ft = full.get("frame_transport")
+    if isinstance(ft, dict):
+        out["frame_transport"] = _pick(ft, ("device_batch_to_ring_and_out_ms", "device_batch_reference_handoff_ms", "frame_ring_put_batch", "mp_queue_pickled"))
+    c0 = full.get("config0")
+    if isinstance(c0, dict):                                                # (the wav2lip headline carries its configs[0] leg at top level)
+        out["config0_b1_streaming"] = {"gpu_ms_per_frame_p50": _dig(c0, "gpu", "ms_per_frame_p50"), "cpu_frames_per_s": _dig(c0, "cpu_baseline", "value")}
+    out["bench_wall_s"] = round(time.perf_counter() - _T0, 1)
+    out["detail"] = DETAIL_NAME
+    # the size guard: drop the optional summaries, last first, until the line fits
+    for k in ("frame_transport", "whisper_ms_per_window", "alt", "with_d2h", "phases", "ernerf", "wav2lip", "node", "sessions", "repeats", "unet_conv_blocks"):
+        if len(json.dumps(out)) <= COMPACT_LIMIT:
+            break
+        out.pop(k, None)
+    return out
+
+
+def emit(full):
+    """bench_detail.json (the full object) beside the script and under gpurun_out/ when that exists; the compact object as the ONE stdout line."""
+    line = compact_line(full)
+    blob = json.dumps(full, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_NAME), "w") as f:
+                    f.write(blob)
+            except OSError as e_:
+                print(f"[bench] could not write {d}/{DETAIL_NAME}: {e_}", file=sys.stderr)
+    text = json.dumps(line)
+    assert len(text) <= COMPACT_LIMIT and "\n" not in text
+    sys.stdout.flush()
+    print(text, flush=True)
+    return line
+
 
 def _stage(name):
     """Wall-clock of the bench's own stages on stderr (the JSON line on stdout stays alone)."""
@@ -1246,7 +1432,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="MuseTalk frames per step (configs[2]: 8)")
     ap.add_argument("--w2l-batch", type=int, default=16, help="Wav2Lip frames per step (configs[1]: 16)")
     ap.add_argument("--precision", default=os.environ.get("MF_PRECISION", "bf16x3"), choices=sorted(MFMA_PASSES))
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 skips the CPU baseline legs")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="0 skips the CPU baseline legs")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = cores available to this process (capped at 64)")
     ap.add_argument("--profile-iters", type=int, default=5)
     ap.add_argument("--dump-layers", default=None, help="write the per-launch tables (JSON) to this path")
@@ -1254,6 +1440,8 @@ def main():
     ap.add_argument("--paced", type=int, default=1, help="0 skips the real-time paced-sessions measurement of the multi_session leg")
     ap.add_argument("--pmc-traffic", type=int, default=1, help="0 skips the two rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--extras", type=int, default=1, help="0: only the headline workload (no second workload, alt mode, CPU legs)")
+    ap.add_argument("--full", type=int, default=0, help="1: the long variants of the secondary legs (40 s paced confirmation + failing N + 1, UNet + VAE only search, per-stage trials, "
+                                                        "8 ranks x 2 sessions on one GPU, the GRBM clock pass): ~6.5 min instead of ~3.5")
     ap.add_argument("--ranks-on-one-gpu", type=int, default=0, help="R > 0: ONLY the host-readiness leg -- R processes sharing GPU 0, each driving --sessions end-to-end "
                                                                       "sessions (default 2) in real time; the default line runs it with R = 8")
     ap.add_argument("--worker-rank", type=int, default=-1, help=argparse.SUPPRESS)
@@ -1300,7 +1488,7 @@ def main():
             for k in ("samples_per_frame", "march_iterations", "field_tflops_algorithmic", "roofline", "parity", "cpu_baseline"):
                 if k in rep:
                     line[k] = rep[k]
-            print(json.dumps(line), flush=True)
+            emit(line)
     elif args.workload == "wav2lip":
         run = Runner(args.precision, args.w2l_batch, device, seed=rank)
         elapsed = harness.timed_steps(run.step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=device)
@@ -1318,7 +1506,7 @@ def main():
             for k in ("roofline", "parity", "alt", "multi_session", "cpu_baseline", "config0"):
                 if k in rep:
                     line[k] = rep[k]
-            print(json.dumps(line), flush=True)
+            emit(line)
     else:
         _stage("build MuseTalk handles")
         run = MuseTalkRunner(args.precision, args.batch, device, seed=rank)
@@ -1371,7 +1559,7 @@ def main():
             rf, by = roofline(rows, args.precision, only_mfma=True)
             if extras and args.pmc_traffic:
                 _stage("musetalk PMC traffic passes")
-                rf["traffic"], rf["traffic_note"], clk = pmc_traffic(rf["kernel"], "musetalk", args.precision, ["--batch", str(args.batch)], grids=set(rf["launch_grids"]))
+                rf["traffic"], rf["traffic_note"], clk = pmc_traffic(rf["kernel"], "musetalk", args.precision, ["--batch", str(args.batch)], want_clock=bool(args.full), grids=set(rf["launch_grids"]))
                 if rf["traffic"]:
                     rf["traffic"] = round(rf["traffic"])
                     rf["traffic_gbytes_per_s"] = round(rf["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9, 1)
@@ -1403,6 +1591,15 @@ def main():
                 t = sum(r["ms"] for r in conv_rows); f = sum(r["flops"] for r in conv_rows)
                 line["unet_conv_blocks"] = {"achieved_tflops": round(f / (t * 1e-3) / 1e12, 1), "ms": round(t, 3),
                                             "mfma_issue_frac_of_bf16_peak": round(MFMA_PASSES[args.precision] * f / (t * 1e-3) / 1e12 / BF16_DENSE_PEAK_TF, 3)}
+            # where the step's time goes, by network: the per-op hipEvent sums (graph off) of the UNet and of the VAE decoder
+            ph = {}
+            for tag in ("unet", "vae"):
+                rr = [r for r in rows if r["layer"].startswith(tag + ":")]
+                ph[tag + "_ms"] = round(sum(r["ms"] for r in rr), 3)
+                ph[tag + "_ops"] = len(rr)
+                fl = sum(r["flops"] for r in rr)
+                ph[tag + "_tflops"] = round(fl / max(ph[tag + "_ms"], 1e-9) / 1e9, 1)
+            line["phases"] = ph
             _stage("parity vs oracle")
             line["parity"] = run.parity()
             # the same step bracketed as the reference brackets it (musereal.py:99-115): uint8 frames copied to the host inside the timed region
@@ -1479,8 +1676,10 @@ def main():
             torch.cuda.empty_cache()
             # 8 x 2 sessions load ONE GPU to ~85 % from eight time-sharing processes (the ranks' p99 then mostly measures that sharing); 8 x 1 leaves it half idle and
             # shows the host side by itself
-            line.setdefault("node", {})["ranks_on_one_gpu"] = ranks_on_one_gpu(args, 8, 2, 20.0)
-            light = ranks_on_one_gpu(args, 8, 1, 12.0)
+            if args.full:
+                line.setdefault("node", {})["ranks_on_one_gpu"] = ranks_on_one_gpu(args, 8, 2, 20.0)
+            light = ranks_on_one_gpu(args, 8, 1, 12.0 if args.full else 8.0)
+            line.setdefault("node", {})
             line["node"]["ranks_on_one_gpu_one_session_each"] = {k: light.get(k) for k in ("ranks", "sessions_per_rank", "seconds", "wall_s", "worst_rank_p99_ms", "all_sustained",
                                                                                               "host_cpu_s_per_wall_s_per_rank", "host_cpu_s_per_wall_s_total", "frames_per_s_total", "error")}
         if rank == 0 and extras:
@@ -1492,7 +1691,7 @@ def main():
             line["ernerf"] = ernerf_report(args, device, world, rank)
         if rank == 0:
             _stage("done")
-            print(json.dumps(line), flush=True)
+            emit(line)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
