@@ -711,33 +711,30 @@ class PacedRig:
                                       asr_stream=os.environ.get("MF_BENCH_ASR_INLINE") != "1")   # (A/B: the Whisper call on the step's own stream)
         else:
             sch = D.SessionScheduler(bat, period_s=P)
-        # the consumer (`process_frames`, lipreal.py:195): one thread draining every session's ring; a batch is delivered when its last tuple is held
+        # the consumers (`process_frames`, lipreal.py:195 / musereal.py:226): one thread per session BLOCKED in its ring's get(timeout), as the reference's are
+        # in `res_frame_queue.get(block=True, timeout=1)`; a batch is delivered when its last tuple is held.  (Round 4 polled all rings from one thread every
+        # millisecond: 22 k get_nowait()s per second were a quarter of the rank's host CPU.)
         got_t = [[] for _ in range(N)]
         stop = threading.Event()
 
-        def drain():
+        def drain(k):
             import queue as _q
-            cnt = [0] * N
+            cnt = 0
             while not stop.is_set():
-                idle = True
-                for k in range(N):
-                    try:
-                        while True:
-                            f, idx, au = rings[k].get(block=False, copy=False)
-                            if f is not None:
-                                rings[k].release()
-                            cnt[k] += 1
-                            if cnt[k] % B == 0:
-                                got_t[k].append(time.perf_counter())
-                            idle = False
-                    except _q.Empty:
-                        pass
-                if idle:
-                    time.sleep(0.001)
-        th = None
+                try:
+                    f, idx, au = rings[k].get(block=True, timeout=0.05, copy=False)
+                except _q.Empty:
+                    continue
+                if f is not None:
+                    rings[k].release()
+                cnt += 1
+                if cnt % B == 0:
+                    got_t[k].append(time.perf_counter())
+        ths = []
         if use_r:
-            th = threading.Thread(target=drain, daemon=True)
-            th.start()
+            ths = [threading.Thread(target=drain, args=(k,), daemon=True) for k in range(N)]
+            for th in ths:
+                th.start()
         import resource
         phase = np.random.default_rng(N).uniform(0.0, P, N)
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
@@ -763,11 +760,13 @@ class PacedRig:
                     lats.extend(d[3] for d in done)
                 continue
             due = [t for t in ([nxt[k] for k in range(N) if issued[k] < periods] + [sch.next_due()]) if t is not None]
-            dt = (min(due) if due else now) - time.perf_counter()
-            if dt > 1e-3:
+            dt = (min(due) if due else now + 0.05) - time.perf_counter()
+            if hasattr(sch, "idle_wait"):
+                sch.idle_wait(dt - 2e-4 if dt > 1e-3 else dt)               # woken by the completion of a step in flight (blocking-sync event on a waiter thread) or at the next due time
+            elif dt > 1e-3:
                 time.sleep(dt - 5e-4)
             elif dt > 0:
-                time.sleep(dt)                                              # (a step is in flight: the scheduler asks to be polled again in 0.5 ms; the consumer thread runs meanwhile)
+                time.sleep(dt)
         wall = time.perf_counter() - t_start
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
         host_cpu = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / wall     # scheduler loop + consumer thread + runtime threads of this process
@@ -776,10 +775,13 @@ class PacedRig:
             while any(len(got_t[k]) < periods for k in range(N)) and time.perf_counter() < t_end:
                 time.sleep(0.001)
             stop.set()
-            th.join(2.0)
+            for th in ths:
+                th.join(2.0)
             # by arrival order over all sessions, so that first / last thirds mean what they mean in the other legs
             pairs = sorted((arrivals[k][j], got_t[k][j] - arrivals[k][j]) for k in range(N) for j in range(min(len(got_t[k]), periods)))
             lats = [l for _, l in pairs]
+        if hasattr(sch, "close"):
+            sch.close()
         l = np.sort(np.asarray(lats)) * 1e3
         p99 = float(l[min(len(l) - 1, int(np.ceil(0.99 * len(l))) - 1)])
         n3 = max(len(lats) // 3, 1)                                          # served first / last: a queue that grows shows up as a drift between them

@@ -137,11 +137,25 @@ __device__ __forceinline__ void store_pair16(bf16_t* base, int64_t yo, int c16, 
 // v_mfma_f32_16x16x32_f16 (wh.xh) and per 64-deep tile ONE v_mfma_scale_f32_16x16x128_f8f6f4 whose K blocks 0 / 1 carry q6(wh).xl / wl.q6(xh) of channels
 // 0..31 and blocks 2 / 3 those of channels 32..63 -- 48 matrix cycles per tile and accumulator where bf16x3 spends 96.  A 32-deep tile (the 8-wave tiles)
 // leaves blocks 2 / 3 off by a zero scale: 32 cycles against 48.
+// LD 3 (round 5): PRODUCER WAVES.  Stamps (MF_DBG_TIMES) on the UNet's batch-8 shapes put the DMA loop at 3325 cycles per 64-deep step of the 128 x 128 tile
+// and 1816 for 128 x 64, whether 20 or 240 workgroups run and whether the bytes come from L2 or HBM: 96 / 48 MFMAs (1536 / 768 cycles) plus the ISSUE cost of
+// the 16 / 12 LDS-DMA pieces each compute wave launches per step (100 - 185 cycles apiece inside a loaded phase, MI355X_MICROARCH.md) plus two exposed LDS
+// fragment-read latencies -- the matrix pipe is busy 23 - 46 % by construction.  Here a workgroup is NW compute waves + NW producer waves (one of each per SIMD):
+// the producers issue every LDS-DMA piece of a stage (pixel rows gathered through s_goff, weight rows) into a ring of igemm_ring<...>() stages and keep
+// (depth - 3) stages in flight behind their own vmcnt; the compute waves touch only LDS and the matrix pipe, and read the fragments of step i + 1 into a
+// second register set while the MFMAs of step i run (the stage has landed: the producers stay two steps ahead of the barrier).
+template <int BM, int BN, int BK, bool X3>
+constexpr int igemm_ring() {
+    constexpr int stage = (BM + BN) * BK * 2 * (X3 ? 2 : 1);
+    constexpr int by_lds = (144 * 1024) / stage;                                         // 160 KB - 16 KB for the gather-offset table of the longest contraction
+    return by_lds < 8 ? by_lds : 8;
+}
+
 template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST, int LD = 0, bool Q = false>
-__global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a) {
+__global__ __launch_bounds__(WGM * WGN * (LD == 3 ? 2 : 1) * 64) void k_conv_igemm(const ConvArgs a) {
     static_assert(!Q || X3, "the f16 + FP6 format has two planes");
-    constexpr int NW = WGM * WGN;         // waves per workgroup
-    constexpr int NT = NW * 64;
+    constexpr int NW = WGM * WGN;         // compute waves per workgroup (LD 3: as many producer waves on top)
+    constexpr int NT = NW * (LD == 3 ? 2 : 1) * 64;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(BK == 32 || BK == 64, "LDS tile depth");
     static_assert(NST == 2, "two LDS stages (deeper rings halved the workgroups per CU and measured slower)");
@@ -160,7 +174,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LDS_STAGES = LD == 2 ? 1 : NST;
-    int* s_goff = reinterpret_cast<int*>(smem + LDS_STAGES * STAGE);
+    constexpr int DR = LD == 3 ? igemm_ring<BM, BN, BK, X3>() : 0;                     // ring depth of the producer-wave path
+    static_assert(LD != 3 || DR >= 4, "producer-wave path: the ring needs >= 4 stages (two ahead of the barrier + one in flight)");
+    int* s_goff = reinterpret_cast<int*>(smem + (LD == 3 ? DR : LDS_STAGES) * STAGE);
     // MF_DBG_TIMES: s_memtime stamps of (entry, loop start, loop end, exit) per workgroup
     unsigned long long* dbg = a.dbg ? a.dbg + 4 * ((size_t)blockIdx.x + gridDim.x * ((size_t)blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
     if (dbg && threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memtime();
@@ -197,13 +213,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
 
     for (int i = tid; i < ph.ngroups; i += NT) s_goff[i] = a.goff[ph.goff_begin + i];
 
-    // ---- DMA assignment: wave w moves chunks w, w+NW, ... of each tile -------------------------
+    // ---- DMA assignment: wave w moves chunks w, w+NW, ... of each tile (LD 3: producer wave NW + w does) -------------------------
+    const int wq = LD == 3 ? (wave >= NW ? wave - NW : wave) : wave;
     const bf16_t* xp[NPC];
     int p_kg[NPC];
     const int64_t x_delta = X3 ? (a.x_lo - a.x_hi) : 0;
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
-        const int row = (wave + NW * i) * RPC + lane / KG;
+        const int row = (wq + NW * i) * RPC + lane / KG;
         p_kg[i] = (lane % KG) ^ swz<BK>(row);
         int m = m0 + row;
         m = m < a.M ? m : a.M - 1;
@@ -216,19 +233,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
     const int64_t w_delta = X3 ? (a.w_lo - a.w_hi) : 0;
 #pragma unroll
     for (int i = 0; i < NWC; ++i) {
-        const int row = (wave + NW * i) * RPC + lane / KG;
+        const int row = (wq + NW * i) * RPC + lane / KG;
         const int kg = (lane % KG) ^ swz<BK>(row);
         int n = n0 + row;
         n = n < a.Npad ? n : a.Npad - 1;
         wp[i] = a.w_hi + ph.w_off + (int64_t)n * 64 + kg * 8;   // packed [K/64][Npad][64]
     }
     const int64_t w_kstep = (int64_t)a.Npad * 64;
-
     auto stage = [&](int kt, int s) __attribute__((always_inline)) {
         char* base = smem + s * STAGE;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
-            const int c = wave + NW * i;
+            const int c = wq + NW * i;
             if (PCH % NW == 0 || c < PCH) {
                 const bf16_t* src = xp[i] + s_goff[kt * KG + p_kg[i]];
                 glds16(src, base + c * 1024);
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
         }
 #pragma unroll
         for (int i = 0; i < NWC; ++i) {
-            const int c = wave + NW * i;
+            const int c = wq + NW * i;
             if (WCH % NW == 0 || c < WCH) {
                 const bf16_t* src = BK == 64 ? wp[i] + kt * w_kstep : wp[i] + (kt >> 1) * w_kstep + (kt & 1) * 32;
                 glds16(src, base + P_BYTES + c * 1024);
@@ -257,8 +273,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int s) __attribute__((always_inline)) {
-        const char* base = smem + s * STAGE;
+    // pb / wb: plane 0 of the pixel / weight tile of this K step; pps / wps: byte distance to plane 1
+    auto compute_at = [&](const char* pb, int pps, const char* wb, int wps) __attribute__((always_inline)) {
         if constexpr (Q) {
             // corrections first (small terms), then the f16 products.  A lane's FP6 block: the 32 bytes at 16-byte slots 2g, 2g + 1 of its plane-1 row, g = its
             // K block (BK 64: lane group fk; BK 32: fk & 1, groups 2 / 3 re-read and are switched off).  The XOR swizzle is even, so the two slots stay adjacent.
@@ -267,7 +283,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
             i32x8 w6[FN];
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
-                const char* q = base + PLANE + P_BYTES + tile_off<BK>(cn0 + i * 16 + fr, 2 * g6);
+                const char* q = wb + wps + tile_off<BK>(cn0 + i * 16 + fr, 2 * g6);
                 w6[i] = __builtin_shufflevector(*reinterpret_cast<const i32x4*>(q), *reinterpret_cast<const i32x4*>(q + 16), 0, 1, 2, 3, 4, 5, 6, 7);
             }
             constexpr int JH = FM > 4 ? 4 : FM;                   // pixel fragments per batch (the 128-pixel wave tiles have no registers for all eight at once)
@@ -276,7 +292,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
                 i32x8 p6[JH];
 #pragma unroll
                 for (int jj = 0; jj < JH; ++jj) {
-                    const char* q = base + PLANE + tile_off<BK>(pm0 + (j0 + jj) * 16 + fr, 2 * g6);
+                    const char* q = pb + pps + tile_off<BK>(pm0 + (j0 + jj) * 16 + fr, 2 * g6);
                     p6[jj] = __builtin_shufflevector(*reinterpret_cast<const i32x4*>(q), *reinterpret_cast<const i32x4*>(q + 16), 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
@@ -289,9 +305,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
             for (int kk = 0; kk < BK / 32; ++kk) {
                 f16x8 pf[FM], wf[FN];
 #pragma unroll
-                for (int i = 0; i < FM; ++i) pf[i] = *reinterpret_cast<const f16x8*>(base + tile_off<BK>(pm0 + i * 16 + fr, kk * 4 + fk));
+                for (int i = 0; i < FM; ++i) pf[i] = *reinterpret_cast<const f16x8*>(pb + tile_off<BK>(pm0 + i * 16 + fr, kk * 4 + fk));
 #pragma unroll
-                for (int i = 0; i < FN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(base + P_BYTES + tile_off<BK>(cn0 + i * 16 + fr, kk * 4 + fk));
+                for (int i = 0; i < FN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(wb + tile_off<BK>(cn0 + i * 16 + fr, kk * 4 + fk));
 #pragma unroll
                 for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -306,10 +322,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
             for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
-                    pf[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + tile_off<BK>(pm0 + i * 16 + fr, kk * 4 + fk));
+                    pf[pl][i] = *reinterpret_cast<const bf16x8*>(pb + pl * pps + tile_off<BK>(pm0 + i * 16 + fr, kk * 4 + fk));
 #pragma unroll
                 for (int i = 0; i < FN; ++i)
-                    wf[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + P_BYTES + tile_off<BK>(cn0 + i * 16 + fr, kk * 4 + fk));
+                    wf[pl][i] = *reinterpret_cast<const bf16x8*>(wb + pl * wps + tile_off<BK>(cn0 + i * 16 + fr, kk * 4 + fk));
             }
 #pragma unroll
             for (int i = 0; i < FN; ++i)
@@ -324,11 +340,104 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_conv_igemm(const ConvArgs a)
                 }
         }
     };
+    auto compute = [&](int s) __attribute__((always_inline)) {
+        const char* base = smem + s * STAGE;
+        compute_at(base, PLANE, base + P_BYTES, PLANE);
+    };
 
     __syncthreads();   // s_goff visible
     if (dbg && threadIdx.x == 0) dbg[1] = __builtin_amdgcn_s_memtime();
     const int nk = kt_end - kt_begin;
-    if constexpr (LD != 0) {
+    if constexpr (LD == 3) {
+        // DMA instructions (= vmcnt ticks) one producer wave issues per stage; the wait immediates below are multiples of it
+        constexpr int NPI = ((PCH + NW - 1) / NW + (WCH + NW - 1) / NW) * NP;
+        static_assert(PCH % NW == 0 && WCH % NW == 0, "producer-wave path: every producer issues the same number of pieces per stage");
+        static_assert((DR - 3) * NPI <= 63, "vmcnt immediate");
+        if (wave >= NW) {
+            // ---- producer waves.  Barrier b (b = 0 opens step 0, b = i + 1 closes step i) is reached with stages <= b + 1 landed: step i reads stage i for its
+            // MFMAs and stage i + 1 for its prefetch.  Stage i + DR - 1 goes into the slot stage i - 1 had, whose last reader finished before barrier i.
+            if (nk > 0) {
+                const int pre = nk < DR - 1 ? nk : DR - 1;
+                for (int d = 0; d < pre; ++d) stage(kt_begin + d, d);
+                if (pre == DR - 1) wait_vm<(DR - 3) * NPI>(); else wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+                int slot = DR - 1;
+                for (int i = 0; i < nk; ++i) {
+                    if (i + DR - 1 < nk) {
+                        stage(kt_begin + i + DR - 1, slot);
+                        slot = slot + 1 == DR ? 0 : slot + 1;
+                        wait_vm<(DR - 3) * NPI>();             // everything but the newest DR - 3 stages: stage i + 2 has landed
+                    } else {
+                        wait_vm<0>();
+                    }
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            return;                                            // (a finished wave no longer counts at the workgroup's barriers: the epilogue's are the compute waves')
+        }
+        // ---- compute waves: LDS fragment reads of step i + 1 fly under the MFMAs of step i -------------------------------------------------------------
+        constexpr int KK = BK / 32;                            // 32-deep MFMA steps per stage
+        bf16x8 pfr[2][NP][FM], wfr[2][NP][FN];
+        auto ldf = [&](auto bufc, int slot, int kk) __attribute__((always_inline)) {
+            constexpr int b = decltype(bufc)::value;
+            const char* base = smem + slot * STAGE;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) pfr[b][pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + tile_off<BK>(pm0 + i * 16 + fr, kk * 4 + fk));
+#pragma unroll
+                for (int i = 0; i < FN; ++i) wfr[b][pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + P_BYTES + tile_off<BK>(cn0 + i * 16 + fr, kk * 4 + fk));
+            }
+        };
+        auto mma = [&](auto bufc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bufc)::value;
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    if (X3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[b][NP - 1][i], pfr[b][0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[b][0][i], pfr[b][NP - 1][j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[b][0][i], pfr[b][0][j], acc[i][j], 0, 0, 0);
+                }
+        };
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        if (nk > 0) {
+            __syncthreads();                                   // barrier 0: stages 0 and 1 have landed
+            ldf(B0{}, 0, 0);
+            int slot = 0;                                      // ring slot of stage i
+            if constexpr (KK == 2) {
+                // 64-deep stages: (stage i, kk 0) in set 0, (stage i, kk 1) in set 1
+                for (int i = 0; i < nk; ++i) {
+                    const int nslot = slot + 1 == DR ? 0 : slot + 1;
+                    ldf(B1{}, slot, 1);
+                    mma(B0{});
+                    if (i + 1 < nk) ldf(B0{}, nslot, 0);
+                    mma(B1{});
+                    slot = nslot;
+                    __syncthreads();
+                }
+            } else {
+                // 32-deep stages: even steps in set 0, odd steps in set 1
+                for (int i = 0; i < nk; i += 2) {
+                    int nslot = slot + 1 == DR ? 0 : slot + 1;
+                    if (i + 1 < nk) ldf(B1{}, nslot, 0);
+                    mma(B0{});
+                    slot = nslot;
+                    __syncthreads();
+                    if (i + 1 < nk) {
+                        nslot = slot + 1 == DR ? 0 : slot + 1;
+                        if (i + 2 < nk) ldf(B0{}, nslot, 0);
+                        mma(B1{});
+                        slot = nslot;
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+    } else if constexpr (LD != 0) {
         static_assert(LD == 2, "register-staged tiles: one LDS stage");
         u32x4 rp[NP][NPC], rw[NP][NWC];
         auto gload = [&](int kt) __attribute__((always_inline)) {
@@ -720,9 +829,13 @@ int launch_cfg_n(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStr
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    const size_t lds = (size_t)(LD == 2 ? 1 : NST) * (BM + BN) * BK * 2 * (X3 ? 2 : 1) + (size_t)goff_max * 4;
+    size_t lds = (size_t)(LD == 2 ? 1 : NST) * (BM + BN) * BK * 2 * (X3 ? 2 : 1) + (size_t)goff_max * 4;
+    if constexpr (LD == 3) {
+        lds = (size_t)igemm_ring<BM, BN, BK, X3>() * (BM + BN) * BK * 2 * (X3 ? 2 : 1) + (size_t)goff_max * 4;
+        if (lds > 160 * 1024) { mf_set_error("conv: producer-wave tile %dx%d needs %zu bytes of LDS", BM, BN, lds); return MF_ERR_INVALID; }
+    }
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.zgroups ? a.zgroups : nphase);
-    hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * (LD == 3 ? 2 : 1) * 64), lds, s, a);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
@@ -735,6 +848,12 @@ int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStrea
     //         still leave 2-3 workgroups per CU; the 8-wave 256-wide tiles have no VGPRs to spare
     // Per-op A/B at batch 8: UNet 11.05 -> 10.62 ms, Wav2Lip 14.6 k -> 15.1 k frames/s with ld 2 as the default; every variant within +-15 % per layer.
     const int regs = a.ld >= 0 ? a.ld : 2;
+    if constexpr (WGM * WGN == 4 && X3 && !Q && BN >= 64 && BM >= 64 && igemm_ring<BM, BN, BK, X3>() >= 4) {
+        //   ld 3 / 4  producer waves own every LDS-DMA piece, the compute waves only LDS reads and MFMAs (k_conv_igemm's LD 3); 3: the deepest stage whose ring
+        //         still holds >= 4 of them, 4: 32-deep stages (launch_prec picks BK)
+        if (regs == 3 || regs == 4) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 3, Q>(a, nphase, nsplit, goff_max, s);
+    }
+    if (regs == 3 || regs == 4) { mf_set_error("conv: no producer-wave kernel for tile %dx%d", BM, BN); return MF_ERR_INVALID; }
     if constexpr (WGM * WGN == 4) {
         if (regs == 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 2, Q>(a, nphase, nsplit, goff_max, s);
     }
@@ -751,6 +870,15 @@ int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3
         } else {
             mf_set_error("conv (f16q): no implicit-GEMM kernel for the narrow %dx%d tile", BM, BN);
             return MF_ERR_INVALID;
+        }
+    }
+    if constexpr (WGM * WGN == 4 && BN >= 64) {
+        // producer-wave path (ld 3): 64-deep stages where the ring still holds >= 4 of them, else 32-deep ones
+        if ((a.ld == 3 || a.ld == 4) && x3) {
+            if constexpr (igemm_ring<BM, BN, 64, true>() >= 4) {
+                if (a.ld == 3) return launch_cfg<BM, BN, WGM, WGN, true, 64>(a, nphase, nsplit, goff_max, s);
+            }
+            return launch_cfg<BM, BN, WGM, WGN, true, 32>(a, nphase, nsplit, goff_max, s);
         }
     }
     // bf16x3 doubles the LDS image: 64-deep tiles only where two stages of (hi, lo) still leave >= 2
@@ -1428,6 +1556,8 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
     {
         auto it = p->tuned.find(batch);
         if (it != p->tuned.end()) a.ld = it->second.ld;
+        static const int force_ld = [] { const char* e = getenv("MF_FORCE_LD"); return e ? atoi(e) : -1; }();   // (measurement, with MF_FORCE_TILE / MF_FORCE_SPLIT)
+        if (force_ld >= 0 && !(force_ld >= 3 && (!x3 || p->q || tc.wgm * tc.wgn != 4 || tc.bn < 64 || tc.bm < 64))) a.ld = force_ld;
     }
     if (tokens > 0) {
         // the cost model priced the full sequence: re-balance the split for the rows actually computed
@@ -1560,7 +1690,7 @@ int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream
 // configuration 3.5 %).
 ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
     {
-        static const bool forced = getenv("MF_FORCE_TILE") || getenv("MF_FORCE_SPLIT");
+        static const bool forced = getenv("MF_FORCE_TILE") || getenv("MF_FORCE_SPLIT") || getenv("MF_FORCE_LD");
         auto it = p->tuned.find(batch);
         if (!forced && it != p->tuned.end()) return it->second.tile;
     }
@@ -1651,7 +1781,9 @@ std::map<std::string, ConvTuned>& tune_cache() {
             static const int tiles[][4] = {{64, 64, 2, 2}, {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 128, 4, 2}, {256, 256, 2, 4}};
             bool tile_ok = false;
             for (const auto& t : tiles) tile_ok |= c.tile.bm == t[0] && c.tile.bn == t[1] && c.tile.wgm == t[2] && c.tile.wgn == t[3];
-            return tile_ok && c.tile.nsplit >= 1 && c.tile.nsplit <= 16 && (c.ld == -1 || c.ld == 0 || c.ld == 2);
+            if ((c.ld == 3 || c.ld == 4) && (c.tile.wgm * c.tile.wgn != 4 || (c.ld == 4 && c.tile.bm + c.tile.bn != 128))) return false;
+            // ld 3 / 4 (round 5's producer-wave path) are additions to generation k4: every older entry still names a kernel this library has
+            return tile_ok && c.tile.nsplit >= 1 && c.tile.nsplit <= 16 && (c.ld == -1 || c.ld == 0 || c.ld == 2 || c.ld == 3 || c.ld == 4);
         };
         int dropped = 0;
         if (FILE* f = path.empty() ? nullptr : fopen(path.c_str(), "r")) {
@@ -1679,7 +1811,7 @@ void tune_cache_store(const std::string& key, const ConvTuned& c) {
     }
 }
 bool tunable_layer(const ConvPlan* p, int batch) {
-    static const bool forced = getenv("MF_FORCE_TILE") || getenv("MF_FORCE_SPLIT");
+    static const bool forced = getenv("MF_FORCE_TILE") || getenv("MF_FORCE_SPLIT") || getenv("MF_FORCE_LD");
     if (p->halo || p->up_hi || forced) return false;                                 // halo-kernel layers keep their own tile choice
     const int M = batch * p->Hq * p->Wq, N = p->d.cout;
     return !(N <= 32 || (M <= 16 && p->d.act != 5 && !p->q));                         // the narrow special tiles have no alternatives
@@ -1787,8 +1919,10 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
         for (int S : splits) {
             if (S > kt_min || (S > 1 && nt >= 1024) || nt * S > 4096) continue;
             if (p->d.act == 5 && t.bn < 32 && S > 1) continue;
-            for (int ld : {2, 0}) {
+            for (int ld : {2, 0, 3, 4}) {
                 if (t.wgm * t.wgn == 8 && ld != 0) continue;                        // the 8-wave tiles only have the LDS-DMA loop
+                // producer-wave path: bf16x3 only; ld 4 (32-deep stages) differs from ld 3 on the 64 x 64 tile only
+                if (ld >= 3 && (p->precision != MF_PREC_BF16X3 || p->q || t.bn < 64 || (ld == 4 && t.bm + t.bn != 128))) continue;
                 const ConvTuned c{ConvTile{t.bm, t.bn, t.wgm, t.wgn, S}, ld};
                 float us = 0.f;
                 if ((rc = measure(c, &us))) break;
@@ -1839,7 +1973,10 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
         // tile depth as launch_prec picks it: 64 everywhere except the 8-wave bf16x3 tiles
         const bool x3b = p->precision == MF_PREC_BF16X3;
         const int bk = ((x3b && t.bm + t.bn > 128 && t.wgm * t.wgn != 4) || (p->q && t.wgm * t.wgn != 4)) ? 32 : 64;
-        snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s,%d>%s", t.bm, t.bn, t.wgm, t.wgn, x3, bk, p->q ? " f16+fp6" : "");
+        int ld = -1;
+        { auto it = p->tuned.find(batch); if (it != p->tuned.end()) ld = it->second.ld; }
+        if (ld >= 3) snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s,%d,pw>", t.bm, t.bn, t.wgm, t.wgn, x3, ld == 3 && t.bm + t.bn == 128 ? 64 : 32);   // pw: producer waves
+        else snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s,%d>%s", t.bm, t.bn, t.wgm, t.wgn, x3, bk, p->q ? " f16+fp6" : "");
     }
 }
 

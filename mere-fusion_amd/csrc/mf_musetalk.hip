@@ -218,8 +218,10 @@ struct Net {
         static const bool q_unet_on = [] { const char* e = getenv("MF_UNET_Q"); return !e || atoi(e) != 0; }();
         // ... and its 640-channel convs on the 16 x 16 maps (one patch per image, five channel tiles): 640 -> 640 360 -> 250 us, 1280 -> 640 651 -> 455, 1920 -> 640 934 -> 675
         // at 64 frames against the bf16x3 implicit GEMM (tools/conv_probe.py with MF_Q_HALO_SMALL=1).
-        const bool q_dual32 = cout >= 256 && cout % 128 != 0 && cout % 64 == 0 && t->H * t->W >= q_minpx;
-        const bool q_dual16 = cout >= 512 && cout % 128 == 0 && cin <= 2048 && t->H == 16 && t->W == 16;
+        // (bounds as mf_conv_plan_create's q_small / odd_wide predicates: a layer outside them gets no f16 + FP6 plan and must stay on the bf16x3 path -- ADVICE r04:
+        // 1280-channel convs on 16 x 16 maps at sample_size 64, or 320-out convs with cin > 1024, failed the whole handle instead)
+        const bool q_dual32 = cout >= 256 && cout % 128 != 0 && cout % 64 == 0 && cin <= 1024 && t->H * t->W >= q_minpx;
+        const bool q_dual16 = cout >= 512 && cout <= 1024 && cout % 128 == 0 && cin <= 2048 && t->H == 16 && t->W == 16;
         const bool q_dual = q_on && q_unet_on && q_dual_allowed && precision == MF_PREC_BF16X3 && (q_dual32 || q_dual16) && cin % 32 == 0 &&
                             t->C == cin && t->H % 16 == 0 && t->W % 16 == 0 && cap >= q_dual_min();
         if (q_dual || (q_on && q_allowed && precision == MF_PREC_BF16X3 && cin % 32 == 0 && cout % 128 == 0 && t->C == cin && t->H * t->W >= q_minpx && cin >= 128 &&

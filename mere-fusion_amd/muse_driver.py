@@ -17,6 +17,8 @@ that bench.py, the tests and a multi-session harness drive directly:
 
 Cross-session batching is what fills an MI355X: the UNet at 8 frames per step is launch-latency bound, at 64 it is not."""
 import ctypes as C
+import queue
+import threading
 import time
 from collections import deque
 
@@ -299,8 +301,42 @@ class EndToEndScheduler(SessionScheduler):
         # the step almost nothing.  asr_stream=False: on the step's stream, as before (A/B, bench `stages`).
         self.asr_stream = torch.cuda.Stream(device=batcher.device) if asr_stream else None
         self.inflight = deque()
-        self.ring_full = 0
+        # Completion is WAITED for, not polled (a 2 - 5 kHz hipEventQuery loop cost a rank 1.3 - 1.9 host cores at capacity): every step's
+        # event is created with the blocking-sync flag and handed to one waiter thread, whose hipEventSynchronize sleeps on the interrupt and then sets
+        # `_wake`; the serving loop sleeps in idle_wait() until then or until the next arrival is due.
+        self._wake = threading.Event()
+        self._evq = queue.SimpleQueue()
+        self._waiter = threading.Thread(target=self._wait_loop, daemon=True)
+        self._waiter.start()
+        self.ring_full = 0                                           # deferral EPISODES (a session found its ring full), not polls
+        self._deferred = {}                                          # session -> time at which it is offered again even if its ring still looks full
         self._busy_until = 0.0
+
+    def _wait_loop(self):
+        while True:
+            ev = self._evq.get()
+            if ev is None:
+                return
+            try:
+                ev.synchronize()                                      # (blocking-sync event: the thread sleeps, the GIL is released)
+            except Exception:
+                pass
+            self._wake.set()
+
+    def idle_wait(self, timeout):
+        """Sleeps until a step in flight completes or `timeout` seconds have passed, whichever is first (nothing in flight: a plain sleep).  What a serving
+        loop calls between run_once()s instead of polling."""
+        if timeout is None or timeout <= 0:
+            return
+        if self.inflight:
+            self._wake.wait(timeout)
+            self._wake.clear()
+        else:
+            time.sleep(timeout)
+
+    def close(self):
+        """stops the waiter thread (after drain())"""
+        self._evq.put(None)
 
     def submit(self, k, pcm_chunks, t_arrival=None):
         """pcm_chunks: the batch's 2B 20 ms chunks -- bare arrays (all speech, type 0) or (chunk, type) pairs exactly as `get_audio_frame` hands them out
@@ -327,24 +363,39 @@ class EndToEndScheduler(SessionScheduler):
                 fr, idx = item["out"][k]
                 tok = item["tokens"].get(k)
                 if tok is not None:
+                    # speech: the B frames' descriptors; a silent batch or a session whose context is still filling: B (None, idx, audio_frames[2i:2i+2])
+                    # tuples as the reference puts them (musereal.py:82-86, lipreal.py:104) -- ONE message either way, on slots reserved before the step
+                    # started, so nothing here can block the scheduler thread
                     self.rings[k].commit_batch(tok, item["audio"][k])
-                    t1 = self.clock()
-                elif self.rings is not None and fr is None:
-                    # a silent batch, or a session whose context is still filling: the reference puts (None, idx, audio_frames[2i:2i+2]) per frame
-                    # (musereal.py:82-86, lipreal.py:104) -- descriptors only, no slot
-                    au = item["audio"][k]
-                    for i, ix in enumerate(idx):
-                        self.rings[k].put((None, ix, au[2 * i:2 * i + 2]))
                     t1 = self.clock()
                 done.append((k, fr, idx, t1 - item["arrival"][k]))
             self.busy_s += max(t1 - max(item["t0"], self._busy_until), 0.0)      # union of the steps' [launch, done] intervals
             self._busy_until = max(self._busy_until, t1)
         return done
 
+    def pending(self):
+        """Sessions whose oldest batch can be picked now.  A session deferred because its ring was full is left out until the ring reports B free slots or a
+        back-off of a quarter period has passed (it otherwise sits at the head of the order with an arrival time in the past, next_due() lies in the
+        past, the serving loop spins a host core on run_once, and its age makes every other session's step launch partly filled)."""
+        p = super().pending()
+        if self._deferred:
+            now, B = self.clock(), self.batcher.batch_size
+            for k in list(self._deferred):
+                if k not in p:
+                    del self._deferred[k]
+                elif self.rings[k].free_slots() >= B or now >= self._deferred[k]:
+                    del self._deferred[k]                            # (a new episode is counted if it is deferred again)
+                else:
+                    del p[k]
+        return p
+
     def next_due(self):
-        if self.inflight:
-            return self.clock() + 5e-4                                # something to retire: poll again shortly (5 kHz polling cost a rank 1.3 - 1.9 host cores at 22 sessions)
-        return super().next_due()
+        """when run_once would next act on what is QUEUED (None: nothing queued).  Steps in flight do not enter: idle_wait() wakes the loop when one completes."""
+        t = super().next_due()
+        if self._deferred:
+            t_def = min(self._deferred.values())
+            t = t_def if t is None else min(t, t_def)
+        return t
 
     def run_once(self, now=None):
         now = self.clock() if now is None else now
@@ -366,12 +417,10 @@ class EndToEndScheduler(SessionScheduler):
             for k in sorted(pend, key=lambda k_: (pend[k_], k_)):     # oldest first; a waiting session takes the place of one that has to be deferred
                 if len(ok) == len(ks):
                     break
-                if self.queues[k][0][1][0] is None:                   # silent / context still filling: descriptors only
-                    ok.append(k)
-                    continue
-                sl = self.rings[k].try_reserve(B)
+                sl = self.rings[k].try_reserve(B)                     # (silent batches too: their B (None, idx, audio) tuples take B of the ring's places)
                 if sl is None:
                     self.ring_full += 1
+                    self._deferred[k] = now + self.period / 4
                     continue
                 reserved[k] = sl
                 ok.append(k)
@@ -402,29 +451,28 @@ class EndToEndScheduler(SessionScheduler):
         tokens = {}
         try:
             out = self.batcher.step(chunks, only=ks)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(blocking=True)
             if self.rings is not None:
                 cur = torch.cuda.current_stream(dev)
                 self.copy_stream.wait_stream(cur)
                 for k in ks:
                     fr, idx = out[k]
-                    if fr is None:
-                        if k in reserved:
-                            self.rings[k].unreserve(reserved.pop(k))
-                        continue
-                    tokens[k] = self.rings[k].begin_batch(fr, idx, stream=self.copy_stream, reserved=reserved.pop(k))
-                    fr.record_stream(self.copy_stream)
+                    tokens[k] = self.rings[k].begin_batch(fr, idx, stream=self.copy_stream, reserved=reserved.pop(k))   # (fr None: B silent frames)
+                    if fr is not None:
+                        fr.record_stream(self.copy_stream)
                 ev.record(self.copy_stream)
         except BaseException:
-            # nothing of this step is published: tokens already begun and reservations not yet used go back (newest first: FrameRing.abort_batch's ordering rule)
-            for k in reversed(list(tokens)):
+            # nothing of this step is published: tokens already begun and reservations not yet used go back (the rings publish in begin order whatever order
+            # this happens in)
+            for k in list(tokens):
                 self.rings[k].abort_batch(tokens[k])
-            for k in reversed(list(reserved)):
+            for k in list(reserved):
                 self.rings[k].unreserve(reserved[k])
             raise
         if self.rings is None:
             ev.record(torch.cuda.current_stream(dev))
         self.inflight.append({"ks": ks, "out": out, "tokens": tokens, "audio": audio, "arrival": arrival, "event": ev, "t0": t0})
+        self._evq.put(ev)
         self.steps += 1
         self.sessions_served += len(ks)
         return done

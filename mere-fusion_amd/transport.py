@@ -25,7 +25,19 @@ from multiprocessing import shared_memory
 import numpy as np
 
 
+class _Slots(list):
+    """The slot numbers of one reservation / batch; `.entry` is the ring's own record of it (state, pending message)."""
+    entry = None
+
+
 class FrameRing:
+    """Every frame -- a silent one (`res_frame` None) included -- holds one ring slot from its put until the consumer has taken it, so the ring bounds what is
+    queued exactly as the reference's `Queue(batch_size * 2)` of per-frame tuples does, every descriptor message carries at least one slot (the bounded descriptor
+    queue can therefore never be the thing a producer blocks on: ADVICE r04), and a reservation (`try_reserve`) is all a producer needs to know that nothing
+    it does later for that batch can block.  Batches are PUBLISHED in the order they were begun, whatever order they are committed or aborted in: the ring keeps
+    its outstanding batches in a deque and releases messages from its head only (a skip descriptor published ahead of an older, still uncommitted
+    batch let the producer wrap onto that batch's DMA target)."""
+
     def __init__(self, slots, frame_shape, dtype=np.uint8, ctx=None):
         """slots: ring capacity (the reference uses batch_size * 2); frame_shape / dtype: the largest frame a slot must hold."""
         ctx = ctx or mp.get_context("spawn")                       # app.py:549 sets the spawn start method
@@ -40,6 +52,7 @@ class FrameRing:
         self._head = 0                                             # producer-side cursor (single producer)
         self._registered = False
         self._inbox = deque()                                      # consumer side: descriptors of the message being unpacked
+        self._open = deque()                                       # producer side: outstanding reservations / batches, oldest first
 
     # ---- pickling: a child process re-attaches to the same block ---------------------------------------------------------------
     def __getstate__(self):
@@ -48,6 +61,7 @@ class FrameRing:
         d["_owner"] = False
         d["_registered"] = False
         d["_inbox"] = deque()
+        d["_open"] = deque()
         return d
 
     def __setstate__(self, d):
@@ -75,7 +89,7 @@ class FrameRing:
 
     def _acquire(self, n, block, timeout):
         """n consecutive ring slots, all or nothing: a time-out part-way hands back what it took and leaves the cursor where it was (a
-        failed put must neither leak slots nor let a later put overwrite an unread one)."""
+        failed put must neither leak slots nor let a later put overwrite an unread one).  Returns the ring's record of the new batch."""
         if n > self.slots:
             raise ValueError(f"a batch of {n} frames can never fit a ring of {self.slots} slots")
         deadline = None if (timeout is None or not block) else time.monotonic() + timeout
@@ -89,20 +103,55 @@ class FrameRing:
             got += 1
         first = self._head
         self._head = (self._head + n) % self.slots
-        return [(first + i) % self.slots for i in range(n)]
+        sl = _Slots((first + i) % self.slots for i in range(n))
+        sl.entry = {"slots": sl, "state": "open", "msg": None, "shape": None, "dtype": None, "idxs": None, "stream": None, "keep": None}
+        self._open.append(sl.entry)
+        return sl.entry
+
+    def _flush(self):
+        """Publishes what can be published, oldest batch first: a committed batch's message; an aborted batch's slots -- as a plain rewind when nothing newer
+        is outstanding (they are then the slots just before the cursor), else as a skip descriptor the consumer releases in ring order.  Stops at the first
+        batch that is still open: nothing newer may overtake it."""
+        while self._open and self._open[0]["state"] != "open":
+            e = self._open.popleft()
+            if e["state"] == "committed":
+                self._desc.put(e["msg"])                            # (cannot block: every message holds >= 1 of `slots` slots, the queue holds `slots` messages)
+            elif not self._open and e["slots"] and (e["slots"][-1] + 1) % self.slots == self._head:
+                self._head = e["slots"][0]
+                for _ in e["slots"]:
+                    self._free.release()
+            elif e["slots"]:
+                self._desc.put([("skip", len(e["slots"]), None, None, None)])
+        # aborted batches at the NEWEST end rewind at once (their slots are the ones just before the cursor), older ones wait their turn above
+        while self._open and self._open[-1]["state"] == "aborted":
+            e = self._open.pop()
+            if e["slots"] and (e["slots"][-1] + 1) % self.slots == self._head:
+                self._head = e["slots"][0]
+                for _ in e["slots"]:
+                    self._free.release()
+            elif e["slots"]:                                        # (cannot happen with a single producer; keep the slots accounted for)
+                self._open.append(e)
+                break
 
     def try_reserve(self, n):
         """n consecutive slots if they are free RIGHT NOW, else None -- for a producer that must know every destination has room BEFORE it does work it
-        cannot undo (EndToEndScheduler.run_once reserves for every picked session before the step advances frame indices and ASR state).  Pass the result
-        to begin_batch(..., reserved=slots), or hand it back with unreserve(slots)."""
+        cannot undo (EndToEndScheduler.run_once reserves for every picked session, silent batches included, before the step advances frame indices and ASR
+        state).  Pass the result to begin_batch(..., reserved=slots), or hand it back with unreserve(slots)."""
         try:
-            return self._acquire(n, False, None)
+            return self._acquire(n, False, None)["slots"]
         except queue.Full:
             return None
 
+    def free_slots(self):
+        """free slots right now (an estimate on the consumer's side of the fence, exact for the single producer's admission decisions)"""
+        try:
+            return self._free.get_value()
+        except NotImplementedError:                                 # (macOS)
+            return self.slots
+
     def unreserve(self, slots):
-        """hands back slots from try_reserve / a token's slots that were never published (see abort_batch for the ordering rule)"""
-        self.abort_batch({"slots": list(slots)})
+        """hands back slots from try_reserve that were never used (in whatever order: the ring publishes in begin order, see _flush)"""
+        self.abort_batch(slots.entry if isinstance(slots, _Slots) else {"slots": list(slots)})
 
     def _check_fits(self, nbytes):
         if nbytes > self.slot_bytes:
@@ -126,24 +175,25 @@ class FrameRing:
 
     def put(self, item, block=True, timeout=None):
         """item = (res_frame, idx, audio_frames) exactly as lipreal.py:136 / musereal.py:116 put it; res_frame is None for an all-silent chunk
-        (lipreal.py:104), a numpy array, or a HIP device tensor (copied by DMA into the slot)."""
+        (lipreal.py:104: it still takes one of the queue's places, here one slot without a payload), a numpy array, or a HIP device tensor (copied by DMA
+        into the slot)."""
         frame, idx, audio = item
         if frame is None:
-            self._desc.put([(None, None, None, idx, audio)], block, timeout)
+            tok = self.begin_batch(None, [idx], block=block, timeout=timeout)
+            self.commit_batch(tok, None, _single_audio=(audio,))
             return
         if self._is_device(frame):
             self.put_batch(frame[None], [idx], audio, block, timeout, _single_audio=(audio,))     # (wrapped: `audio` itself may be None)
             return
         a = np.asarray(frame)
         self._check_fits(a.nbytes)                                  # everything that can fail, before a slot is taken
-        slot = self._acquire(1, block, timeout)[0]
-        self._slot_view(slot, a.shape, a.dtype)[...] = a
-        self._desc.put([(slot, a.shape, a.dtype.str, idx, audio)])
+        tok = self.begin_batch(a[None], [idx], block=block, timeout=timeout)
+        self.commit_batch(tok, None, _single_audio=(audio,))
 
     def put_batch(self, frames, idxs, audio_frames, block=True, timeout=None, _single_audio=None):
         """A whole batch (`for i, res_frame in enumerate(recon): res_frame_queue.put(...)`, musereal.py:116-119): frames [B, ...] on the device
-        or the host, idxs the B frame indices, audio_frames the 2B (pcm, type) pairs (two per frame).  A device batch travels as ONE DMA per run
-        of consecutive slots (the ring wraps at most once per batch) behind ONE stream fence, and its B descriptors as ONE queue message --
+        or the host (None: B silent frames), idxs the B frame indices, audio_frames the 2B (pcm, type) pairs (two per frame).  A device batch travels as ONE DMA
+        per run of consecutive slots (the ring wraps at most once per batch) behind ONE stream fence, and its B descriptors as ONE queue message --
         the per-frame pickle + pipe round trip was what the ring's device path cost in round 2 (0.39 ms per batch of 8 against 0.05 ms of DMA)."""
         tok = self.begin_batch(frames, idxs, block=block, timeout=timeout)
         if tok is None:
@@ -161,32 +211,44 @@ class FrameRing:
         """First half of put_batch, for a producer that overlaps the copy with its next step: takes the slots and ENQUEUES the DMA on `stream`
         (a torch stream; default: the current one) without waiting.  Once the caller knows the copy is complete (an event recorded behind it on
         that stream) it calls commit_batch(token, audio_frames); abort_batch(token) hands the slots back instead.  Returns None for an empty batch.
-        reserved: slots from try_reserve(len(idxs)) (then nothing here can block).  Tokens are COMMITTED in the order they were begun (the consumer reads
-        slots in ring order); see abort_batch for aborting."""
+        frames None: B silent frames (slots without a payload).  reserved: slots from try_reserve(len(idxs)) (then nothing here can block); they are adopted
+        FIRST, so that whatever fails afterwards hands them back.  Commit / abort in any order: the ring publishes in begin order."""
         B = len(idxs)
-        if B == 0:
+        if reserved is not None:
+            tok = reserved.entry if isinstance(reserved, _Slots) else None
+            if tok is None or tok["state"] != "open" or tok["idxs"] is not None:
+                raise ValueError("reserved: not an unused reservation of this ring (use the list try_reserve returned)")
+        elif B == 0:
             return None
-        is_dev = self._is_device(frames)
-        if is_dev:
-            import torch
-            t = frames.contiguous()
-            if stream is not None and t is not frames:
-                # the compaction above ran on the CURRENT stream; the DMA below is enqueued on `stream`: order it behind (ADVICE r03: a silent race otherwise)
-                stream.wait_stream(torch.cuda.current_stream(t.device))
-            shape, dtype = tuple(t.shape[1:]), np.dtype(str(t.dtype).replace("torch.", ""))
-            self._check_fits(t[0].numel() * t.element_size())
         else:
-            a = np.asarray(frames)
-            shape, dtype = a.shape[1:], a.dtype
-            self._check_fits(int(np.prod(shape)) * dtype.itemsize)
-        if len(frames) != B:
-            raise ValueError(f"{len(frames)} frames for {B} indices")
-        if reserved is not None and len(reserved) != B:
-            raise ValueError(f"{len(reserved)} reserved slots for {B} frames")
-        slots = list(reserved) if reserved is not None else self._acquire(B, block, timeout)
-        tok = {"slots": slots, "shape": shape, "dtype": dtype.str, "idxs": list(idxs), "stream": None, "keep": None}
+            tok = None
         try:
-            if is_dev:
+            is_dev = self._is_device(frames)
+            if reserved is not None and len(reserved) != B:
+                raise ValueError(f"{len(reserved)} reserved slots for {B} frames")
+            if frames is None:
+                shape = dtype = None
+            elif is_dev:
+                import torch
+                t = frames.contiguous()
+                if stream is not None and t is not frames:
+                    # the compaction above ran on the CURRENT stream; the DMA below is enqueued on `stream`: order it behind (ADVICE r03: a silent race otherwise)
+                    stream.wait_stream(torch.cuda.current_stream(t.device))
+                shape, dtype = tuple(t.shape[1:]), np.dtype(str(t.dtype).replace("torch.", ""))
+                self._check_fits(t[0].numel() * t.element_size())
+            else:
+                a = np.asarray(frames)
+                shape, dtype = a.shape[1:], a.dtype
+                self._check_fits(int(np.prod(shape)) * dtype.itemsize)
+            if frames is not None and len(frames) != B:
+                raise ValueError(f"{len(frames)} frames for {B} indices")
+            if tok is None:
+                tok = self._acquire(B, block, timeout)
+            slots = tok["slots"]
+            tok.update(shape=shape, dtype=None if dtype is None else dtype.str, idxs=list(idxs))
+            if frames is None:
+                pass
+            elif is_dev:
                 from . import _lib
                 lib = _lib.lib()
                 self.register_pinned()
@@ -205,33 +267,39 @@ class FrameRing:
                 for i, sl in enumerate(slots):
                     self._slot_view(sl, shape, dtype)[...] = a[i]
         except BaseException:
-            self.abort_batch(tok)
+            if tok is not None:
+                self.abort_batch(tok)
             raise
         return tok
 
     def abort_batch(self, tok):
-        """Nothing of this batch was published: give the slots back.  If the token is the NEWEST one outstanding (its last slot is the one before the cursor)
-        the cursor is rewound and the slots are simply free again.  With newer tokens outstanding (begin_batch / commit_batch allow several in flight) a rewind
-        would hand out the newer tokens' slots a second time: the slots are then published as a SKIP descriptor instead -- the consumer releases them in ring
-        order without surfacing a frame."""
-        sl = tok["slots"]
-        if not sl:
+        """Nothing of this batch is to be published: its slots go back.  The newest outstanding batch is a plain rewind of the cursor; with newer batches
+        outstanding a rewind would hand out THEIR slots a second time, so the slots travel as a SKIP descriptor the consumer releases in ring order without
+        surfacing a frame -- and, like every message, only once every older batch has been published or aborted (_flush)."""
+        if not tok.get("slots"):
             return
-        if (sl[-1] + 1) % self.slots == self._head:
-            self._head = sl[0]
-            for _ in sl:
-                self._free.release()
-        else:
-            self._desc.put([("skip", len(sl), None, None, None)])
+        if "state" not in tok:                                       # (a bare {"slots": [...]}: find the ring's record of it)
+            tok = next((e for e in self._open if list(e["slots"]) == list(tok["slots"])), None)
+            if tok is None:
+                raise ValueError("abort_batch: these slots are not an outstanding batch of this ring")
+        if tok["state"] != "open":
+            return
+        tok["state"], tok["keep"] = "aborted", None
+        self._flush()
 
     def commit_batch(self, tok, audio_frames, _single_audio=None):
-        """Second half of put_batch: publishes the batch's descriptors as one message.  The copy must be complete."""
+        """Second half of put_batch: the batch's descriptors become one message, published as soon as every older batch is (normally: at once).  The copy
+        must be complete."""
         sl, shape, dt, idxs = tok["slots"], tok["shape"], tok["dtype"], tok["idxs"]
+        if tok["state"] != "open" or idxs is None:
+            raise ValueError("commit_batch: not a begun, uncommitted batch")
         tok["keep"] = None
         if _single_audio is not None:
-            self._desc.put([(sl[0], shape, dt, idxs[0], _single_audio[0])])
+            tok["msg"] = [(sl[0], shape, dt, idxs[0], _single_audio[0])]
         else:
-            self._desc.put([(s_, shape, dt, idxs[i], audio_frames[2 * i:2 * i + 2]) for i, s_ in enumerate(sl)])
+            tok["msg"] = [(s_, shape, dt, idxs[i], audio_frames[2 * i:2 * i + 2]) for i, s_ in enumerate(sl)]
+        tok["state"] = "committed"
+        self._flush()
 
     # ---- consumer -----------------------------------------------------------------------------------------------------------
     def get(self, block=True, timeout=None, copy=True):
@@ -246,7 +314,9 @@ class FrameRing:
                     self._free.release()
                 continue
             break
-        if slot is None:
+        if shape is None:                                            # a silent frame: a slot without a payload, free again at once
+            if slot is not None:
+                self._free.release()
             return None, idx, audio
         view = self._slot_view(slot, shape, dtype)
         if copy:

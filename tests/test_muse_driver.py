@@ -358,3 +358,87 @@ def test_hip_end_to_end_scheduler_stalled_consumer_and_silent_batches(lib_built)
     assert [g[1] for g in last] == [D.mirror_index(4, 2 * B + i) for i in range(B)] and all(g[0] is not None for g in last)
     for r in rings:
         r.close()
+
+
+def test_end_to_end_scheduler_leaves_a_deferred_session_out_until_its_ring_has_room():
+    """ADVICE r04 (host logic only, no device): a session deferred because its ring was full must not sit at the head of the order with an arrival time in the
+    past -- next_due() would lie in the past and the serving loop would spin on run_once -- it is offered again when its ring reports B free slots or after a
+    quarter period."""
+    from collections import deque
+    from types import SimpleNamespace
+
+    class Ring:
+        def __init__(self, free):
+            self.free = free
+
+        def free_slots(self):
+            return self.free
+
+    now = [1.0]
+    sch = D.EndToEndScheduler.__new__(D.EndToEndScheduler)          # (the constructor needs a device for its copy stream; the policy under test does not)
+    sch.queues = [deque([(0.2, ("win", []))]), deque([(0.9, ("win", []))])]
+    sch.capacity, sch.hold, sch.period, sch.clock = 2, 0.08, 0.32, (lambda: now[0])
+    sch.batcher = SimpleNamespace(batch_size=8)
+    sch.rings = [Ring(0), Ring(16)]
+    sch.inflight, sch._deferred = deque(), {0: 1.05}                # session 0 was deferred at t = 0.97 (+ period / 4)
+    assert sch.pending() == {1: 0.9}                                # the stalled session does not age the order ...
+    assert abs(sch.next_due() - 0.98) < 1e-9 or sch.next_due() == 0.98   # ... session 1's own hold decides (0.9 + 0.08), not a time in the past
+    sch.queues[1].clear()
+    assert sch.pending() == {} and sch.next_due() == 1.05           # nothing else queued: wake up when the back-off ends, do not spin
+    now[0] = 1.06
+    assert sch.pending() == {0: 0.2} and 0 not in sch._deferred     # back-off over: offered again (and counted as a new episode if still full)
+    sch._deferred = {0: 9.0}
+    sch.rings[0].free = 8
+    assert sch.pending() == {0: 0.2}                                # ... or as soon as the consumer has freed a batch's worth of slots
+
+
+@pytest.mark.gpu
+def test_hip_end_to_end_scheduler_silent_batches_with_a_stalled_consumer_never_block(lib_built):
+    """silent batches used to take no slot and B descriptor messages each, so with a stalled consumer two of them filled the bounded descriptor
+    queue and the NEXT publish blocked the single scheduler thread for ever -- every session of the GPU with it.  They now reserve B of the ring's places
+    before the step and travel as one message: the third silent batch of the stalled session is deferred, the other session is served throughout."""
+    from mere_fusion_amd.musetalk.models.unet import UNet
+    from mere_fusion_amd.musetalk.models.vae import VAE
+    from mere_fusion_amd.musetalk.whisper.audio2feature import Audio2Feature
+    from mere_fusion_amd.musetalk.config import unet_config_json, vae_config_json
+    from mere_fusion_amd.transport import FrameRing
+    from oracle import musetalk_ref as R
+    cfg = R.MUSETALK_SMALL
+    usd, vsd = W.make_musetalk_unet_state_dict(cfg, 0), W.make_musetalk_vae_state_dict(cfg, 0)
+    B, S = 2, 2
+    unet = UNet(unet_config_json(cfg["unet"]), usd, max_batch=B * S)
+    vae = VAE(config=vae_config_json(cfg["vae"]), state_dict=vsd, max_batch=B * S)
+    a2f = Audio2Feature(state_dict=W.make_whisper_encoder_state_dict(0), n_head=6)
+    lat = [[W.make_musetalk_inputs(1, 900 + 10 * s + i)[0] for i in range(4)] for s in range(S)]
+    fes = [D.MuseASRFrontend(a2f, B) for _ in range(S)]
+    for fe in fes:
+        fe.warm_up()
+    rings = [FrameRing(2 * B, (256, 256, 3)) for _ in range(S)]
+    bat = D.MuseBatcher(unet, vae, [D.MuseSession(lat[s]) for s in range(S)], batch_size=B, max_sessions_per_step=S)
+    now = [0.0]
+    sch = D.EndToEndScheduler(bat, fes, a2f, rings=rings, clock=lambda: now[0], hold_s=0.0)
+    pcm = lambda s, j: [W.make_speech_like_wav(320, 31 * s + 5 * j + i) for i in range(2 * B)]
+    for j in range(4):
+        sch.submit(0, [(c, 1) for c in pcm(0, j)], 0.01 * j)          # session 0: silence only, and nobody reads its ring
+        sch.submit(1, pcm(1, j), 0.01 * j + 0.001)
+    served, got1 = [], 0
+    for _ in range(40):                                              # (a blocked publish would hang here: the test's time-out is the failure mode of the old code)
+        now[0] += 0.1
+        done = sch.run_once() + sch.drain()
+        served += [k for k, *_ in done]
+        for k, fr, idx, _ in done:
+            if k == 1:
+                for i in range(B):
+                    assert rings[1].get(timeout=5)[0] is not None
+                    got1 += 1
+    assert served.count(1) == 4 and got1 == 4 * B                    # the healthy session got everything
+    assert served.count(0) == 2 and sch.ring_full >= 1 and len(sch.queues[0]) == 2    # two silent batches fill session 0's ring (2B places), the rest wait
+    assert sch.ring_full <= 12                                       # deferral episodes, not polls (40 polls happened)
+    first = [rings[0].get(timeout=5) for _ in range(2 * B)]          # the consumer wakes up: (None, idx, audio) tuples with the type-1 audio, in order
+    assert [g[1] for g in first] == [D.mirror_index(4, i) for i in range(2 * B)] and all(g[0] is None and g[2][0][1] == 1 for g in first)
+    for _ in range(10):
+        now[0] += 0.1
+        served += [k for k, *_ in sch.run_once() + sch.drain()]
+    assert served.count(0) == 4 and not sch.pending()
+    for r in rings:
+        r.close()

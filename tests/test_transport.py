@@ -181,3 +181,54 @@ def test_ring_takes_device_frames_by_dma(lib_built):
         f, idx, _ = ring2.get(timeout=5)
         assert f.dtype == np.float32 and np.array_equal(f, f32[i].cpu().numpy())
     ring.close(); ring2.close()
+
+
+def test_ring_publishes_in_begin_order_when_the_middle_of_three_batches_is_aborted():
+    """a skip descriptor published ahead of an older, still uncommitted batch let the producer wrap onto that batch's slots (its in-flight DMA
+    target).  The ring now publishes strictly in begin order: the aborted middle batch's slots stay taken until the oldest batch is committed."""
+    ring = FrameRing(slots=16, frame_shape=(4, 4, 3))
+    f = lambda v: np.full((4, 4, 4, 3), v, np.uint8)
+    audio = [(np.zeros(320, np.float32), 0)] * 8
+    z = ring.begin_batch(f(1), [0, 1, 2, 3])                        # slots 0-3: "its DMA is still in flight"
+    a = ring.begin_batch(f(2), [4, 5, 6, 7])                        # slots 4-7
+    b = ring.begin_batch(f(3), [8, 9, 10, 11])                      # slots 8-11
+    ring.abort_batch(a)                                             # the MIDDLE one
+    assert ring.empty()                                             # nothing may overtake z: no skip message yet
+    r = ring.try_reserve(8)                                         # 4 free slots (12-15): a wrap onto 0-3 must be impossible
+    assert r is None
+    r4 = ring.try_reserve(4)
+    assert r4 == [12, 13, 14, 15] and ring.try_reserve(1) is None
+    ring.commit_batch(b, audio)                                     # committed out of order: held back behind z
+    assert ring.empty()
+    ring.commit_batch(z, audio)                                     # now z, the skip for a, and b go out, in that order
+    got = [ring.get(timeout=5) for _ in range(8)]
+    assert [g[1] for g in got] == [0, 1, 2, 3, 8, 9, 10, 11] and [int(g[0][0, 0, 0]) for g in got] == [1] * 4 + [3] * 4
+    ring.unreserve(r4)                                              # newest: a plain rewind
+    assert ring.try_reserve(16) == list(range(12, 16)) + list(range(0, 12))
+    ring.close()
+
+
+def test_ring_silent_frames_take_places_and_a_failed_begin_returns_its_reservation():
+    """(1) a silent frame holds one of the ring's places like any other frame (the reference's Queue(2B) counts per-frame tuples), so a stalled
+    consumer stops silent batches at the ring's size instead of filling the descriptor queue, and every message holds >= 1 slot: publishing never blocks;
+    (2) a begin_batch that fails AFTER adopting a reservation hands the slots back."""
+    ring = FrameRing(slots=4, frame_shape=(4, 4, 3))
+    audio = [(np.zeros(320, np.float32), 1)] * 4
+    for j in range(2):                                              # two silent batches of 2 fill the ring ...
+        r = ring.try_reserve(2)
+        assert r is not None
+        tok = ring.begin_batch(None, [2 * j, 2 * j + 1], reserved=r)
+        ring.commit_batch(tok, audio)
+    assert ring.try_reserve(1) is None and ring.free_slots() == 0   # ... and the producer KNOWS (it would have queue.Full'ed four puts later before)
+    with pytest.raises(queue.Full):
+        ring.put((None, 9, []), block=True, timeout=0.05)
+    got = [ring.get(timeout=5) for _ in range(4)]                   # silent frames come out as (None, idx, audio) and free their place at once
+    assert [g[1] for g in got] == [0, 1, 2, 3] and all(g[0] is None and g[2][0][1] == 1 for g in got)
+    assert ring.free_slots() == 4
+    r = ring.try_reserve(2)
+    with pytest.raises(ValueError, match="does not fit"):
+        ring.begin_batch(np.zeros((2, 5, 4, 3), np.uint8), [0, 1], reserved=r)     # fails after adoption: the two slots come back
+    with pytest.raises(ValueError, match="3 frames for 2"):
+        ring.begin_batch(np.zeros((3, 4, 4, 3), np.uint8), [0, 1], reserved=ring.try_reserve(2))
+    assert ring.free_slots() == 4 and ring.try_reserve(4) == [0, 1, 2, 3]
+    ring.close()
