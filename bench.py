@@ -219,6 +219,21 @@ class MuseTalkRunner:
                 "gflops": round(n * self.gflop_per_frame() / el, 1)}
 
 
+def lean_runner(precision, batch, device):
+    """The handles of a serving rank in its host-lean mode: created under MF_NO_GRAPH=2 every forward is a plain launch chain on the caller's stream -- no
+    hipGraphLaunch and no cross-stream event wait, either of which keeps a ROCm 7.2 runtime thread spinning for as long as the GPU is busy (0.8 - 0.9 host core
+    per process: tools/host_wait_probe2.py).  At 56 - 64 frames per step the ~450 eager launches are 2 % of the step; the graphs stay where a step is 8 frames."""
+    old = os.environ.get("MF_NO_GRAPH")
+    os.environ["MF_NO_GRAPH"] = "2"
+    try:
+        return MuseTalkRunner(precision, batch, device)
+    finally:
+        if old is None:
+            os.environ.pop("MF_NO_GRAPH", None)
+        else:
+            os.environ["MF_NO_GRAPH"] = old
+
+
 class MultiSession:
     """S independent talking-head sessions on one GPU, one hipStream + one generator handle each
     (BASELINE.json configs[3] per-GPU shape: lipreal.py runs one inference loop per session)."""
@@ -615,17 +630,46 @@ def muse_multi_session(args, device):
             rep["ms_per_step"] = round(el / 5 * 1e3, 3)
             rep["sessions_at_25fps"] = round(S * B * 5 / el / 25.0, 1)
             rep["fps_per_session"] = round(B * 5 / el, 1)
-    if getattr(args, "paced", 1):
-        _stage("paced sessions")
-        rep["paced_sessions"] = muse_paced_sessions(big, args, device, rep["value"], full=bool(getattr(args, "full", 0)))
     rows_b = big.profile(2)
     cb = [r for r in rows_b if r["layer"].startswith("unet:") and r["flops"] > 0 and "attention" not in r["layer"]]
     tb, fb = sum(r["ms"] for r in cb), sum(r["flops"] for r in cb)
     rep["unet_conv_blocks"] = {"achieved_tflops": round(fb / (tb * 1e-3) / 1e12, 1),
                                "mfma_issue_frac_of_bf16_peak": round(MFMA_PASSES[args.precision] * fb / (tb * 1e-3) / 1e12 / BF16_DENSE_PEAK_TF, 3)}
-    del big
+    del big, bat, sessions
     torch.cuda.empty_cache()
+    if getattr(args, "paced", 1):
+        _stage("paced sessions")
+        lean = lean_runner(args.precision, S * B, device)            # the serving rank's handles: eager, single stream (host-lean)
+        rep["paced_sessions"] = muse_paced_sessions(lean, args, device, rep["value"], full=bool(getattr(args, "full", 0)), lean=True)
+        rep["paced_sessions"]["rank_mode"] = "host-lean: handles under MF_NO_GRAPH=2 (eager launch chain, no side branches), single-stream scheduler"
+        if getattr(args, "full", 0):
+            # the same search with graph-replayed handles and the copy / Whisper side streams (round 4's rank): what the host-lean mode costs in sessions
+            _stage("paced sessions, graph-mode handles")
+            big2 = MuseTalkRunner(args.precision, S * B, device)
+            g = muse_paced_sessions(big2, args, device, rep["value"], full=False, lean=False)
+            rep["paced_sessions"]["graph_mode_rank"] = {"max_sessions_sustained": g.get("max_sessions_sustained"), "at_max": g["end_to_end"]["at_max"]}
+            del big2
+        del lean
+        torch.cuda.empty_cache()
     return rep
+
+
+def thread_cpu_times():
+    """{tid: (comm, utime + stime seconds)} of this process's threads (/proc/self/task): who spends the host CPU of a serving rank"""
+    out = {}
+    try:
+        tck = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                st = open(f"/proc/self/task/{tid}/stat").read()
+                comm = st[st.index("(") + 1:st.rindex(")")]
+                f = st[st.rindex(")") + 2:].split()
+                out[int(tid)] = (comm, (int(f[11]) + int(f[12])) / tck)
+            except (OSError, ValueError, IndexError):
+                pass
+    except (OSError, ValueError):
+        pass
+    return out
 
 
 class PacedRig:
@@ -633,8 +677,9 @@ class PacedRig:
     720p frames with paste geometry on the device), an endless 16 kHz PCM stream cut into 20 ms chunks, a MuseASRFrontend and a FrameRing of 2B slots
     (musereal.py:153) -- built once for the largest N a search can reach and reused by every trial."""
 
-    def __init__(self, big, args, device, n_max):
+    def __init__(self, big, args, device, n_max, lean=False):
         from mere_fusion_amd import muse_driver as D
+        self.lean = bool(lean)          # handles created under MF_NO_GRAPH=2 + a single-stream scheduler: no hipGraphLaunch, no cross-stream wait anywhere
         from mere_fusion_amd.paste import AvatarFrames
         from mere_fusion_amd.transport import FrameRing
         from mere_fusion_amd.musetalk.whisper.audio2feature import Audio2Feature
@@ -708,7 +753,7 @@ class PacedRig:
             for fe in fes:
                 fe.warm_up()
             sch = D.EndToEndScheduler(bat, fes, self.a2f, rings=rings, period_s=P, fixed_chunks=None if use_w else self.chunk,
-                                      asr_stream=os.environ.get("MF_BENCH_ASR_INLINE") != "1")   # (A/B: the Whisper call on the step's own stream)
+                                      asr_stream=os.environ.get("MF_BENCH_ASR_INLINE") != "1", single_stream=self.lean)
         else:
             sch = D.SessionScheduler(bat, period_s=P)
         # the consumers (`process_frames`, lipreal.py:195 / musereal.py:226): one thread per session BLOCKED in its ring's get(timeout), as the reference's are
@@ -716,9 +761,11 @@ class PacedRig:
         # millisecond: 22 k get_nowait()s per second were a quarter of the rank's host CPU.)
         got_t = [[] for _ in range(N)]
         stop = threading.Event()
+        cons_tids = set()
 
         def drain(k):
             import queue as _q
+            cons_tids.add(threading.get_native_id())
             cnt = 0
             while not stop.is_set():
                 try:
@@ -738,6 +785,7 @@ class PacedRig:
         import resource
         phase = np.random.default_rng(N).uniform(0.0, P, N)
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
+        th0, main_tid = thread_cpu_times(), threading.get_native_id()
         t_start = time.perf_counter() + 0.01
         nxt = [t_start + float(ph) for ph in phase]
         issued, arrivals, lats, total = [0] * N, [[] for _ in range(N)], [], N * periods
@@ -769,7 +817,16 @@ class PacedRig:
                 time.sleep(dt)
         wall = time.perf_counter() - t_start
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
-        host_cpu = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / wall     # scheduler loop + consumer thread + runtime threads of this process
+        host_cpu = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / wall     # scheduler loop + consumer threads + runtime threads of this process
+        th1 = thread_cpu_times()
+        by = {}
+        for tid, (comm, sec) in th1.items():
+            d = sec - th0.get(tid, (comm, 0.0))[1]
+            waiter = getattr(getattr(sch, "_waiter", None), "native_id", None)
+            key = ("scheduler loop (main thread)" if tid == main_tid else "consumer threads" if tid in cons_tids else "completion waiter thread" if tid == waiter
+                   else f"{comm} (tid {tid}, runtime / other)")
+            by[key] = by.get(key, 0.0) + d
+        host_by_thread = {k: round(v / wall, 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:6] if v / wall >= 0.005}
         if use_r:
             t_end = time.perf_counter() + 2.0
             while any(len(got_t[k]) < periods for k in range(N)) and time.perf_counter() < t_end:
@@ -793,7 +850,7 @@ class PacedRig:
                 "sustained": bool(len(l) == total and p99 <= P * 1e3 and drift <= 0.1 * P * 1e3),
                 "sessions_per_step_mean": round(sch.sessions_served / max(sch.steps, 1), 2),
                 "gpu_busy_frac": round(sch.busy_s / wall, 3), "frames_per_s": round(N * periods * B / wall, 1),
-                "host_cpu_s_per_wall_s": round(host_cpu, 3)}
+                "host_cpu_s_per_wall_s": round(host_cpu, 3), "host_cpu_by_thread": host_by_thread}
 
     def search(self, cap, stages, screen_s, confirm_s, fail_s):
         """Largest N whose trial holds the bound: short screening trials walk from cap + 1 (which should fail) to the first N that holds, then ONE long
@@ -821,7 +878,7 @@ class PacedRig:
         return best, trials
 
 
-def muse_paced_sessions(big, args, device, free_fps, full=True):
+def muse_paced_sessions(big, args, device, free_fps, full=True, lean=False):
     """BASELINE.json's second metric -- "max concurrent >= 25 fps sessions" -- measured instead of extrapolated (a session is
     sustained when the p99 latency of its B-frame batches is <= B x 40 ms).  N sessions run on their own clocks in real time; the per-GPU
     scheduler (mere_fusion_amd.muse_driver) packs whoever waits into steps of up to `--sessions` sessions on the one UNet / VAE pair.
@@ -833,7 +890,7 @@ def muse_paced_sessions(big, args, device, free_fps, full=True):
     S, B = args.sessions, args.batch
     P = B * 0.040
     cap = max(int(free_fps / 25.0), 1)
-    rig = PacedRig(big, args, device, n_max=cap + 4)
+    rig = PacedRig(big, args, device, n_max=cap + 4, lean=lean)
     try:
         # default run: 3 s screening trials + ONE 15 s confirmation (the whole bench stays under ~4 minutes); --full 1: the 40 s confirmation, N + 1 shown failing
         # over 20 s, the UNet + VAE only search and the per-stage trials (round 4's measurement, ~150 s)
@@ -867,12 +924,12 @@ def muse_node_rank_leg(args, device):
     end-to-end paced search -- every rank runs this at the same time on its own GPU (host cores and PCIe are shared, as on a serving node)."""
     from mere_fusion_amd import muse_driver as D
     S, B = args.sessions, args.batch
-    big = MuseTalkRunner(args.precision, S * B, device)
+    big = lean_runner(args.precision, S * B, device)
     bat = D.MuseBatcher(big.unet, big.vae, [D.MuseSession(W.make_musetalk_inputs(25, 500 + s)[0]) for s in range(S)], batch_size=B, device=device)
     chunks = [W.make_musetalk_inputs(B, 700 + s)[1].to(device) for s in range(S)]
     bat.prewarm()
     el = harness.timed_steps(lambda: bat.step(chunks), 5, 2, sync_fn=lambda: torch.cuda.synchronize(device), device=device)
-    rep = muse_paced_sessions(big, args, device, S * B * 5 / el, full=False)
+    rep = muse_paced_sessions(big, args, device, S * B * 5 / el, full=False, lean=True)
     rep["free_running_8x8_frames_per_s"] = round(S * B * 5 / el, 1)
     del big
     torch.cuda.empty_cache()
@@ -884,8 +941,8 @@ def ranks_on_one_gpu_worker(args, device):
     time for --worker-seconds, started together with the other workers (ready files in --worker-dir).  Prints one JSON line."""
     import resource
     S, B = args.sessions, args.batch
-    big = MuseTalkRunner(args.precision, S * B, device)
-    rig = PacedRig(big, args, device, n_max=S)
+    big = lean_runner(args.precision, S * B, device)
+    rig = PacedRig(big, args, device, n_max=S, lean=True)
     k, R, d = args.worker_rank, args.ranks_on_one_gpu, args.worker_dir
     open(os.path.join(d, f"ready_{k}"), "w").close()
     t_wait = time.perf_counter()
@@ -1345,6 +1402,11 @@ def compact_line(full):
         at = _dig(ms_, "paced_sessions", "end_to_end", "at_max", default={}) or {}
         s_ = _pick(ms_, ("sessions_per_step", "batch_per_session", "value", "ms_per_step", "with_gpu_paste_back_720p"), {"value": "frames_per_s"})
         s_["sessions_per_gpu_at_25fps_end_to_end"] = _dig(ms_, "paced_sessions", "max_sessions_sustained")
+        if _dig(ms_, "paced_sessions", "rank_mode"):
+            s_["rank_mode"] = "host-lean (eager single-stream handles)"
+        gm = _dig(ms_, "paced_sessions", "graph_mode_rank", "max_sessions_sustained")
+        if gm is not None:
+            s_["graph_mode_rank_sessions"] = gm
         s_.update(_pick(at, ("p50_ms", "p99_ms", "seconds", "gpu_busy_frac", "host_cpu_s_per_wall_s")))
         uv = _dig(ms_, "paced_sessions", "unet_vae_only", "max_sessions_sustained")
         if uv is not None:

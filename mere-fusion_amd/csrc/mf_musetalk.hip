@@ -810,9 +810,12 @@ struct Net {
         MF_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
         MF_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
         MF_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-        fork_on = true;
+        // MF_NO_GRAPH=1: every forward an eager launch chain (side branches still forked onto the second stream).  MF_NO_GRAPH=2: eager AND single-stream, no
+        // side branches -- the host-lean mode of a serving rank: on ROCm 7.2 any hipGraphLaunch or cross-stream event wait keeps a runtime thread spinning for
+        // as long as the GPU is busy (0.8 - 0.9 host core per process, tools/host_wait_probe2.py), a plain launch chain on one stream does not.
         const char* ng = std::getenv("MF_NO_GRAPH");
-        use_graph = !(ng && ng[0] == '1');
+        use_graph = !(ng && (ng[0] == '1' || ng[0] == '2'));
+        fork_on = !(ng && ng[0] == '2');
         return MF_OK;
     }
 };

@@ -288,22 +288,28 @@ class EndToEndScheduler(SessionScheduler):
     complete in HBM (ring stage off).  Stages can be switched off individually to price them (bench.py `paced_sessions.stages`)."""
 
     def __init__(self, batcher, frontends, audio_processor, rings=None, period_s=None, hold_s=None, clock=time.perf_counter, depth=2, fixed_chunks=None,
-                 asr_stream=True):
+                 asr_stream=True, single_stream=False):
         super().__init__(batcher, period_s=period_s, hold_s=hold_s, clock=clock)
         self.fixed_chunks = fixed_chunks                             # (measurement only: this [B, 50, 384] tensor instead of the Whisper stage)
         if len(frontends) != len(batcher.sessions):
             raise RuntimeError("one MuseASRFrontend per session is required")
         self.frontends, self.audio_processor, self.rings = list(frontends), audio_processor, rings
         self.depth = max(int(depth), 1)                              # steps in flight: the one computing + the one whose frames are being copied
-        self.copy_stream = torch.cuda.Stream(device=batcher.device) if rings is not None else None
+        # single_stream: the Whisper call, the step and the D2H of its frames all on the caller's stream -- no cross-stream event wait anywhere (with handles
+        # created under MF_NO_GRAPH=2 the whole rank is one launch chain: no runtime thread spins, see mf_musetalk.hip); costs the copy / Whisper overlap
+        self.single_stream = bool(single_stream)
+        if self.single_stream:
+            asr_stream = False
+        self.copy_stream = torch.cuda.Stream(device=batcher.device) if rings is not None and not self.single_stream else None
         # The Whisper front-end of a step on its OWN stream: with two steps in flight it runs beside the previous step's VAE instead of between that VAE and
         # this step's UNet.  Its ~25 launches are latency-bound (1.5 ms for seven windows with the GPU mostly idle); beside the VAE's full-chip kernels they cost
         # the step almost nothing.  asr_stream=False: on the step's stream, as before (A/B, bench `stages`).
         self.asr_stream = torch.cuda.Stream(device=batcher.device) if asr_stream else None
         self.inflight = deque()
-        # Completion is WAITED for, not polled (VERDICT r04 item 4: a 2 - 5 kHz hipEventQuery loop cost a rank 1.3 - 1.9 host cores at capacity): every step's
-        # event is created with the blocking-sync flag and handed to one waiter thread, whose hipEventSynchronize sleeps on the interrupt and then sets
-        # `_wake`; the serving loop sleeps in idle_wait() until then or until the next arrival is due.
+        # The serving loop SLEEPS between steps (VERDICT r04 item 4: polling run_once at 2 - 5 kHz was part of the 1.3 - 1.9 host cores a rank cost at
+        # capacity): every step's event goes to one waiter thread that does nothing but hipEventQuery it every 0.5 ms and then sets `_wake`; the loop sleeps
+        # in idle_wait() until then or until the next arrival is due.  (Not hipEventSynchronize: on ROCm 7.2 it spins a full core for as long as the GPU is
+        # busy, with or without the blocking-sync event flag, and hipDeviceScheduleBlockingSync hangs on this driver: tools/host_wait_probe.py.)
         self._wake = threading.Event()
         self._evq = queue.SimpleQueue()
         self._waiter = threading.Thread(target=self._wait_loop, daemon=True)
@@ -318,7 +324,8 @@ class EndToEndScheduler(SessionScheduler):
             if ev is None:
                 return
             try:
-                ev.synchronize()                                      # (blocking-sync event: the thread sleeps, the GIL is released)
+                while not ev.query():
+                    time.sleep(5e-4)
             except Exception:
                 pass
             self._wake.set()
@@ -451,16 +458,17 @@ class EndToEndScheduler(SessionScheduler):
         tokens = {}
         try:
             out = self.batcher.step(chunks, only=ks)
-            ev = torch.cuda.Event(blocking=True)
+            ev = torch.cuda.Event()
             if self.rings is not None:
                 cur = torch.cuda.current_stream(dev)
-                self.copy_stream.wait_stream(cur)
+                if self.copy_stream is not None:
+                    self.copy_stream.wait_stream(cur)
                 for k in ks:
                     fr, idx = out[k]
                     tokens[k] = self.rings[k].begin_batch(fr, idx, stream=self.copy_stream, reserved=reserved.pop(k))   # (fr None: B silent frames)
-                    if fr is not None:
+                    if fr is not None and self.copy_stream is not None:
                         fr.record_stream(self.copy_stream)
-                ev.record(self.copy_stream)
+                ev.record(self.copy_stream if self.copy_stream is not None else cur)
         except BaseException:
             # nothing of this step is published: tokens already begun and reservations not yet used go back (the rings publish in begin order whatever order
             # this happens in)
