@@ -753,7 +753,7 @@ class PacedRig:
             for fe in fes:
                 fe.warm_up()
             sch = D.EndToEndScheduler(bat, fes, self.a2f, rings=rings, period_s=P, fixed_chunks=None if use_w else self.chunk,
-                                      asr_stream=os.environ.get("MF_BENCH_ASR_INLINE") != "1", single_stream=self.lean)
+                                      single_stream=self.lean)
         else:
             sch = D.SessionScheduler(bat, period_s=P)
         # the consumers (`process_frames`, lipreal.py:195 / musereal.py:226): one thread per session BLOCKED in its ring's get(timeout), as the reference's are
@@ -1156,8 +1156,7 @@ class ErNeRFRunner:
             self.last = self.r.render(self.ro, self.rd, self.auds, self.bg_coords, self.pose, self.d_eye, bg_color=1.0, want_u8=True)
             self.trace = self.last["trace"]
         else:
-            self.last = self.r.render(self.ro, self.rd, self.auds, self.bg_coords, self.pose, self.eye, bg_color=1.0, want_u8=True, loop="device",
-                                      graph=os.environ.get("MF_NERF_GRAPH") == "1")   # replaying the head as a graph measured no faster: GPU bound
+            self.last = self.r.render(self.ro, self.rd, self.auds, self.bg_coords, self.pose, self.eye, bg_color=1.0, want_u8=True, loop="device")
 
     def roofline(self, iters=5):
         """Per-kernel rates of one frame's head loop, measured live: the reference-shaped host loop (renderer.run_cuda) enqueues every kernel

@@ -487,13 +487,12 @@ int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* s
     MF_REQUIRE((int64_t)batch * xb.per_batch() < ((int64_t)1 << 31) && (int64_t)batch * dst.per_batch() < ((int64_t)1 << 31),
                "affine_silu_to_act_q: tensors of 2^31 elements or more are not supported (32-bit offsets)");
     const int64_t total = (int64_t)batch * xb.H * xb.W * (x.C / 32);
-    // MF_AFFQ_VARIANT (measurement, tools/affine_q_probe.hip): 0 = the per-thread-parameter kernel everywhere, 1 = wave-uniform blocks in launch order,
-    // 2 (default) = wave-uniform blocks, XCD-ordered when a pixel row is wider than one workgroup's four blocks
-    static const int variant = getenv("MF_AFFQ_VARIANT") ? atoi(getenv("MF_AFFQ_VARIANT")) : 2;
-    if (variant >= 1 && (xb.H * xb.W) % 64 == 0) {
+    // wave-uniform channel blocks, XCD-ordered when a pixel row is wider than one workgroup's four blocks; maps that are not a multiple of 64 pixels keep the
+    // per-thread-parameter kernel below (the three implementations measured in round 4: tools/affine_q_probe.hip, profiles/r04_affine_q_probe.txt)
+    if ((xb.H * xb.W) % 64 == 0) {
         const int cpb = xb.H * xb.W / 64, nchunk = batch * cpb, nblk = x.C / 32;
         const int64_t waves = (int64_t)nchunk * nblk;
-        const int xcd_order = variant >= 2 && nblk > 4 && waves >= 16384;
+        const int xcd_order = nblk > 4 && waves >= 16384;
         const int64_t waves_per_xcd = (int64_t)((nchunk + 7) / 8) * nblk;
         const dim3 grid(xcd_order ? (unsigned)(8 * ((waves_per_xcd + 3) / 4)) : (unsigned)((waves + 3) / 4));
 #define MF_AFFQ_U(S, P)                                                                                                                                                     \

@@ -4,12 +4,22 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdarg>
+#include <cstdlib>
 #include <string>
 #include "../../include/merefusion.h"
 
 typedef uint16_t bf16_t;  // raw bf16 bits; kernels reinterpret as needed
 
 void mf_set_error(const char* fmt, ...);
+
+// MF_DEBUG: comma-separated words for development output -- "times" (per-workgroup s_memtime stamps of the conv kernels), "tune" (one line per measured layer in
+// mf_*_tune).  One variable instead of one per facility (switch creep).
+static inline bool mf_debug_has(const char* word) {
+    const char* e = getenv("MF_DEBUG");
+    if (!e) return false;
+    const std::string s = std::string(",") + e + ",";
+    return s.find(std::string(",") + word + ",") != std::string::npos;
+}
 
 #define MF_HIP(call)                                                                       \
     do {                                                                                   \

@@ -56,7 +56,7 @@ struct ConvArgs {
     int act;                  // 0 none, 1 relu, 2 sigmoid, 3 gelu(erf), 4 silu
     int res_after_act;        // residual added after the activation (x = act(conv) + r)
     int tiles_m, tiles_n;
-    unsigned long long* dbg;  // MF_DBG_TIMES: 4 s_memtime stamps per workgroup, or null
+    unsigned long long* dbg;  // MF_DEBUG=times: 4 s_memtime stamps per workgroup, or null
     int m_fastest;            // XCD tile order: pixel tiles fastest (weight-heavy layers), see k_conv_igemm
     int ld;                   // operand path of the 4-wave tiles (k_conv_igemm's LD): -1 = the library default, 0 / 1 / 2 = measured choice (mf_conv_tune)
     int wide_store;           // output view starts on an 8-channel group and N % 8 == 0: 16-byte epilogue stores (lane pairs exchange halves)
@@ -89,14 +89,10 @@ struct HaloArgs {
     int patches_x, patches_per_img, n_patches, tiles_n;   // filled by mf_halo_launch
     // LDS-weights kernel only: channel slices split over blockIdx.y, fp32 partial tiles [split][B][H][W][N] combined by k_splitk_epilogue
     float* ws; int64_t ws_split; int nsplit;
-    unsigned long long* dbg;                    // MF_DBG_TIMES: 4 s_memtime stamps per workgroup (entry, loop start, loop end, exit), or null
+    unsigned long long* dbg;                    // MF_DEBUG=times: 4 s_memtime stamps per workgroup (entry, loop start, loop end, exit), or null
     int q;                                      // operands in the f16 + FP6-residual format (MF_PREC_F16Q): x_lo / w_lo hold [q6 block | q6 block] rows
     double* gn_out; int gn_out_cpg, gn_out_groups;   // f16 + FP6 kernel: (sum, sum of squares) of the OUTPUT per (sample, group) added here for the consumer GroupNorm; null = off
     int wide_store;                             // f16 + FP6 tiles: the output view starts on an 8-channel group, C % 8 == 0, N % 32 == 0: 16-byte epilogue stores
-    // f16 + FP6 specialised workgroup, GroupNorm fused into the conv (gn_scale != null): x_hi / x_lo are the RAW bf16 (hi, lo) planes of the tensor the
-    // GroupNorm reads; the producer waves turn each landed halo image into silu(x * gn_scale[b][c] + gn_shift[b][c]) * gn_post[c] in the f16 + FP6 format in
-    // place (what k_affine_silu_to_q wrote to a scratch tensor: 4 B read + 4 B written per value and a launch per layer), pixels outside the map zero.
-    const float* gn_scale; const float* gn_shift; const float* gn_post; int gn_silu; int gn_C;
 };
 struct HaloTile { int ph, bn, wgm, wgn; };
 HaloTile mf_halo_pick_tile(int H, int W, int N, int batch, int cin = 0);
@@ -123,9 +119,6 @@ struct ConvPlan {
     int* goff = nullptr;
     double* out_stats = nullptr; int out_stats_groups = 0;   // GroupNorm (sum, sum of squares) of the output, left in out_stats by every launch (set by the network builder): from the
                                                              // epilogue where the kernel can (f16 + FP6 tiles, 4-wave implicit-GEMM tiles, split-K combine), else by a k_gn_stats pass behind the conv
-    // f16 + FP6 plans only: GroupNorm-apply (+ SiLU, + channel equalisation) fused into the conv's halo load (set by the network builder; the launch then takes the
-    // GroupNorm's INPUT tensor as `in`): per-(sample, channel) scale / shift [cap][cin] written by mf_groupnorm_affine in front of every launch, per-channel post [cin] or null
-    const float* gn_scale = nullptr; const float* gn_shift = nullptr; const float* gn_post = nullptr; int gn_silu = 0;
     bool q_small_maps = false;   // set BEFORE mf_conv_plan_create (MF_PREC_F16Q): take the f16 + FP6 halo tile on maps from 16 x 16 and up to 2048 input channels as well
                                  // (the UNet's 640-channel 16 x 16 layers at >= 40 frames per step; the caller keeps a bf16x3 plan for smaller steps)
     bool q = false;       // MF_PREC_F16Q: w_hi = f16 [slice][tap][Npad][32], w_lo = [slice][tap][Npad][q6(wh) 32 B | q6(wl) 32 B] (24 B codes + E8M0 byte + pad)

@@ -137,7 +137,7 @@ __device__ __forceinline__ void store_pair16(bf16_t* base, int64_t yo, int c16, 
 // v_mfma_f32_16x16x32_f16 (wh.xh) and per 64-deep tile ONE v_mfma_scale_f32_16x16x128_f8f6f4 whose K blocks 0 / 1 carry q6(wh).xl / wl.q6(xh) of channels
 // 0..31 and blocks 2 / 3 those of channels 32..63 -- 48 matrix cycles per tile and accumulator where bf16x3 spends 96.  A 32-deep tile (the 8-wave tiles)
 // leaves blocks 2 / 3 off by a zero scale: 32 cycles against 48.
-// LD 3 (round 5): PRODUCER WAVES.  Stamps (MF_DBG_TIMES) on the UNet's batch-8 shapes put the DMA loop at 3325 cycles per 64-deep step of the 128 x 128 tile
+// LD 3 (round 5): PRODUCER WAVES.  Stamps (MF_DEBUG=times) on the UNet's batch-8 shapes put the DMA loop at 3325 cycles per 64-deep step of the 128 x 128 tile
 // and 1816 for 128 x 64, whether 20 or 240 workgroups run and whether the bytes come from L2 or HBM: 96 / 48 MFMAs (1536 / 768 cycles) plus the ISSUE cost of
 // the 16 / 12 LDS-DMA pieces each compute wave launches per step (100 - 185 cycles apiece inside a loaded phase, MI355X_MICROARCH.md) plus two exposed LDS
 // fragment-read latencies -- the matrix pipe is busy 23 - 46 % by construction.  Here a workgroup is NW compute waves + NW producer waves (one of each per SIMD):
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(WGM * WGN * (LD == 3 ? 2 : 1) * 64) void k_conv_ige
     constexpr int DR = LD == 3 ? igemm_ring<BM, BN, BK, X3>() : 0;                     // ring depth of the producer-wave path
     static_assert(LD != 3 || DR >= 4, "producer-wave path: the ring needs >= 4 stages (two ahead of the barrier + one in flight)");
     int* s_goff = reinterpret_cast<int*>(smem + (LD == 3 ? DR : LDS_STAGES) * STAGE);
-    // MF_DBG_TIMES: s_memtime stamps of (entry, loop start, loop end, exit) per workgroup
+    // MF_DEBUG=times: s_memtime stamps of (entry, loop start, loop end, exit) per workgroup
     unsigned long long* dbg = a.dbg ? a.dbg + 4 * ((size_t)blockIdx.x + gridDim.x * ((size_t)blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
     if (dbg && threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memtime();
 
@@ -728,6 +728,82 @@ __global__ __launch_bounds__(WGM * WGN * (LD == 3 ? 2 : 1) * 64) void k_conv_ige
     if (dbg && threadIdx.x == 0) dbg[3] = __builtin_amdgcn_s_memtime();
 }
 
+// fp32 partials of one channel quad, summed in split order (bias first): the loads of four splits are issued together and added one after the other, so
+// the value is the one a serial loop gives while the thread waits for ONE round trip per four splits instead of four (the combine kernels are pure latency:
+// 4 - 16 dependent loads of a few MB in all took 6 - 12 us per launch, 111 launches per UNet step and 27 per Wav2Lip step).
+__device__ __forceinline__ float4 splitk_sum(const float* w, int64_t ws_split, int nsplit, float4 s) {
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(w + (int64_t)k * ws_split);
+        const float4 v1 = *reinterpret_cast<const float4*>(w + (int64_t)(k + 1) * ws_split);
+        const float4 v2 = *reinterpret_cast<const float4*>(w + (int64_t)(k + 2) * ws_split);
+        const float4 v3 = *reinterpret_cast<const float4*>(w + (int64_t)(k + 3) * ws_split);
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+        s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+        s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+        s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    }
+    if (k + 2 <= nsplit) {
+        const float4 v0 = *reinterpret_cast<const float4*>(w + (int64_t)k * ws_split);
+        const float4 v1 = *reinterpret_cast<const float4*>(w + (int64_t)(k + 1) * ws_split);
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+        s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+        k += 2;
+    }
+    if (k < nsplit) {
+        const float4 v0 = *reinterpret_cast<const float4*>(w + (int64_t)k * ws_split);
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+    }
+    return s;
+}
+
+// the residual quad of a pixel, requested BEFORE the partials are summed (one more load in flight beside them) and applied where epilogue_store_v would
+struct ResQuad { uint2 h, l; };
+__device__ __forceinline__ ResQuad load_residual(const ConvArgs& a, int64_t ro, int c, bool x3) {
+    ResQuad r{make_uint2(0u, 0u), make_uint2(0u, 0u)};
+    if (a.r_hi) {
+        r.h = *reinterpret_cast<const uint2*>(a.r_hi + ro + c);
+        if (x3) r.l = *reinterpret_cast<const uint2*>(a.r_lo + ro + c);
+    }
+    return r;
+}
+__device__ __forceinline__ void apply_residual(float (&v)[4], const ResQuad& r, bool x3) {
+    v[0] += bf2f(r.h.x & 0xffffu); v[1] += bf2f(r.h.x >> 16);
+    v[2] += bf2f(r.h.y & 0xffffu); v[3] += bf2f(r.h.y >> 16);
+    if (x3) {
+        v[0] += bf2f(r.l.x & 0xffffu); v[1] += bf2f(r.l.x >> 16);
+        v[2] += bf2f(r.l.y & 0xffffu); v[3] += bf2f(r.l.y >> 16);
+    }
+}
+// epilogue_store_v with the residual already in registers (same operation order)
+__device__ __forceinline__ void epilogue_store_pre(const ConvArgs& a, float (&v)[4], int64_t yo, int c, bool x3, const ResQuad& r) {
+    if (a.r_hi && !a.res_after_act) apply_residual(v, r, x3);
+    if (a.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (a.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+    } else if (a.act == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+    } else if (a.act == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.f + expf(-v[e]));
+    }
+    if (a.r_hi && a.res_after_act) apply_residual(v, r, x3);
+    uint32_t h[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
+    *reinterpret_cast<uint2*>(a.y_hi + yo + c) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    if (x3) {
+        uint32_t l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
+        *reinterpret_cast<uint2*>(a.y_lo + yo + c) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    }
+}
+
 // Combines the split-K partial tiles: one thread per (output pixel, 4 channels).
 // ws layout: [split][B][Ho][Wo][N] fp32 (unpadded); output / residual are padded NHWC planes.
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int nsplit, int Ho, int Wo, int64_t total) {
@@ -741,31 +817,26 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int n
     const int ox = (int)(p % Wo); p /= Wo;
     const int oy = (int)(p % Ho);
     const int b = (int)(p / Ho);
-    const float* w = a.ws + (((int64_t)b * Ho + oy) * Wo + ox) * a.N + c;
-    float4 s = *reinterpret_cast<const float4*>(a.bias + c);
-    for (int k = 0; k < nsplit; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)k * a.ws_split);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    float v[4] = {s.x, s.y, s.z, s.w};
-    if (geglu) {
-        float4 g = *reinterpret_cast<const float4*>(a.bias + c + 16);
-        for (int k = 0; k < nsplit; ++k) {
-            const float4 t = *reinterpret_cast<const float4*>(w + 16 + (int64_t)k * a.ws_split);
-            g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
-        }
-        v[0] *= gelu_erf(g.x); v[1] *= gelu_erf(g.y); v[2] *= gelu_erf(g.z); v[3] *= gelu_erf(g.w);
-    }
+    const bool x3 = a.y_lo != nullptr;
     // y/r strides of the UNIT output grid are passed in (yi, yj) / (ri, rj) by the launcher
     const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
     const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)ox * a.rj;
-    epilogue_store(a, v, yo, ro, co, a.y_lo != nullptr);
+    const ResQuad rq = load_residual(a, ro, co, x3);
+    const float* w = a.ws + (((int64_t)b * Ho + oy) * Wo + ox) * a.N + c;
+    const float4 s = splitk_sum(w, a.ws_split, nsplit, *reinterpret_cast<const float4*>(a.bias + c));
+    float v[4] = {s.x, s.y, s.z, s.w};
+    if (geglu) {
+        const float4 g = splitk_sum(w + 16, a.ws_split, nsplit, *reinterpret_cast<const float4*>(a.bias + c + 16));
+        v[0] *= gelu_erf(g.x); v[1] *= gelu_erf(g.y); v[2] *= gelu_erf(g.z); v[3] *= gelu_erf(g.w);
+    }
+    epilogue_store_pre(a, v, yo, co, x3, rq);
 }
 
 // The same combine for a layer whose consumer is a GroupNorm (a.gn_out): the (sum, sum of squares) of the stored values per (sample, group)
 // come out of this pass instead of a k_gn_stats pass over the tensor.  grid (pixel blocks of P, batch); a thread owns a channel quad and walks
-// the block's pixels pp, pp + ppi, ... (one pixel's quads are contiguous: coalesced as in k_gn_stats); fp32 partials over <= 64 pixels, then
-// fp64 LDS bins per group and one global fp64 atomic per (workgroup, group, moment).  No GEGLU (its consumer is a Linear).
+// the block's pixels pp, pp + ppi, ... (one pixel's quads are contiguous: coalesced as in k_gn_stats), two pixels per iteration with both pixels' loads in
+// flight together; fp32 partials over <= 64 pixels, then fp64 LDS bins per group and one global fp64 atomic per (workgroup, group, moment).  No GEGLU (its
+// consumer is a Linear).
 __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const ConvArgs a, int nsplit, int Ho, int Wo, int P) {
     __shared__ double bins[2 * 64];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -775,6 +846,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const ConvArgs a,
     const int k0 = tid % cols, pp = tid / cols;
     const int T = Ho * Wo, t0 = blockIdx.x * P, t1 = min(T, t0 + P);
     const int groups = a.gn_out_groups, cpg = a.gn_out_cpg;
+    const bool x3 = a.y_lo != nullptr;
     for (int i = tid; i < 2 * groups; i += 256) bins[i] = 0.0;
     __syncthreads();
     if (pp < ppi) {
@@ -782,20 +854,41 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const ConvArgs a,
             const int c = k * 4;
             const float4 bq = *reinterpret_cast<const float4*>(a.bias + c);
             float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int t = t0 + pp; t < t1; t += ppi) {
-                const int oy = t / Wo, ox = t - oy * Wo;
-                const float* w = a.ws + (((int64_t)b * Ho + oy) * Wo + ox) * a.N + c;
-                float4 s = bq;
-                for (int sp = 0; sp < nsplit; ++sp) {
-                    const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)sp * a.ws_split);
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            for (int t = t0 + pp; t < t1; t += 2 * ppi) {
+                const int tb = t + ppi;
+                const bool two = tb < t1;
+                const int ta = t, tc = two ? tb : t;                  // (the second pixel clamped onto the first when the block ends: loaded, not stored)
+                const int oy0 = ta / Wo, ox0 = ta - oy0 * Wo, oy1 = tc / Wo, ox1 = tc - oy1 * Wo;
+                const int64_t yo0 = (int64_t)b * a.yb + (int64_t)oy0 * a.yi + (int64_t)ox0 * a.yj, yo1 = (int64_t)b * a.yb + (int64_t)oy1 * a.yi + (int64_t)ox1 * a.yj;
+                const int64_t ro0 = (int64_t)b * a.rb + (int64_t)oy0 * a.ri + (int64_t)ox0 * a.rj, ro1 = (int64_t)b * a.rb + (int64_t)oy1 * a.ri + (int64_t)ox1 * a.rj;
+                const ResQuad r0 = load_residual(a, ro0, c, x3), r1 = load_residual(a, ro1, c, x3);
+                const float* w0 = a.ws + (((int64_t)b * Ho + oy0) * Wo + ox0) * a.N + c;
+                const float* w1 = a.ws + (((int64_t)b * Ho + oy1) * Wo + ox1) * a.N + c;
+                float4 sa = bq, sb = bq;
+                int sp = 0;
+                for (; sp + 2 <= nsplit; sp += 2) {                   // four loads in flight (two pixels x two splits), each pixel's sum in split order
+                    const float4 a0 = *reinterpret_cast<const float4*>(w0 + (int64_t)sp * a.ws_split), a1 = *reinterpret_cast<const float4*>(w0 + (int64_t)(sp + 1) * a.ws_split);
+                    const float4 b0 = *reinterpret_cast<const float4*>(w1 + (int64_t)sp * a.ws_split), b1 = *reinterpret_cast<const float4*>(w1 + (int64_t)(sp + 1) * a.ws_split);
+                    sa.x += a0.x; sa.y += a0.y; sa.z += a0.z; sa.w += a0.w;
+                    sa.x += a1.x; sa.y += a1.y; sa.z += a1.z; sa.w += a1.w;
+                    sb.x += b0.x; sb.y += b0.y; sb.z += b0.z; sb.w += b0.w;
+                    sb.x += b1.x; sb.y += b1.y; sb.z += b1.z; sb.w += b1.w;
                 }
-                float v[4] = {s.x, s.y, s.z, s.w};
-                const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
-                const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)ox * a.rj;
-                epilogue_store_v(a, v, yo, ro, c, a.y_lo != nullptr);
+                if (sp < nsplit) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(w0 + (int64_t)sp * a.ws_split), b0 = *reinterpret_cast<const float4*>(w1 + (int64_t)sp * a.ws_split);
+                    sa.x += a0.x; sa.y += a0.y; sa.z += a0.z; sa.w += a0.w;
+                    sb.x += b0.x; sb.y += b0.y; sb.z += b0.z; sb.w += b0.w;
+                }
+                float v[4] = {sa.x, sa.y, sa.z, sa.w};
+                epilogue_store_pre(a, v, yo0, c, x3, r0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s4[e] += v[e]; q4[e] += v[e] * v[e]; }
+                if (two) {
+                    float u[4] = {sb.x, sb.y, sb.z, sb.w};
+                    epilogue_store_pre(a, u, yo1, c, x3, r1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s4[e] += u[e]; q4[e] += u[e] * u[e]; }
+                }
             }
             int g_cur = c / cpg;
             double as = 0.0, aq = 0.0;
@@ -1127,8 +1220,7 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     // slice instead of once per tap; smaller steps launch the twin (mf_halo_w_pick_tile).  Whole step, same-box A/B: 112.6 -> 111.8 ms at 64 frames, equal at
     // 48 and below.  On the 16 x 16 maps (640 channels: one patch per image) it does not pay.
     const bool odd_wide = d.cout >= 256 && d.cout % 128 != 0 && d.cout % 64 == 0 && d.in_h * d.in_w >= 32 * 32;
-    static const bool q_small_env = getenv("MF_Q_HALO_SMALL") != nullptr;  // (measurement: tools/conv_probe.py has no plan to set the flag on)
-    const bool q_small = (p->q_small_maps || q_small_env) && precision == MF_PREC_F16Q && d.cin % 32 == 0 && d.cout % 128 == 0 && d.cin <= 2048 && d.cout <= 1024;
+    const bool q_small = p->q_small_maps && precision == MF_PREC_F16Q && d.cin % 32 == 0 && d.cout % 128 == 0 && d.cin <= 2048 && d.cout <= 1024;
     const bool wide_ok = (!g_no_halo_wide && d.cin <= 1024 && d.cout <= 1024 && (d.cout % 128 == 0 || odd_wide) && d.cin % 32 == 0 &&
                          (d.in_h * d.in_w >= 64 * 64 || (d.cout % 256 == 0 && d.cin >= 512) || odd_wide)) ||   // small maps: only the 256-channel tile pays
                          q_small;   // ... and the f16 + FP6 tile where the caller asked for it: 640 -> 640 @16^2 at 64 frames 360 -> 250 us against the bf16x3 implicit GEMM
@@ -1273,7 +1365,7 @@ void mf_conv_plan_destroy(ConvPlan* p) {
 
 int mf_conv_bind(ConvPlan* p, const ActBuf& in) {
     // (a plan with the GroupNorm fused into its halo load reads the GroupNorm's INPUT: pixels outside the map are masked by coordinate, no zero ring needed)
-    MF_REQUIRE(p->gn_scale || in.halo >= p->in_halo_need, "conv: input halo %d < required %d", in.halo, p->in_halo_need);
+    MF_REQUIRE(in.halo >= p->in_halo_need, "conv: input halo %d < required %d", in.halo, p->in_halo_need);
     MF_REQUIRE(in.H == p->d.in_h && in.W == p->d.in_w, "conv: plan built for %dx%d input, bound to %dx%d",
                p->d.in_h, p->d.in_w, in.H, in.W);
     MF_REQUIRE(in.C % 8 == 0 && in.C >= p->cin_pad, "conv: input buffer has %d channels, need >= %d (multiple of 8)", in.C, p->cin_pad);
@@ -1393,17 +1485,7 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
         ha.act = p->d.act;
         const HaloTile tw = mf_halo_w_pick_tile(p->out_h, p->out_w, p->d.cout, batch, p->d.cin);
         if (p->q) {                             // the f16 + FP6 format has one kernel: the 8-wave 16 x 16 x 128-channel tile
-            MF_REQUIRE(!ha.res_from_halo || p->gn_scale, "conv (f16q): residual-from-input is not built for this format");
-            if (p->gn_scale) {                  // GroupNorm + SiLU fused into the halo load: `in` is the GroupNorm's input (raw bf16 hi / lo planes)
-                ha.gn_scale = p->gn_scale; ha.gn_shift = p->gn_shift; ha.gn_post = p->gn_post; ha.gn_silu = p->gn_silu; ha.gn_C = p->d.cin;
-                if (ha.res_from_halo) {         // (the residual is the RAW tensor, which is what the halo image no longer holds: read it from HBM in the epilogue)
-                    ha.res_from_halo = 0;
-                    const ActBuf& rb = *res.buf;
-                    const int64_t rb0 = ((int64_t)rb.halo * rb.Wp() + rb.halo) * rb.C + res.coff;
-                    ha.r_hi = rb.hi + rb0; ha.r_lo = rb.lo + rb0;
-                    ha.rb = rb.per_batch(); ha.ri = rb.Wp() * rb.C; ha.rj = rb.C;
-                }
-            }
+            MF_REQUIRE(!ha.res_from_halo, "conv (f16q): residual-from-input is not built for this format");
             if (p->out_stats) {
                 const int cpg = p->d.cout / p->out_stats_groups;
                 if (p->d.cout % p->out_stats_groups == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && !ha.ws) {   // (other group widths: k_gn_stats behind the conv)
@@ -1573,7 +1655,7 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
         const int64_t w_elems = (int64_t)a.Npad * p->ph[0].KT * 64 * p->nphase;
         const int64_t x_elems = (int64_t)batch * ib.H * ib.W * in.C;
         a.m_fastest = w_elems > x_elems;
-        static const bool dbg_times = getenv("MF_DBG_TIMES") != nullptr;
+        static const bool dbg_times = mf_debug_has("times");
         if (dbg_times) {
             static unsigned long long* dbg_buf = nullptr;
             if (!dbg_buf) MF_HIP(hipMalloc(&dbg_buf, (size_t)4 * 65536 * sizeof(unsigned long long)));
@@ -1632,7 +1714,7 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
             for (size_t w = 0; w < nwg; ++w) { start.push_back((double)(t[4 * w] - lo)); end.push_back((double)(t[4 * w + 3] - lo)); }
             auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
             auto mx = [](const std::vector<double>& v) { return *std::max_element(v.begin(), v.end()); };
-            fprintf(stderr, "[MF_DBG_TIMES] %zu WGs tile %dx%d split %d: span %llu ticks; prologue med %.0f max %.0f; loop med %.0f max %.0f; "
+            fprintf(stderr, "[MF_DEBUG=times] %zu WGs tile %dx%d split %d: span %llu ticks; prologue med %.0f max %.0f; loop med %.0f max %.0f; "
                             "epilogue med %.0f max %.0f; WG start med %.0f max %.0f; WG end med %.0f\n",
                     nwg, tc.bm, tc.bn, tc.nsplit, hi - lo, med(d[0]), mx(d[0]), med(d[1]), mx(d[1]), med(d[2]), mx(d[2]), med(start), mx(start), med(end));
         }
@@ -1936,7 +2018,7 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
     // keep the model's pick unless the measured winner is clearly ahead (event timing of a 10-100 us launch is good to ~1 us)
     if (best_us > 0.97f * base_us) { p->tuned.erase(batch); tune_cache_store(key, ConvTuned{ConvTile{0, 0, 0, 0, 0}, -1}); }
     else { p->tuned[batch] = best_c; tune_cache_store(key, best_c); }
-    static const bool verbose = getenv("MF_TUNE_VERBOSE") != nullptr;
+    static const bool verbose = mf_debug_has("tune");
     if (verbose)
         fprintf(stderr, "[mf_conv_tune] M %d N %d K %d: model %dx%d split %d %.1f us -> %s %dx%d split %d ld %d %.1f us\n", M, N, kt_min * 64, base.bm, base.bn, base.nsplit,
                 base_us, p->tuned.count(batch) ? "tuned" : "kept", best_c.tile.bm, best_c.tile.bn, best_c.tile.nsplit, best_c.ld, best_us);
@@ -1945,9 +2027,8 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
 
 void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
     const char* x3 = p->precision != MF_PREC_BF16 ? "true" : "false";
-    // (the f16 + FP6 tile: the specialised workgroup <16,128,2,2,...> -- 4 compute + 4 producer waves -- unless MF_HALO_Q_SP=0 selects the eight-compute-wave one)
-    static const bool q_sp = !(getenv("MF_HALO_Q_SP") && atoi(getenv("MF_HALO_Q_SP")) == 0);
-    const char* qt = q_sp ? "2,2" : "4,2";
+    // (the f16 + FP6 tile: the specialised workgroup <16,128,2,2,...> -- 4 compute + 4 producer waves)
+    const char* qt = "2,2";
     if (p->q && p->up_hi) { snprintf(buf, cap, "4 x k_conv3x3_halo_w<16,128,%s,true,1,phase> f16+fp6", qt); return; }
     if (p->q && p->halo) {
         // (" grid N": the launch's thread count as rocprofv3 reports it, so that a counter pass can be matched to exactly these launches -- the split

@@ -166,7 +166,7 @@ __global__ __launch_bounds__((WGM * WGN + (SP ? 4 : 0)) * 64, HS == 1 ? 2 : 1) v
     for (int i = 0; i < NHC; ++i) {
         int hr = ((hwave < 0 ? 0 : hwave) + NHW * i) * RPC + lane / KG;
         const int kg = (lane % KG) ^ hswz<CK>(hr % HW);
-        if (Q) hq[i] = (SP && a.gn_scale) ? 0 : (((lane % KG) ^ qswz(hr % HW)) - kg) * 8;   // (GroupNorm fused: the raw lo plane lands in the hi plane's slot order)
+        if (Q) hq[i] = (((lane % KG) ^ qswz(hr % HW)) - kg) * 8;
         hr = hr < HROWS ? hr : HROWS - 1;
         const int hy = hr / HW, hx = hr - hy * HW;
         int iy = y0 + hy + a.in_halo - 1, ix = x0 + hx + a.in_halo - 1;
@@ -387,86 +387,15 @@ __global__ __launch_bounds__((WGM * WGN + (SP ? 4 : 0)) * 64, HS == 1 ? 2 : 1) v
     // channel slices of this workgroup: all of them, or the blockIdx.y-th share when the layer is split for lack of patches
     const int s_begin = a.nsplit > 1 ? (int)((int64_t)a.n_slices * blockIdx.y / a.nsplit) : 0;
     const int s_end = a.nsplit > 1 ? (int)((int64_t)a.n_slices * (blockIdx.y + 1) / a.nsplit) : a.n_slices;
-    // ---- GroupNorm + SiLU + conversion into the f16 + FP6 format, in place on a landed RAW halo image (specialised workgroup, a.gn_scale != null) ----------
-    // One lane owns one halo pixel (64 B per plane): reads its (hi, lo) bf16 channels in LOGICAL order (physical slot = logical ^ hswz, conflict-free for
-    // consecutive pixels as for the compute waves' fragment reads), computes exactly what k_affine_silu_to_q computes (same operations, same conversion
-    // instructions: the two paths give the same bits), and writes the f16 plane back in the hswz order and the two FP6 blocks in the qswz order.  Pixels outside
-    // the map become zeros BEHIND the activation.  `part` = 0 / 1: rows [pw * 81, pw * 81 + 64) / the remaining 17 of producer wave pw's 81 rows.
-    auto gn_transform = [&](int slice, int stage, int part) __attribute__((always_inline)) {
-        if constexpr (SP && Q) {
-            constexpr int RPW = (HROWS + NPW - 1) / NPW;                     // 81 rows per producer wave
-            const int pw = wave - NW;
-            const int rr = part * 64 + lane;
-            const int r = pw * RPW + rr;
-            const bool mine = rr < RPW && r < HROWS;
-            const int rc = mine ? r : 0;
-            const int hy = rc / HW, hx = rc - hy * HW;
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-            const bool inside = mine && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            char* rowp = smem + stage * STAGE + rc * ROWB;
-            const int sw = hswz<CK>(hx), qw = qswz(hx);
-            typedef float v16f __attribute__((ext_vector_type(16)));
-            typedef _Float16 v32h __attribute__((ext_vector_type(32)));
-            typedef unsigned v6u __attribute__((ext_vector_type(6)));
-            typedef unsigned v16u __attribute__((ext_vector_type(16)));
-            v16f le, lod;
-            v16u hbits;
-            float mh = 0.f, ml = 0.f;
-            const float* sc = a.gn_scale + (size_t)b * a.gn_C + slice * CK;   // wave-uniform: scalar loads
-            const float* sh = a.gn_shift + (size_t)b * a.gn_C + slice * CK;
-            const float* po = a.gn_post ? a.gn_post + slice * CK : nullptr;
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                const uint4 hv = *reinterpret_cast<const uint4*>(rowp + ((kg ^ sw) << 4));
-                const uint4 lv = *reinterpret_cast<const uint4*>(rowp + H_BYTES + ((kg ^ sw) << 4));
-                const uint32_t aw[4] = {hv.x, hv.y, hv.z, hv.w}, cw[4] = {lv.x, lv.y, lv.z, lv.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = 8 * kg + e;
-                    const uint32_t hw_ = (e & 1) ? aw[e >> 1] >> 16 : aw[e >> 1] & 0xffffu, lw_ = (e & 1) ? cw[e >> 1] >> 16 : cw[e >> 1] & 0xffffu;
-                    float v = hbf2f(hw_) + hbf2f(lw_);
-                    v = v * sc[k] + sh[k];
-                    if (a.gn_silu) v = v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
-                    if (po) v *= po[k];
-                    const _Float16 h = (_Float16)v;
-                    const float vhk = (float)h, vlk = v - vhk;
-                    mh = fmaxf(mh, fabsf(vhk)); ml = fmaxf(ml, fabsf(vlk));
-                    if (k & 1) lod[k >> 1] = vlk; else le[k >> 1] = vlk;
-                    const uint32_t hb = __builtin_bit_cast(uint16_t, h);
-                    if (k & 1) hbits[k >> 1] |= hb << 16; else hbits[k >> 1] = hb;
-                }
-            }
-            const uint32_t bl = max((__float_as_uint(ml) >> 23) & 0xffu, 2u) - 2u, bh = max((__float_as_uint(mh) >> 23) & 0xffu, 2u) - 2u;
-            const v6u ql = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(le, lod, __uint_as_float(bl << 23));
-            const v6u qh = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(v32h, hbits), __uint_as_float(bh << 23));
-            if (mine) {
-                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-                for (int kg = 0; kg < 4; ++kg)
-                    *reinterpret_cast<uint4*>(rowp + ((kg ^ sw) << 4)) = inside ? make_uint4(hbits[4 * kg], hbits[4 * kg + 1], hbits[4 * kg + 2], hbits[4 * kg + 3]) : z;
-                char* qrow = rowp + H_BYTES;
-                *reinterpret_cast<uint4*>(qrow + ((0 ^ qw) << 4)) = inside ? make_uint4(ql[0], ql[1], ql[2], ql[3]) : z;
-                *reinterpret_cast<uint4*>(qrow + ((1 ^ qw) << 4)) = inside ? make_uint4(ql[4], ql[5], bl, 0u) : z;
-                *reinterpret_cast<uint4*>(qrow + ((2 ^ qw) << 4)) = inside ? make_uint4(qh[0], qh[1], qh[2], qh[3]) : z;
-                *reinterpret_cast<uint4*>(qrow + ((3 ^ qw) << 4)) = inside ? make_uint4(qh[4], qh[5], bh, 0u) : z;
-            }
-        }
-    };
     if constexpr (SP) {
         // Two instruction streams with the same barrier sequence (the branch is wave-uniform): the DMA pointers live only in the producers' stream, the
         // accumulators and fragment addresses only in the compute waves' -- written as one loop, the producers' pointers were spilled around the MFMAs.
         constexpr int NPAIR = (NT + 1) / 2;
-        const bool gn_in = a.gn_scale != nullptr;           // GroupNorm fused: the halo images land RAW and the producer waves convert them in place
         if (!cons) {
             load_halo(s_begin, 0);
             load_wrow(s_begin, 0, 0);
             load_wrow(s_begin, 1, 1);
             __syncthreads();
-            if (gn_in) {                                    // (the first image: converted with the compute waves waiting -- once per workgroup)
-                gn_transform(s_begin, 0, 0);
-                gn_transform(s_begin, 0, 1);
-                __syncthreads();
-            }
             int wb = 0;
             for (int slice = s_begin; slice < s_end; ++slice) {
                 const bool more = slice + 1 < s_end;
@@ -478,12 +407,6 @@ __global__ __launch_bounds__((WGM * WGN + (SP ? 4 : 0)) * 64, HS == 1 ? 2 : 1) v
                     if (MF_HALO_ABLATE & 64) {}            // (timing-only build: no DMA in the loop)
                     else if (p < NPAIR - 1) { load_wrow(slice, 2 * p + 2, nb); if (2 * p + 3 < NT) load_wrow(slice, 2 * p + 3, nb + 1); }
                     else if (more) { load_wrow(slice + 1, 0, nb); load_wrow(slice + 1, 1, nb + 1); }
-                    // the next slice's image landed behind the first pair's barrier (its vmcnt(0) covers every DMA of this wave, the barrier everyone else's): it is
-                    // converted under the MFMAs of the following pairs, one part per pair, and is complete at the slice's last barrier
-                    if (gn_in && more && (p == 1 || p == (NPAIR > 2 ? 2 : 1))) {
-                        if (NPAIR > 2) gn_transform(slice + 1, nst, p - 1);
-                        else { gn_transform(slice + 1, nst, 0); gn_transform(slice + 1, nst, 1); }
-                    }
                     if (p < NPAIR - 1 || more) __syncthreads();
                     wb ^= 1;
                 }
@@ -631,7 +554,6 @@ __global__ __launch_bounds__((WGM * WGN + (SP ? 4 : 0)) * 64, HS == 1 ? 2 : 1) v
                 }
             };
             __syncthreads();
-            if (gn_in) __syncthreads();                                // (the producers convert the first halo image)
             if (dbg && threadIdx.x == 0) dbg[1] = __builtin_amdgcn_s_memtime();
             int slice = s_begin;
             for (; slice + 1 < s_end; slice += 2) {
@@ -896,7 +818,7 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
     constexpr int CK = X3 ? 32 : 64, RPC = 1024 / (CK * 2), NP = X3 ? 2 : 1;
     constexpr int HCH = ((PH + 2) * (PW + 2) + RPC - 1) / RPC;
     const size_t lds = (size_t)HS * NP * HCH * 1024 + (size_t)(Q ? 4 : 2) * TR * NP * BN * CK * 2;   // (the two-taps-per-instruction loop of the f16 + FP6 format: four ring slots)
-    static const bool dbg_times = getenv("MF_DBG_TIMES") != nullptr;
+    static const bool dbg_times = mf_debug_has("times");
     HaloArgs aa = a;
     const size_t nwg = (size_t)a.n_patches * a.tiles_n * (a.nsplit > 1 ? a.nsplit : 1);
     if (dbg_times && nwg <= 65536) {
@@ -922,7 +844,7 @@ int halo_w_launch_cfg(const HaloArgs& a, hipStream_t s) {
             auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
             auto mx = [](const std::vector<double>& v) { return *std::max_element(v.begin(), v.end()); };
             // s_memtime ticks at 100 MHz on gfx9: 10 ns per tick
-            fprintf(stderr, "[MF_DBG_TIMES halo_w<%d,%d,%d,%d>] %zu WGs, %d slices: span %.1f; prologue med %.1f max %.1f; loop med %.1f max %.1f; "
+            fprintf(stderr, "[MF_DEBUG=times halo_w<%d,%d,%d,%d>] %zu WGs, %d slices: span %.1f; prologue med %.1f max %.1f; loop med %.1f max %.1f; "
                             "epilogue (to store acks) med %.1f max %.1f; WG start med %.1f max %.1f; WG end med %.1f (s_memtime ticks)\n",
                     PH, BN, WGM, WGN, nwg, a.n_slices, (hi - lo) * 1.0, med(d[0]), mx(d[0]), med(d[1]), mx(d[1]), med(d[2]),
                     mx(d[2]), med(start), mx(start), med(end));
@@ -949,23 +871,14 @@ int mf_halo_w_launch(const HaloArgs& a0, const HaloTile& t, bool x3, hipStream_t
         // the f16 + FP6 format has ONE tile: 16 x 16 pixels x 128 channels, 8 waves of 64 px x 64 ch (the 256-channel tile does not fit its registers,
         // four waves of 128 px x 64 ch measured 6 % slower); nearest 2x upsample + 3x3 runs it as four 2 x 2-tap phases on the same four-slot ring
         if (t.ph != 16 || t.bn != 128 || t.wgm != 4 || (phase >= 0 && a.nsplit > 1)) { mf_set_error("halo conv (f16 + FP6 format): plain 3x3 layers and unsplit upsample phases on the 16 x 16 x 128 tile only"); return MF_ERR_INVALID; }
-        // the specialised workgroup (4 compute + 4 producer waves) is the default: 25 % fewer LDS fragment reads per MFMA, 4-7 % faster on every VAE grid in
-        // same-box A/B (profiles/r04_halo_sp_study.md); MF_HALO_Q_SP=0 selects the eight-compute-wave kernel
-        static const bool sp = !(getenv("MF_HALO_Q_SP") && atoi(getenv("MF_HALO_Q_SP")) == 0);
-        if (a.gn_scale && !sp) { mf_set_error("halo conv (f16 + FP6 format): the fused GroupNorm needs the specialised workgroup (MF_HALO_Q_SP=0 is set)"); return MF_ERR_INVALID; }
-        if (sp) switch (phase) {
+        // the specialised workgroup (4 compute + 4 producer waves): 25 % fewer LDS fragment reads per MFMA than eight compute waves, 4-7 % faster on every VAE grid
+        // in same-box A/B (profiles/r04_halo_sp_study.md; the eight-compute-wave instantiation of round 3 left the library in round 5)
+        switch (phase) {
             case 0: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, 0, 2, true, true>(a, s);
             case 1: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, 1, 2, true, true>(a, s);
             case 2: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, 2, 2, true, true>(a, s);
             case 3: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, 3, 2, true, true>(a, s);
             default: return halo_w_launch_cfg<16, 128, 2, 2, true, 1, -1, 2, true, true>(a, s);
-        }
-        switch (phase) {
-            case 0: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 0, 2, true>(a, s);
-            case 1: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 1, 2, true>(a, s);
-            case 2: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 2, 2, true>(a, s);
-            case 3: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, 3, 2, true>(a, s);
-            default: return halo_w_launch_cfg<16, 128, 4, 2, true, 1, -1, 2, true>(a, s);
         }
     }
     if (phase >= 0) { mf_set_error("halo conv (LDS weights): upsample phases exist in the f16 + FP6 format only"); return MF_ERR_INVALID; }

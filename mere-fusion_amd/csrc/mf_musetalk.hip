@@ -82,7 +82,7 @@ struct Net {
     ActBuf* kv_all = nullptr; int kv_off = 0, kv_op = -1; std::vector<float> kv_w; ActView kv_ctx{}; bool kv_joined = false;
     bool q_allowed = false;     // the f16 + FP6 conv format: the VAE decoder's resnets (set by the builder of a network whose parity was established with it)
     bool q_dual_allowed = false;   // ... and, from q_dual_min() frames per step, the UNet's 320-channel 3x3 convs on its 32 x 32 maps (gn_conv builds both paths, a launch picks by its batch)
-    static int q_dual_min() { static const int v = getenv("MF_UNET_Q_MIN") ? atoi(getenv("MF_UNET_Q_MIN")) : 16; return v; }   // frames per step from which the dual-path convs take the f16 + FP6 kernel
+    static int q_dual_min() { return 16; }   // frames per step from which the dual-path convs take the f16 + FP6 tile (profiles/r04_unet_q_dual.md)
     // (whole step, same box, bf16x3 -> f16 + FP6 on those twenty layers: 8 frames 18.78 -> 18.78 ms, 16: 32.0 -> 31.6, 24: 45.5 -> 44.7, 32: 58.7 -> 57.4, 64: 109.05 -> 107.66)
     int next_pad_hi = 0;        // consumed by the next conv(): extra zero rows / columns bottom-right (the VAE encoder's Downsample2D)
     std::string err;
@@ -214,15 +214,14 @@ struct Net {
         const int q_minpx = 32 * 32;
         // The UNet's 320-channel convs on its 32 x 32 maps (cout = 2.5 tiles of 128): from 16 frames per step (q_dual_min) the f16 + FP6 tile runs them at 640-730 TF where the
         // bf16x3 LDS-weights tile reaches 405-440 (conv alone, 64 frames: 320 -> 320 298 -> 222 us, 640 -> 320 570 -> 412, 960 -> 320 824 -> 599).  A handle serves
-        // steps of every size up to its capacity, so BOTH paths are built and a launch picks by its batch (MF_UNET_Q=0: bf16x3 only).
-        static const bool q_unet_on = [] { const char* e = getenv("MF_UNET_Q"); return !e || atoi(e) != 0; }();
+        // steps of every size up to its capacity, so BOTH paths are built and a launch picks by its batch.
         // ... and its 640-channel convs on the 16 x 16 maps (one patch per image, five channel tiles): 640 -> 640 360 -> 250 us, 1280 -> 640 651 -> 455, 1920 -> 640 934 -> 675
-        // at 64 frames against the bf16x3 implicit GEMM (tools/conv_probe.py with MF_Q_HALO_SMALL=1).
+        // at 64 frames against the bf16x3 implicit GEMM.
         // (bounds as mf_conv_plan_create's q_small / odd_wide predicates: a layer outside them gets no f16 + FP6 plan and must stay on the bf16x3 path -- ADVICE r04:
         // 1280-channel convs on 16 x 16 maps at sample_size 64, or 320-out convs with cin > 1024, failed the whole handle instead)
         const bool q_dual32 = cout >= 256 && cout % 128 != 0 && cout % 64 == 0 && cin <= 1024 && t->H * t->W >= q_minpx;
         const bool q_dual16 = cout >= 512 && cout <= 1024 && cout % 128 == 0 && cin <= 2048 && t->H == 16 && t->W == 16;
-        const bool q_dual = q_on && q_unet_on && q_dual_allowed && precision == MF_PREC_BF16X3 && (q_dual32 || q_dual16) && cin % 32 == 0 &&
+        const bool q_dual = q_on && q_dual_allowed && precision == MF_PREC_BF16X3 && (q_dual32 || q_dual16) && cin % 32 == 0 &&
                             t->C == cin && t->H % 16 == 0 && t->W % 16 == 0 && cap >= q_dual_min();
         if (q_dual || (q_on && q_allowed && precision == MF_PREC_BF16X3 && cin % 32 == 0 && cout % 128 == 0 && t->C == cin && t->H * t->W >= q_minpx && cin >= 128 &&
             (int64_t)cap * ((t->H + 15) / 16) * ((t->W + 15) / 16) * (cout / 128) >= 64)) {
@@ -323,28 +322,9 @@ struct Net {
                 stats_remember(p3, out);
                 return MF_OK;
             }
-            // MF_GN_FUSE_Q=1 (opt-in, measured and NOT adopted): GroupNorm-apply + SiLU + the conversion into the operand format INSIDE the conv -- the producer waves
-            // of its specialised workgroup rewrite each landed halo image in LDS, so the normalised tensor is neither written nor re-read (k_affine_silu_to_q: 4 B + 4 B
-            // per value and a launch per layer, 8 % of the step).  Bit-identical frames (tools/gn_fuse_check.py), but the ~700 VALU instructions per 64 pixels and
-            // slice that four producer waves then execute beside the compute waves' MFMAs cost the conv far more than the pass they replace: 128 ch @256^2 295 + 104
-            // -> 490 us, 256 ch @128^2 245 + 60 -> 457, 512 ch @64^2 217 + 25 -> 414 (every one of the 2 / 4 channel tiles converts the same image again);
-            // MuseTalk step 18.75 -> 21.97 ms (profiles/r04_gn_fuse_q.md).
-            static const bool fuse = [] {
-                const char* e = getenv("MF_GN_FUSE_Q"); const char* sp = getenv("MF_HALO_Q_SP");
-                return (e && atoi(e) != 0) && !(sp && atoi(sp) == 0);
-            }();
+            // (GroupNorm-apply + SiLU + the format conversion INSIDE this conv -- the producer waves rewriting each landed halo image -- was built in round 4,
+            // bit-identical and 2 x slower than the pass it replaces, and removed in round 5: profiles/r04_gn_fuse_q.md keeps the measurement)
             const bool epi = take_stats(x, groups, st);
-            if (fuse && x.buf->lo && x.coff % 8 == 0 && x.buf->H == t->H && x.buf->W == t->W) {
-                p->gn_scale = scale; p->gn_shift = shift; p->gn_post = d_post; p->gn_silu = 1;
-                if ((rc = mf_conv_bind(p, *x.buf))) return rc;
-                push(gname, epi ? "k_gn_affine (statistics from the producer's epilogue; apply + SiLU + f16/FP6 conversion inside the conv)" : "k_gn_stats+k_gn_affine (apply inside the conv)",
-                     0.0, [=](int B, hipStream_t s) { return mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s, epi); });
-                char kn[96];
-                mf_conv_kernel_name(p, cap, kn, sizeof(kn));
-                push(cname, std::string(kn) + " +gn", mf_conv_flops(p, 1), [=](int B, hipStream_t s) { return mf_conv_launch(p, x, out, res, B, s); });
-                stats_remember(p, out);
-                return MF_OK;
-            }
             if ((rc = mf_conv_bind(p, *t))) return rc;
             const ActBuf* tq = t;
             push(gname, epi ? "k_affine_silu_to_q (statistics from the producer's epilogue)" : "k_gn_stats+k_affine_silu_to_q", 0.0, [=](int B, hipStream_t s) {

@@ -32,8 +32,7 @@ class HipHeadRenderer:
     def render(self, rays_o, rays_d, auds, bg_coords, poses, eye, bg_color=None, **kw):
         """One frame as `NeRFRenderer.render` -> `run_cuda` does it (renderer.py:657-677, 158-291): audio window -> enc_a (+ the lip
         smoothing EMA of :190-194), fixed individual code 0 (:197-202), head loop, torso / background mix (:272-277).
-        loop="device" runs the head with device-side round control; MF_NERF_TORSO_STREAM=1 puts the torso on a second stream beside it (the
-        head only needs the torso's colours for the final mix)."""
+        loop="device" runs the head with device-side round control."""
         def audio_part():
             if self.audio is not None and self.smooth_lips and hasattr(self.audio, "encode_audio_smooth"):
                 # the EMA of renderer.py:190-194 inside the encoder's launch (three torch elementwise launches per frame otherwise; same bits)
@@ -48,20 +47,8 @@ class HipHeadRenderer:
                 self.enc_a = enc_a
             return enc_a
         device_loop = kw.pop("loop", "host") == "device"
-        # torso on a second stream beside the head: paid while the torso was a ~0.3 ms launch chain; as one 71 us kernel the cross-stream
-        # dependency costs more than the overlap returns (0.737 vs 0.711 ms per frame), so it is opt-in now (MF_NERF_TORSO_STREAM=1)
-        if device_loop and self.torso is not None and os.environ.get("MF_NERF_TORSO_STREAM", "0") == "1":
-            cur = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            self._side.wait_stream(cur)
-            enc_a = audio_part()                           # enqueued first: the head's first field evaluation waits for it
-            with torch.cuda.stream(self._side):
-                bg = self.torso.run_torso(bg_coords, poses, bg_color)["bg_color"]
-            out = self.run_cuda_device(rays_o, rays_d, enc_a, self.ind_code, eye, bg_color=None, finish=False, **kw)
-            cur.wait_stream(self._side)
-            bg.record_stream(cur)
-            return self.finish_device(out, bg)
+        # (the torso on a second stream beside the head paid while it was a ~0.3 ms launch chain; as one 71 us kernel the cross-stream dependency cost more
+        # than the overlap returned, 0.737 vs 0.711 ms per frame: the path left in round 5)
         enc_a = audio_part()
         if self.torso is not None:
             bg_color = self.torso.run_torso(bg_coords, poses, bg_color)["bg_color"]

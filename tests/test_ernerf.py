@@ -825,13 +825,10 @@ def test_hip_device_controlled_loop_matches_host_loop(lib_built, W):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("torso_stream", ["0", "1"])
-def test_hip_full_frame_device_loop_with_torso_stream(lib_built, monkeypatch, torso_stream):
-    """`render(loop="device")`: head with device-side round control, torso on the head's stream (default) or on a second stream with a deferred
-    finish (MF_NERF_TORSO_STREAM=1) -- the same frame as the host-driven `render` (audio nets, EMA, torso mix included), three frames in a
-    row so the stream joins are exercised."""
+def test_hip_full_frame_device_loop(lib_built):
+    """`render(loop="device")`: head with device-side round control, torso on the head's stream -- the same frame as the host-driven `render` (audio nets,
+    EMA, torso mix included), three frames in a row."""
     import bench
-    monkeypatch.setenv("MF_NERF_TORSO_STREAM", torso_stream)
     a = bench.ErNeRFRunner("bf16x3", 128, torch.device("cuda:0"), seed=3)
     b = bench.ErNeRFRunner("bf16x3", 128, torch.device("cuda:0"), seed=3)
     for i in range(3):

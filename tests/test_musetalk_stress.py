@@ -68,23 +68,3 @@ def test_vae_f16_fp6_under_channel_scale_stress(lib_built, seed, one_sided):
           f"on values up to {scale:.2f} (gate {TOL_IMAGE}); uint8 max diff {d.max()}, differing pixels {100 * (d > 0).mean():.3f} %")
     assert np.isfinite(ierr) and ierr <= TOL_IMAGE, (ierr, scale)
     assert d.max() <= 1 and (d > 0).mean() < TOL_U8_FRACTION, (d.max(), (d > 0).mean())
-
-
-def test_gn_fused_into_the_conv_is_bit_identical(lib_built, tmp_path):
-    """Three implementations of GroupNorm-apply + SiLU + the f16 / FP6 conversion must give IDENTICAL frames of the full decoder (same operations on the same values):
-    k_affine_silu_to_q_u (shipped: the channel block uniform over a wave), k_affine_silu_to_q (MF_AFFQ_VARIANT=0: the kernel for maps that are not a multiple of 64 pixels)
-    and MF_GN_FUSE_Q=1 (opt-in, profiles/r04_gn_fuse_q.md: the producer waves of the f16 + FP6 conv convert the raw halo images in LDS).
-    (The switches are read once per process: one child process each.)"""
-    import os, subprocess, sys
-    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-    legs = (("shipped", {"MF_GN_FUSE_Q": "0"}), ("per_thread_parameters", {"MF_GN_FUSE_Q": "0", "MF_AFFQ_VARIANT": "0"}), ("fused", {"MF_GN_FUSE_Q": "1"}))
-    out = {}
-    for name, env in legs:
-        path = str(tmp_path / (name + ".npz"))
-        subprocess.run([sys.executable, os.path.join(root, "tools", "gn_fuse_check.py"), path], check=True, env=dict(os.environ, **env), timeout=600,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        out[name] = np.load(path)
-    fa = out["shipped"]
-    assert fa["frames"].std() > 10
-    for name in ("per_thread_parameters", "fused"):
-        assert np.array_equal(fa["frames"], out[name]["frames"]) and np.array_equal(fa["image"], out[name]["image"]), name

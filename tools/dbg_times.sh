@@ -1,10 +1,10 @@
 #!/bin/bash
-# per-workgroup s_memtime stamps (MF_DBG_TIMES) of k_conv_igemm on a few UNet shapes, for the forced configurations given as "tile split ld" triples
+# per-workgroup s_memtime stamps (MF_DEBUG=times) of k_conv_igemm on a few UNet shapes, for the forced configurations given as "tile split ld" triples
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 OUT=gpurun_out/${1:-dbg}_times.txt; : > $OUT
 run() { # shape-args, tile, split, ld
   echo "== $1 | tile $2 split $3 ld $4" >> $OUT
-  MF_DBG_TIMES=1 MF_FORCE_TILE=$2 MF_FORCE_SPLIT=$3 MF_FORCE_LD=$4 timeout 300 python tools/conv_probe.py $1 --batch 8 --iters 20 2>&1 | grep -E "DBG_TIMES|alone" >> $OUT
+  MF_DEBUG=times MF_FORCE_TILE=$2 MF_FORCE_SPLIT=$3 MF_FORCE_LD=$4 timeout 300 python tools/conv_probe.py $1 --batch 8 --iters 20 2>&1 | grep -E "MF_DEBUG=times|alone" >> $OUT
 }
 S1="--cin 1280 --cout 1280 --k 3 --hw 4"
 S2="--cin 1280 --cout 1280 --k 3 --hw 8"

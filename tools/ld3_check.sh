@@ -14,7 +14,7 @@ echo "== reference: model pick"
 for shape in "--cin 1280 --cout 1280 --k 3 --hw 8" "--cin 1280 --cout 1280 --k 3 --hw 4"; do timeout 300 python tools/conv_probe.py $shape --batch 8 --check 1 --iters 20 2>&1 | tail -3; done
 } > gpurun_out/${TAG}_check.txt 2>&1
 rm -f gpurun_out/${TAG}_tune.txt
-MF_TUNE_CACHE=gpurun_out/${TAG}_tune.txt MF_TUNE_VERBOSE=1 timeout 1200 python tools/tune_one_batch.py 8 > gpurun_out/${TAG}_tune_log.txt 2>&1
+MF_TUNE_CACHE=gpurun_out/${TAG}_tune.txt MF_DEBUG=tune timeout 1200 python tools/tune_one_batch.py 8 > gpurun_out/${TAG}_tune_log.txt 2>&1
 MF_TUNE_CACHE=gpurun_out/${TAG}_tune.txt timeout 600 python bench.py --extras 0 --cpu-seconds 0 --pmc-traffic 0 --dump-layers gpurun_out/${TAG}_layers.json > gpurun_out/${TAG}_line.json 2> gpurun_out/${TAG}_err.txt
 timeout 600 python bench.py --extras 0 --cpu-seconds 0 --pmc-traffic 0 > gpurun_out/${TAG}_line_shipped.json 2>> gpurun_out/${TAG}_err.txt
 cat gpurun_out/${TAG}_check.txt; grep -c "ld [34]" gpurun_out/${TAG}_tune_log.txt; tail -3 gpurun_out/${TAG}_tune_log.txt; cut -c1-400 gpurun_out/${TAG}_line.json; echo; cut -c1-400 gpurun_out/${TAG}_line_shipped.json

@@ -8,6 +8,6 @@ for v in "$@"; do
   echo "== variant: [$v]" | tee -a $OUT
   for s in ${SHAPES:-"128,128,256" "256,256,128" "512,512,64"}; do IFS=, read c1 c2 hw <<< "$s"
     env $v python tools/conv_probe.py --cin $c1 --cout $c2 --hw $hw --batch 8 --residual ${RES:-0} --precision f16q --iters 30 --check 1 2>&1 | grep -E "check|alone|rror" | cut -c1-200 | tee -a $OUT
-    [ "${DBG:-0}" != 0 ] && env $v MF_DBG_TIMES=1 python tools/conv_probe.py --cin $c1 --cout $c2 --hw $hw --batch 8 --residual ${RES:-0} --precision f16q --iters 10 2>&1 | grep -E "DBG" | tail -1 | cut -c1-260 | tee -a $OUT
+    [ "${DBG:-0}" != 0 ] && env $v MF_DEBUG=times python tools/conv_probe.py --cin $c1 --cout $c2 --hw $hw --batch 8 --residual ${RES:-0} --precision f16q --iters 10 2>&1 | grep -E "DBG" | tail -1 | cut -c1-260 | tee -a $OUT
   done
 done

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Measures the launch configurations of the MuseTalk UNet + VAE (and optionally Wav2Lip) at the given batch sizes into MF_TUNE_CACHE (MF_TUNE_VERBOSE=1 prints
+"""Measures the launch configurations of the MuseTalk UNet + VAE (and optionally Wav2Lip) at the given batch sizes into MF_TUNE_CACHE (MF_DEBUG=tune prints
 every layer's model pick against the measured winner): the quick form of tools/make_tune_cache.py for kernel work on one batch size.
 
-    MF_TUNE_CACHE=gpurun_out/tune_b8.txt MF_TUNE_VERBOSE=1 python tools/tune_one_batch.py 8 [16 ...] [--wav2lip 16]
+    MF_TUNE_CACHE=gpurun_out/tune_b8.txt MF_DEBUG=tune python tools/tune_one_batch.py 8 [16 ...] [--wav2lip 16]
 """
 import os
 import sys
