@@ -151,11 +151,21 @@ constexpr int igemm_ring() {
     return by_lds < 8 ? by_lds : 8;
 }
 
+#ifndef MF_PW_NPW
+#define MF_PW_NPW 4          // producer waves per workgroup on the LD 3 path (A/B builds: 8)
+#endif
+// producer waves of a tile on the LD 3 path: MF_PW_NPW where both operands' 1-KiB pieces divide evenly among them, else 4
+template <int BM, int BN, int BK>
+constexpr int igemm_producers() {
+    constexpr int rpc = 1024 / (BK * 2), pch = (BM + rpc - 1) / rpc, wch = (BN + rpc - 1) / rpc;
+    return (pch % MF_PW_NPW == 0 && wch % MF_PW_NPW == 0) ? MF_PW_NPW : 4;
+}
 template <int BM, int BN, int WGM, int WGN, bool X3, int BK, int NST, int LD = 0, bool Q = false>
-__global__ __launch_bounds__(WGM * WGN * (LD == 3 ? 2 : 1) * 64) void k_conv_igemm(const ConvArgs a) {
+__global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>() : 0)) * 64) void k_conv_igemm(const ConvArgs a) {
     static_assert(!Q || X3, "the f16 + FP6 format has two planes");
-    constexpr int NW = WGM * WGN;         // compute waves per workgroup (LD 3: as many producer waves on top)
-    constexpr int NT = NW * (LD == 3 ? 2 : 1) * 64;
+    constexpr int NW = WGM * WGN;         // compute waves per workgroup (LD 3: producer waves on top)
+    constexpr int NS = LD == 3 ? igemm_producers<BM, BN, BK>() : NW;   // waves that share the DMA pieces of a stage
+    constexpr int NT = (NW + (LD == 3 ? NS : 0)) * 64;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(BK == 32 || BK == 64, "LDS tile depth");
     static_assert(NST == 2, "two LDS stages (deeper rings halved the workgroups per CU and measured slower)");
@@ -170,12 +180,12 @@ __global__ __launch_bounds__(WGM * WGN * (LD == 3 ? 2 : 1) * 64) void k_conv_ige
     constexpr int PLANE = P_BYTES + W_BYTES;
     constexpr int STAGE = PLANE * NP;
     constexpr int PCH = (BM + RPC - 1) / RPC, WCH = (BN + RPC - 1) / RPC;   // DMA chunks per tile
-    constexpr int NPC = (PCH + NW - 1) / NW, NWC = (WCH + NW - 1) / NW;      // ... per wave
+    constexpr int NPC = (PCH + NS - 1) / NS, NWC = (WCH + NS - 1) / NS;      // ... per wave
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LDS_STAGES = LD == 2 ? 1 : NST;
     constexpr int DR = LD == 3 ? igemm_ring<BM, BN, BK, X3>() : 0;                     // ring depth of the producer-wave path
-    static_assert(LD != 3 || DR >= 4, "producer-wave path: the ring needs >= 4 stages (two ahead of the barrier + one in flight)");
+    static_assert(LD != 3 || DR >= 2, "producer-wave path: at least a double buffer");
     int* s_goff = reinterpret_cast<int*>(smem + (LD == 3 ? DR : LDS_STAGES) * STAGE);
     // MF_DEBUG=times: s_memtime stamps of (entry, loop start, loop end, exit) per workgroup
     unsigned long long* dbg = a.dbg ? a.dbg + 4 * ((size_t)blockIdx.x + gridDim.x * ((size_t)blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(WGM * WGN * (LD == 3 ? 2 : 1) * 64) void k_conv_ige
     const int64_t x_delta = X3 ? (a.x_lo - a.x_hi) : 0;
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
-        const int row = (wq + NW * i) * RPC + lane / KG;
+        const int row = (wq + NS * i) * RPC + lane / KG;
         p_kg[i] = (lane % KG) ^ swz<BK>(row);
         int m = m0 + row;
         m = m < a.M ? m : a.M - 1;
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(WGM * WGN * (LD == 3 ? 2 : 1) * 64) void k_conv_ige
     const int64_t w_delta = X3 ? (a.w_lo - a.w_hi) : 0;
 #pragma unroll
     for (int i = 0; i < NWC; ++i) {
-        const int row = (wq + NW * i) * RPC + lane / KG;
+        const int row = (wq + NS * i) * RPC + lane / KG;
         const int kg = (lane % KG) ^ swz<BK>(row);
         int n = n0 + row;
         n = n < a.Npad ? n : a.Npad - 1;
@@ -244,8 +254,8 @@ __global__ __launch_bounds__(WGM * WGN * (LD == 3 ? 2 : 1) * 64) void k_conv_ige
         char* base = smem + s * STAGE;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
-            const int c = wq + NW * i;
-            if (PCH % NW == 0 || c < PCH) {
+            const int c = wq + NS * i;
+            if (PCH % NS == 0 || c < PCH) {
                 const bf16_t* src = xp[i] + s_goff[kt * KG + p_kg[i]];
                 glds16(src, base + c * 1024);
                 if (X3) glds16(src + x_delta, base + PLANE + c * 1024);
@@ -253,8 +263,8 @@ __global__ __launch_bounds__(WGM * WGN * (LD == 3 ? 2 : 1) * 64) void k_conv_ige
         }
 #pragma unroll
         for (int i = 0; i < NWC; ++i) {
-            const int c = wq + NW * i;
-            if (WCH % NW == 0 || c < WCH) {
+            const int c = wq + NS * i;
+            if (WCH % NS == 0 || c < WCH) {
                 const bf16_t* src = BK == 64 ? wp[i] + kt * w_kstep : wp[i] + (kt >> 1) * w_kstep + (kt & 1) * 32;
                 glds16(src, base + P_BYTES + c * 1024);
                 if (X3) glds16(src + w_delta, base + PLANE + P_BYTES + c * 1024);
@@ -350,23 +360,32 @@ __global__ __launch_bounds__(WGM * WGN * (LD == 3 ? 2 : 1) * 64) void k_conv_ige
     const int nk = kt_end - kt_begin;
     if constexpr (LD == 3) {
         // DMA instructions (= vmcnt ticks) one producer wave issues per stage; the wait immediates below are multiples of it
-        constexpr int NPI = ((PCH + NW - 1) / NW + (WCH + NW - 1) / NW) * NP;
-        static_assert(PCH % NW == 0 && WCH % NW == 0, "producer-wave path: every producer issues the same number of pieces per stage");
-        static_assert((DR - 3) * NPI <= 63, "vmcnt immediate");
+        constexpr int NPI = (NPC + NWC) * NP;
+        static_assert(PCH % NS == 0 && WCH % NS == 0, "producer-wave path: every producer issues the same number of pieces per stage");
+        // LEAD: how many stages beyond the one a step multiplies have landed when the step starts.  2: the compute waves read step i + 1's fragments under step
+        // i's MFMAs (no exposed LDS latency) and DR - 3 stages stay in flight; 1: a step reads its own stage (the compiler interleaves the reads with the MFMAs)
+        // and DR - 2 stages stay in flight.  The ring is what bounds the bytes in flight, and bytes in flight over the loaded L2 / Infinity-Cache round trip is
+        // the rate the operands arrive at: a 4-stage ring (the 128 x 128 and 64-deep 64 x 64 tiles) takes LEAD 1, deeper rings LEAD 2.
+#ifndef MF_PW_LEAD
+        constexpr int LEAD = DR >= 5 ? 2 : 1;
+#else
+        constexpr int LEAD = MF_PW_LEAD;                           // (A/B builds: tools/ab_build.sh ... "-DMF_PW_LEAD=2")
+#endif
+        static_assert((DR - 1 - LEAD) * NPI <= 63 && DR - 1 - LEAD >= 0, "vmcnt immediate");   // (DR 2: the classic double buffer -- the next stage lands under this one's MFMAs)
         if (wave >= NW) {
-            // ---- producer waves.  Barrier b (b = 0 opens step 0, b = i + 1 closes step i) is reached with stages <= b + 1 landed: step i reads stage i for its
-            // MFMAs and stage i + 1 for its prefetch.  Stage i + DR - 1 goes into the slot stage i - 1 had, whose last reader finished before barrier i.
+            // ---- producer waves.  Barrier b (b = 0 opens step 0, b = i + 1 closes step i) is reached with stages <= b + LEAD - 1 landed.  Stage i + DR - 1 goes
+            // into the slot stage i - 1 had, whose last reader finished before barrier i.
             if (nk > 0) {
                 const int pre = nk < DR - 1 ? nk : DR - 1;
                 for (int d = 0; d < pre; ++d) stage(kt_begin + d, d);
-                if (pre == DR - 1) wait_vm<(DR - 3) * NPI>(); else wait_vm<0>();
+                if (pre == DR - 1) wait_vm<(DR - 1 - LEAD) * NPI>(); else wait_vm<0>();
                 __builtin_amdgcn_s_barrier();
                 int slot = DR - 1;
                 for (int i = 0; i < nk; ++i) {
                     if (i + DR - 1 < nk) {
                         stage(kt_begin + i + DR - 1, slot);
                         slot = slot + 1 == DR ? 0 : slot + 1;
-                        wait_vm<(DR - 3) * NPI>();             // everything but the newest DR - 3 stages: stage i + 2 has landed
+                        wait_vm<(DR - 1 - LEAD) * NPI>();      // everything but the newest DR - 1 - LEAD stages: stage i + LEAD has landed
                     } else {
                         wait_vm<0>();
                     }
@@ -404,7 +423,18 @@ __global__ __launch_bounds__(WGM * WGN * (LD == 3 ? 2 : 1) * 64) void k_conv_ige
         };
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;
-        if (nk > 0) {
+        if (nk > 0 && LEAD == 1) {
+            __syncthreads();                                   // barrier 0: stage 0 has landed
+            int slot = 0;
+            for (int i = 0; i < nk; ++i) {
+                ldf(B0{}, slot, 0);
+                if constexpr (KK == 2) ldf(B1{}, slot, 1);
+                mma(B0{});
+                if constexpr (KK == 2) mma(B1{});
+                slot = slot + 1 == DR ? 0 : slot + 1;
+                __syncthreads();
+            }
+        } else if (nk > 0) {
             __syncthreads();                                   // barrier 0: stages 0 and 1 have landed
             ldf(B0{}, 0, 0);
             int slot = 0;                                      // ring slot of stage i
@@ -928,7 +958,7 @@ int launch_cfg_n(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStr
         if (lds > 160 * 1024) { mf_set_error("conv: producer-wave tile %dx%d needs %zu bytes of LDS", BM, BN, lds); return MF_ERR_INVALID; }
     }
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.zgroups ? a.zgroups : nphase);
-    hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * (LD == 3 ? 2 : 1) * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>() : 0)) * 64), lds, s, a);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
@@ -941,9 +971,10 @@ int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStrea
     //         still leave 2-3 workgroups per CU; the 8-wave 256-wide tiles have no VGPRs to spare
     // Per-op A/B at batch 8: UNet 11.05 -> 10.62 ms, Wav2Lip 14.6 k -> 15.1 k frames/s with ld 2 as the default; every variant within +-15 % per layer.
     const int regs = a.ld >= 0 ? a.ld : 2;
-    if constexpr (WGM * WGN == 4 && X3 && !Q && BN >= 64 && BM >= 64 && igemm_ring<BM, BN, BK, X3>() >= 4) {
-        //   ld 3 / 4  producer waves own every LDS-DMA piece, the compute waves only LDS reads and MFMAs (k_conv_igemm's LD 3); 3: the deepest stage whose ring
-        //         still holds >= 4 of them, 4: 32-deep stages (launch_prec picks BK)
+    if constexpr (WGM * WGN == 4 && X3 && !Q && BN >= 64 && BM >= 64 && igemm_ring<BM, BN, BK, X3>() >= 2) {
+        //   ld 3 / 4  producer waves own every LDS-DMA piece, the compute waves only LDS reads and MFMAs (k_conv_igemm's LD 3); 3: 64-deep stages (128-byte
+        //         operand rows: every L2 request a full line -- the 64-byte rows of 32-deep stages cap the L2 -> LDS path at 15 - 18 TB/s chip-wide, which is what
+        //         the 128 x 128 tile's loop ran at), ring of 4 / 3 / 2 stages for the 64 x 64 / 128 x 64 / 128 x 128 tiles; 4: 32-deep stages, ring of 8 / 6 / 4
         if (regs == 3 || regs == 4) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 3, Q>(a, nphase, nsplit, goff_max, s);
     }
     if (regs == 3 || regs == 4) { mf_set_error("conv: no producer-wave kernel for tile %dx%d", BM, BN); return MF_ERR_INVALID; }
@@ -966,11 +997,9 @@ int launch_prec(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3
         }
     }
     if constexpr (WGM * WGN == 4 && BN >= 64) {
-        // producer-wave path (ld 3): 64-deep stages where the ring still holds >= 4 of them, else 32-deep ones
+        // producer-wave path: ld 3 = 64-deep stages, ld 4 = 32-deep stages
         if ((a.ld == 3 || a.ld == 4) && x3) {
-            if constexpr (igemm_ring<BM, BN, 64, true>() >= 4) {
-                if (a.ld == 3) return launch_cfg<BM, BN, WGM, WGN, true, 64>(a, nphase, nsplit, goff_max, s);
-            }
+            if (a.ld == 3) return launch_cfg<BM, BN, WGM, WGN, true, 64>(a, nphase, nsplit, goff_max, s);
             return launch_cfg<BM, BN, WGM, WGN, true, 32>(a, nphase, nsplit, goff_max, s);
         }
     }
@@ -1863,7 +1892,7 @@ std::map<std::string, ConvTuned>& tune_cache() {
             static const int tiles[][4] = {{64, 64, 2, 2}, {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 128, 4, 2}, {256, 256, 2, 4}};
             bool tile_ok = false;
             for (const auto& t : tiles) tile_ok |= c.tile.bm == t[0] && c.tile.bn == t[1] && c.tile.wgm == t[2] && c.tile.wgn == t[3];
-            if ((c.ld == 3 || c.ld == 4) && (c.tile.wgm * c.tile.wgn != 4 || (c.ld == 4 && c.tile.bm + c.tile.bn != 128))) return false;
+            if ((c.ld == 3 || c.ld == 4) && c.tile.wgm * c.tile.wgn != 4) return false;
             // ld 3 / 4 (round 5's producer-wave path) are additions to generation k4: every older entry still names a kernel this library has
             return tile_ok && c.tile.nsplit >= 1 && c.tile.nsplit <= 16 && (c.ld == -1 || c.ld == 0 || c.ld == 2 || c.ld == 3 || c.ld == 4);
         };
@@ -2003,8 +2032,8 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
             if (p->d.act == 5 && t.bn < 32 && S > 1) continue;
             for (int ld : {2, 0, 3, 4}) {
                 if (t.wgm * t.wgn == 8 && ld != 0) continue;                        // the 8-wave tiles only have the LDS-DMA loop
-                // producer-wave path: bf16x3 only; ld 4 (32-deep stages) differs from ld 3 on the 64 x 64 tile only
-                if (ld >= 3 && (p->precision != MF_PREC_BF16X3 || p->q || t.bn < 64 || (ld == 4 && t.bm + t.bn != 128))) continue;
+                // producer-wave path: bf16x3 only (ld 3: 64-deep stages, ld 4: 32-deep ones)
+                if (ld >= 3 && (p->precision != MF_PREC_BF16X3 || p->q || t.bn < 64)) continue;
                 const ConvTuned c{ConvTile{t.bm, t.bn, t.wgm, t.wgn, S}, ld};
                 float us = 0.f;
                 if ((rc = measure(c, &us))) break;
@@ -2056,7 +2085,7 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
         const int bk = ((x3b && t.bm + t.bn > 128 && t.wgm * t.wgn != 4) || (p->q && t.wgm * t.wgn != 4)) ? 32 : 64;
         int ld = -1;
         { auto it = p->tuned.find(batch); if (it != p->tuned.end()) ld = it->second.ld; }
-        if (ld >= 3) snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s,%d,pw>", t.bm, t.bn, t.wgm, t.wgn, x3, ld == 3 && t.bm + t.bn == 128 ? 64 : 32);   // pw: producer waves
+        if (ld >= 3) snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s,%d,pw>", t.bm, t.bn, t.wgm, t.wgn, x3, ld == 3 ? 64 : 32);   // pw: producer waves
         else snprintf(buf, cap, "k_conv_igemm<%d,%d,%d,%d,%s,%d>%s", t.bm, t.bn, t.wgm, t.wgn, x3, bk, p->q ? " f16+fp6" : "");
     }
 }
