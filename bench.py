@@ -329,7 +329,8 @@ def mfma_only_ceiling(precision):
     `roofline.peak` assumes 2.4 GHz, which an MFMA-dense kernel never holds."""
     l = _lib.lib()
     out = {}
-    for mix, key in ((0, "bf16x3_12_bf16_mfma_per_128k"), (1, "f16_plus_2_mx_fp8"), (2, "f16_plus_2_mx_fp6")):
+    for mix, key in ((0, "bf16x3_12_bf16_mfma_per_128k"), (1, "f16_plus_2_mx_fp8"), (2, "f16_plus_2_mx_fp6"), (3, "f16_plus_2_mx_fp6_layer_data"),
+                     (4, "bf16x3_12_bf16_mfma_per_128k_layer_data")):
         v = C.c_float()
         _lib.check(l.mf_probe_mfma_ceiling(mix, C.byref(v)), "probe_mfma_ceiling")
         out[key] = round(float(v.value), 1)

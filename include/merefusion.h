@@ -510,7 +510,9 @@ void mf_net_destroy(mf_net* h);
 /* ---- measurement seam --------------------------------------------------------------------------------------------- */
 /* TFLOP/s of the convolution's own arithmetic that a kernel issuing NOTHING but matrix instructions sustains on this device (random operand bits, 8
  * waves per CU) for the instruction mix one product costs: mix 0 = bf16x3 as shipped (3 bf16 MFMAs), 1 = f16 + two FP8 block-scaled correction
- * terms, 2 = f16 + two FP6 ones.  bench.py reports it beside the nominal peak.  (ABI version 3) */
+ * terms, 2 = f16 + two FP6 ones.  bench.py reports it beside the nominal peak.  (ABI version 3)
+ * mix 3 / 4 = mix 2 / 0 with operand VALUES drawn the way the layers' are (activations silu(z), z ~ N(0, 1); He-initialised weights) and split by the packers'
+ * own rules: the ceiling is data dependent (the chip clocks to its power budget), random bits are the pessimistic end. */
 int mf_probe_mfma_ceiling(int mix, float* tflops_algorithmic);
 
 /* ---- frame transport ----------------------------------------------------------------------- */

@@ -146,7 +146,16 @@ __global__ __launch_bounds__((WGM * WGN + (SP ? 4 : 0)) * 64, HS == 1 ? 2 : 1) v
     const int bid = blockIdx.x;
     const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+#ifndef MF_HALO_ORDER
+#define MF_HALO_ORDER 0       // (A/B builds, profiles/r05_halo_refetch_ab.md) 1: patch fastest -- an XCD walks every patch of one channel tile; 2: plain launch order
+#endif
+#if MF_HALO_ORDER == 1
+    const int tn = t / a.n_patches, patch = t - tn * a.n_patches;
+#elif MF_HALO_ORDER == 2
+    const int patch = bid / a.tiles_n, tn = bid - patch * a.tiles_n;
+#else
     const int patch = t / a.tiles_n, tn = t - patch * a.tiles_n;
+#endif
     const int b = patch / a.patches_per_img;
     const int pr = patch - b * a.patches_per_img;
     const int py = pr / a.patches_x, px = pr - py * a.patches_x;

@@ -1,4 +1,4 @@
-"""The producer-wave operand path of k_conv_igemm (LD 3: four DMA-only waves feed a ring of LDS stages, the compute waves double-buffer their fragments).
+"""The producer-wave operand path of k_conv_igemm (LD 3: four DMA-only waves feed a ring of LDS stages; ld 3 = 64-deep stages, ld 4 = 32-deep ones).
 The tuning table selects it per layer; here it is FORCED onto every layer it can run (MF_FORCE_LD, read once per process: hence child processes) and the
 conv goldens recorded from the reference's own modules, the Wav2Lip generator golden, the reduced-config MuseTalk parity tests and the GroupNorm-statistics
 epilogue must hold unchanged -- 64-deep stages (ld 3) and 32-deep ones on the 64 x 64 tile (ld 4)."""
@@ -27,7 +27,7 @@ def test_forced_on_every_eligible_layer_goldens_hold(lib_built):
     assert " passed" in out
 
 
-@pytest.mark.parametrize("tile,split,ld", [("64x64", "3", "4"), ("128x128", "2", "3"), ("128x64", "1", "3"), ("64x64", "16", "3")])
+@pytest.mark.parametrize("tile,split,ld", [("64x64", "3", "4"), ("128x128", "2", "3"), ("128x128", "3", "4"), ("128x64", "1", "3"), ("128x64", "2", "4"), ("64x64", "16", "3")])
 def test_forced_tiles_and_splits(lib_built, tile, split, ld):
     """every tile of the path, shallow and deep split-K (a workgroup with fewer K steps than the ring has stages included), against the conv goldens + the UNet"""
     out = _run({"MF_FORCE_LD": ld, "MF_FORCE_TILE": tile, "MF_FORCE_SPLIT": split},
