@@ -5,7 +5,7 @@
 # MuseTalk steps at both batch sizes (each counter set in its own pass, --kernel-trace the only trace domain beside --pmc).
 # Launch configurations: the tuning table shipped beside the library -- what a deployment runs.  Outputs under gpurun_out/ (copied into profiles/ afterwards).
 #   usage: tools/round_profile.sh [tag] [parts: tests,bench,stats,b64,pmc]
-TAG=${1:-r03}; PARTS=${2:-tests,bench,stats,b64,pmc}
+TAG=${1:-r05}; PARTS=${2:-tests,bench,stats,b64,pmc}
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
 cd $R
 has() { case ",$PARTS," in *",$1,"*) return 0;; esac; return 1; }
@@ -16,6 +16,8 @@ if has tests; then
 fi
 if has bench; then
   python bench.py --dump-layers gpurun_out/${TAG}_layers.json > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_err.txt
+  cp bench_detail.json gpurun_out/${TAG}_bench_detail.json
+  python tools/unet_floor_table.py gpurun_out/${TAG}_layers.json > gpurun_out/${TAG}_unet_b8_floor.md 2>> gpurun_out/${TAG}_bench_err.txt
 fi
 cd /tmp && export TMPDIR=/tmp
 if has stats; then
