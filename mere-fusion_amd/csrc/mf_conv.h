@@ -69,6 +69,12 @@ struct ConvArgs {
     // GroupNorm statistics of the OUTPUT for the layer's consumer: (sum, sum of squares) per (sample, group) added to gn_out[2 * (b * groups + g)]
     // by the epilogue (4-wave tiles whose pixel tile lies in one sample) or by the split-K combine; null = off
     double* gn_out; int gn_out_cpg, gn_out_groups;
+    // LayerNorm folded into the GEMMs either side of it (round 5; 1 x 1 layers over token sequences).  PRODUCER (ln_out != null): the epilogue adds every
+    // output row's (sum, sum of squares) over this tile's channels to ln_out[2 * m], one fp64 atomic per (wave, row, moment).  CONSUMER (ln_in != null): the
+    // layer multiplies the RAW tensor by gamma-scaled weights and its epilogue finishes the normalisation,
+    //     y[m][n] = rstd_m * (acc[m][n] - mean_m * ln_cs[n]) + bias'[n],   ln_cs[n] = sum_k (gamma_k W[n][k]) as the kernel multiplies it,  bias' = bias + W beta
+    // -- the k_layernorm pass between the two (read + write of the tensor, one launch per LayerNorm: 48 per UNet step) disappears.
+    double* ln_out; const double* ln_in; const float* ln_cs; float ln_inv_c, ln_eps;
     ConvPhase ph[MF_MAX_PHASE];
 };
 
@@ -119,6 +125,11 @@ struct ConvPlan {
     int* goff = nullptr;
     double* out_stats = nullptr; int out_stats_groups = 0;   // GroupNorm (sum, sum of squares) of the output, left in out_stats by every launch (set by the network builder): from the
                                                              // epilogue where the kernel can (f16 + FP6 tiles, 4-wave implicit-GEMM tiles, split-K combine), else by a k_gn_stats pass behind the conv
+    // LayerNorm folding (ConvArgs::ln_*).  Consumer: set ln_gamma / ln_beta (host, cin floats, read by mf_conv_plan_create only) BEFORE the plan is created -- the
+    // weights are scaled by gamma, the bias takes W beta, ln_cs (device, Npad floats) the column sums -- and ln_in / ln_eps before the first launch.  Producer: ln_out.
+    const float* ln_gamma = nullptr; const float* ln_beta = nullptr;
+    float* ln_cs = nullptr; const double* ln_in = nullptr; float ln_eps = 1e-5f;
+    double* ln_out = nullptr;
     bool q_small_maps = false;   // set BEFORE mf_conv_plan_create (MF_PREC_F16Q): take the f16 + FP6 halo tile on maps from 16 x 16 and up to 2048 input channels as well
                                  // (the UNet's 640-channel 16 x 16 layers at >= 40 frames per step; the caller keeps a bf16x3 plan for smaller steps)
     bool q = false;       // MF_PREC_F16Q: w_hi = f16 [slice][tap][Npad][32], w_lo = [slice][tap][Npad][q6(wh) 32 B | q6(wl) 32 B] (24 B codes + E8M0 byte + pad)

@@ -568,7 +568,71 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
         bq[i] = *reinterpret_cast<const float4*>(a.bias + c);
     }
     const int ACT = a.act;
-    if (FN % 2 == 0 && ACT == 5) {
+    if (a.ln_in) {
+        // ---- LayerNorm folded into this layer (its consumers have no residual and act 0 or GEGLU: conv_launch_impl checks).  Its own short epilogue: the general one
+        // below sits at the register limit of the 128 x 128 tile (two workgroups per CU), and the column-sum quads are fetched per use (L1-resident) ----
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = m0 + pm0 + j * 16 + fr;
+            const bool row_ok = m < a.M;
+            const int mc = row_ok ? m : a.M - 1;
+            const int b = mc / a.HqWq;
+            const int rem = mc - b * a.HqWq;
+            const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+            const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
+            const double2 sq = *reinterpret_cast<const double2*>(a.ln_in + 2 * (int64_t)mc);
+            const double mean = sq.x * (double)a.ln_inv_c, var = sq.y * (double)a.ln_inv_c - mean * mean;
+            const float mu = (float)mean, rs = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)a.ln_eps));
+            auto quad = [&](int i, float (&v)[4]) __attribute__((always_inline)) {       // rstd * (acc - mean * colsum) + bias' of fragment i
+                int c = n0 + cn0 + i * 16 + fk * 4;
+                c = c < a.Npad - 3 ? c : a.Npad - 4;
+                const float4 cs = *reinterpret_cast<const float4*>(a.ln_cs + c);
+                v[0] = rs * (acc[i][j][0] - mu * cs.x) + bq[i].x; v[1] = rs * (acc[i][j][1] - mu * cs.y) + bq[i].y;
+                v[2] = rs * (acc[i][j][2] - mu * cs.z) + bq[i].z; v[3] = rs * (acc[i][j][3] - mu * cs.w) + bq[i].w;
+            };
+            auto pack = [&](const float (&v)[4], uint2& hi2, uint2& lo2) __attribute__((always_inline)) {
+                uint32_t h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
+                hi2 = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                if (X3) {
+                    uint32_t l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
+                    lo2 = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                }
+            };
+            if (FN % 2 == 0 && ACT == 5) {
+                const int NO = a.N >> 1;
+#pragma unroll
+                for (int i = 0; i + 1 < FN; i += 2) {
+                    float val[4], gate[4];
+                    quad(i, val); quad(i + 1, gate);
+                    const float v[4] = {val[0] * gelu_erf(gate[0]), val[1] * gelu_erf(gate[1]), val[2] * gelu_erf(gate[2]), val[3] * gelu_erf(gate[3])};
+                    uint2 h2, l2 = make_uint2(0u, 0u);
+                    pack(v, h2, l2);
+                    const int c = n0 + cn0 + i * 16 + fk * 4;
+                    if (!row_ok || c >= a.N) continue;
+                    const int co = (n0 + cn0 + i * 16) / 2 + fk * 4;
+                    (void)NO;
+                    *reinterpret_cast<uint2*>(a.y_hi + yo + co) = h2;
+                    if (X3) *reinterpret_cast<uint2*>(a.y_lo + yo + co) = l2;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    float v[4];
+                    quad(i, v);
+                    uint2 h2, l2 = make_uint2(0u, 0u);
+                    pack(v, h2, l2);
+                    const int c = n0 + cn0 + i * 16 + fk * 4;
+                    if (!row_ok || c >= a.N) continue;
+                    *reinterpret_cast<uint2*>(a.y_hi + yo + c) = h2;
+                    if (X3) *reinterpret_cast<uint2*>(a.y_lo + yo + c) = l2;
+                }
+            }
+        }
+    } else if (FN % 2 == 0 && ACT == 5) {
         // GEGLU: GEMM rows alternate 16 value channels / their 16 gate channels (packed that way at plan creation), so
         // fragment i holds the values and fragment i + 1 the gates of the same 4 output channels of this lane
 #pragma unroll
@@ -666,6 +730,7 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
                 const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
                 const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
                 uint2 pk_hi[FN], pk_lo[FN];
+                float row_s = 0.f, row_q = 0.f;
 #pragma unroll
                 for (int i = 0; i < FN; ++i) {
                     float v[4] = {acc[i][j][0] + bq[i].x, acc[i][j][1] + bq[i].y, acc[i][j][2] + bq[i].z, acc[i][j][3] + bq[i].w};
@@ -689,6 +754,10 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { gs[i][e] += v[e]; gq[i][e] += v[e] * v[e]; }
                     }
+                    if (a.ln_out && n0 + cn0 + i * 16 + fk * 4 < a.N) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { row_s += v[e]; row_q += v[e] * v[e]; }
+                    }
                     uint32_t h[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
@@ -698,6 +767,14 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
 #pragma unroll
                         for (int e = 0; e < 4; ++e) l[e] = f2bf(v[e] - bf2f(h[e]));
                         pk_lo[i] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                    }
+                }
+                if (a.ln_out) {
+                    row_s += __shfl_xor(row_s, 16); row_q += __shfl_xor(row_q, 16);
+                    row_s += __shfl_xor(row_s, 32); row_q += __shfl_xor(row_q, 32);
+                    if (fk == 0 && row_ok) {
+                        atomicAdd(a.ln_out + 2 * (int64_t)m, (double)row_s);
+                        atomicAdd(a.ln_out + 2 * (int64_t)m + 1, (double)row_q);
                     }
                 }
                 if (FN % 2 == 0 && a.wide_store) {
@@ -837,8 +914,10 @@ __device__ __forceinline__ void epilogue_store_pre(const ConvArgs& a, float (&v)
 // Combines the split-K partial tiles: one thread per (output pixel, 4 channels).
 // ws layout: [split][B][Ho][Wo][N] fp32 (unpadded); output / residual are padded NHWC planes.
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int nsplit, int Ho, int Wo, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    const int64_t idx0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx0 < total;
+    if (!live && !a.ln_out) return;
+    const int64_t idx = live ? idx0 : total - 1;          // (a LayerNorm producer's tail lanes stay for the wave reduction below: they recompute the last quad, store nothing)
     const bool geglu = a.act == 5;
     const int nq = (geglu ? a.N >> 1 : a.N) >> 2;         // output channel quads
     const int co = (int)(idx % nq) * 4;                   // output channel
@@ -853,13 +932,49 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int n
     const int64_t ro = (int64_t)b * a.rb + (int64_t)oy * a.ri + (int64_t)ox * a.rj;
     const ResQuad rq = load_residual(a, ro, co, x3);
     const float* w = a.ws + (((int64_t)b * Ho + oy) * Wo + ox) * a.N + c;
-    const float4 s = splitk_sum(w, a.ws_split, nsplit, *reinterpret_cast<const float4*>(a.bias + c));
-    float v[4] = {s.x, s.y, s.z, s.w};
-    if (geglu) {
-        const float4 g = splitk_sum(w + 16, a.ws_split, nsplit, *reinterpret_cast<const float4*>(a.bias + c + 16));
-        v[0] *= gelu_erf(g.x); v[1] *= gelu_erf(g.y); v[2] *= gelu_erf(g.z); v[3] *= gelu_erf(g.w);
+    float v[4];
+    if (a.ln_in) {
+        // LayerNorm folded into this layer (ConvArgs::ln_in): the partials sum the RAW tensor's products; mean / rstd of the row finish the normalisation
+        const int64_t m = ((int64_t)b * Ho + oy) * Wo + ox;
+        const double2 sq = *reinterpret_cast<const double2*>(a.ln_in + 2 * m);
+        const double mean = sq.x * (double)a.ln_inv_c, var = sq.y * (double)a.ln_inv_c - mean * mean;
+        const float mu = (float)mean, rs = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)a.ln_eps));
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 s = splitk_sum(w, a.ws_split, nsplit, z), cs = *reinterpret_cast<const float4*>(a.ln_cs + c), bb = *reinterpret_cast<const float4*>(a.bias + c);
+        v[0] = rs * (s.x - mu * cs.x) + bb.x; v[1] = rs * (s.y - mu * cs.y) + bb.y; v[2] = rs * (s.z - mu * cs.z) + bb.z; v[3] = rs * (s.w - mu * cs.w) + bb.w;
+        if (geglu) {
+            const float4 g = splitk_sum(w + 16, a.ws_split, nsplit, z), cg = *reinterpret_cast<const float4*>(a.ln_cs + c + 16), bg = *reinterpret_cast<const float4*>(a.bias + c + 16);
+            v[0] *= gelu_erf(rs * (g.x - mu * cg.x) + bg.x); v[1] *= gelu_erf(rs * (g.y - mu * cg.y) + bg.y);
+            v[2] *= gelu_erf(rs * (g.z - mu * cg.z) + bg.z); v[3] *= gelu_erf(rs * (g.w - mu * cg.w) + bg.w);
+        }
+    } else {
+        const float4 s = splitk_sum(w, a.ws_split, nsplit, *reinterpret_cast<const float4*>(a.bias + c));
+        v[0] = s.x; v[1] = s.y; v[2] = s.z; v[3] = s.w;
+        if (geglu) {
+            const float4 g = splitk_sum(w + 16, a.ws_split, nsplit, *reinterpret_cast<const float4*>(a.bias + c + 16));
+            v[0] *= gelu_erf(g.x); v[1] *= gelu_erf(g.y); v[2] *= gelu_erf(g.z); v[3] *= gelu_erf(g.w);
+        }
     }
-    epilogue_store_pre(a, v, yo, co, x3, rq);
+    if (live) epilogue_store_pre(a, v, yo, co, x3, rq);
+    if (a.ln_out) {
+        // LayerNorm statistics of the stored row for the consumer: (sum, sum of squares) of this thread's quad, added up over the lanes of the wave that hold the
+        // same pixel (a segmented suffix sum: consecutive lanes = consecutive quads of a pixel), one fp64 atomic per (wave, pixel, moment)
+        float ps = (v[0] + v[1]) + (v[2] + v[3]), pq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        const int64_t pix = live ? idx / nq : -1;
+        if (!live) { ps = 0.f; pq = 0.f; }
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float os = __shfl_down(ps, off), oq = __shfl_down(pq, off);
+            const int64_t op = __shfl_down(pix, off);
+            if (lane + off < 64 && op == pix) { ps += os; pq += oq; }
+        }
+        const int64_t prev = __shfl_up(pix, 1);
+        if (live && (lane == 0 || prev != pix)) {
+            atomicAdd(a.ln_out + 2 * pix, (double)ps);
+            atomicAdd(a.ln_out + 2 * pix + 1, (double)pq);
+        }
+    }
 }
 
 // The same combine for a layer whose consumer is a GroupNorm (a.gn_out): the (sum, sum of squares) of the stored values per (sample, group)
@@ -1098,6 +1213,28 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
         }
         weight = gw.data();
         bias = gb.data();
+    }
+    // LayerNorm folded into this layer (ConvPlan::ln_gamma set by the network builder): W' = W diag(gamma), bias' = bias + W beta (fp64 sums), and the column sums
+    // of W' AS THE KERNEL MULTIPLIES IT (hi + lo bf16, or hi alone in the single-pass mode) for the epilogue's mean correction
+    std::vector<float> lw, lb, lcs;
+    if (p->ln_gamma) {
+        MF_REQUIRE(d.kh == 1 && d.kw == 1 && d.stride_h == 1 && d.stride_w == 1 && d.pad_h == 0 && d.pad_w == 0 && !d.transposed && !d.upsample && !bn_gamma && !d.residual &&
+                   precision != MF_PREC_F16Q && p->ln_beta, "conv: LayerNorm folding serves plain 1x1 layers without residual (bf16 / bf16x3)");
+        lw.resize((size_t)d.cout * d.cin); lb.assign(d.cout, 0.f); lcs.assign(d.cout, 0.f);
+        for (int n = 0; n < d.cout; ++n) {
+            double sb = bias ? (double)bias[n] : 0.0, cs = 0.0;
+            for (int c = 0; c < d.cin; ++c) {
+                const float w0 = weight[(size_t)n * d.cin + c];
+                sb += (double)w0 * (double)p->ln_beta[c];
+                const float wf = w0 * p->ln_gamma[c];
+                lw[(size_t)n * d.cin + c] = wf;
+                const bf16_t h = mf_f2bf(wf);
+                cs += (double)mf_bf2f(h) + (precision == MF_PREC_BF16 ? 0.0 : (double)mf_bf2f(mf_f2bf(wf - mf_bf2f(h))));
+            }
+            lb[n] = (float)sb; lcs[n] = (float)cs;
+        }
+        weight = lw.data();
+        bias = lb.data();
     }
     p->d = d;
     p->precision = precision;
@@ -1371,6 +1508,13 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
     }
     MF_HIP(hipMalloc(&p->bias, p->Npad * sizeof(float)));
     MF_HIP(hipMemcpy(p->bias, fbias.data(), p->Npad * sizeof(float), hipMemcpyHostToDevice));
+    if (!lcs.empty()) {
+        MF_REQUIRE(!p->halo && p->nphase == 1, "conv: LayerNorm folding needs the implicit-GEMM path");
+        lcs.resize(p->Npad, 0.f);
+        MF_HIP(hipMalloc(&p->ln_cs, p->Npad * sizeof(float)));
+        MF_HIP(hipMemcpy(p->ln_cs, lcs.data(), p->Npad * sizeof(float), hipMemcpyHostToDevice));
+    }
+    p->ln_gamma = p->ln_beta = nullptr;            // (host pointers of the builder: not kept)
     MF_HIP(hipMalloc(&p->goff, goff_total * sizeof(int)));
     p->bound_in_ld = p->bound_in_wp = -1;
     return MF_OK;
@@ -1382,6 +1526,8 @@ void mf_conv_plan_destroy(ConvPlan* p) {
     if (p->w_hi) (void)hipFree(p->w_hi);
     if (p->w_lo) (void)hipFree(p->w_lo);
     if (p->bias) (void)hipFree(p->bias);
+    if (p->ln_cs) (void)hipFree(p->ln_cs);
+    p->ln_cs = nullptr;
     if (p->goff) (void)hipFree(p->goff);
     if (p->ws) (void)hipFree(p->ws);
     if (p->up_hi) (void)hipFree(p->up_hi);
@@ -1649,6 +1795,14 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
     }
     a.act = p->d.act;
     a.res_after_act = p->d.residual == 2;
+    if (p->ln_cs) {
+        MF_REQUIRE(p->ln_in && !res.buf && (p->d.act == 0 || p->d.act == 5), "conv: a LayerNorm-folded layer needs its statistics buffer, no residual and act 0 or GEGLU");
+        a.ln_in = p->ln_in; a.ln_cs = p->ln_cs; a.ln_inv_c = 1.f / (float)p->d.cin; a.ln_eps = p->ln_eps;
+    }
+    if (p->ln_out) {
+        MF_REQUIRE(p->d.act != 5 && p->nphase == 1 && p->out_step == 1, "conv: LayerNorm statistics come from plain 1x1 producers");
+        a.ln_out = p->ln_out;
+    }
     {
         const int n_out = p->d.act == 5 ? p->d.cout / 2 : p->d.cout;
         a.wide_store = out.coff % 8 == 0 && ob.C % 8 == 0 && n_out % 8 == 0 && p->d.cout % 16 == 0;

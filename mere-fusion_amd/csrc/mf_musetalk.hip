@@ -145,6 +145,28 @@ struct Net {
     // ---- ops ----------------------------------------------------------------------------------------------
     // Conv2d / Linear `name` (k x k, stride, pad), optional SiLU etc., optional residual view, optional
     // nearest-2x upsample in front, optional per-channel constant added to the bias, optional input scale.
+    // ---- LayerNorm folded into the GEMMs either side of it (ConvArgs::ln_*): per LayerNorm one fp64 (sum, sum of squares) pair per token, zeroed by the
+    // statistics-reset kernel at the head of the list, filled by the producing layer's epilogue, consumed by the epilogue of the layer that follows the norm ----
+    double* ln_stats = nullptr;              // [ln_total] doubles behind gn_stats (one allocation, one reset launch)
+    size_t ln_used = 0, ln_cap_doubles = 0;
+    ConvPlan* last_plan = nullptr;           // the plan of the op conv() / linear_raw() pushed last
+    const float* ln_fold_g = nullptr; const float* ln_fold_b = nullptr; const double* ln_fold_in = nullptr;   // set for the NEXT conv() / linear_raw() call only
+    double* ln_slot(const ActBuf* t) {       // statistics of one LayerNorm over token buffer t
+        const size_t n = (size_t)2 * cap * t->H * t->W;
+        if (!ln_stats || ln_used + n > ln_cap_doubles) return nullptr;
+        double* p = ln_stats + ln_used;
+        ln_used += n;
+        return p;
+    }
+    int ln_fold_next(const std::string& name, int C, const double* stats) {
+        ln_fold_g = T(name + ".weight", C);
+        ln_fold_b = T(name + ".bias", C);
+        ln_fold_in = stats;
+        return (ln_fold_g && ln_fold_b && stats) ? MF_OK : MF_ERR_INVALID;
+    }
+    void ln_apply_fold(ConvPlan* p) { p->ln_gamma = ln_fold_g; p->ln_beta = ln_fold_b; }
+    void ln_finish_fold(ConvPlan* p) { if (ln_fold_in) { p->ln_in = ln_fold_in; p->ln_eps = 1e-5f; } ln_fold_g = ln_fold_b = nullptr; ln_fold_in = nullptr; }
+
     int conv(const std::string& name, ActView in, ActView out, int cin, int cout, int k, int stride, int pad, int act,
              ActView res, int upsample = 0, const std::vector<float>* extra_bias = nullptr, float w_scale = 1.f, bool bias = true,
              ConvPlan** plan_out = nullptr) {
@@ -181,9 +203,12 @@ struct Net {
         d.pad_hi = next_pad_hi; next_pad_hi = 0;
         stats_forget(out.buf);
         ConvPlan* p = new_plan();
+        ln_apply_fold(p);
         int rc = mf_conv_plan_create(p, d, w, bb.data(), nullptr, nullptr, nullptr, nullptr, precision);
+        ln_finish_fold(p);
         if (rc) return rc;
         if ((rc = mf_conv_bind(p, *in.buf))) return rc;
+        last_plan = p;
         if (plan_out) { *plan_out = p; return MF_OK; }     // the caller pushes its own op around this plan (gn_conv)
         char kn[96];
         mf_conv_kernel_name(p, cap, kn, sizeof(kn));
@@ -512,8 +537,14 @@ struct Net {
         int rc;
         if ((rc = gn(p + ".norm", x, ActView{g0, 0, C}, groups, 1e-6f, false))) return rc;
         if ((rc = conv(p + ".proj_in", ActView{g0, 0, C}, ActView{hA, 0, C}, C, C, 1, 1, 0, 0, ActView{}))) return rc;
+        // The three LayerNorms are FOLDED into the GEMMs around them where the statistics buffer has room (it has, for the shipped configurations): the producer of
+        // the residual stream (proj_in, attn1.to_out + x, attn2.to_out + x) leaves every token's (sum, sum of squares), the consumer (q | k | v, attn2.to_q, the
+        // GEGLU projection) multiplies the RAW stream by gamma-scaled weights and its epilogue applies rstd * (acc - mean * colsum) + (bias + W beta).
+        double *st1 = ln_slot(hA), *st2 = ln_slot(hB), *st3 = ln_slot(hA);
+        const bool fold = st1 && st2 && st3;
         // self attention: q | k | v in one GEMM (no bias)
-        if ((rc = ln(t + ".norm1", ActView{hA, 0, C}, ActView{nb, 0, C}))) return rc;
+        if (fold) { last_plan->ln_out = st1; if ((rc = ln_fold_next(t + ".norm1", C, st1))) return rc; }
+        else if ((rc = ln(t + ".norm1", ActView{hA, 0, C}, ActView{nb, 0, C}))) return rc;
         {
             const float *wq = T(t + ".attn1.to_q.weight", (int64_t)C * C), *wk = T(t + ".attn1.to_k.weight", (int64_t)C * C),
                         *wv = T(t + ".attn1.to_v.weight", (int64_t)C * C);
@@ -522,13 +553,14 @@ struct Net {
             std::copy(wq, wq + (size_t)C * C, w.begin());
             std::copy(wk, wk + (size_t)C * C, w.begin() + (size_t)C * C);
             std::copy(wv, wv + (size_t)C * C, w.begin() + (size_t)2 * C * C);
-            if ((rc = linear_raw(w.data(), nullptr, ActView{nb, 0, C}, ActView{qkv, 0, 3 * C}, C, 3 * C, ActView{}))) return rc;
+            if ((rc = linear_raw(w.data(), nullptr, fold ? ActView{hA, 0, C} : ActView{nb, 0, C}, ActView{qkv, 0, 3 * C}, C, 3 * C, ActView{}))) return rc;
         }
         if ((rc = attention(ActView{qkv, 0, C}, ActView{qkv, C, C}, ActView{qkv, 2 * C, C}, ActView{ao, 0, C}, heads))) return rc;
         if ((rc = conv(t + ".attn1.to_out.0", ActView{ao, 0, C}, ActView{hB, 0, C}, C, C, 1, 1, 0, 0, ActView{hA, 0, C}))) return rc;
         // cross attention over the audio tokens: k | v in one GEMM
-        if ((rc = ln(t + ".norm2", ActView{hB, 0, C}, ActView{nb, 0, C}))) return rc;
-        if ((rc = conv(t + ".attn2.to_q", ActView{nb, 0, C}, ActView{qkv, 0, C}, C, C, 1, 1, 0, 0, ActView{}, 0, nullptr, 1.f, false))) return rc;
+        if (fold) { last_plan->ln_out = st2; if ((rc = ln_fold_next(t + ".norm2", C, st2))) return rc; }
+        else if ((rc = ln(t + ".norm2", ActView{hB, 0, C}, ActView{nb, 0, C}))) return rc;
+        if ((rc = conv(t + ".attn2.to_q", fold ? ActView{hB, 0, C} : ActView{nb, 0, C}, ActView{qkv, 0, C}, C, C, 1, 1, 0, 0, ActView{}, 0, nullptr, 1.f, false))) return rc;
         ActView kk{kv, 0, C}, vv{kv, C, C};
         {
             const float *wk = T(t + ".attn2.to_k.weight", (int64_t)C * X), *wv = T(t + ".attn2.to_v.weight", (int64_t)C * X);
@@ -550,9 +582,10 @@ struct Net {
         if ((rc = attention(ActView{qkv, 0, C}, kk, vv, ActView{ao, 0, C}, heads))) return rc;
         if ((rc = conv(t + ".attn2.to_out.0", ActView{ao, 0, C}, ActView{hA, 0, C}, C, C, 1, 1, 0, 0, ActView{hB, 0, C}))) return rc;
         // GEGLU feed-forward
-        if ((rc = ln(t + ".norm3", ActView{hA, 0, C}, ActView{nb, 0, C}))) return rc;
+        if (fold) { last_plan->ln_out = st3; if ((rc = ln_fold_next(t + ".norm3", C, st3))) return rc; }
+        else if ((rc = ln(t + ".norm3", ActView{hA, 0, C}, ActView{nb, 0, C}))) return rc;
         // GEGLU in the GEMM epilogue (act 5): the 8C-wide projection never reaches HBM, only value * gelu(gate)
-        if ((rc = conv(t + ".ff.net.0.proj", ActView{nb, 0, C}, ActView{gg, 0, 4 * C}, C, 8 * C, 1, 1, 0, 5, ActView{}))) return rc;
+        if ((rc = conv(t + ".ff.net.0.proj", fold ? ActView{hA, 0, C} : ActView{nb, 0, C}, ActView{gg, 0, 4 * C}, C, 8 * C, 1, 1, 0, 5, ActView{}))) return rc;
         if ((rc = conv(t + ".ff.net.2", ActView{gg, 0, 4 * C}, ActView{hB, 0, C}, 4 * C, C, 1, 1, 0, 0, ActView{hA, 0, C}))) return rc;
         return conv(p + ".proj_out", ActView{hB, 0, C}, y, C, C, 1, 1, 0, 0, x);
     }
@@ -624,9 +657,12 @@ struct Net {
         d.cin = cin; d.cout = cout; d.kh = d.kw = 1; d.stride_h = d.stride_w = 1; d.residual = res.buf ? 1 : 0;
         d.in_h = in.buf->H; d.in_w = in.buf->W;
         ConvPlan* p = new_plan();
+        ln_apply_fold(p);
         int rc = mf_conv_plan_create(p, d, w, b, nullptr, nullptr, nullptr, nullptr, precision);
+        ln_finish_fold(p);
         if (rc) return rc;
         if ((rc = mf_conv_bind(p, *in.buf))) return rc;
+        last_plan = p;
         char kn[96];
         mf_conv_kernel_name(p, cap, kn, sizeof(kn));
         push("fused linear " + std::to_string(cin) + "->" + std::to_string(cout), kn, mf_conv_flops(p, 1),
@@ -770,7 +806,7 @@ struct Net {
         MF_HIP(hipStreamWaitEvent(s, ev_out, 0));
         return MF_OK;
     }
-    int init(const mf_tensor* weights, int n, int prec, int max_batch, int max_groups) {
+    int init(const mf_tensor* weights, int n, int prec, int max_batch, int max_groups, int ln_tokens_per_sample = 0) {
         precision = prec; cap = max_batch;
         for (int i = 0; i < n; ++i) {
             if (!weights[i].name || !weights[i].data) { mf_set_error("tensor %d has no name/data", i); return MF_ERR_INVALID; }
@@ -779,12 +815,16 @@ struct Net {
         // one slice of fp64 (sum, sum of squares) per GroupNorm op; the whole array is zeroed by ONE kernel at the head
         // of the op list, so a GroupNorm is two launches (statistics, apply) instead of four
         gn_slice = (size_t)max_batch * max_groups * 2;
-        MF_HIP(hipMalloc(&gn_stats, GN_MAX_OPS * gn_slice * sizeof(double)));
+        // ... and behind them the LayerNorm statistics: two doubles per token and LayerNorm (ln_slot); the caller says how many token slots per sample its
+        // transformer blocks need (mf_unet_create counts them from the config; 0: no folding)
+        ln_cap_doubles = (size_t)max_batch * ln_tokens_per_sample * 2;
+        MF_HIP(hipMalloc(&gn_stats, (GN_MAX_OPS * gn_slice + ln_cap_doubles) * sizeof(double)));
         dev.push_back(gn_stats);
+        ln_stats = gn_stats + GN_MAX_OPS * gn_slice;
         {
             double* st = gn_stats;
-            const int n = (int)(GN_MAX_OPS * gn_slice);
-            push("groupnorm statistics reset", "k_zero_f64", 0.0, [=](int, hipStream_t s) { return mf_zero_f64(st, n, s); });
+            const int n = (int)(GN_MAX_OPS * gn_slice + ln_cap_doubles);
+            push("groupnorm / layernorm statistics reset", "k_zero_f64", 0.0, [=](int, hipStream_t s) { return mf_zero_f64(st, n, s); });
         }
         MF_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
         MF_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
@@ -835,7 +875,21 @@ extern "C" int mf_unet_create(const mf_unet_config* c, const mf_tensor* weights,
     std::unique_ptr<mf_unet> h(new mf_unet());
     h->cfg = *c;
     Net& net = h->net;
-    int rc = net.init(weights, n_weights, precision, max_batch, c->norm_num_groups);
+    // token slots per sample of the folded LayerNorms: three per transformer block, each over the block's map
+    int ln_tokens = 0;
+    {
+        int sz = c->sample_size;
+        for (int b = 0; b < c->n_blocks; ++b) {
+            if (c->down_attn[b]) ln_tokens += 3 * c->layers_per_block * sz * sz;
+            if (b < c->n_blocks - 1) sz /= 2;
+        }
+        ln_tokens += 3 * sz * sz;                                                  // mid block
+        for (int b = 0; b < c->n_blocks; ++b) {
+            if (c->up_attn[b]) ln_tokens += 3 * (c->layers_per_block + 1) * sz * sz;
+            if (b < c->n_blocks - 1) sz *= 2;
+        }
+    }
+    int rc = net.init(weights, n_weights, precision, max_batch, c->norm_num_groups, ln_tokens);
     if (rc) return rc;
     net.q_dual_allowed = true;   // (tests/test_musetalk_full.py holds the 40-frame handle to the batch-8 parity gate with it)
     const int nb = c->n_blocks, L = c->layers_per_block, G = c->norm_num_groups, heads = c->attention_heads;
