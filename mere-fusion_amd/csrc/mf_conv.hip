@@ -604,31 +604,56 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
             };
             if (FN % 2 == 0 && ACT == 5) {
                 const int NO = a.N >> 1;
+                uint2 pk_hi[FN / 2 > 0 ? FN / 2 : 1], pk_lo[FN / 2 > 0 ? FN / 2 : 1];
 #pragma unroll
                 for (int i = 0; i + 1 < FN; i += 2) {
                     float val[4], gate[4];
                     quad(i, val); quad(i + 1, gate);
                     const float v[4] = {val[0] * gelu_erf(gate[0]), val[1] * gelu_erf(gate[1]), val[2] * gelu_erf(gate[2]), val[3] * gelu_erf(gate[3])};
-                    uint2 h2, l2 = make_uint2(0u, 0u);
-                    pack(v, h2, l2);
-                    const int c = n0 + cn0 + i * 16 + fk * 4;
-                    if (!row_ok || c >= a.N) continue;
-                    const int co = (n0 + cn0 + i * 16) / 2 + fk * 4;
-                    (void)NO;
-                    *reinterpret_cast<uint2*>(a.y_hi + yo + co) = h2;
-                    if (X3) *reinterpret_cast<uint2*>(a.y_lo + yo + co) = l2;
+                    pk_lo[i / 2] = make_uint2(0u, 0u);
+                    pack(v, pk_hi[i / 2], pk_lo[i / 2]);
+                }
+                if (FN % 4 == 0 && a.wide_store) {
+#pragma unroll
+                    for (int q = 0; q + 1 < FN / 2; q += 2) {
+                        const int c16 = (n0 + cn0 + 2 * q * 16) / 2;
+                        store_pair16(a.y_hi, yo, c16, 16, fk, pk_hi[q], pk_hi[q + 1], NO, row_ok);
+                        if (X3) store_pair16(a.y_lo, yo, c16, 16, fk, pk_lo[q], pk_lo[q + 1], NO, row_ok);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < FN / 2; ++q) {
+                        const int c = n0 + cn0 + 2 * q * 16 + fk * 4;
+                        if (!row_ok || c >= a.N) continue;
+                        const int co = (n0 + cn0 + 2 * q * 16) / 2 + fk * 4;
+                        *reinterpret_cast<uint2*>(a.y_hi + yo + co) = pk_hi[q];
+                        if (X3) *reinterpret_cast<uint2*>(a.y_lo + yo + co) = pk_lo[q];
+                    }
                 }
             } else {
+                uint2 pk_hi[FN], pk_lo[FN];
 #pragma unroll
                 for (int i = 0; i < FN; ++i) {
                     float v[4];
                     quad(i, v);
-                    uint2 h2, l2 = make_uint2(0u, 0u);
-                    pack(v, h2, l2);
-                    const int c = n0 + cn0 + i * 16 + fk * 4;
-                    if (!row_ok || c >= a.N) continue;
-                    *reinterpret_cast<uint2*>(a.y_hi + yo + c) = h2;
-                    if (X3) *reinterpret_cast<uint2*>(a.y_lo + yo + c) = l2;
+                    pk_lo[i] = make_uint2(0u, 0u);
+                    pack(v, pk_hi[i], pk_lo[i]);
+                }
+                if (FN % 2 == 0 && a.wide_store) {
+#pragma unroll
+                    for (int i = 0; i + 1 < FN; i += 2) {
+                        const int c16 = n0 + cn0 + i * 16;
+                        store_pair16(a.y_hi, yo, c16, 16, fk, pk_hi[i], pk_hi[i + 1], a.N, row_ok);
+                        if (X3) store_pair16(a.y_lo, yo, c16, 16, fk, pk_lo[i], pk_lo[i + 1], a.N, row_ok);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) {
+                        const int c = n0 + cn0 + i * 16 + fk * 4;
+                        if (!row_ok || c >= a.N) continue;
+                        *reinterpret_cast<uint2*>(a.y_hi + yo + c) = pk_hi[i];
+                        if (X3) *reinterpret_cast<uint2*>(a.y_lo + yo + c) = pk_lo[i];
+                    }
                 }
             }
         }
