@@ -531,14 +531,9 @@ struct Net {
         const int H = x.buf->H, W = x.buf->W, X = ctx.C;
         ActBuf *g0 = tmp("xf.gn", C, H, W, 0), *hA = tmp("xf.hA", C, H, W, 0), *hB = tmp("xf.hB", C, H, W, 0);
         ActBuf *nb = tmp("xf.ln", C, H, W, 0), *qkv = tmp("xf.qkv", 3 * C, H, W, 0), *ao = tmp("xf.ao", C, H, W, 0);
-        // `gg`: the GEGLU output (4 C) with the residual stream of the feed-forward behind it in the same rows ([g | a], 5 C): the block's last two linear maps,
-        // ff.net.2 + a and proj_out + x, are ONE GEMM over that concatenation where the caller handed in the merged weights (musetalk/models/unet.py
-        // merged_ff2_proj_out: [Wp W2 | Wp], Wp b2 + bp); `a` is written there by attn2.to_out instead of into hA -- the skip-connection trick of the up blocks
-        ActBuf *kv = tmp("xf.kv", 2 * C, ctx.buf->H, ctx.buf->W, 0), *gg = tmp("xf.geglu", 5 * C, H, W, 0);
+        ActBuf *kv = tmp("xf.kv", 2 * C, ctx.buf->H, ctx.buf->W, 0), *gg = tmp("xf.geglu", 4 * C, H, W, 0);
         if (!g0 || !hA || !hB || !nb || !qkv || !ao || !kv || !gg) return MF_ERR_HIP;
         const std::string t = p + ".transformer_blocks.0";
-        const bool merged = sd.count(p + ".proj_out_ff2.weight") && sd.count(p + ".proj_out_ff2.bias");
-        const ActView aF = merged ? ActView{gg, 4 * C, C} : ActView{hA, 0, C};      // the residual stream entering the feed-forward
         int rc;
         if ((rc = gn(p + ".norm", x, ActView{g0, 0, C}, groups, 1e-6f, false))) return rc;
         if ((rc = conv(p + ".proj_in", ActView{g0, 0, C}, ActView{hA, 0, C}, C, C, 1, 1, 0, 0, ActView{}))) return rc;
@@ -585,24 +580,13 @@ struct Net {
         }
         if (kk.buf == kv_all && kv_op >= 0 && !kv_joined) { join_here(kv_op); kv_joined = true; }
         if ((rc = attention(ActView{qkv, 0, C}, kk, vv, ActView{ao, 0, C}, heads))) return rc;
-        if ((rc = conv(t + ".attn2.to_out.0", ActView{ao, 0, C}, aF, C, C, 1, 1, 0, 0, ActView{hB, 0, C}))) return rc;
+        if ((rc = conv(t + ".attn2.to_out.0", ActView{ao, 0, C}, ActView{hA, 0, C}, C, C, 1, 1, 0, 0, ActView{hB, 0, C}))) return rc;
         // GEGLU feed-forward
         if (fold) { last_plan->ln_out = st3; if ((rc = ln_fold_next(t + ".norm3", C, st3))) return rc; }
-        else if ((rc = ln(t + ".norm3", aF, ActView{nb, 0, C}))) return rc;
+        else if ((rc = ln(t + ".norm3", ActView{hA, 0, C}, ActView{nb, 0, C}))) return rc;
         // GEGLU in the GEMM epilogue (act 5): the 8C-wide projection never reaches HBM, only value * gelu(gate)
-        if ((rc = conv(t + ".ff.net.0.proj", fold ? aF : ActView{nb, 0, C}, ActView{gg, 0, 4 * C}, C, 8 * C, 1, 1, 0, 5, ActView{}))) return rc;
-        if (merged) {
-            const float* wm = T(p + ".proj_out_ff2.weight", (int64_t)C * 5 * C);
-            const float* bm = T(p + ".proj_out_ff2.bias", C);
-            if (!wm || !bm) return MF_ERR_INVALID;
-            const size_t before = ops.size();
-            stats_forget(y.buf);
-            if ((rc = linear_raw(wm, bm, ActView{gg, 0, 5 * C}, y, 5 * C, C, x))) return rc;
-            if (ops.size() == before + 1) info.back().name = p + ".proj_out_ff2 (ff.net.2 + proj_out as one GEMM over [geglu | residual])";
-            stats_remember(last_plan, y);                                           // (the next resnet's GroupNorm takes its statistics from this epilogue, as from proj_out)
-            return MF_OK;
-        }
-        if ((rc = conv(t + ".ff.net.2", ActView{gg, 0, 4 * C}, ActView{hB, 0, C}, 4 * C, C, 1, 1, 0, 0, aF))) return rc;
+        if ((rc = conv(t + ".ff.net.0.proj", fold ? ActView{hA, 0, C} : ActView{nb, 0, C}, ActView{gg, 0, 4 * C}, C, 8 * C, 1, 1, 0, 5, ActView{}))) return rc;
+        if ((rc = conv(t + ".ff.net.2", ActView{gg, 0, 4 * C}, ActView{hB, 0, C}, 4 * C, C, 1, 1, 0, 0, ActView{hA, 0, C}))) return rc;
         return conv(p + ".proj_out", ActView{hB, 0, C}, y, C, C, 1, 1, 0, 0, x);
     }
 

@@ -63,28 +63,6 @@ class _Sample:
         self.sample = sample
 
 
-def merged_ff2_proj_out(state_dict):
-    """Every Transformer2DModel ends in two linear maps with nothing but a residual between them (diffusers BasicTransformerBlock -> Transformer2DModel):
-        h = ff.net.2(g) + a;  y = proj_out(h) + x      =>      y = [Wp W2 | Wp] [g | a] + (Wp b2 + bp) + x
-    so the pair is ONE GEMM over the concatenated input [GEGLU output | residual stream] (same FLOPs: 4 C^2 + C^2 = 5 C^2; one launch, and h never reaches HBM).
-    The products are taken in fp64 here and handed to mf_unet_create as extra tensors `<attention>.proj_out_ff2.{weight, bias}`; the library uses them where present."""
-    out = {}
-    for k, wp in state_dict.items():
-        if not k.endswith(".proj_out.weight"):
-            continue
-        p = k[:-len(".proj_out.weight")]
-        w2, b2, bp = (state_dict.get(p + n) for n in (".transformer_blocks.0.ff.net.2.weight", ".transformer_blocks.0.ff.net.2.bias", ".proj_out.bias"))
-        if w2 is None or b2 is None or bp is None:
-            continue
-        wp64 = torch.as_tensor(wp).double().reshape(wp.shape[0], -1)
-        w2_64, b2_64 = torch.as_tensor(w2).double(), torch.as_tensor(b2).double()
-        if wp64.shape[1] != w2_64.shape[0]:
-            continue
-        out[p + ".proj_out_ff2.weight"] = torch.cat([wp64 @ w2_64, wp64], dim=1).float().contiguous()
-        out[p + ".proj_out_ff2.bias"] = (wp64 @ b2_64 + torch.as_tensor(bp).double()).float().contiguous()
-    return out
-
-
 class HipUNetModel:
     """Stands where `UNet2DConditionModel` stood: callable, `.dtype`, `.half()`, `.to()`."""
 
@@ -98,9 +76,7 @@ class HipUNetModel:
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.init_device(idx)
         self._cfg = unet_config_struct(config)
-        sd = dict(state_dict)
-        sd.update(merged_ff2_proj_out(state_dict))
-        arr, keep = _lib.tensor_array(sd)
+        arr, keep = _lib.tensor_array(state_dict)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().mf_unet_create(C.byref(self._cfg), arr, len(keep), _lib.PRECISIONS[precision], int(max_batch), C.byref(h)),

@@ -36,10 +36,6 @@ for i, r in enumerate(rows):
     name, flops, us = r["layer"][5:], r["flops"], r["ms"] * 1e3
     by, kind = 0.0, "other"
     w = weight_of(name)
-    if ".proj_out_ff2" in name:                                    # ff.net.2 + proj_out as one GEMM over [geglu 4C | residual C]: a C x 5C linear with a residual
-        wp = weight_of(name.split(".proj_out_ff2")[0] + ".proj_out")
-        w = (wp[0], 5 * wp[0])
-        name = name.split(" ")[0] + ".ff.net.2"                    # (counts its residual below)
     m = re.match(r"fused linear (\d+)->(\d+)", name)
     if name.startswith("attention "):
         mm = re.match(r"attention (\d+)x(\d+) heads (\d+) dh (\d+)", name)
