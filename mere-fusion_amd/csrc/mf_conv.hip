@@ -27,6 +27,7 @@
 #include <cstring>
 #include <algorithm>
 #include <map>
+#include <set>
 #include <string>
 #include <type_traits>
 
@@ -243,7 +244,10 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
     const int64_t w_delta = X3 ? (a.w_lo - a.w_hi) : 0;
 #pragma unroll
     for (int i = 0; i < NWC; ++i) {
-        const int row = (wq + NS * i) * RPC + lane / KG;
+        // (LD 3 with a piece count that does not divide among the producers -- the 80-channel tile: a producer without an i-th piece re-issues its
+        // previous one, so that every producer retires the same number of vmcnt ticks per stage)
+        const int cw = (LD == 3 && WCH % NS != 0 && wq + NS * i >= WCH) ? wq + NS * (i - 1) : wq + NS * i;
+        const int row = cw * RPC + lane / KG;
         const int kg = (lane % KG) ^ swz<BK>(row);
         int n = n0 + row;
         n = n < a.Npad ? n : a.Npad - 1;
@@ -263,8 +267,8 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
         }
 #pragma unroll
         for (int i = 0; i < NWC; ++i) {
-            const int c = wq + NS * i;
-            if (WCH % NS == 0 || c < WCH) {
+            const int c = (LD == 3 && WCH % NS != 0 && wq + NS * i >= WCH) ? wq + NS * (i - 1) : wq + NS * i;
+            if (LD == 3 || WCH % NS == 0 || c < WCH) {
                 const bf16_t* src = BK == 64 ? wp[i] + kt * w_kstep : wp[i] + (kt >> 1) * w_kstep + (kt & 1) * 32;
                 glds16(src, base + P_BYTES + c * 1024);
                 if (X3) glds16(src + w_delta, base + PLANE + P_BYTES + c * 1024);
@@ -361,7 +365,7 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
     if constexpr (LD == 3) {
         // DMA instructions (= vmcnt ticks) one producer wave issues per stage; the wait immediates below are multiples of it
         constexpr int NPI = (NPC + NWC) * NP;
-        static_assert(PCH % NS == 0 && WCH % NS == 0, "producer-wave path: every producer issues the same number of pieces per stage");
+        static_assert(PCH % NS == 0 && WCH >= NS, "producer-wave path: every producer issues the same number of pieces per stage (weight pieces: duplicates fill up)");
         // LEAD: how many stages beyond the one a step multiplies have landed when the step starts.  2: the compute waves read step i + 1's fragments under step
         // i's MFMAs (no exposed LDS latency) and DR - 3 stages stay in flight; 1: a step reads its own stage (the compiler interleaves the reads with the MFMAs)
         // and DR - 2 stages stay in flight.  The ring is what bounds the bytes in flight, and bytes in flight over the loaded L2 / Infinity-Cache round trip is
@@ -1122,6 +1126,16 @@ int launch_cfg(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStrea
         if (regs == 2) return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 2, Q>(a, nphase, nsplit, goff_max, s);
     }
     return launch_cfg_n<BM, BN, WGM, WGN, X3, BK, 2, 0, Q>(a, nphase, nsplit, goff_max, s);
+}
+
+// the 128 x 80 tile exists for ONE reason: 320 output channels over 8192 pixels (the UNet's outer level at batch 8) are 64 x 4 = 256 workgroups -- one round of
+// the chip's 256 CUs -- where 128 x 64 makes 320 (two rounds, the second a quarter full).  Producer-wave path, bf16x3 only.
+template <int BM, int BN, int WGM, int WGN>
+int launch_pw_only(const ConvArgs& a, int nphase, int nsplit, int goff_max, bool x3, bool q, hipStream_t s) {
+    if (x3 && !q && a.ld == 3) return launch_cfg_n<BM, BN, WGM, WGN, true, 64, 2, 3, false>(a, nphase, nsplit, goff_max, s);
+    if (x3 && !q && a.ld == 4) return launch_cfg_n<BM, BN, WGM, WGN, true, 32, 2, 3, false>(a, nphase, nsplit, goff_max, s);
+    mf_set_error("conv: the %dx%d tile has only the bf16x3 producer-wave kernels (ld 3 / 4)", BM, BN);
+    return MF_ERR_INVALID;
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -1902,6 +1916,7 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
     MF_CASE(128, 64, 2, 2)
     MF_CASE(64, 64, 2, 2)
 #undef MF_CASE
+    if (tc.bm == 128 && tc.bn == 80) rc = launch_pw_only<128, 80, 4, 1>(a, p->nphase, tc.nsplit, goff_max, x3, p->q, stream);
     if (rc != MF_OK) {
         if (rc == MF_ERR_INVALID) mf_set_error("conv: no kernel for tile %dx%d", tc.bm, tc.bn);
         return rc;
@@ -1978,6 +1993,9 @@ int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream
 // rounds of (256 CUs x resident per CU); a split pays the fp32 partial round trip and one more launch.  Constants were
 // fitted to 386 measured (shape, tile, split) points of the MuseTalk UNet / VAE layers (mean loss vs the best measured
 // configuration 3.5 %).
+// layers the 128 x 80 producer-wave tile can run: bf16x3, channel count a multiple of 80, no GEGLU pairing (its 5 channel fragments do not pair)
+static bool mf_tile80_ok(const ConvPlan* p) { return p->precision == MF_PREC_BF16X3 && !p->q && p->d.act != 5 && p->d.cout % 80 == 0; }
+
 ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
     {
         static const bool forced = getenv("MF_FORCE_TILE") || getenv("MF_FORCE_SPLIT") || getenv("MF_FORCE_LD");
@@ -1998,7 +2016,7 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
     static const int force_tile = [] { const char* e = getenv("MF_FORCE_TILE"); int a = 0, b = 0; return e && sscanf(e, "%dx%d", &a, &b) == 2 ? a * 1000 + b : 0; }();
     static const int force_split = [] { const char* e = getenv("MF_FORCE_SPLIT"); return e ? atoi(e) : 0; }();
     struct Cand { int bm, bn, wgm, wgn, resident; };
-    static const Cand cands[] = {{64, 64, 2, 2, 2}, {128, 64, 2, 2, 2}, {128, 128, 2, 2, 2}, {256, 128, 4, 2, 1}, {256, 256, 2, 4, 1}};
+    static const Cand cands[] = {{64, 64, 2, 2, 2}, {128, 64, 2, 2, 2}, {128, 128, 2, 2, 2}, {256, 128, 4, 2, 1}, {256, 256, 2, 4, 1}, {128, 80, 4, 1, 1}};
     static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
     if (modelled) {
         const double planes = p->precision != MF_PREC_BF16 ? 2.0 : 1.0;
@@ -2008,6 +2026,7 @@ ConvTile mf_conv_pick_tile(const ConvPlan* p, int batch) {
         double best = 1e30;
         for (const Cand& c : cands) {
             if (force_tile && (c.bm != force_tile / 1000 || c.bn != force_tile % 1000)) continue;
+            if (c.bn == 80 && (force_tile != 128080 || !mf_tile80_ok(p))) continue;   // measured only (mf_conv_tune), never the model's pick
             if (c.bn == 128 && c.bm == 128 && N % 128) continue;
             for (int si = 0; si < (fs ? 1 : (int)(sizeof(splits) / sizeof(splits[0]))); ++si) {
                 const int S = fs ? fs : splits[si];
@@ -2068,10 +2087,11 @@ std::map<std::string, ConvTuned>& tune_cache() {
         auto valid = [](const std::string& k, const ConvTuned& c) {
             if (k.rfind("g950k4:", 0) != 0) return false;
             if (c.tile.bm == 0) return true;                                          // "the cost model's pick stays"
-            static const int tiles[][4] = {{64, 64, 2, 2}, {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 128, 4, 2}, {256, 256, 2, 4}};
+            static const int tiles[][4] = {{64, 64, 2, 2}, {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 128, 4, 2}, {256, 256, 2, 4}, {128, 80, 4, 1}};
             bool tile_ok = false;
             for (const auto& t : tiles) tile_ok |= c.tile.bm == t[0] && c.tile.bn == t[1] && c.tile.wgm == t[2] && c.tile.wgn == t[3];
             if ((c.ld == 3 || c.ld == 4) && c.tile.wgm * c.tile.wgn != 4) return false;
+            if (c.tile.bn == 80 && c.ld != 3 && c.ld != 4) return false;                // (the 128 x 80 tile: producer-wave kernels only)
             // ld 3 / 4 (round 5's producer-wave path) are additions to generation k4: every older entry still names a kernel this library has
             return tile_ok && c.tile.nsplit >= 1 && c.tile.nsplit <= 16 && (c.ld == -1 || c.ld == 0 || c.ld == 2 || c.ld == 3 || c.ld == 4);
         };
@@ -2148,14 +2168,22 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
     }
     if (!tunable_layer(p, batch)) return MF_OK;
     const std::string key = tune_key(p, in, batch);
-    if (mf_conv_tune_lookup(p, in, batch)) return MF_OK;                              // measured before (this process, MF_TUNE_CACHE, or the shipped table)
-    p->tuned.erase(batch);
+    // MF_TUNE_EXTEND=80 (table maintenance): a layer that HAS an entry is measured again, its entry against the tiles of that channel width only (a tile added
+    // to the library after the table was made), and the entry is replaced where the new tile is clearly ahead -- minutes instead of the full hour of measurements
+    static const int extend_bn = [] { const char* e = getenv("MF_TUNE_EXTEND"); return e ? atoi(e) : 0; }();
+    const bool found = mf_conv_tune_lookup(p, in, batch);                             // measured before (this process, MF_TUNE_CACHE, or the shipped table)
+    static std::set<std::string> extended;                                            // (layers of one signature share the measurement)
+    const bool extend = found && extend_bn == 80 && mf_tile80_ok(p) && extended.insert(key).second;
+    if (found && !extend) return MF_OK;
+    const bool had_entry = p->tuned.count(batch) != 0;
+    const ConvTuned entry = had_entry ? p->tuned[batch] : ConvTuned{ConvTile{0, 0, 0, 0, 0}, -1};
+    if (!extend) p->tuned.erase(batch);
     const int M = batch * p->Hq * p->Wq, N = p->d.cout;
     const ConvTile base = mf_conv_pick_tile(p, batch);                                // what the cost model would launch
     int kt_min = p->ph[0].KT;
     for (int ph = 0; ph < p->nphase; ++ph) kt_min = std::min(kt_min, p->ph[ph].KT);
     struct Cand { int bm, bn, wgm, wgn; };
-    static const Cand tiles[] = {{64, 64, 2, 2}, {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 128, 4, 2}, {256, 256, 2, 4}};
+    static const Cand tiles[] = {{64, 64, 2, 2}, {128, 64, 2, 2}, {128, 128, 2, 2}, {256, 128, 4, 2}, {256, 256, 2, 4}, {128, 80, 4, 1}};
     static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
     hipEvent_t e0, e1;
     MF_HIP(hipEventCreate(&e0)); MF_HIP(hipEventCreate(&e1));
@@ -2197,13 +2225,15 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
         *us = best;
         return MF_OK;
     };
-    ConvTuned best_c{base, -1};
+    ConvTuned best_c{base, extend && had_entry ? entry.ld : -1};
     float base_us = 0.f;
     int rc = measure(best_c, &base_us);
     float best_us = base_us;
     for (const Cand& t : tiles) {
         if (rc) break;
         if (t.bn == 128 && t.bm == 128 && N % 128) continue;
+        if (t.bn == 80 && !mf_tile80_ok(p)) continue;
+        if (extend && t.bn != extend_bn) continue;
         if (t.bm >= 256 && M < 256) continue;
         const int64_t nt = (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn) * p->nphase;
         for (int S : splits) {
@@ -2213,6 +2243,7 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
                 if (t.wgm * t.wgn == 8 && ld != 0) continue;                        // the 8-wave tiles only have the LDS-DMA loop
                 // producer-wave path: bf16x3 only (ld 3: 64-deep stages, ld 4: 32-deep ones)
                 if (ld >= 3 && (p->precision != MF_PREC_BF16X3 || p->q || t.bn < 64)) continue;
+                if (t.bn == 80 && ld < 3) continue;
                 const ConvTuned c{ConvTile{t.bm, t.bn, t.wgm, t.wgn, S}, ld};
                 float us = 0.f;
                 if ((rc = measure(c, &us))) break;
@@ -2224,7 +2255,9 @@ int mf_conv_tune(ConvPlan* p, const ActView& in, const ActView& out, const ActVi
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (rc) { p->tuned.erase(batch); return rc; }
     // keep the model's pick unless the measured winner is clearly ahead (event timing of a 10-100 us launch is good to ~1 us)
-    if (best_us > 0.97f * base_us) { p->tuned.erase(batch); tune_cache_store(key, ConvTuned{ConvTile{0, 0, 0, 0, 0}, -1}); }
+    if (extend && best_us > 0.97f * base_us) {                                        // the entry stands (nothing is appended)
+        if (had_entry) p->tuned[batch] = entry; else p->tuned.erase(batch);
+    } else if (best_us > 0.97f * base_us) { p->tuned.erase(batch); tune_cache_store(key, ConvTuned{ConvTile{0, 0, 0, 0, 0}, -1}); }
     else { p->tuned[batch] = best_c; tune_cache_store(key, best_c); }
     static const bool verbose = mf_debug_has("tune");
     if (verbose)

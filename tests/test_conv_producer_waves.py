@@ -33,3 +33,13 @@ def test_forced_tiles_and_splits(lib_built, tile, split, ld):
     out = _run({"MF_FORCE_LD": ld, "MF_FORCE_TILE": tile, "MF_FORCE_SPLIT": split},
                ["tests/test_wav2lip_gpu.py::test_conv_geometry_vs_golden", "tests/test_musetalk.py::test_hip_unet_vs_oracle", "tests/test_musetalk.py::test_hip_geglu_projection"])
     assert " passed" in out
+
+
+@pytest.mark.parametrize("split,ld", [("1", "3"), ("1", "4"), ("3", "3")])
+def test_forced_128x80_tile(lib_built, split, ld):
+    """the 80-channel tile (five channel fragments per wave, weight pieces that do not divide among the four producers): outputs against fp64 and the GroupNorm
+    statistics epilogue at 10 / 20 / 40 channels per group; layers it cannot take (channels not a multiple of 80) fall back to the 64 x 64 tile"""
+    out = _run({"MF_FORCE_LD": ld, "MF_FORCE_TILE": "128x80", "MF_FORCE_SPLIT": split},
+               ["tests/test_conv_wide.py::test_channel_multiples_of_80_vs_fp64", "tests/test_conv_wide.py::test_conv_leaves_groupnorm_statistics_of_its_output",
+                "tests/test_musetalk.py::test_hip_unet_vs_oracle"])
+    assert " passed" in out

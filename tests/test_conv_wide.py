@@ -200,3 +200,38 @@ def test_f16q_upsample_phases_vs_fp64(lib_built, cin, cout, H, W, B):
         l.mf_conv2d_destroy(h)
     print(f"[f16q upsample {cin}->{cout} @{H}x{W}] L-inf vs fp64: bf16x3 {errs['bf16x3']:.2e}, f16 + FP6 {errs['f16q']:.2e} (max |y| {float(ref.abs().max()):.2f})")
     assert errs["f16q"] <= 3e-4 and errs["f16q"] <= 6 * errs["bf16x3"] + 1e-5
+
+# Channel counts that are multiples of 80 (the UNet's 320 / 640 / 1280): the shapes the 128 x 80 producer-wave tile can take (256 workgroups for 320 channels over
+# 8192 pixels).  Run as is this checks whatever the tuning table picks; tests/test_conv_producer_waves.py re-runs it with that tile forced.  Ragged pixel counts,
+# contractions that are not multiples of 64, one and several channel tiles, residual on / off.
+C80_CASES = [(320, 320, 3, 32, 32, 8, 1), (72, 160, 3, 13, 13, 8, 0), (640, 320, 1, 32, 32, 8, 0), (100, 80, 3, 9, 11, 5, 0), (1280, 640, 3, 16, 16, 3, 0),
+             (320, 320, 1, 32, 32, 2, 1)]
+
+
+@pytest.mark.parametrize("cin,cout,k,H,W,B,res", C80_CASES)
+def test_channel_multiples_of_80_vs_fp64(lib_built, cin, cout, k, H, W, B, res):
+    from mere_fusion_amd import _lib
+    l = _lib.lib()
+    _lib.init_device(0)
+    g = torch.Generator().manual_seed(cin + 5 * H + k)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.2
+    d = _lib.MfConv2dDesc(cin=cin, cout=cout, kh=k, kw=k, stride_h=1, stride_w=1, pad_h=k // 2, pad_w=k // 2, transposed=0, output_padding=0,
+                          residual=res, act=1, in_h=H, in_w=W, upsample=0)
+    h = C.c_void_p()
+    _lib.check(l.mf_conv2d_create(C.byref(d), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), None, None, None, None,
+                                  _lib.PRECISIONS["bf16x3"], C.byref(h)))
+    try:
+        x = torch.randn(B, cin, H, W, generator=g).cuda()
+        ref = torch.nn.functional.conv2d(x.double(), w.cuda().double(), b.cuda().double(), padding=k // 2)
+        if res:
+            ref = ref + x.double()
+        ref = torch.relu(ref).float()
+        for nb in (B, 1):
+            y = torch.empty(nb, cout, H, W, device="cuda")
+            _lib.check(l.mf_conv2d_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), nb, None))
+            torch.cuda.synchronize()
+            err = float((y - ref[:nb]).abs().max() / ref.abs().max())
+            assert err <= 1e-4, (nb, err)                # bf16x3: observed ~5e-6
+    finally:
+        l.mf_conv2d_destroy(h)
