@@ -593,11 +593,14 @@ struct Net {
     // diffusers Upsample2D (nearest 2x + conv 3x3) in the f16 + FP6 operand format where the layer fills the chip that way: a converter pass writes
     // the input in the format (identity affine, no SiLU), then four 2 x 2-tap phase launches of the f16 + FP6 halo tile, which also leave the
     // consumer GroupNorm's statistics.  Elsewhere (small maps, other precisions, MF_CONV_Q=0): the 4-phase implicit GEMM on bf16x3.
+#ifndef MF_UP_Q_MIN_WG
+#define MF_UP_Q_MIN_WG 256            // workgroups per phase launch from which the f16 + FP6 phases beat the bf16x3 implicit GEMM (A/B build with 128 -- the 512-channel 32^2 -> 64^2 upsampler at batch 8 as four 128-workgroup phase launches: 18.29 vs 18.32 ms per step, no gain)
+#endif
     int upsample_conv(const std::string& name, ActView x, ActView out, int C) {
         static const bool on = [] { const char* e = getenv("MF_CONV_Q"); return !e || atoi(e) != 0; }();
         const int H = x.buf->H, W = x.buf->W;
         if (!(on && q_allowed && precision == MF_PREC_BF16X3 && C % 128 == 0 && x.C == C && x.coff % 8 == 0 && H * W >= 32 * 32 &&
-              (int64_t)cap * ((H + 15) / 16) * ((W + 15) / 16) * (C / 128) >= 256))
+              (int64_t)cap * ((H + 15) / 16) * ((W + 15) / 16) * (C / 128) >= MF_UP_Q_MIN_WG))
             return conv(name, x, out, C, C, 3, 1, 1, 0, ActView{}, 1);
         const float* w = T(name + ".weight", (int64_t)C * C * 9);
         const float* b = T(name + ".bias", C);
