@@ -172,6 +172,40 @@ def test_hip_musetalk_step_and_replay(hip_small, small):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_hip_eager_handles_bit_equal_to_graph_handles(hip_small, small, mode):
+    """MF_NO_GRAPH at create time: 1 = eager launches (side branches on their own streams), 2 = eager and single-stream -- the host-lean serving rank of
+    bench.py's paced legs and INTEGRATION 6d.  Same kernels, same launch configurations, same summation orders: latents and frames must be the bits the
+    graph-replaying handles produce, on the eager first call and on the replays."""
+    import os
+    from mere_fusion_amd.musetalk.models.unet import UNet
+    from mere_fusion_amd.musetalk.models.vae import VAE
+    unet, vae = hip_small
+    usd, vsd = small
+    old = os.environ.get("MF_NO_GRAPH")
+    os.environ["MF_NO_GRAPH"] = mode
+    try:
+        unet2 = UNet(_cfg_json(CFG["unet"]), usd, max_batch=4)
+        vc = dict(CFG["vae"]); vc["block_out_channels"] = list(vc["block_out_channels"])
+        vae2 = VAE(config=vc, state_dict=vsd, max_batch=4)
+    finally:
+        if old is None:
+            del os.environ["MF_NO_GRAPH"]
+        else:
+            os.environ["MF_NO_GRAPH"] = old
+    for batch, seed in ((2, 11), (3, 12), (2, 11)):
+        lat, aud = W.make_musetalk_inputs(batch, seed)
+        got = []
+        for u, v in ((unet, vae), (unet2, vae2)):
+            for _ in range(3 if u is unet else 2):               # graph handles: eager, capture, replay
+                pred = u.model(lat.cuda(), torch.tensor([0]).cuda(), encoder_hidden_states=u.pe(aud.cuda())).sample
+                frames = v.decode_latents(pred)
+            got.append((pred.cpu(), frames))
+        assert torch.equal(got[0][0], got[1][0])
+        assert np.array_equal(got[0][1], got[1][1])
+
+
+@pytest.mark.gpu
 def test_hip_unet_rejects_other_timesteps_and_cpu(hip_small):
     unet, vae = hip_small
     lat, aud = W.make_musetalk_inputs(1, 0)
