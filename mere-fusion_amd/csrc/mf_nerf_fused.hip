@@ -91,37 +91,6 @@ __device__ __forceinline__ BFrag join(const Half& p0, const Half& p1) {
 // per-level constants in LDS: the level index differs from lane to lane, which kernel-argument arrays cannot serve
 struct LevelTab { float scale[NLEV]; uint32_t resolution[NLEV], offset[NLEV], hashmap_size[NLEV], mask[NLEV]; };   // mask: hashmap_size - 1 if that is a power of two, else 0
 
-// one grid feature: level `lv` of plane table `tab` at (u, v) in [0, 1]^2 (gridencoder.cu:76-165 with D = 2, C = 1, hash grid)
-__device__ __forceinline__ float grid_feat(const LevelTab& a, const float* __restrict__ tab, int lv, float u, float v) {
-    if (u < 0.f || u > 1.f || v < 0.f || v > 1.f) return 0.f;
-    const float scale = a.scale[lv];
-    const uint32_t res = a.resolution[lv], hs = a.hashmap_size[lv], msk = a.mask[lv];
-    const float* g = tab + a.offset[lv];
-    float pu = u * scale + 0.5f, pv = v * scale + 0.5f;
-    const float fu = floorf(pu), fv = floorf(pv);
-    const uint32_t iu = (uint32_t)fu, iv = (uint32_t)fv;
-    pu -= fu; pv -= fv;
-    // get_grid_index (gridencoder.cu:54-72) for the four corners at once.  With s = res + 1: the level is DENSE iff s * s <= hashmap_size (then
-    // index = x + y s, below s * s, so `% hashmap_size` is the identity); otherwise index = x ^ (y * 2654435761) reduced mod hashmap_size -- a
-    // mask when the table is a power of two (2^log2_hashmap_size: grid.py:108-123), the division for any other size.  One multiply per form and
-    // level instead of one of each per corner, and no 32-bit urem (~25 instructions) on the 144 lookups of a sample: the kernel is VALU-bound.
-    const uint32_t s1 = res + 1;
-    const uint32_t d00 = iu + iv * s1;
-    const uint32_t h0 = iv * 2654435761u, h1 = h0 + 2654435761u;
-    uint32_t i00 = iu ^ h0, i10 = (iu + 1) ^ h0, i01 = iu ^ h1, i11 = (iu + 1) ^ h1;
-    if (msk) { i00 &= msk; i10 &= msk; i01 &= msk; i11 &= msk; }
-    else { i00 %= hs; i10 %= hs; i01 %= hs; i11 %= hs; }
-    const bool dense = s1 * s1 <= hs;
-    i00 = dense ? d00 : i00; i10 = dense ? d00 + 1 : i10; i01 = dense ? d00 + s1 : i01; i11 = dense ? d00 + s1 + 1 : i11;
-    const float qu = 1.f - pu, qv = 1.f - pv;
-    float r = 0.f;                     // corner order and arithmetic of the reference's loop: (0,0), (1,0), (0,1), (1,1)
-    r += (qu * qv) * g[i00];
-    r += (pu * qv) * g[i10];
-    r += (qu * pv) * g[i01];
-    r += (pu * pv) * g[i11];
-    return r;
-}
-
 template <bool X3>
 __global__ __launch_bounds__(NWAVE * 64) void k_nerf_field_fused(const FusedArgs a) {
     constexpr int NP = X3 ? 2 : 1;
@@ -174,27 +143,66 @@ __global__ __launch_bounds__(NWAVE * 64) void k_nerf_field_fused(const FusedArgs
             px[sf] = (a.xyzs[3 * m] + a.bound) * inv2b; py[sf] = (a.xyzs[3 * m + 1] + a.bound) * inv2b; pz[sf] = (a.xyzs[3 * m + 2] + a.bound) * inv2b;
             dx[sf] = a.dirs[3 * m]; dy[sf] = a.dirs[3 * m + 1]; dz[sf] = a.dirs[3 * m + 2];
         }
-        // enc_x channel c = plane * 12 + level (network.py:204-219): blocks X0 = 0..15, X1 = 16..31, X2 = 32..35
-        auto enc4 = [&](int sf, int c0) __attribute__((always_inline)) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = c0 + j;
-                if (c >= 36) { v[j] = 0.f; continue; }
-                const int plane = c / 12, lv = c - plane * 12;
-                const float u = plane == 1 ? py[sf] : px[sf];                 // xy, yz, xz
-                const float w = plane == 0 ? py[sf] : pz[sf];
-                v[j] = grid_feat(lt, plane == 0 ? emb0 : (plane == 1 ? emb1 : emb2), lv, u, w);
-            }
-            __builtin_amdgcn_sched_barrier(0);      // keep the 16 gathers of one block together, not all 48 of the lane in flight
-            return pack4(v[0], v[1], v[2], v[3]);
-        };
+        // enc_x channel c = plane * 12 + level (network.py:204-219).  The contraction order of a layer is free (the weights are packed to it on the host), so the 36
+        // channels are dealt to a sample's four lanes by LEVEL: lane group g gathers levels g, g + 4, g + 8 of all three planes -- nine lookups in every lane (the
+        // block order 0..15 | 16..31 | 32..35 gave lane group 0 twelve and made the wave wait for them), the plane of every lookup a compile-time constant (its table a
+        // scalar base, its coordinate pair fixed) and the level arithmetic -- constants from LDS, floor / fraction of x, y, z, dense-or-hashed -- done once per level
+        // instead of once per lookup.  Values per channel are bit-identical to the per-channel form of rounds 3 - 4.  Slots: X0 = (l0 p0, l0 p1, l0 p2, l1 p0), X1 = (l1 p1, l1 p2, l2 p0,
+        // l2 p1), X2 = (l2 p2, 0, 0, 0) of the lane's own three levels (mf_nerf_fused_pack: xblock()).
         Half x0[NSF], x1[NSF], x2[NSF];
 #pragma unroll
         for (int sf = 0; sf < NSF; ++sf) {
-            x0[sf] = enc4(sf, 4 * g);
-            x1[sf] = enc4(sf, 16 + 4 * g);
-            x2[sf] = g == 0 ? enc4(sf, 32) : zero_half();
+            const bool okx = px[sf] >= 0.f && px[sf] <= 1.f, oky = py[sf] >= 0.f && py[sf] <= 1.f, okz = pz[sf] >= 0.f && pz[sf] <= 1.f;
+            // outside [0, 1] a plane's feature is 0 (gridencoder.cu:96-104); the clamp only keeps the discarded lookup's addresses inside the table
+            const float cx = __builtin_amdgcn_fmed3f(px[sf], 0.f, 1.f), cy = __builtin_amdgcn_fmed3f(py[sf], 0.f, 1.f), cz = __builtin_amdgcn_fmed3f(pz[sf], 0.f, 1.f);
+            float v[3][3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int lv = g + 4 * t;
+                const float scale = lt.scale[lv];
+                const uint32_t res = lt.resolution[lv], hs = lt.hashmap_size[lv], msk = lt.mask[lv], off = lt.offset[lv];
+                const uint32_t s1 = res + 1;
+                const bool dense = s1 * s1 <= hs;
+                float fx = cx * scale + 0.5f, fy = cy * scale + 0.5f, fz = cz * scale + 0.5f;
+                const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+                const uint32_t ix = (uint32_t)flx, iy = (uint32_t)fly, iz = (uint32_t)flz;
+                fx -= flx; fy -= fly; fz -= flz;
+                // one plane of this level (gridencoder.cu:76-165 with D = 2, C = 1, hash grid): get_grid_index (gridencoder.cu:54-72) for the four corners at once.
+                // With s = res + 1 the level is DENSE iff s * s <= hashmap_size (then index = x + y s, below s * s, so `% hashmap_size` is the identity); otherwise
+                // index = x ^ (y * 2654435761) reduced mod hashmap_size -- a mask when the table is a power of two (2^log2_hashmap_size: grid.py:108-123), the
+                // division for any other size.  One multiply per form instead of one of each per corner, and no 32-bit urem (~25 instructions) per lookup.
+                auto plane = [&](const float* __restrict__ tab, uint32_t iu, uint32_t iv, float pu, float pv, bool ok) __attribute__((always_inline)) {
+                    // (a dense level's table size is (res + 1)^2 rounded up to 8 -- not a power of two: taking the hashed form first and selecting afterwards, as
+                    // rounds 3 - 4 did, ran the four divisions for every dense level and threw the results away)
+                    uint32_t i00, i10, i01, i11;
+                    if (dense) {
+                        i00 = iu + iv * s1; i10 = i00 + 1; i01 = i00 + s1; i11 = i01 + 1;
+                    } else {
+                        const uint32_t h0 = iv * 2654435761u, h1 = h0 + 2654435761u;
+                        i00 = iu ^ h0; i10 = (iu + 1) ^ h0; i01 = iu ^ h1; i11 = (iu + 1) ^ h1;
+                        if (msk) { i00 &= msk; i10 &= msk; i01 &= msk; i11 &= msk; }
+                        else { i00 %= hs; i10 %= hs; i01 %= hs; i11 %= hs; }
+                    }
+                    // scalar table base + 32-bit byte offset (the tables are a few MB): no 64-bit address arithmetic per corner
+                    const char* base = reinterpret_cast<const char*>(tab);
+                    const float g00 = *reinterpret_cast<const float*>(base + ((off + i00) << 2)), g10 = *reinterpret_cast<const float*>(base + ((off + i10) << 2));
+                    const float g01 = *reinterpret_cast<const float*>(base + ((off + i01) << 2)), g11 = *reinterpret_cast<const float*>(base + ((off + i11) << 2));
+                    const float qu = 1.f - pu, qv = 1.f - pv;
+                    float r = 0.f;                     // corner order and arithmetic of the reference's loop: (0,0), (1,0), (0,1), (1,1)
+                    r += (qu * qv) * g00;
+                    r += (pu * qv) * g10;
+                    r += (qu * pv) * g01;
+                    r += (pu * pv) * g11;
+                    return ok ? r : 0.f;
+                };
+                v[t][0] = plane(emb0, ix, iy, fx, fy, okx && oky);                // xy
+                v[t][1] = plane(emb1, iy, iz, fy, fz, oky && okz);                // yz
+                v[t][2] = plane(emb2, ix, iz, fx, fz, okx && okz);                // xz
+                __builtin_amdgcn_sched_barrier(0);      // keep the 12 gathers of one level together, not all 36 of the lane in flight
+            }
+            x0[sf] = pack4(v[0][0], v[0][1], v[0][2], v[1][0]);
+            x1[sf] = pack4(v[1][1], v[1][2], v[2][0], v[2][1]);
+            x2[sf] = pack4(v[2][2], 0.f, 0.f, 0.f);
         }
         const Half Z = zero_half();
         BFrag bx0[NSF], bx1[NSF];
@@ -437,7 +445,16 @@ int mf_nerf_fused_pack(const float* const w[9], int n_ind, bool has_eye, bool x3
     std::vector<bf16_t> buf((size_t)NFRAG * np * 64 * 8, 0);
     const std::vector<int> Z(16, -1);
     const int sig_in = 36 + 32 + (has_eye ? 1 : 0), col_in = 16 + 64 + n_ind;
-    const std::vector<std::vector<int>> X = {kblock(0), kblock(16), kblock(32, 4), Z};
+    // enc_x blocks in the kernel's gather order: lane group g holds levels g, g + 4, g + 8; slot i of block b is (level t, plane p) of that lane, channel p * 12 + level
+    auto xblock = [](int which) {
+        static const int tp[3][4][2] = {{{0, 0}, {0, 1}, {0, 2}, {1, 0}}, {{1, 1}, {1, 2}, {2, 0}, {2, 1}}, {{2, 2}, {-1, -1}, {-1, -1}, {-1, -1}}};
+        std::vector<int> b(16, -1);
+        for (int g = 0; g < 4; ++g)
+            for (int i = 0; i < 4; ++i)
+                if (tp[which][i][0] >= 0) b[4 * g + i] = tp[which][i][1] * 12 + g + 4 * tp[which][i][0];
+        return b;
+    };
+    const std::vector<std::vector<int>> X = {xblock(0), xblock(1), xblock(2), Z};
     const std::vector<std::vector<int>> H64 = {kblock(0), kblock(16), kblock(32), kblock(48)};
     pack_layer(w[0], 64, 36, X, 4, 2, x3, buf, frag_base(L_AUD0));
     pack_layer(w[1], 32, 64, H64, 2, 2, x3, buf, frag_base(L_AUD1));
@@ -446,7 +463,7 @@ int mf_nerf_fused_pack(const float* const w[9], int n_ind, bool has_eye, bool x3
         pack_layer(w[3], 1, 16, {kblock(0), Z}, 1, 1, x3, buf, frag_base(L_EYE1));
     }
     // sigma_net.0: reference columns [enc_x 0..35 | enc_w 36..67 | e 68]; K blocks (X0, X1), (X2, W0), (W1, eye)
-    pack_layer(w[4], 64, sig_in, {kblock(0), kblock(16), kblock(32, 4), kblock(36), kblock(52), has_eye ? kblock(68, 1) : Z}, 4, 3, x3, buf, frag_base(L_SIG0));
+    pack_layer(w[4], 64, sig_in, {xblock(0), xblock(1), xblock(2), kblock(36), kblock(52), has_eye ? kblock(68, 1) : Z}, 4, 3, x3, buf, frag_base(L_SIG0));
     pack_layer(w[5], 64, 64, H64, 4, 2, x3, buf, frag_base(L_SIG1));
     pack_layer(w[6], 65, 64, H64, 5, 2, x3, buf, frag_base(L_SIG2));
     {
