@@ -521,13 +521,17 @@ __global__ __launch_bounds__(CT) void k_loop_composite(int* ctl, int N, int max_
         float sg[LOOP_MAX_STEP], d0[LOOP_MAX_STEP], d1[LOOP_MAX_STEP], cr[LOOP_MAX_STEP], cg[LOOP_MAX_STEP], cb[LOOP_MAX_STEP], aa[LOOP_MAX_STEP],
             ae[LOOP_MAX_STEP], un[LOOP_MAX_STEP];
         const size_t o = (size_t)n * n_step;
+        // (n_step is uniform: a scalar branch per k, so a round of n_step = 1 -- every ray alive -- issues 9 loads per ray, not 72 of which 63 re-read sample 0)
 #pragma unroll
         for (uint32_t k = 0; k < LOOP_MAX_STEP; ++k) {
-            const bool in = k < n_step;
-            const size_t q = in ? o + k : o;
-            sg[k] = sigmas[q]; d0[k] = deltas[2 * q]; d1[k] = deltas[2 * q + 1];
-            cr[k] = rgbs[3 * q]; cg[k] = rgbs[3 * q + 1]; cb[k] = rgbs[3 * q + 2];
-            aa[k] = ambs_aud[q]; ae[k] = ambs_eye[q]; un[k] = uncertainties[q];
+            if (k < n_step) {
+                const size_t q = o + k;
+                sg[k] = sigmas[q]; d0[k] = deltas[2 * q]; d1[k] = deltas[2 * q + 1];
+                cr[k] = rgbs[3 * q]; cg[k] = rgbs[3 * q + 1]; cb[k] = rgbs[3 * q + 2];
+                aa[k] = ambs_aud[q]; ae[k] = ambs_eye[q]; un[k] = uncertainties[q];
+            } else {
+                sg[k] = d0[k] = d1[k] = cr[k] = cg[k] = cb[k] = aa[k] = ae[k] = un[k] = 0.f;
+            }
         }
         float t = rays_t[v];
         float weight_sum = weights_sum[v], d = depth[v];

@@ -221,7 +221,10 @@ __global__ __launch_bounds__(NWAVE * 64) void k_nerf_field_fused(const FusedArgs
             mma(frag_base(L_AUD0) + blk * 2 + 1, bx1, h1[blk]);
         }
         LAYER_FENCE();
-        auto relu_half = [&](const f32x4& v) __attribute__((always_inline)) { return pack4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)); };
+        // ReLU as ONE integer instruction on the float's bits (v_max_i32 with 0: non-negative floats are non-negative integers, every negative one -- -0 included --
+        // becomes +0); fmaxf() costs two (it first quiets its operand) and the kernel is VALU-bound
+        auto relu1 = [](float x) __attribute__((always_inline)) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); };
+        auto relu_half = [&](const f32x4& v) __attribute__((always_inline)) { return pack4(relu1(v[0]), relu1(v[1]), relu1(v[2]), relu1(v[3])); };
         auto lin_half = [&](const f32x4& v) __attribute__((always_inline)) { return pack4(v[0], v[1], v[2], v[3]); };
         BFrag t0[NSF], t1[NSF];
 #pragma unroll
