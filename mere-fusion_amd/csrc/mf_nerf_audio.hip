@@ -14,54 +14,48 @@
 namespace {
 
 constexpr int SEQ = 8, WIN = 16, AUD_DIM = 32;
-constexpr int MAX_ACT = 8 * 64 * 16;     // largest intermediate: 8 windows x 64 channels x 16 steps (the input for in_dim <= 64)
-constexpr int MAX_W = 64 * 64 * 3;
-constexpr size_t AUDIO_LDS = (MAX_ACT + MAX_ACT / 2 + SEQ * AUD_DIM + 64 + MAX_W) * sizeof(float);
+constexpr int ACT_A = 64 * 16;           // one window's largest intermediate: the input, in_dim <= 64 channels x 16 steps
+constexpr int ACT_B = 32 * 8;            // conv[0]'s output, 32 channels x 8 steps (every later one is smaller)
 
-struct Layer { const float* w; const float* b; int cin, cout; };
+// Every layer's weights and bias live in ONE arena (device copy made at create time; offsets in floats, each block padded to 4): a workgroup copies the
+// whole arena -- 132 KB at audio_in_dim 29, 145 KB at 64 -- into LDS with one burst of 16-byte loads before its first layer, so the 13 layers pay ONE
+// memory round trip between them.  (Rounds 3 - 4 streamed a layer's weights one layer ahead through registers: each of the 13 commits still waited for
+// its own L2 / HBM round trip, ~2 - 3 us against ~1 us of MACs -- most of the kernel's 46 us.)
+struct Layer { int woff, boff, cin, cout; };
 struct AudioArgs {
     Layer conv[4];       // AudioNet.encoder_conv, Conv1d(k3, s2, p1) + LeakyReLU(0.02)
     Layer fc[2];         // AudioNet.encoder_fc1: Linear + LeakyReLU, Linear
     Layer att[5];        // AudioAttNet.attentionConvNet, Conv1d(k3, s1, p1) + LeakyReLU(0.02)
     Layer att_fc;        // AudioAttNet.attentionNet: Linear(8, 8) + Softmax
+    const float* arena;
+    int arena_n;         // floats, a multiple of 4
     int in_dim, use_att;
 };
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.02f * v; }
 
-// Weights travel global -> registers -> LDS one layer ahead: a layer's loads are issued before the previous layer's MAC loop and land
-// in LDS after it, so no layer waits on HBM / L2 latency (17 tiny layers: the latency chain was most of the kernel).
-constexpr int WREG = (MAX_W + 1023) / 1024;       // floats of the largest layer per thread
-struct Prefetch { float w[WREG]; float b; };
-
-__device__ __forceinline__ void prefetch(const Layer& L, int k, Prefetch& p) {
-    const int nw = L.cout * L.cin * k;
-#pragma unroll
-    for (int r = 0; r < WREG; ++r) {
-        const int i = threadIdx.x + r * 1024;
-        p.w[r] = i < nw ? L.w[i] : 0.f;
-    }
-    p.b = (int)threadIdx.x < L.cout ? L.b[threadIdx.x] : 0.f;
+// lanes that share one output's reduction: as many as keep the workgroup's 1024 threads busy -- at most a wave, at most the layer's input channels.  The small
+// layers were the kernel: conv[3] has 64 outputs of 192 MACs each, so ONE wave walked 192-step chains of LDS reads (~7 us) while fifteen waves waited; split 16
+// ways and folded by butterfly it is 12 MACs + 4 shuffles.  (fp32 sums in another order than a serial loop: ~1e-7 relative, the golden's gate is 2e-5.)
+__device__ __forceinline__ int lanes_per_output(int nout, int cin) {
+    int P = 1;
+    while (P < 64 && nout * P * 2 <= (int)blockDim.x && P * 2 <= cin) P <<= 1;
+    return P;
 }
-// call after the barrier that ended the previous layer's reads of wbuf / bbuf
-__device__ __forceinline__ void commit(const Layer& L, int k, const Prefetch& p, float* wbuf, float* bbuf) {
-    const int nw = L.cout * L.cin * k;
-#pragma unroll
-    for (int r = 0; r < WREG; ++r) {
-        const int i = threadIdx.x + r * 1024;
-        if (i < nw) wbuf[i] = p.w[r];
-    }
-    if ((int)threadIdx.x < L.cout) bbuf[threadIdx.x] = p.b;
-    __syncthreads();
+__device__ __forceinline__ float group_sum(float acc, int P) {
+    for (int off = P >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    return acc;
 }
 
 // out[n][co][t] = act(b[co] + sum_{ci,k} w[co][ci][k] * in[n][ci][t*stride + k - 1]), zero padding 1; weights already in wbuf / bbuf
 __device__ void conv1d(const float* in, float* out, const Layer& L, int n, int tin, int stride, bool act, const float* wbuf, const float* bbuf) {
     const int tout = (tin + 2 - 3) / stride + 1;
-    for (int idx = threadIdx.x; idx < n * L.cout * tout; idx += blockDim.x) {
+    const int nout = n * L.cout * tout;
+    const int P = lanes_per_output(nout, L.cin), sub = threadIdx.x & (P - 1), groups = blockDim.x / P;
+    for (int idx = threadIdx.x / P; idx < nout; idx += groups) {
         const int t = idx % tout, co = (idx / tout) % L.cout, b = idx / (tout * L.cout);
-        float acc = bbuf[co];
-        for (int ci = 0; ci < L.cin; ++ci) {
+        float acc = 0.f;
+        for (int ci = sub; ci < L.cin; ci += P) {
             const float* wr = wbuf + ((size_t)co * L.cin + ci) * 3;
             const float* xr = in + ((size_t)b * L.cin + ci) * tin;
 #pragma unroll
@@ -70,18 +64,22 @@ __device__ void conv1d(const float* in, float* out, const Layer& L, int n, int t
                 if (ti >= 0 && ti < tin) acc += wr[k] * xr[ti];
             }
         }
-        out[idx] = act ? lrelu(acc) : acc;
+        acc = group_sum(acc, P) + bbuf[co];
+        if (sub == 0) out[idx] = act ? lrelu(acc) : acc;
     }
     __syncthreads();
 }
 
 // out[n][o] = act(b[o] + sum_i w[o][i] * in[n][i])
 __device__ void linear(const float* in, float* out, const Layer& L, int n, bool act, const float* wbuf, const float* bbuf) {
-    for (int idx = threadIdx.x; idx < n * L.cout; idx += blockDim.x) {
+    const int nout = n * L.cout;
+    const int P = lanes_per_output(nout, L.cin), sub = threadIdx.x & (P - 1), groups = blockDim.x / P;
+    for (int idx = threadIdx.x / P; idx < nout; idx += groups) {
         const int o = idx % L.cout, b = idx / L.cout;
-        float acc = bbuf[o];
-        for (int i = 0; i < L.cin; ++i) acc += wbuf[(size_t)o * L.cin + i] * in[(size_t)b * L.cin + i];
-        out[idx] = act ? lrelu(acc) : acc;
+        float acc = 0.f;
+        for (int i = sub; i < L.cin; i += P) acc += wbuf[(size_t)o * L.cin + i] * in[(size_t)b * L.cin + i];
+        acc = group_sum(acc, P) + bbuf[o];
+        if (sub == 0) out[idx] = act ? lrelu(acc) : acc;
     }
     __syncthreads();
 }
@@ -99,24 +97,33 @@ __global__ __launch_bounds__(1024) void k_audio_encode(const AudioArgs a, const 
     const float* auds = auds_all + (size_t)blockIdx.x * a.in_dim * WIN;
     constexpr int n_win = 1;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
-    float* bufA = dyn;                        // MAX_ACT
-    float* bufB = bufA + MAX_ACT;             // MAX_ACT / 2
-    float* feat = bufB + MAX_ACT / 2;         // SEQ * AUD_DIM
-    float* bbuf = feat + SEQ * AUD_DIM;       // 64
-    float* wbuf = bbuf + 64;                  // MAX_W: the largest layer, 64 x 64 x 3
-    // network.py:61-62: the centre 16 steps of the window (win_size 16 -> all of them)
-    Prefetch pf;
+    float* bufA = dyn;                        // ACT_A
+    float* bufB = bufA + ACT_A;               // ACT_B
+    float* feat = bufB + ACT_B;               // SEQ * AUD_DIM
+    float* wts = feat + SEQ * AUD_DIM;        // the arena
     const bool att = a.use_att && n_win_all == SEQ;
-    prefetch(a.conv[0], 3, pf);
-    for (int i = threadIdx.x; i < n_win * a.in_dim * WIN; i += blockDim.x) bufA[i] = auds[i];
-    commit(a.conv[0], 3, pf, wbuf, bbuf);
-    prefetch(a.conv[1], 3, pf); conv1d(bufA, bufB, a.conv[0], n_win, 16, 2, true, wbuf, bbuf); commit(a.conv[1], 3, pf, wbuf, bbuf);
-    prefetch(a.conv[2], 3, pf); conv1d(bufB, bufA, a.conv[1], n_win, 8, 2, true, wbuf, bbuf); commit(a.conv[2], 3, pf, wbuf, bbuf);
-    prefetch(a.conv[3], 3, pf); conv1d(bufA, bufB, a.conv[2], n_win, 4, 2, true, wbuf, bbuf); commit(a.conv[3], 3, pf, wbuf, bbuf);
-    prefetch(a.fc[0], 1, pf); conv1d(bufB, bufA, a.conv[3], n_win, 2, 2, true, wbuf, bbuf); commit(a.fc[0], 1, pf, wbuf, bbuf);        // [n, 64, 1]
-    prefetch(a.fc[1], 1, pf); linear(bufA, bufB, a.fc[0], n_win, true, wbuf, bbuf); commit(a.fc[1], 1, pf, wbuf, bbuf);
-    if (att) prefetch(a.att[0], 3, pf);
-    linear(bufB, feat, a.fc[1], n_win, false, wbuf, bbuf);               // [n, 32]
+    {
+        // the arena in one burst: <= 9 independent 16-byte loads per thread, then the LDS stores
+        constexpr int R = 9;                  // ceil(37 k floats / 4 / 1024)
+        float4 r[R];
+        const float4* src = reinterpret_cast<const float4*>(a.arena);
+        const int n4 = a.arena_n >> 2;
+#pragma unroll
+        for (int k = 0; k < R; ++k) { const int i = threadIdx.x + k * 1024; if (i < n4) r[k] = src[i]; }
+        // network.py:61-62: the centre 16 steps of the window (win_size 16 -> all of them)
+        for (int i = threadIdx.x; i < n_win * a.in_dim * WIN; i += blockDim.x) bufA[i] = auds[i];
+#pragma unroll
+        for (int k = 0; k < R; ++k) { const int i = threadIdx.x + k * 1024; if (i < n4) reinterpret_cast<float4*>(wts)[i] = r[k]; }
+        __syncthreads();
+    }
+    auto W = [&](const Layer& L) { return wts + L.woff; };
+    auto B = [&](const Layer& L) { return wts + L.boff; };
+    conv1d(bufA, bufB, a.conv[0], n_win, 16, 2, true, W(a.conv[0]), B(a.conv[0]));
+    conv1d(bufB, bufA, a.conv[1], n_win, 8, 2, true, W(a.conv[1]), B(a.conv[1]));
+    conv1d(bufA, bufB, a.conv[2], n_win, 4, 2, true, W(a.conv[2]), B(a.conv[2]));
+    conv1d(bufB, bufA, a.conv[3], n_win, 2, 2, true, W(a.conv[3]), B(a.conv[3]));        // [n, 64, 1]
+    linear(bufA, bufB, a.fc[0], n_win, true, W(a.fc[0]), B(a.fc[0]));
+    linear(bufB, feat, a.fc[1], n_win, false, W(a.fc[1]), B(a.fc[1]));               // [n, 32]
     if (!att) {
         // att == 0: encode_audio returns audio_net's output as is (network.py:230-235); callers pass one window then
         for (int i = threadIdx.x; i < AUD_DIM; i += blockDim.x) enc_a[i] = ema_out(prev, i, feat[i]);
@@ -139,13 +146,12 @@ __global__ __launch_bounds__(1024) void k_audio_encode(const AudioArgs a, const 
     // AudioAttNet: y = x.permute(0, 2, 1) -> [1, 32, 8]
     for (int i = threadIdx.x; i < SEQ * AUD_DIM; i += blockDim.x) { const int t = i % SEQ, c = i / SEQ; bufA[c * SEQ + t] = feat[t * AUD_DIM + c]; }
     __syncthreads();
-    commit(a.att[0], 3, pf, wbuf, bbuf);
-    prefetch(a.att[1], 3, pf); conv1d(bufA, bufB, a.att[0], 1, SEQ, 1, true, wbuf, bbuf); commit(a.att[1], 3, pf, wbuf, bbuf);
-    prefetch(a.att[2], 3, pf); conv1d(bufB, bufA, a.att[1], 1, SEQ, 1, true, wbuf, bbuf); commit(a.att[2], 3, pf, wbuf, bbuf);
-    prefetch(a.att[3], 3, pf); conv1d(bufA, bufB, a.att[2], 1, SEQ, 1, true, wbuf, bbuf); commit(a.att[3], 3, pf, wbuf, bbuf);
-    prefetch(a.att[4], 3, pf); conv1d(bufB, bufA, a.att[3], 1, SEQ, 1, true, wbuf, bbuf); commit(a.att[4], 3, pf, wbuf, bbuf);
-    prefetch(a.att_fc, 1, pf); conv1d(bufA, bufB, a.att[4], 1, SEQ, 1, true, wbuf, bbuf); commit(a.att_fc, 1, pf, wbuf, bbuf);           // [1, 1, 8]
-    linear(bufB, bufA, a.att_fc, 1, false, wbuf, bbuf);                  // [1, 8]
+    conv1d(bufA, bufB, a.att[0], 1, SEQ, 1, true, W(a.att[0]), B(a.att[0]));
+    conv1d(bufB, bufA, a.att[1], 1, SEQ, 1, true, W(a.att[1]), B(a.att[1]));
+    conv1d(bufA, bufB, a.att[2], 1, SEQ, 1, true, W(a.att[2]), B(a.att[2]));
+    conv1d(bufB, bufA, a.att[3], 1, SEQ, 1, true, W(a.att[3]), B(a.att[3]));
+    conv1d(bufA, bufB, a.att[4], 1, SEQ, 1, true, W(a.att[4]), B(a.att[4]));           // [1, 1, 8]
+    linear(bufB, bufA, a.att_fc, 1, false, W(a.att_fc), B(a.att_fc));                  // [1, 8]
     if (threadIdx.x == 0) {
         float m = bufA[0];
         for (int t = 1; t < SEQ; ++t) m = fmaxf(m, bufA[t]);
@@ -167,6 +173,7 @@ struct mf_audio_encoder {
     AudioArgs a{};
     float* feat_g = nullptr;
     int* done = nullptr;
+    size_t lds = 0;
     std::vector<float*> dev;
     ~mf_audio_encoder() { for (float* d : dev) (void)hipFree(d); }
 };
@@ -180,23 +187,23 @@ extern "C" int mf_audio_encoder_create(const mf_tensor* weights, int n_weights, 
         sd[weights[i].name] = &weights[i];
     }
     std::unique_ptr<mf_audio_encoder> h(new mf_audio_encoder());
-    auto up = [&](const std::string& k, int64_t n, const float** dst) -> int {
+    std::vector<float> arena;                                   // every layer's [weight | bias], each padded to 4 floats
+    auto up = [&](const std::string& k, int64_t n, int* off) -> int {
         auto it = sd.find(k);
         if (it == sd.end()) { mf_set_error("audio_encoder_create: tensor '%s' missing", k.c_str()); return MF_ERR_INVALID; }
         int64_t have = 1;
         for (int d = 0; d < it->second->ndim; ++d) have *= it->second->shape[d];
         if (have != n) { mf_set_error("audio_encoder_create: '%s' has %lld elements, expected %lld", k.c_str(), (long long)have, (long long)n); return MF_ERR_INVALID; }
-        float* dptr = nullptr;
-        MF_HIP(hipMalloc(&dptr, n * sizeof(float)));
-        h->dev.push_back(dptr);
-        MF_HIP(hipMemcpy(dptr, it->second->data, n * sizeof(float), hipMemcpyHostToDevice));
-        *dst = dptr;
+        *off = (int)arena.size();
+        const float* src = static_cast<const float*>(it->second->data);
+        arena.insert(arena.end(), src, src + n);
+        arena.resize((arena.size() + 3) / 4 * 4, 0.f);
         return MF_OK;
     };
     auto layer = [&](const std::string& p, int cin, int cout, int k, Layer* L) -> int {
         L->cin = cin; L->cout = cout;
-        int rc = up(p + ".weight", (int64_t)cout * cin * k, &L->w);
-        return rc ? rc : up(p + ".bias", cout, &L->b);
+        int rc = up(p + ".weight", (int64_t)cout * cin * k, &L->woff);
+        return rc ? rc : up(p + ".bias", cout, &L->boff);
     };
     auto it = sd.find("audio_net.encoder_conv.0.weight");
     MF_REQUIRE(it != sd.end() && it->second->ndim == 3 && it->second->shape[0] == 32 && it->second->shape[2] == 3,
@@ -216,6 +223,15 @@ extern "C" int mf_audio_encoder_create(const mf_tensor* weights, int n_weights, 
             if ((rc = layer("audio_att_net.attentionConvNet." + std::to_string(2 * i), ac[i], ac[i + 1], 3, &h->a.att[i]))) return rc;
         if ((rc = layer("audio_att_net.attentionNet.0", SEQ, SEQ, 1, &h->a.att_fc))) return rc;
     }
+    {
+        float* d = nullptr;
+        MF_HIP(hipMalloc(&d, arena.size() * sizeof(float)));
+        h->dev.push_back(d);
+        MF_HIP(hipMemcpy(d, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice));
+        h->a.arena = d; h->a.arena_n = (int)arena.size();
+        h->lds = (size_t)(ACT_A + ACT_B + SEQ * AUD_DIM + h->a.arena_n) * sizeof(float);
+        MF_REQUIRE(h->a.arena_n <= 9 * 4 * 1024 && h->lds <= 160 * 1024 - 256, "audio_encoder_create: %d floats of weights do not fit the kernel's LDS arena", h->a.arena_n);
+    }
     MF_HIP(hipMalloc(&h->feat_g, (SEQ * AUD_DIM + 1) * sizeof(float)));
     h->dev.push_back(h->feat_g);
     h->done = reinterpret_cast<int*>(h->feat_g + SEQ * AUD_DIM);
@@ -230,10 +246,10 @@ static int audio_encoder_launch(mf_audio_encoder* h, const float* auds, int n_wi
                "audio_encoder_forward: %d windows (the attention net pools exactly 8, network.py:10; without it one window)", n_windows);
     static bool attr_done = false;
     if (!attr_done) {
-        MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_audio_encode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AUDIO_LDS));
+        MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_audio_encode), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));   // (the kernel's static s_last shares the 160 KB)
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_audio_encode, dim3(n_windows), dim3(1024), AUDIO_LDS, (hipStream_t)stream, h->a, auds, n_windows, enc_a, h->feat_g, h->done, prev);
+    hipLaunchKernelGGL(k_audio_encode, dim3(n_windows), dim3(1024), h->lds, (hipStream_t)stream, h->a, auds, n_windows, enc_a, h->feat_g, h->done, prev);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
