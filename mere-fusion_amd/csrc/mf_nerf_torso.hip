@@ -34,8 +34,10 @@ struct TorsoFusedArgs {
     float *out, *alpha_out, *deform;
 };
 
-// one out-of-line copy of the accurate sine (32 calls per pixel would otherwise inline 32 range reductions)
-__device__ __attribute__((noinline)) float torso_sin(float x) { return sinf(x); }
+// the frequency features' sine is the reference's own: freqencoder.cu:56 calls __sinf -- the hardware sine of x / 2 pi -- and so does k_freq_encode (mf_nerf.hip);
+// rounds 3 - 4 called the accurate sinf() here, 32 range reductions of ~50 instructions per pixel: a quarter of the kernel's VALU work for a feature the
+// reference does not compute that way
+__device__ __forceinline__ float torso_sin(float x) { return __sinf(x); }
 
 // The weight table is read through the CONSTANT address space: a uniform load from it is always a scalar load (s_load -> SGPR operand of
 // v_pk_fma), whatever stores the kernel has issued before -- through a global pointer the compiler falls back to per-lane
@@ -68,10 +70,28 @@ __device__ __forceinline__ float row_dot(cw_ptr wr, float bias, const f32x2 (&x)
 // ever touches its own column, so there is no barrier), from where the next stage reads it back with compile-time indices.
 template <int IN2, int OUT, bool RELU, bool BIAS>
 __device__ __forceinline__ void dense_to_lds(cw_ptr w, const float* __restrict__ bias, const f32x2 (&x)[IN2], float* col) {
+    if constexpr (IN2 <= 17 && OUT % 2 == 0) {
+        // two rows per iteration where both fit the scalar registers (the 32- and 34-wide inputs): their s_loads go out together, and two independent
+        // accumulator chains interleave -- a lone chain of v_pk_fma_f32 pays a wait state after every instruction (the packed op's result is not forwarded)
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-    for (int o = 0; o < OUT; ++o) {
-        const float v = row_dot<IN2>(w + o * 2 * IN2, BIAS ? bias[o] : 0.f, x);
-        col[o * 256] = RELU ? fmaxf(v, 0.f) : v;
+        for (int o = 0; o < OUT; o += 2) {
+            cw2_ptr w0 = (cw2_ptr)(w + o * 2 * IN2), w1 = (cw2_ptr)(w + (o + 1) * 2 * IN2);
+            f32x2 a0 = {BIAS ? bias[o] : 0.f, 0.f}, a1 = {BIAS ? bias[o + 1] : 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < IN2; ++j) {
+                a0 = __builtin_elementwise_fma(w0[j], x[j], a0);
+                a1 = __builtin_elementwise_fma(w1[j], x[j], a1);
+            }
+            const float v0 = a0.x + a0.y, v1 = a1.x + a1.y;
+            col[o * 256] = RELU ? fmaxf(v0, 0.f) : v0;
+            col[(o + 1) * 256] = RELU ? fmaxf(v1, 0.f) : v1;
+        }
+    } else {
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int o = 0; o < OUT; ++o) {
+            const float v = row_dot<IN2>(w + o * 2 * IN2, BIAS ? bias[o] : 0.f, x);
+            col[o * 256] = RELU ? fmaxf(v, 0.f) : v;
+        }
     }
 }
 __device__ __forceinline__ void from_lds(const float* col, f32x2 (&x)[HID / 2]) {
@@ -143,7 +163,15 @@ __global__ __launch_bounds__(256) void k_torso_fused(const TorsoFusedArgs a) {
                     if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
                     else { w *= pos[d]; pl[d] = pg[d] + 1; }
                 }
-                const uint32_t index = grid_index<2>(2, 1, false, a.hashmap_size[l], a.resolution[l], pl);
+                // get_grid_index (gridencoder.cu:54-72) for D = 2, C = 2, the tiled type, with the level's constants -- wave-uniform kernel arguments -- deciding
+                // on the SCALAR unit what the lanes must do: a level whose (res + 1)^2 cells fit the table is addressed directly (`% hashmap_size` is the
+                // identity there: no instruction), a larger one wraps by a mask when the table is a power of two (2^log2_hashmap_size, grid.py:108-123) and by
+                // the division only otherwise.  grid_index<2>() divided for all 64 corners of a pixel: ~1 600 of the kernel's VALU instructions.
+                const uint32_t hs = a.hashmap_size[l], s1 = a.resolution[l] + 1;
+                uint32_t index = pl[0];
+                if (s1 <= hs) index += pl[1] * s1;
+                if (!(s1 <= hs && s1 * s1 <= hs)) index = (hs & (hs - 1)) == 0 ? (index & (hs - 1)) : index % hs;
+                index *= 2;
                 const float2 g = *reinterpret_cast<const float2*>(grid + index);          // index is a multiple of C = 2: 8-byte aligned
                 r0 += w * g.x;
                 r1 += w * g.y;
