@@ -70,17 +70,22 @@ __device__ __forceinline__ float row_dot(cw_ptr wr, float bias, const f32x2 (&x)
 // ever touches its own column, so there is no barrier), from where the next stage reads it back with compile-time indices.
 template <int IN2, int OUT, bool RELU, bool BIAS>
 __device__ __forceinline__ void dense_to_lds(cw_ptr w, const float* __restrict__ bias, const f32x2 (&x)[IN2], float* col) {
-    if constexpr (IN2 <= 17 && OUT % 2 == 0) {
-        // two rows per iteration where both fit the scalar registers (the 32- and 34-wide inputs): their s_loads go out together, and two independent
+    if constexpr (OUT % 2 == 0) {
+        // two rows per iteration: their s_loads go out together, and two independent
         // accumulator chains interleave -- a lone chain of v_pk_fma_f32 pays a wait state after every instruction (the packed op's result is not forwarded)
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (int o = 0; o < OUT; o += 2) {
             cw2_ptr w0 = (cw2_ptr)(w + o * 2 * IN2), w1 = (cw2_ptr)(w + (o + 1) * 2 * IN2);
             f32x2 a0 = {BIAS ? bias[o] : 0.f, 0.f}, a1 = {BIAS ? bias[o + 1] : 0.f, 0.f};
+            // <= 17 weight pairs of each row in flight (2 x 34 scalars): the 66-wide rows go in two halves -- all of a pair of them at once overflows the ~100 SGPRs
 #pragma unroll
-            for (int j = 0; j < IN2; ++j) {
-                a0 = __builtin_elementwise_fma(w0[j], x[j], a0);
-                a1 = __builtin_elementwise_fma(w1[j], x[j], a1);
+            for (int c = 0; c < IN2; c += 17) {
+#pragma unroll
+                for (int j = c; j < (c + 17 < IN2 ? c + 17 : IN2); ++j) {
+                    a0 = __builtin_elementwise_fma(w0[j], x[j], a0);
+                    a1 = __builtin_elementwise_fma(w1[j], x[j], a1);
+                }
+                if (c + 17 < IN2) __builtin_amdgcn_sched_barrier(0);
             }
             const float v0 = a0.x + a0.y, v1 = a1.x + a1.y;
             col[o * 256] = RELU ? fmaxf(v0, 0.f) : v0;
