@@ -502,7 +502,10 @@ __global__ void k_loop_init(int* ctl, int N, int max_steps, int* alive, float* r
 // tail of a round in one launch: composite (raymarching.cu:2142-2249), `rays_alive = rays_alive[rays_alive >= 0]` (renderer.py:266) as a
 // wave-aggregated append (the order of the survivors is not kept: rays are independent, only their slot changes), and -- by the last
 // block to finish -- the head of the next round.
-constexpr int CT = 1024;           // composite block: one contended 64-bit atomic per 1024 rays
+#ifndef MF_NERF_CT
+#define MF_NERF_CT 1024
+#endif
+constexpr int CT = MF_NERF_CT;           // composite block: one contended 64-bit atomic per 1024 rays
 __global__ __launch_bounds__(CT) void k_loop_composite(int* ctl, int N, int max_steps, float T_thresh, const int* __restrict__ alive_in, int* alive_out,
                                                        float* rays_t, const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                        const float* __restrict__ deltas, const float* __restrict__ ambs_aud,
