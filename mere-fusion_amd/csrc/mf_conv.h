@@ -50,6 +50,10 @@ struct ConvArgs {
     const int* goff;
     int M, N, Npad;
     int HqWq, Wq;
+    // m / HqWq and rem / Wq by multiplication (mf_fastdiv below): the kernels split a pixel index into (image, row, column) per fragment row in the prologue and again
+    // in the epilogue -- as hardware-less 32-bit divisions that was ~30 vector instructions each, 16 - 24 of them per lane and workgroup
+    uint32_t dv_hw_mul, dv_hw_shr, dv_w_mul, dv_w_shr;
+    uint32_t dv_t_mul, dv_t_shr, dv_s_mul, dv_s_shr;     // tile index / (tiles_m or tiles_n, whichever runs fastest) and K tiles / split count: set by the launcher
     int64_t xb; int xi, xj;   // input element strides per (batch, quotient row, quotient col)
     int64_t yb; int yi, yj;   // output strides
     int64_t rb; int ri, rj;   // residual strides
@@ -211,3 +215,16 @@ int mf_groupnorm_stats(const ActView& x, int groups, double* stats, int batch, h
 // prefix.  The buffers keep their geometry (base pointers, batch strides); the GEMM simply has M = batch * tokens rows.
 int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
                    int batch, hipStream_t stream, int tokens = 0);
+
+// n / d for 0 <= n < 2^31 as (n * mul) >> (32 + shr): s = ceil(log2 d), mul = floor(2^(31 + s) / d) + 1, shr = s - 1 (mul * d = 2^(31 + s) + e with 0 < e <= d <= 2^s, so
+// the error term n e / (d 2^(31 + s)) stays below 1 / d).  d == 1 is mul = 0: the quotient is n.
+inline void mf_fastdiv(uint32_t d, uint32_t* mul, uint32_t* shr) {
+    if (d <= 1) { *mul = 0; *shr = 0; return; }
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    *mul = (uint32_t)(((1ull << (31 + s)) / d) + 1);
+    *shr = s - 1;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ int mf_fdiv(int n, uint32_t mul, uint32_t shr) { return mul ? (int)(__umulhi((uint32_t)n, mul) >> shr) : n; }
+#endif

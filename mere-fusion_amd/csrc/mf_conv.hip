@@ -213,14 +213,15 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
     // activations: the UNet's small maps): an XCD walks all pixel tiles of one or two channel tiles, so each XCD pulls
     // its slice of the weights from HBM once instead of every XCD pulling all of them.
     int tm, tn;
-    if (a.m_fastest) { tn = t / a.tiles_m; tm = t - tn * a.tiles_m; }
-    else { tm = t / a.tiles_n; tn = t - tm * a.tiles_n; }
+    if (a.m_fastest) { tn = mf_fdiv(t, a.dv_t_mul, a.dv_t_shr); tm = t - tn * a.tiles_m; }
+    else { tm = mf_fdiv(t, a.dv_t_mul, a.dv_t_shr); tn = t - tm * a.tiles_n; }
     const int m0 = tm * BM, n0 = tn * BN;
 
     // split-K slice of this workgroup (ph.KT counts 64-deep packed tiles; this kernel steps BK)
     const int KTk = ph.KT * (64 / BK);
-    const int kt_begin = (int)((int64_t)KTk * blockIdx.y / gridDim.y);
-    const int kt_end = (int)((int64_t)KTk * (blockIdx.y + 1) / gridDim.y);
+    // (KTk * split index < 2^31; as 64-bit divisions these two lines were ~200 vector instructions at the head of every workgroup)
+    const int kt_begin = mf_fdiv(KTk * (int)blockIdx.y, a.dv_s_mul, a.dv_s_shr);
+    const int kt_end = mf_fdiv(KTk * ((int)blockIdx.y + 1), a.dv_s_mul, a.dv_s_shr);
 
     for (int i = tid; i < ph.ngroups; i += NT) s_goff[i] = a.goff[ph.goff_begin + i];
 
@@ -235,9 +236,9 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
         p_kg[i] = (lane % KG) ^ swz<BK>(row);
         int m = m0 + row;
         m = m < a.M ? m : a.M - 1;
-        const int b = m / a.HqWq;
+        const int b = mf_fdiv(m, a.dv_hw_mul, a.dv_hw_shr);
         const int rem = m - b * a.HqWq;
-        const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+        const int qi = mf_fdiv(rem, a.dv_w_mul, a.dv_w_shr), qj = rem - qi * a.Wq;
         xp[i] = a.x_hi + (zx + (int64_t)b * a.xb + (int64_t)qi * a.xi + (int64_t)qj * a.xj);
     }
     const bf16_t* wp[NWC];
@@ -544,9 +545,9 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
         for (int j = 0; j < FM; ++j) {
             const int m = m0 + pm0 + j * 16 + fr;
             if (m >= a.M) continue;
-            const int b = m / a.HqWq;
+            const int b = mf_fdiv(m, a.dv_hw_mul, a.dv_hw_shr);
             const int rem = m - b * a.HqWq;
-            const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+            const int qi = mf_fdiv(rem, a.dv_w_mul, a.dv_w_shr), qj = rem - qi * a.Wq;
             float* wo = a.ws + (int64_t)blockIdx.y * a.ws_split + (int64_t)b * a.wsb + (int64_t)qi * a.wsi +
                         (int64_t)qj * a.wsj + ph.ws_off;
 #pragma unroll
@@ -580,9 +581,9 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
             const int m = m0 + pm0 + j * 16 + fr;
             const bool row_ok = m < a.M;
             const int mc = row_ok ? m : a.M - 1;
-            const int b = mc / a.HqWq;
+            const int b = mf_fdiv(mc, a.dv_hw_mul, a.dv_hw_shr);
             const int rem = mc - b * a.HqWq;
-            const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+            const int qi = mf_fdiv(rem, a.dv_w_mul, a.dv_w_shr), qj = rem - qi * a.Wq;
             const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
             const double2 sq = *reinterpret_cast<const double2*>(a.ln_in + 2 * (int64_t)mc);
             const double mean = sq.x * (double)a.ln_inv_c, var = sq.y * (double)a.ln_inv_c - mean * mean;
@@ -669,9 +670,9 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
             const int m = m0 + pm0 + j * 16 + fr;
             const bool row_ok = m < a.M;
             const int mc = row_ok ? m : a.M - 1;
-            const int b = mc / a.HqWq;
+            const int b = mf_fdiv(mc, a.dv_hw_mul, a.dv_hw_shr);
             const int rem = mc - b * a.HqWq;
-            const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+            const int qi = mf_fdiv(rem, a.dv_w_mul, a.dv_w_shr), qj = rem - qi * a.Wq;
             const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
             uint2 pk_hi[FN / 2 > 0 ? FN / 2 : 1], pk_lo[FN / 2 > 0 ? FN / 2 : 1];
 #pragma unroll
@@ -734,9 +735,9 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
                     if (j0 + jj >= FM) break;
                     int m = m0 + pm0 + (j0 + jj) * 16 + fr;
                     m = m < a.M ? m : a.M - 1;                      // clamped, never branched around: the stores are masked
-                    const int b = m / a.HqWq;
+                    const int b = mf_fdiv(m, a.dv_hw_mul, a.dv_hw_shr);
                     const int rem = m - b * a.HqWq;
-                    const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+                    const int qi = mf_fdiv(rem, a.dv_w_mul, a.dv_w_shr), qj = rem - qi * a.Wq;
                     const int64_t ro = (int64_t)b * a.rb + (int64_t)qi * a.ri + (int64_t)qj * a.rj;
 #pragma unroll
                     for (int i = 0; i < FN; ++i) {
@@ -754,9 +755,9 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
                 const int m = m0 + pm0 + j * 16 + fr;
                 const bool row_ok = m < a.M;
                 const int mc = row_ok ? m : a.M - 1;
-                const int b = mc / a.HqWq;
+                const int b = mf_fdiv(mc, a.dv_hw_mul, a.dv_hw_shr);
                 const int rem = mc - b * a.HqWq;
-                const int qi = rem / a.Wq, qj = rem - qi * a.Wq;
+                const int qi = mf_fdiv(rem, a.dv_w_mul, a.dv_w_shr), qj = rem - qi * a.Wq;
                 const int64_t yo = zy + (int64_t)b * a.yb + (int64_t)qi * a.yi + (int64_t)qj * a.yj + ph.y_off;
                 uint2 pk_hi[FN], pk_lo[FN];
                 float row_s = 0.f, row_q = 0.f;
@@ -856,7 +857,7 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
                 for (int c = c_lo; c < c_hi; ++c)
 #pragma unroll
                     for (int wm = 0; wm < WGM; ++wm) acc_d += (double)sb[((size_t)wm * BN + (c - n0)) * 2 + mo];
-                const int b = m0 / a.HqWq;
+                const int b = mf_fdiv(m0, a.dv_hw_mul, a.dv_hw_shr);
                 atomicAdd(a.gn_out + 2 * ((size_t)b * a.gn_out_groups + g) + mo, acc_d);
             }
         }
@@ -1102,7 +1103,10 @@ int launch_cfg_n(const ConvArgs& a, int nphase, int nsplit, int goff_max, hipStr
         if (lds > 160 * 1024) { mf_set_error("conv: producer-wave tile %dx%d needs %zu bytes of LDS", BM, BN, lds); return MF_ERR_INVALID; }
     }
     dim3 grid(a.tiles_m * a.tiles_n, nsplit, a.zgroups ? a.zgroups : nphase);
-    hipLaunchKernelGGL(kern, grid, dim3((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>() : 0)) * 64), lds, s, a);
+    ConvArgs b = a;
+    mf_fastdiv((uint32_t)(a.m_fastest ? a.tiles_m : a.tiles_n), &b.dv_t_mul, &b.dv_t_shr);
+    mf_fastdiv((uint32_t)nsplit, &b.dv_s_mul, &b.dv_s_shr);
+    hipLaunchKernelGGL(kern, grid, dim3((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>() : 0)) * 64), lds, s, b);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }
@@ -1820,6 +1824,7 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
     a.w_hi = p->w_hi; a.w_lo = p->w_lo; a.bias = p->bias; a.goff = p->goff;
     a.M = batch * p->Hq * Wq_eff; a.N = p->d.cout; a.Npad = p->Npad;
     a.HqWq = p->Hq * Wq_eff; a.Wq = Wq_eff;
+    mf_fastdiv((uint32_t)a.HqWq, &a.dv_hw_mul, &a.dv_hw_shr); mf_fastdiv((uint32_t)a.Wq, &a.dv_w_mul, &a.dv_w_shr);
     a.xb = ib.per_batch(); a.xi = p->in_step_h * ib.Wp() * ib.C; a.xj = p->in_step_w * ib.C;
     const int64_t ybase = ((int64_t)ob.halo * ob.Wp() + ob.halo) * ob.C + out.coff;
     a.y_hi = ob.hi + ybase; a.y_lo = x3 ? ob.lo + ybase : nullptr;
@@ -1963,6 +1968,7 @@ int mf_gemm_grouped_launch(ConvPlan* p, const GroupedGemm& g, hipStream_t stream
     a.w_hi = p->w_hi; a.w_lo = p->w_lo; a.bias = p->bias; a.goff = p->goff;
     a.M = g.M; a.N = p->d.cout; a.Npad = p->Npad;
     a.HqWq = g.M; a.Wq = g.M;          // rows are linear: (b, i, j) = (0, 0, m)
+    mf_fastdiv((uint32_t)a.HqWq, &a.dv_hw_mul, &a.dv_hw_shr); mf_fastdiv((uint32_t)a.Wq, &a.dv_w_mul, &a.dv_w_shr);
     a.xb = 0; a.xi = 0; a.xj = g.x_row;
     a.y_hi = g.y_hi; a.y_lo = x3 ? g.y_lo : nullptr;
     a.yb = 0; a.yi = 0; a.yj = g.y_row;
