@@ -943,19 +943,22 @@ __device__ __forceinline__ void epilogue_store_pre(const ConvArgs& a, float (&v)
 
 // Combines the split-K partial tiles: one thread per (output pixel, 4 channels).
 // ws layout: [split][B][Ho][Wo][N] fp32 (unpadded); output / residual are padded NHWC planes.
-__global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int nsplit, int Ho, int Wo, int64_t total) {
-    const int64_t idx0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// (thread index -> (pixel, channel quad) -> (image, row, column) by multiply-shift, EpiDiv: as three 64-bit divisions this was ~400 of the thread's ~450 instructions)
+struct EpiDiv { uint32_t nq_mul, nq_shr, w_mul, w_shr, h_mul, h_shr, g_mul, g_shr, c_mul, c_shr; };
+__global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int nsplit, int Ho, int Wo, int total, const EpiDiv dv) {
+    const int idx0 = (int)blockIdx.x * 256 + (int)threadIdx.x;
     const bool live = idx0 < total;
     if (!live && !a.ln_out) return;
-    const int64_t idx = live ? idx0 : total - 1;          // (a LayerNorm producer's tail lanes stay for the wave reduction below: they recompute the last quad, store nothing)
+    const int idx = live ? idx0 : total - 1;              // (a LayerNorm producer's tail lanes stay for the wave reduction below: they recompute the last quad, store nothing)
     const bool geglu = a.act == 5;
     const int nq = (geglu ? a.N >> 1 : a.N) >> 2;         // output channel quads
-    const int co = (int)(idx % nq) * 4;                   // output channel
+    const int pix0 = mf_fdiv(idx, dv.nq_mul, dv.nq_shr);
+    const int co = (idx - pix0 * nq) * 4;                 // output channel
     const int c = geglu ? (co >> 4) * 32 + (co & 15) : co; // GEMM row of its value (GEGLU: the gate sits 16 rows on)
-    int64_t p = idx / nq;
-    const int ox = (int)(p % Wo); p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
+    const int prow = mf_fdiv(pix0, dv.w_mul, dv.w_shr);
+    const int ox = pix0 - prow * Wo;
+    const int b = mf_fdiv(prow, dv.h_mul, dv.h_shr);
+    const int oy = prow - b * Ho;
     const bool x3 = a.y_lo != nullptr;
     // y/r strides of the UNIT output grid are passed in (yi, yj) / (ri, rj) by the launcher
     const int64_t yo = (int64_t)b * a.yb + (int64_t)oy * a.yi + (int64_t)ox * a.yj;
@@ -990,7 +993,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int n
         // LayerNorm statistics of the stored row for the consumer: (sum, sum of squares) of this thread's quad, added up over the lanes of the wave that hold the
         // same pixel (a segmented suffix sum: consecutive lanes = consecutive quads of a pixel), one fp64 atomic per (wave, pixel, moment)
         float ps = (v[0] + v[1]) + (v[2] + v[3]), pq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        const int64_t pix = live ? idx / nq : -1;
+        const int64_t pix = live ? (int64_t)pix0 : -1;
         if (!live) { ps = 0.f; pq = 0.f; }
         const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -1012,13 +1015,13 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int n
 // the block's pixels pp, pp + ppi, ... (one pixel's quads are contiguous: coalesced as in k_gn_stats), two pixels per iteration with both pixels' loads in
 // flight together; fp32 partials over <= 64 pixels, then fp64 LDS bins per group and one global fp64 atomic per (workgroup, group, moment).  No GEGLU (its
 // consumer is a Linear).
-__global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const ConvArgs a, int nsplit, int Ho, int Wo, int P) {
+__global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const ConvArgs a, int nsplit, int Ho, int Wo, int P, const EpiDiv dv) {
     __shared__ double bins[2 * 64];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int nq = a.N >> 2;
     const int cols = nq < 256 ? nq : 256;
     const int ppi = 256 / cols;
-    const int k0 = tid % cols, pp = tid / cols;
+    const int pp = mf_fdiv(tid, dv.c_mul, dv.c_shr), k0 = tid - pp * cols;
     const int T = Ho * Wo, t0 = blockIdx.x * P, t1 = min(T, t0 + P);
     const int groups = a.gn_out_groups, cpg = a.gn_out_cpg;
     const bool x3 = a.y_lo != nullptr;
@@ -1033,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const ConvArgs a,
                 const int tb = t + ppi;
                 const bool two = tb < t1;
                 const int ta = t, tc = two ? tb : t;                  // (the second pixel clamped onto the first when the block ends: loaded, not stored)
-                const int oy0 = ta / Wo, ox0 = ta - oy0 * Wo, oy1 = tc / Wo, ox1 = tc - oy1 * Wo;
+                const int oy0 = mf_fdiv(ta, dv.w_mul, dv.w_shr), ox0 = ta - oy0 * Wo, oy1 = mf_fdiv(tc, dv.w_mul, dv.w_shr), ox1 = tc - oy1 * Wo;
                 const int64_t yo0 = (int64_t)b * a.yb + (int64_t)oy0 * a.yi + (int64_t)ox0 * a.yj, yo1 = (int64_t)b * a.yb + (int64_t)oy1 * a.yi + (int64_t)ox1 * a.yj;
                 const int64_t ro0 = (int64_t)b * a.rb + (int64_t)oy0 * a.ri + (int64_t)ox0 * a.rj, ro1 = (int64_t)b * a.rb + (int64_t)oy1 * a.ri + (int64_t)ox1 * a.rj;
                 const ResQuad r0 = load_residual(a, ro0, c, x3), r1 = load_residual(a, ro1, c, x3);
@@ -1065,11 +1068,11 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const ConvArgs a,
                     for (int e = 0; e < 4; ++e) { s4[e] += u[e]; q4[e] += u[e] * u[e]; }
                 }
             }
-            int g_cur = c / cpg;
+            int g_cur = mf_fdiv(c, dv.g_mul, dv.g_shr);
             double as = 0.0, aq = 0.0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int g = (c + e) / cpg;
+                const int g = mf_fdiv(c + e, dv.g_mul, dv.g_shr);
                 if (g != g_cur) {
                     atomicAdd(&bins[2 * g_cur], as); atomicAdd(&bins[2 * g_cur + 1], aq);
                     g_cur = g; as = 0.0; aq = 0.0;
@@ -1081,6 +1084,19 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_stats(const ConvArgs a,
     }
     __syncthreads();
     for (int i = tid; i < 2 * groups; i += 256) atomicAdd(&a.gn_out[2 * ((size_t)b * groups) + i], bins[i]);
+}
+
+// the multiply-shift constants of the combine kernels: channel quads per pixel, output width / height, channels per GroupNorm group, quad columns per 256 threads
+static EpiDiv epi_div(const ConvArgs& e, int Ho, int Wo) {
+    EpiDiv d{};
+    const int nq = ((e.act == 5 ? e.N >> 1 : e.N) >> 2);
+    const int nq_all = e.N >> 2, cols = nq_all < 256 ? nq_all : 256;
+    mf_fastdiv((uint32_t)nq, &d.nq_mul, &d.nq_shr);
+    mf_fastdiv((uint32_t)Wo, &d.w_mul, &d.w_shr);
+    mf_fastdiv((uint32_t)Ho, &d.h_mul, &d.h_shr);
+    mf_fastdiv((uint32_t)(e.gn_out_cpg > 0 ? e.gn_out_cpg : 1), &d.g_mul, &d.g_shr);
+    mf_fastdiv((uint32_t)(cols > 0 ? cols : 1), &d.c_mul, &d.c_shr);
+    return d;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1646,7 +1662,7 @@ static bool launch_combine_stats(const ConvPlan* p, ConvArgs e, int nsplit, int 
     const int nq = p->d.cout / 4, cols = std::min(256, nq), ppi = 256 / cols, T = Ho * Wo;
     const int target = 1024;                                         // workgroups aimed for (each issues 2 * groups fp64 atomics): 128 / 256 and 2048 / 4096 all measured slower
     const int P = std::max(ppi, std::min(64 * ppi, (int)(((int64_t)T * batch + target - 1) / target)));
-    hipLaunchKernelGGL(k_splitk_epilogue_stats, dim3((unsigned)((T + P - 1) / P), batch), dim3(256), 0, stream, e, nsplit, Ho, Wo, P);
+    hipLaunchKernelGGL(k_splitk_epilogue_stats, dim3((unsigned)((T + P - 1) / P), batch), dim3(256), 0, stream, e, nsplit, Ho, Wo, P, epi_div(e, Ho, Wo));
     return true;
 }
 
@@ -1736,8 +1752,9 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
                 e.y_hi = ha.y_hi; e.y_lo = ha.y_lo; e.yb = ha.yb; e.yi = ha.yi; e.yj = ha.yj;
                 e.r_hi = ha.r_hi; e.r_lo = ha.r_lo; e.rb = ha.rb; e.ri = ha.ri; e.rj = ha.rj;
                 const int64_t total = (int64_t)batch * p->out_h * p->out_w * (p->d.cout / 4);
+                MF_REQUIRE(total < 0x7fffffffll, "conv: split-K combine over %lld channel quads (32-bit thread index)", (long long)total);
                 if (launch_combine_stats(p, e, ns, p->out_h, p->out_w, batch, stream)) *stats_done = true;
-                else hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e, ns, p->out_h, p->out_w, total);
+                else hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e, ns, p->out_h, p->out_w, (int)total, epi_div(e, p->out_h, p->out_w));
                 MF_HIP(hipGetLastError());
                 return MF_OK;
             }
@@ -1774,8 +1791,9 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
                     e.rb = rb.per_batch(); e.ri = rb.Wp() * rb.C; e.rj = rb.C;
                 }
                 const int64_t total = (int64_t)batch * p->out_h * p->out_w * (p->d.cout / 4);
+                MF_REQUIRE(total < 0x7fffffffll, "conv: split-K combine over %lld channel quads (32-bit thread index)", (long long)total);
                 if (launch_combine_stats(p, e, ns, p->out_h, p->out_w, batch, stream)) *stats_done = true;
-                else hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e, ns, p->out_h, p->out_w, total);
+                else hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e, ns, p->out_h, p->out_w, (int)total, epi_div(e, p->out_h, p->out_w));
                 MF_HIP(hipGetLastError());
                 return MF_OK;
             }
@@ -1952,9 +1970,10 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
         ConvArgs e = a;   // unit-grid strides for the combine pass
         e.yi = ob.Wp() * ob.C; e.yj = ob.C;
         const int64_t total = (int64_t)batch * p->out_h * out_w_eff * ((a.act == 5 ? a.N / 2 : a.N) / 4);
+        MF_REQUIRE(total < 0x7fffffffll, "conv: split-K combine over %lld channel quads (32-bit thread index)", (long long)total);
         if (tokens == 0 && launch_combine_stats(p, e, tc.nsplit, p->out_h, out_w_eff, batch, stream)) *stats_done = true;
         else hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, e,
-                                tc.nsplit, p->out_h, out_w_eff, total);
+                                tc.nsplit, p->out_h, out_w_eff, (int)total, epi_div(e, p->out_h, out_w_eff));
         MF_HIP(hipGetLastError());
     }
     return MF_OK;

@@ -40,8 +40,11 @@ constexpr int MAXPL = 32;   // channels per lane held in registers: C <= 2048
 struct Rows {
     const bf16_t* hi; const bf16_t* lo;
     int64_t bstride; int W, Wp, halo, C, T;
+    uint32_t w_mul, w_shr;            // t / W by multiply-shift (mf_fastdiv): every kernel here turns a token index into (row, column) per token it touches
+    uint32_t g_mul, g_shr;            // channel / channels-per-group, set by the GroupNorm launchers (0, 0 elsewhere)
+    __device__ int group_of(int c) const { return mf_fdiv(c, g_mul, g_shr); }
     __host__ __device__ int64_t off(int b, int t) const {
-        const int y = t / W, x = t - y * W;
+        const int y = w_mul ? (int)((uint32_t)(((uint64_t)(uint32_t)t * w_mul) >> 32) >> w_shr) : t, x = t - y * W;
         return (int64_t)b * bstride + ((int64_t)(y + halo) * Wp + x + halo) * C;
     }
 };
@@ -277,11 +280,11 @@ __global__ __launch_bounds__(256) void k_gn_stats(Rows X, int groups, int cpg, i
             const int k = k0 + 256 * j;
             if (k >= c8) break;
             // channels of this chunk -> groups (cpg may be smaller or larger than 8, and need not divide it)
-            int g_cur = (k * 8) / cpg;
+            int g_cur = X.group_of(k * 8);
             double as = 0.0, aq = 0.0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int g = (k * 8 + e) / cpg;
+                const int g = X.group_of(k * 8 + e);
                 if (g != g_cur) {
                     atomicAdd(&bins[2 * g_cur], as); atomicAdd(&bins[2 * g_cur + 1], aq);
                     g_cur = g; as = 0.0; aq = 0.0;
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* _
         float2 st2 = make_float2(0.f, 1.f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int g = (c0 + e) / cpg;
+            const int g = X.group_of(c0 + e);
             if (g != g_prev) {
                 // finalise (sum, sum of squares) -> (mean, rstd): a handful of fp64 ops per thread and group
                 const double2 sq = *reinterpret_cast<const double2*>(stats + 2 * (b * groups + g));
@@ -420,9 +423,12 @@ __global__ __launch_bounds__(256) void k_vae_post(Rows X, int H, int W, uint8_t*
     }
 }
 
-Rows rows_of(const ActView& v) {
+Rows rows_of(const ActView& v, int cpg = 0) {     // cpg: channels per GroupNorm group for the kernels that map channels to groups
     const ActBuf& b = *v.buf;
-    return Rows{b.hi + v.coff, b.lo ? b.lo + v.coff : nullptr, b.per_batch(), b.W, b.Wp(), b.halo, b.C, b.H * b.W};
+    Rows r{b.hi + v.coff, b.lo ? b.lo + v.coff : nullptr, b.per_batch(), b.W, b.Wp(), b.halo, b.C, b.H * b.W, 0u, 0u, 0u, 0u};
+    mf_fastdiv((uint32_t)b.W, &r.w_mul, &r.w_shr);
+    if (cpg > 0) mf_fastdiv((uint32_t)cpg, &r.g_mul, &r.g_shr);
+    return r;
 }
 
 }  // namespace
@@ -494,8 +500,8 @@ __global__ void k_gn_affine(const double* __restrict__ stats, const float* __res
 int mf_groupnorm_affine(const ActView& x, const float* gamma, const float* beta, int groups, float eps, double* stats, float* scale, float* shift,
                         int batch, hipStream_t s, bool have_stats) {
     MF_REQUIRE(x.C % groups == 0 && x.C % 8 == 0 && x.coff % 8 == 0, "groupnorm: C=%d groups=%d", x.C, groups);
-    const Rows xr = rows_of(x);
     const int cpg = x.C / groups;
+    const Rows xr = rows_of(x, cpg);
     MF_REQUIRE(groups <= 64 && x.C <= 8 * 256 * GN_MAXCOL, "groupnorm: groups=%d / C=%d beyond the kernel's limits", groups, x.C);
     const int cols = std::min(256, x.C / 8), ppi = 256 / cols;
     int P = std::max(ppi, std::min(64 * ppi, (xr.T * batch + 1023) / 1024));
@@ -512,7 +518,7 @@ int mf_groupnorm_affine(const ActView& x, const float* gamma, const float* beta,
 int mf_groupnorm_stats(const ActView& x, int groups, double* stats, int batch, hipStream_t s) {
     MF_REQUIRE(x.C % groups == 0 && x.C % 8 == 0 && x.coff % 8 == 0, "groupnorm: C=%d groups=%d", x.C, groups);
     MF_REQUIRE(groups <= 64 && x.C <= 8 * 256 * GN_MAXCOL, "groupnorm: groups=%d / C=%d beyond the kernel's limits", groups, x.C);
-    const Rows xr = rows_of(x);
+    const Rows xr = rows_of(x, x.C / groups);
     const int cols = std::min(256, x.C / 8), ppi = 256 / cols;
     const int P = std::max(ppi, std::min(64 * ppi, (xr.T * batch + 1023) / 1024));
     hipLaunchKernelGGL(k_gn_stats, dim3((xr.T + P - 1) / P, batch), dim3(256), 0, s, xr, groups, x.C / groups, x.C, P, stats);
@@ -524,8 +530,8 @@ int mf_groupnorm(const ActView& x, const ActView& y, const float* gamma, const f
                  bool silu, double* stats, int batch, hipStream_t s, bool have_stats) {
     MF_REQUIRE(x.C == y.C && x.C % groups == 0 && x.C % 8 == 0 && x.coff % 8 == 0 && y.coff % 8 == 0, "groupnorm: C=%d groups=%d", x.C, groups);
     MF_REQUIRE(x.buf->H == y.buf->H && x.buf->W == y.buf->W, "groupnorm: spatial mismatch");
-    const Rows xr = rows_of(x), yr = rows_of(y);
     const int cpg = x.C / groups;
+    const Rows xr = rows_of(x, cpg), yr = rows_of(y);
     MF_REQUIRE(groups <= 64 && x.C <= 8 * 256 * GN_MAXCOL, "groupnorm: groups=%d / C=%d beyond the kernel's limits", groups, x.C);
     // pixels per workgroup: enough workgroups to fill the chip, at most 64 pixels per thread column
     const int cols = std::min(256, x.C / 8), ppi = 256 / cols;
