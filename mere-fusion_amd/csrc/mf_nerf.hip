@@ -253,7 +253,19 @@ __global__ __launch_bounds__(NT) void k_loop_march(const int* __restrict__ ctl, 
     const uint32_t total = rays_here * n_step;
     const size_t slab = (size_t)base * n_step;
     for (uint32_t i = threadIdx.x; i < total; i += NT) {
-        const uint32_t r = i / n_step, k = i - r * n_step;
+        // (n_step is 1 ... 8 and wave-uniform: a division by a CONSTANT is a multiply and a shift, by a register ~25 instructions)
+        uint32_t r;
+        switch (n_step) {
+            case 1: r = i; break;
+            case 2: r = i >> 1; break;
+            case 3: r = i / 3u; break;
+            case 4: r = i >> 2; break;
+            case 5: r = i / 5u; break;
+            case 6: r = i / 6u; break;
+            case 7: r = i / 7u; break;
+            default: r = n_step == 8 ? i >> 3 : i / n_step; break;
+        }
+        const uint32_t k = i - r * n_step;
         float x = 0.f, y = 0.f, z = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, dt = 0.f, t1 = 0.f;
         if ((int)k < s_cnt[r]) {
             const float t = s_t[k][r];
