@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(Rows X, Rows Y, const float* _
                 for (int q = 0; q < 2; ++q) {
                     const float x = nbf2f(q ? hh[e] >> 16 : hh[e] & 0xffffu) + nbf2f(q ? ll[e] >> 16 : ll[e] & 0xffffu);
                     float v = (x - mu[2 * e + q]) * rs[2 * e + q] * sc[2 * e + q] + sh[2 * e + q];
-                    if (silu) v = v / (1.f + __expf(-v));
+                    if (silu) v = v * __builtin_amdgcn_rcpf(1.f + __expf(-v));   // (v_rcp_f32, 1 ulp, as the VAE's converter pass: the IEEE division is ~10 instructions per value)
                     out2[q] = v;
                 }
                 const uint32_t h0 = nf2bf(out2[0]), h1 = nf2bf(out2[1]);
