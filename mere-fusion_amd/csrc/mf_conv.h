@@ -216,15 +216,4 @@ int mf_groupnorm_stats(const ActView& x, int groups, double* stats, int batch, h
 int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
                    int batch, hipStream_t stream, int tokens = 0);
 
-// n / d for 0 <= n < 2^31 as (n * mul) >> (32 + shr): s = ceil(log2 d), mul = floor(2^(31 + s) / d) + 1, shr = s - 1 (mul * d = 2^(31 + s) + e with 0 < e <= d <= 2^s, so
-// the error term n e / (d 2^(31 + s)) stays below 1 / d).  d == 1 is mul = 0: the quotient is n.
-inline void mf_fastdiv(uint32_t d, uint32_t* mul, uint32_t* shr) {
-    if (d <= 1) { *mul = 0; *shr = 0; return; }
-    uint32_t s = 0;
-    while ((1ull << s) < d) ++s;
-    *mul = (uint32_t)(((1ull << (31 + s)) / d) + 1);
-    *shr = s - 1;
-}
-#ifdef __HIPCC__
-__device__ __forceinline__ int mf_fdiv(int n, uint32_t mul, uint32_t shr) { return mul ? (int)(__umulhi((uint32_t)n, mul) >> shr) : n; }
-#endif
+#include "mf_fastdiv.h"
