@@ -304,6 +304,9 @@ template <int DH, int KT>
 int launch_qb(AttnArgs& a, int groups, bool x3, hipStream_t s) {
     // 32 queries per wave halve the K / V^T fragment reads per MFMA; take them when the chip still gets >= 2 waves of
     // workgroups, otherwise spread the queries over more workgroups
+    // (round 5 A/Bs on the UNet's 1024 x 1024 self-attention, 64 us per launch: 16 instead of 32 queries per wave -- same step time; two LDS images and one barrier
+    // per key tile instead of two -- same step time.  The loop is vector-bound: softmax + the (hi, lo) split of P are ~600 instructions + 34 exponentials per wave and
+    // 64-key tile against 84 MFMAs.)
     const bool wide = (int64_t)groups * ((a.Tq + 127) / 128) >= 512;
     if (DH <= 80 && wide) {
         a.qtiles = (a.Tq + 127) / 128;
