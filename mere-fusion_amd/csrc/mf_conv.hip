@@ -74,7 +74,36 @@ __device__ __forceinline__ void add_residual(const ConvArgs& a, float (&v)[4], i
 }
 
 // act: 0 none, 1 ReLU, 2 sigmoid, 3 GELU (erf form, torch.nn.GELU default), 4 SiLU
+// GELU (erf form) of the GEGLU epilogue: erf by Abramowitz & Stegun 7.1.26 -- 1 - (a1 t + ... + a5 t^5) exp(-x^2), t = 1 / (1 + p |x|), |error| <= 1.5e-7 -- in ~12
+// vector instructions where the library's erff() takes ~30: a 128 x 128 GEGLU tile evaluates it 32 times per lane, after its MFMAs and with nothing to overlap it
+// (one workgroup per CU), and the stored (hi, lo) pair resolves 2^-17 of the value anyway.  MF_GELU_EXACT builds keep erff() (A/B, tools/ab_build.sh).
+#ifndef MF_GELU_EXACT
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+#if defined(MF_ERF_V) && (MF_ERF_V & 1)
+    const float t = 1.f / fmaf(0.3275911f, ax, 1.f);
+#else
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+#endif
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+#if defined(MF_ERF_V) && (MF_ERF_V & 2)
+    const float r = 1.f - p * t * expf(-ax * ax);
+#else
+    const float r = 1.f - p * t * __expf(-ax * ax);
+#endif
+#if defined(MF_ERF_V) && (MF_ERF_V & 4)
+    return x < 0.f ? -r : r;
+#else
+    return copysignf(r, x);
+#endif
+}
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erf_as(g * 0.70710678118654752f)); }
+#else
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
+#endif
 
 // residual / activation / (hi, lo) store of one channel quad; v holds the stored values on return
 __device__ __forceinline__ void epilogue_store_v(const ConvArgs& a, float (&v)[4], int64_t yo, int64_t ro, int c, bool x3) {
@@ -538,6 +567,9 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
+#ifdef MF_EPI_NOPS
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
     if (dbg && threadIdx.x == 0) dbg[2] = __builtin_amdgcn_s_memtime();
     if (a.ws) {
         // split-K: fp32 partial tile, combined by k_splitk_epilogue
@@ -592,8 +624,15 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
                 int c = n0 + cn0 + i * 16 + fk * 4;
                 c = c < a.Npad - 3 ? c : a.Npad - 4;
                 const float4 cs = *reinterpret_cast<const float4*>(a.ln_cs + c);
-                v[0] = rs * (acc[i][j][0] - mu * cs.x) + bq[i].x; v[1] = rs * (acc[i][j][1] - mu * cs.y) + bq[i].y;
-                v[2] = rs * (acc[i][j][2] - mu * cs.z) + bq[i].z; v[3] = rs * (acc[i][j][3] - mu * cs.w) + bq[i].w;
+                // One scalar FMA per value, pinned by empty asm statements: left alone the compiler packs these into v_pk_fma_f32 with op_sel broadcasts of mu / rs (which
+                // come out of fp64 conversions just above), and THAT form returned wrong values for one channel of a 16-pixel fragment now and then -- different rows
+                // on every call, whole-network error 1e-2 in one build, a 1.6e-5 dependence of a frame's latents on its position in the batch in another (found with
+                // MF_DEBUG=copies / tools/unet_copies_probe.py after an unrelated change to this kernel moved its registers).  With the scalar form every copy of a
+                // frame is bit-identical wherever it sits.  Eight instructions per fragment quad more, in an epilogue.
+                float t0 = acc[i][j][0] - mu * cs.x, t1 = acc[i][j][1] - mu * cs.y, t2 = acc[i][j][2] - mu * cs.z, t3 = acc[i][j][3] - mu * cs.w;
+                asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+                v[0] = rs * t0 + bq[i].x; v[1] = rs * t1 + bq[i].y; v[2] = rs * t2 + bq[i].z; v[3] = rs * t3 + bq[i].w;
+                asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
             };
             auto pack = [&](const float (&v)[4], uint2& hi2, uint2& lo2) __attribute__((always_inline)) {
                 uint32_t h[4];
@@ -974,11 +1013,19 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int n
         const float mu = (float)mean, rs = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)a.ln_eps));
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 s = splitk_sum(w, a.ws_split, nsplit, z), cs = *reinterpret_cast<const float4*>(a.ln_cs + c), bb = *reinterpret_cast<const float4*>(a.bias + c);
-        v[0] = rs * (s.x - mu * cs.x) + bb.x; v[1] = rs * (s.y - mu * cs.y) + bb.y; v[2] = rs * (s.z - mu * cs.z) + bb.z; v[3] = rs * (s.w - mu * cs.w) + bb.w;
+        // (scalar FMAs pinned against packing, as in k_conv_igemm's LayerNorm epilogue: see the note there)
+        auto ln4 = [&](const float4& q, const float4& cq, const float4& bq4, float (&o)[4]) __attribute__((always_inline)) {
+            float t0 = q.x - mu * cq.x, t1 = q.y - mu * cq.y, t2 = q.z - mu * cq.z, t3 = q.w - mu * cq.w;
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+            o[0] = rs * t0 + bq4.x; o[1] = rs * t1 + bq4.y; o[2] = rs * t2 + bq4.z; o[3] = rs * t3 + bq4.w;
+            asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+        };
+        ln4(s, cs, bb, v);
         if (geglu) {
             const float4 g = splitk_sum(w + 16, a.ws_split, nsplit, z), cg = *reinterpret_cast<const float4*>(a.ln_cs + c + 16), bg = *reinterpret_cast<const float4*>(a.bias + c + 16);
-            v[0] *= gelu_erf(rs * (g.x - mu * cg.x) + bg.x); v[1] *= gelu_erf(rs * (g.y - mu * cg.y) + bg.y);
-            v[2] *= gelu_erf(rs * (g.z - mu * cg.z) + bg.z); v[3] *= gelu_erf(rs * (g.w - mu * cg.w) + bg.w);
+            float gt[4];
+            ln4(g, cg, bg, gt);
+            v[0] *= gelu_erf(gt[0]); v[1] *= gelu_erf(gt[1]); v[2] *= gelu_erf(gt[2]); v[3] *= gelu_erf(gt[3]);
         }
     } else {
         const float4 s = splitk_sum(w, a.ws_split, nsplit, *reinterpret_cast<const float4*>(a.bias + c));
@@ -1672,9 +1719,71 @@ static bool launch_combine_stats(const ConvPlan* p, ConvArgs e, int nsplit, int 
 int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,
                    int batch, hipStream_t stream, int tokens) {
     bool stats_done = false;
-    const int rc = conv_launch_impl(p, in, out, res, batch, stream, tokens, &stats_done);
-    if (rc || !p->out_stats || stats_done) return rc;
-    return mf_groupnorm_stats(out, p->out_stats_groups, p->out_stats, batch, stream);
+    int rc = conv_launch_impl(p, in, out, res, batch, stream, tokens, &stats_done);
+    if (!rc && p->out_stats && !stats_done) rc = mf_groupnorm_stats(out, p->out_stats_groups, p->out_stats, batch, stream);
+    // MF_DEBUG=copies (development, eager launches only: it synchronises): for a batch of IDENTICAL items, reports every layer whose input, output or statistics of
+    // an item differ from item 0's -- a row's result may not depend on where its image sits in the batch (tools/unet_copies_probe.py)
+    static const bool copies = mf_debug_has("copies");
+    if (copies && !rc && batch > 1) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cs);
+        if (cs == hipStreamCaptureStatusNone) {
+            MF_HIP(hipStreamSynchronize(stream));
+            auto differ = [&](const ActView& v, int* first) -> double {
+                const ActBuf& b = *v.buf;
+                const size_t n = (size_t)b.per_batch();
+                std::vector<bf16_t> h0(n), hk(n), l0(b.lo ? n : 0), lk(b.lo ? n : 0);
+                (void)hipMemcpy(h0.data(), b.hi, n * sizeof(bf16_t), hipMemcpyDeviceToHost);
+                if (b.lo) (void)hipMemcpy(l0.data(), b.lo, n * sizeof(bf16_t), hipMemcpyDeviceToHost);
+                double worst = 0.0;
+                for (int k = 1; k < batch; ++k) {
+                    (void)hipMemcpy(hk.data(), b.hi + (size_t)k * n, n * sizeof(bf16_t), hipMemcpyDeviceToHost);
+                    if (b.lo) (void)hipMemcpy(lk.data(), b.lo + (size_t)k * n, n * sizeof(bf16_t), hipMemcpyDeviceToHost);
+                    double w = 0.0;
+                    size_t cnt = 0, first_i = 0, last_i = 0;
+                    int cmin = 1 << 30, cmax = -1;
+                    for (size_t i = 0; i < n; ++i) {
+                        const int c = (int)(i % b.C);
+                        if (c < v.coff || c >= v.coff + v.C) continue;
+                        const double a0 = (double)mf_bf2f(h0[i]) + (b.lo ? (double)mf_bf2f(l0[i]) : 0.0), ak = (double)mf_bf2f(hk[i]) + (b.lo ? (double)mf_bf2f(lk[i]) : 0.0);
+                        const double e = std::fabs(a0 - ak);
+                        if (e > 1e-3) { if (!cnt) first_i = i; last_i = i; ++cnt; cmin = std::min(cmin, c); cmax = std::max(cmax, c); }
+                        w = std::max(w, e);
+                    }
+                    if (cnt && w > worst)
+                        fprintf(stderr, "[MF_DEBUG=copies]   item %d: %zu elements off by > 1e-3, padded pixels %zu .. %zu (row pitch %d px), channels %d .. %d\n", k, cnt, first_i / b.C,
+                                last_i / b.C, b.Wp(), cmin, cmax);
+                    if (w > worst) { worst = w; *first = k; }
+                }
+                return worst;
+            };
+            int ki = 0, ko = 0;
+            const double di = differ(in, &ki), dout = differ(out, &ko);
+            // the per-token LayerNorm statistics this layer reads / leaves ([item][token][2] doubles)
+            auto stats_differ = [&](const double* dev, int tokens_per_item, int* first) -> double {
+                if (!dev) return 0.0;
+                std::vector<double> h((size_t)batch * tokens_per_item * 2);
+                (void)hipMemcpy(h.data(), dev, h.size() * sizeof(double), hipMemcpyDeviceToHost);
+                double worst = 0.0;
+                for (int k = 1; k < batch; ++k)
+                    for (int i = 0; i < tokens_per_item * 2; ++i) {
+                        const double w = std::fabs(h[(size_t)k * tokens_per_item * 2 + i] - h[i]);
+                        if (w > worst) { worst = w; *first = k; }
+                    }
+                return worst;
+            };
+            int ksi = 0, kso = 0;
+            const double dsi = stats_differ(p->ln_in, in.buf->H * in.buf->W, &ksi), dso = stats_differ(p->ln_out, out.buf->H * out.buf->W, &kso);
+            if (dsi > 0.0 || dso > 0.0) fprintf(stderr, "[MF_DEBUG=copies] LayerNorm statistics: read differ by %.3e (item %d), left differ by %.3e (item %d)\n", dsi, ksi, dso, kso);
+            if (di > 0.0 || dout > 0.0) {
+                char kn[96];
+                mf_conv_kernel_name(p, batch, kn, sizeof(kn));
+                fprintf(stderr, "[MF_DEBUG=copies] %d->%d k%d @%dx%d act %d%s%s: input differs by %.3e (item %d), output by %.3e (item %d)  %s\n", p->d.cin, p->d.cout, p->d.kh, p->d.in_h,
+                        p->d.in_w, p->d.act, p->ln_in ? " ln_in" : "", p->ln_out ? " ln_out" : "", di, ki, dout, ko, kn);
+            }
+        }
+    }
+    return rc;
 }
 
 static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, const ActView& res,

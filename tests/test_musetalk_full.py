@@ -129,6 +129,25 @@ def test_full_vae_batch8_matches_batch1(hip_full):
         assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 0.01, (i, int(d.max()), float((d > 0).float().mean()))
 
 
+def test_full_unet_copies_of_a_frame_are_bit_identical_at_every_batch_position(hip_full):
+    """Eight copies of ONE frame in a batch: the eight outputs must be the same bits, call after call.  (The five-copy check of the 40-frame handle below places
+    copies 8 frames apart, where every copy meets the same tile and fragment positions.  This one caught a LayerNorm-folding epilogue whose packed FMAs returned a
+    wrong channel for a 16-pixel fragment now and then -- 1.6e-5 between copies 0 and 3 in one build of the library, 1e-2 noise in another: DESIGN.md section 4.)"""
+    unet, vae = hip_full
+    lat, aud = W.make_musetalk_inputs(1, 3)
+    lat, aud = lat.repeat(B, 1, 1, 1).cuda(), aud.repeat(B, 1, 1).cuda()
+    first = None
+    for call in range(3):
+        pred = unet.model(lat, torch.tensor([0]).cuda(), encoder_hidden_states=unet.pe(aud)).sample
+        frames = vae.decode_latents_device(pred)
+        for k in range(1, B):
+            assert torch.equal(pred[k], pred[0]), (call, k, float((pred[k] - pred[0]).abs().max()))
+            assert torch.equal(frames[k], frames[0]), (call, k)
+        if first is None:
+            first = pred.clone()
+        assert torch.equal(pred, first), call
+
+
 def test_full_unet_large_batch_handle_vs_oracle(full_sd, oracle_full):
     """A UNet handle at 40 frames per step (five sessions in one MuseBatcher step): the 320-channel 3x3 convs of the 32 x 32 level run on the LDS-weights
     halo tile there (the implicit GEMM below 40 frames), the 256 x 256 implicit-GEMM tiles appear -- kernel choices the batch-8 handle never makes.  The
