@@ -80,25 +80,13 @@ __device__ __forceinline__ void add_residual(const ConvArgs& a, float (&v)[4], i
 #ifndef MF_GELU_EXACT
 __device__ __forceinline__ float erf_as(float x) {
     const float ax = fabsf(x);
-#if defined(MF_ERF_V) && (MF_ERF_V & 1)
-    const float t = 1.f / fmaf(0.3275911f, ax, 1.f);
-#else
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
-#endif
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
-#if defined(MF_ERF_V) && (MF_ERF_V & 2)
-    const float r = 1.f - p * t * expf(-ax * ax);
-#else
     const float r = 1.f - p * t * __expf(-ax * ax);
-#endif
-#if defined(MF_ERF_V) && (MF_ERF_V & 4)
-    return x < 0.f ? -r : r;
-#else
     return copysignf(r, x);
-#endif
 }
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erf_as(g * 0.70710678118654752f)); }
 #else
@@ -567,9 +555,6 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
-#ifdef MF_EPI_NOPS
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
     if (dbg && threadIdx.x == 0) dbg[2] = __builtin_amdgcn_s_memtime();
     if (a.ws) {
         // split-K: fp32 partial tile, combined by k_splitk_epilogue
