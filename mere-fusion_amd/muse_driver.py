@@ -19,6 +19,7 @@ Cross-session batching is what fills an MI355X: the UNet at 8 frames per step is
 import ctypes as C
 import queue
 import threading
+import weakref
 import time
 from collections import deque
 
@@ -312,23 +313,39 @@ class EndToEndScheduler(SessionScheduler):
         # busy, with or without the blocking-sync event flag, and hipDeviceScheduleBlockingSync hangs on this driver: tools/host_wait_probe.py.)
         self._wake = threading.Event()
         self._evq = queue.SimpleQueue()
-        self._waiter = threading.Thread(target=self._wait_loop, daemon=True)
-        self._waiter.start()
+        self._waiter = None                                          # started by the first step: a scheduler that never steps owns no thread
+        self.waiter_errors = []                                      # exceptions hipEventQuery raised in the waiter (a device error is not a completion)
         self.ring_full = 0                                           # deferral EPISODES (a session found its ring full), not polls
         self._deferred = {}                                          # session -> time at which it is offered again even if its ring still looks full
         self._busy_until = 0.0
 
-    def _wait_loop(self):
+    @staticmethod
+    def _wait_loop(evq, wake, errors):
+        """The waiter holds the queue, the wake flag and the error list -- NOT the scheduler: an abandoned scheduler (no close()) is collected with its batcher,
+        rings and GPU handles, and its finaliser below stops this thread."""
         while True:
-            ev = self._evq.get()
+            ev = evq.get()
             if ev is None:
                 return
             try:
                 while not ev.query():
                     time.sleep(5e-4)
-            except Exception:
-                pass
-            self._wake.set()
+            except Exception as e:                                   # recorded, then the loop is woken: _retire's own query raises the same error to the caller
+                errors.append(e)
+            wake.set()
+
+    def _start_waiter(self):
+        if self._waiter is None:
+            self._waiter = threading.Thread(target=EndToEndScheduler._wait_loop, args=(self._evq, self._wake, self.waiter_errors), daemon=True)
+            self._waiter.start()
+            weakref.finalize(self, self._evq.put, None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def idle_wait(self, timeout):
         """Sleeps until a step in flight completes or `timeout` seconds have passed, whichever is first (nothing in flight: a plain sleep).  What a serving
@@ -342,8 +359,11 @@ class EndToEndScheduler(SessionScheduler):
             time.sleep(timeout)
 
     def close(self):
-        """stops the waiter thread (after drain())"""
-        self._evq.put(None)
+        """stops the waiter thread (after drain(); `with EndToEndScheduler(...) as sch:` calls it)"""
+        if self._waiter is not None:
+            self._evq.put(None)
+            self._waiter.join(timeout=2.0)
+            self._waiter = None
 
     def submit(self, k, pcm_chunks, t_arrival=None):
         """pcm_chunks: the batch's 2B 20 ms chunks -- bare arrays (all speech, type 0) or (chunk, type) pairs exactly as `get_audio_frame` hands them out
@@ -421,42 +441,51 @@ class EndToEndScheduler(SessionScheduler):
             B = self.batcher.batch_size
             pend = self.pending()
             ok = []
-            for k in sorted(pend, key=lambda k_: (pend[k_], k_)):     # oldest first; a waiting session takes the place of one that has to be deferred
-                if len(ok) == len(ks):
-                    break
-                sl = self.rings[k].try_reserve(B)                     # (silent batches too: their B (None, idx, audio) tuples take B of the ring's places)
-                if sl is None:
-                    self.ring_full += 1
-                    self._deferred[k] = now + self.period / 4
-                    continue
-                reserved[k] = sl
-                ok.append(k)
+            try:
+                for k in sorted(pend, key=lambda k_: (pend[k_], k_)):     # oldest first; a waiting session takes the place of one that has to be deferred
+                    if len(ok) == len(ks):
+                        break
+                    sl = self.rings[k].try_reserve(B)                     # (silent batches too: their B (None, idx, audio) tuples take B of the ring's places)
+                    if sl is None:
+                        self.ring_full += 1
+                        self._deferred[k] = now + self.period / 4
+                        continue
+                    reserved[k] = sl
+                    ok.append(k)
+            except BaseException:
+                for k in list(reserved):                                  # a ring that raised (closed, torn down) must not leave the others' places open
+                    self.rings[k].unreserve(reserved[k])
+                raise
             ks = ok
             if not ks:
                 return done
-        arrival, audio, wins = {}, {}, {}
-        for k in ks:
-            arrival[k], (wins[k], audio[k]) = self.queues[k].popleft()
-        t0 = self.clock()
-        chunks = [None] * len(self.queues)
-        speaking = [k for k in ks if wins[k] is not None]
-        if speaking and self.fixed_chunks is not None:
-            for k in speaking:
-                chunks[k] = self.fixed_chunks
-        elif speaking:
-            cur = torch.cuda.current_stream(dev)
-            side = self.asr_stream if self.asr_stream is not None else cur
-            with torch.cuda.stream(side):
-                wav = torch.from_numpy(np.stack([wins[k] for k in speaking])).to(dev, non_blocking=True)
-                feats = self.audio_processor.audio2feat_windows_device(wav)        # every picked session's window in one encoder call
-                for i, k in enumerate(speaking):
-                    chunks[k] = self.frontends[k].chunks_from_features(feats[i])
-            if side is not cur:
-                cur.wait_stream(side)                                              # the UNet below reads the chunks
-                for t in [wav, feats] + [chunks[k] for k in speaking]:
-                    t.record_stream(cur)
-        tokens = {}
+        # Everything from here to the last begin_batch sits in ONE try: the rings publish in begin order, so a reservation left open by an exception anywhere
+        # on the way (the queue pop, the H2D copy, the Whisper call, the step, a begin_batch) would wedge its ring for good -- every later batch queued behind
+        # an entry that never completes.  On any exception the reservations go back and the popped batches return to the HEAD of their queues.
+        arrival, audio, wins, tokens, popped = {}, {}, {}, {}, []
         try:
+            for k in ks:
+                item = self.queues[k].popleft()
+                popped.append((k, item))
+                arrival[k], (wins[k], audio[k]) = item
+            t0 = self.clock()
+            chunks = [None] * len(self.queues)
+            speaking = [k for k in ks if wins[k] is not None]
+            if speaking and self.fixed_chunks is not None:
+                for k in speaking:
+                    chunks[k] = self.fixed_chunks
+            elif speaking:
+                cur = torch.cuda.current_stream(dev)
+                side = self.asr_stream if self.asr_stream is not None else cur
+                with torch.cuda.stream(side):
+                    wav = torch.from_numpy(np.stack([wins[k] for k in speaking])).to(dev, non_blocking=True)
+                    feats = self.audio_processor.audio2feat_windows_device(wav)        # every picked session's window in one encoder call
+                    for i, k in enumerate(speaking):
+                        chunks[k] = self.frontends[k].chunks_from_features(feats[i])
+                if side is not cur:
+                    cur.wait_stream(side)                                              # the UNet below reads the chunks
+                    for t in [wav, feats] + [chunks[k] for k in speaking]:
+                        t.record_stream(cur)
             out = self.batcher.step(chunks, only=ks)
             ev = torch.cuda.Event()
             if self.rings is not None:
@@ -476,10 +505,13 @@ class EndToEndScheduler(SessionScheduler):
                 self.rings[k].abort_batch(tokens[k])
             for k in list(reserved):
                 self.rings[k].unreserve(reserved[k])
+            for k, item in reversed(popped):                       # the batches of this step are not lost: they are picked again
+                self.queues[k].appendleft(item)
             raise
         if self.rings is None:
             ev.record(torch.cuda.current_stream(dev))
         self.inflight.append({"ks": ks, "out": out, "tokens": tokens, "audio": audio, "arrival": arrival, "event": ev, "t0": t0})
+        self._start_waiter()
         self._evq.put(ev)
         self.steps += 1
         self.sessions_served += len(ks)

@@ -52,6 +52,7 @@ class FrameRing:
         self._head = 0                                             # producer-side cursor (single producer)
         self._registered = False
         self._inbox = deque()                                      # consumer side: descriptors of the message being unpacked
+        self._views_out, self._held = 0, 0                         # consumer side: get(copy=False) views not yet released / releases held behind them
         self._open = deque()                                       # producer side: outstanding reservations / batches, oldest first
 
     # ---- pickling: a child process re-attaches to the same block ---------------------------------------------------------------
@@ -316,18 +317,35 @@ class FrameRing:
             break
         if shape is None:                                            # a silent frame: a slot without a payload, free again at once
             if slot is not None:
-                self._free.release()
+                self._release_in_order()
             return None, idx, audio
         view = self._slot_view(slot, shape, dtype)
         if copy:
             out = view.copy()
-            self._free.release()
+            self._release_in_order()
             return out, idx, audio
+        self._views_out += 1
         return view, idx, audio
 
+    def _release_in_order(self):
+        """The free count is a counter and the producer hands slots out by cursor order, so "one more free slot" always means the OLDEST unreleased one.  While
+        the consumer still holds a copy=False view of an earlier frame, a later frame's slot (a silent frame's, or one taken with copy=True) may therefore not be
+        released yet -- the producer could wrap onto the slot still being read.  Its release is held until the outstanding views are back."""
+        if self._views_out > 0:
+            self._held += 1
+        else:
+            self._free.release()
+
     def release(self, view=None):
-        """Hands a slot obtained with get(copy=False) back to the producer (slots are consumed in order)."""
+        """Hands a slot obtained with get(copy=False) back to the producer (slots are consumed in order: views are released oldest first)."""
+        if self._views_out <= 0:
+            raise RuntimeError("FrameRing.release: no get(copy=False) view is outstanding")
+        self._views_out -= 1
         self._free.release()
+        if self._views_out == 0:
+            while self._held:
+                self._held -= 1
+                self._free.release()
 
     def qsize(self):
         """frames waiting on the consumer's side (an estimate, like mp.Queue.qsize): unpacked descriptors + whole messages still in the pipe"""

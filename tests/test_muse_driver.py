@@ -442,3 +442,83 @@ def test_hip_end_to_end_scheduler_silent_batches_with_a_stalled_consumer_never_b
     assert served.count(0) == 4 and not sch.pending()
     for r in rings:
         r.close()
+
+
+def test_end_to_end_scheduler_returns_reservations_and_batches_when_a_step_fails():
+    """ADVICE r05 (host logic only): the rings publish in begin order, so a reservation leaked by an exception between try_reserve and begin_batch -- the queue
+    pop, the Whisper stage, the step -- would wedge that ring for good.  Whatever raises, every reservation goes back and the popped batches return to the head
+    of their queues."""
+    from collections import deque
+    from types import SimpleNamespace
+    import queue as _q
+    import threading
+
+    class Ring:
+        def __init__(self):
+            self.open, self.begun, self.aborted = [], [], []
+
+        def free_slots(self):
+            return 16
+
+        def try_reserve(self, n):
+            tok = object()
+            self.open.append(tok)
+            return tok
+
+        def unreserve(self, tok):
+            self.open.remove(tok)
+
+        def begin_batch(self, fr, idx, stream=None, reserved=None):
+            self.open.remove(reserved)
+            self.begun.append(reserved)
+            return reserved
+
+        def abort_batch(self, tok):
+            self.aborted.append(tok)
+
+    def make(step, fixed_chunks):
+        sch = D.EndToEndScheduler.__new__(D.EndToEndScheduler)
+        sch.queues = [deque([(0.1, ("win0", ["a0"])), (0.5, ("win0b", ["a0b"]))]), deque([(0.2, ("win1", ["a1"]))])]
+        sch.capacity, sch.hold, sch.period, sch.clock, sch.depth = 2, 0.0, 0.32, (lambda: 1.0), 2
+        sch.batcher = SimpleNamespace(batch_size=8, device="cpu", step=step)
+        sch.rings = [Ring(), Ring()]
+        sch.inflight, sch._deferred, sch.ring_full, sch.copy_stream, sch.asr_stream = deque(), {}, 0, None, None
+        sch.fixed_chunks, sch.frontends, sch.audio_processor = fixed_chunks, [None, None], None
+        sch._evq, sch._wake, sch._waiter, sch.waiter_errors = _q.SimpleQueue(), threading.Event(), None, []
+        sch.steps = sch.sessions_served = 0
+        sch.busy_s, sch._busy_until = 0.0, 0.0
+        return sch
+
+    def boom(chunks, only=None):
+        raise RuntimeError("step failed")
+
+    # (a) the step itself raises
+    sch = make(boom, fixed_chunks="chunks")
+    with pytest.raises(RuntimeError, match="step failed"):
+        sch.run_once(now=1.0)
+    assert all(not r.open and not r.begun for r in sch.rings)                     # no reservation left open
+    assert [q[0][0] for q in sch.queues] == [0.1, 0.2] and len(sch.queues[0]) == 2   # both batches back at the head of their queues, order kept
+    # (b) the Whisper stage raises (no device here: torch.cuda.current_stream is the first thing it touches)
+    sch = make(boom, fixed_chunks=None)
+    with pytest.raises(Exception):
+        sch.run_once(now=1.0)
+    assert all(not r.open for r in sch.rings) and [q[0][0] for q in sch.queues] == [0.1, 0.2]
+    # (c) the second ring's begin_batch raises after the first one's succeeded: the begun token is aborted, the other reservation returned
+    def ok_step(chunks, only=None):
+        return {k: (None, [0]) for k in only}
+    sch = make(ok_step, fixed_chunks="chunks")
+    def bad_begin(fr, idx, stream=None, reserved=None):
+        sch.rings[1].unreserve(reserved)                                             # (FrameRing.begin_batch returns its reservation itself when it fails)
+        raise RuntimeError("ring torn down")
+    sch.rings[1].begin_batch = bad_begin
+    import torch
+    real_event, real_cur = torch.cuda.Event, torch.cuda.current_stream
+    torch.cuda.Event = lambda *a, **k: SimpleNamespace(record=lambda *_: None, query=lambda: True, synchronize=lambda: None)
+    torch.cuda.current_stream = lambda *a, **k: None
+    try:
+        with pytest.raises(RuntimeError, match="ring torn down"):
+            sch.run_once(now=1.0)
+    finally:
+        torch.cuda.Event, torch.cuda.current_stream = real_event, real_cur
+    assert sch.rings[0].aborted == sch.rings[0].begun and len(sch.rings[0].aborted) == 1 and not sch.rings[1].open
+    assert sch._waiter is None                                                       # no step succeeded: no waiter thread was ever started

@@ -232,3 +232,29 @@ def test_ring_silent_frames_take_places_and_a_failed_begin_returns_its_reservati
         ring.begin_batch(np.zeros((3, 4, 4, 3), np.uint8), [0, 1], reserved=ring.try_reserve(2))
     assert ring.free_slots() == 4 and ring.try_reserve(4) == [0, 1, 2, 3]
     ring.close()
+
+
+def test_a_later_slot_is_not_released_while_an_earlier_view_is_held():
+    """the free count is a counter and the producer takes slots in cursor order, so releasing a silent frame's slot (or a copied frame's) while a
+    copy=False view of an EARLIER frame is still held would let the producer wrap onto the slot being read.  The release is held until the view is back."""
+    ring = FrameRing(slots=2, frame_shape=(4, 4, 3))
+    a = np.full((4, 4, 3), 7, np.uint8)
+    ring.put((a, 0, []))
+    ring.put((None, 1, []))                                          # a silent frame holds a ring place too
+    time.sleep(0.05)
+    view, idx, _ = ring.get(timeout=5, copy=False)
+    assert idx == 0 and int(view[0, 0, 0]) == 7
+    f, idx, _ = ring.get(timeout=5)                                  # the silent frame, taken while the view is still out
+    assert f is None and idx == 1
+    with pytest.raises(queue.Full):
+        ring.put((a * 2, 2, []), block=True, timeout=0.05)           # its place is NOT free yet: the producer's next slot is the one under the view
+    assert int(view[0, 0, 0]) == 7
+    ring.release()                                                   # the view goes back, and the held release with it
+    ring.put((a * 2, 2, []), timeout=5)
+    ring.put((a * 3, 3, []), timeout=5)
+    f2, i2, _ = ring.get(timeout=5)
+    f3, i3, _ = ring.get(timeout=5)
+    assert (i2, i3) == (2, 3) and int(f2[0, 0, 0]) == 14 and int(f3[0, 0, 0]) == 21
+    with pytest.raises(RuntimeError, match="no get"):
+        ring.release()                                               # nothing outstanding: a stray release would corrupt the count
+    ring.close()
