@@ -354,6 +354,9 @@ int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const float* rays_
  * NULL when none was passed to the render call. */
 int mf_nerf_head_finish(mf_nerf_head* h, int n_rays, const float* bg_color, int bg_per_ray, float bg_const, float* image, float* depth,
                         const float* weights_sum, uint8_t* frame_u8, void* stream);
+/* The per-ray sums `run_cuda` also returns at inference (`results['ambient_aud' | 'ambient_eye' | 'uncertainty']`, renderer.py:286-288) of the LAST frame
+ * rendered through `h`: device-to-device copies enqueued on `stream` behind that frame (any of the three may be NULL). */
+int mf_nerf_head_sums(mf_nerf_head* h, int n_rays, float* ambient_aud, float* ambient_eye, float* uncertainty, void* stream);
 void mf_nerf_head_destroy(mf_nerf_head* h);
 
 /* ---- ER-NeRF torso branch --------------------------------------------------------------------- */

@@ -162,6 +162,7 @@ SIGNATURES = {
     "mf_nerf_head_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 5),
     "mf_nerf_head_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 5),
+    "mf_nerf_head_sums": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4),
     "mf_nerf_head_destroy": (None, [C.c_void_p]),
     "mf_nerf_torso_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mf_nerf_torso_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 4),
@@ -212,9 +213,12 @@ def check(rc, what=""):
 
 
 _inited = set()
+_device_inited = False          # read by placement.py: once HIP is up in this process, HIP_VISIBLE_DEVICES can no longer choose its GPU
 
 
 def init_device(index):
+    global _device_inited
     if index not in _inited:
         check(lib().mf_init(int(index)), "mf_init")
         _inited.add(index)
+        _device_inited = True

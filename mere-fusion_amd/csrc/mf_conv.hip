@@ -609,11 +609,13 @@ __global__ __launch_bounds__((WGM * WGN + (LD == 3 ? igemm_producers<BM, BN, BK>
                 int c = n0 + cn0 + i * 16 + fk * 4;
                 c = c < a.Npad - 3 ? c : a.Npad - 4;
                 const float4 cs = *reinterpret_cast<const float4*>(a.ln_cs + c);
-                // One scalar FMA per value, pinned by empty asm statements: left alone the compiler packs these into v_pk_fma_f32 with op_sel broadcasts of mu / rs (which
-                // come out of fp64 conversions just above), and THAT form returned wrong values for one channel of a 16-pixel fragment now and then -- different rows
-                // on every call, whole-network error 1e-2 in one build, a 1.6e-5 dependence of a frame's latents on its position in the batch in another (found with
-                // MF_DEBUG=copies / tools/unet_copies_probe.py after an unrelated change to this kernel moved its registers).  With the scalar form every copy of a
-                // frame is bit-identical wherever it sits.  Eight instructions per fragment quad more, in an epilogue.
+                // One scalar FMA per value, pinned by empty asm statements.  Left alone the compiler packs these into v_pk_fma_f32 and keeps (mu, rs) in ONE register pair,
+                // and for the last fragment of a wave it multiplies by rs as `v_pk_fma_f32 ... op_sel:[0,1,0]` -- the LOW result takes src1's HIGH register.  On gfx950 that
+                // form returns a wrong low half in lanes 48..63 (src1 read as zero: the value comes out as the bias alone) whenever another wave of the same SIMD is
+                // issuing MFMAs, which the neighbouring workgroups of this kernel are: one channel of a 16-pixel fragment wrong now and then, elsewhere on every call
+                // (round 5: 1e-2 noise on the UNet's latents in one build, a 1.6e-5 dependence on the batch position in another).  Round 6 reproduced the erratum in
+                // isolation (tools/pkfma_repro.hip: 0.09 % of executions; op_sel_hi forms and src0 / src2 selects are clean) and checks every build for the form
+                // (tools/isa_scan.py, mf_common.h mf_opaque).  Eight instructions per fragment quad more than the packed form, in an epilogue.
                 float t0 = acc[i][j][0] - mu * cs.x, t1 = acc[i][j][1] - mu * cs.y, t2 = acc[i][j][2] - mu * cs.z, t3 = acc[i][j][3] - mu * cs.w;
                 asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
                 v[0] = rs * t0 + bq[i].x; v[1] = rs * t1 + bq[i].y; v[2] = rs * t2 + bq[i].z; v[3] = rs * t3 + bq[i].w;
@@ -998,7 +1000,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int n
         const float mu = (float)mean, rs = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)a.ln_eps));
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 s = splitk_sum(w, a.ws_split, nsplit, z), cs = *reinterpret_cast<const float4*>(a.ln_cs + c), bb = *reinterpret_cast<const float4*>(a.bias + c);
-        // (scalar FMAs pinned against packing, as in k_conv_igemm's LayerNorm epilogue: see the note there)
+        // (scalar FMAs pinned against packing, as in k_conv_igemm's LayerNorm epilogue: the gfx950 packed-fp32 op_sel erratum, see the note there)
         auto ln4 = [&](const float4& q, const float4& cq, const float4& bq4, float (&o)[4]) __attribute__((always_inline)) {
             float t0 = q.x - mu * cq.x, t1 = q.y - mu * cq.y, t2 = q.z - mu * cq.z, t3 = q.w - mu * cq.w;
             asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
@@ -1760,6 +1762,46 @@ int mf_conv_launch(ConvPlan* p, const ActView& in, const ActView& out, const Act
             int ksi = 0, kso = 0;
             const double dsi = stats_differ(p->ln_in, in.buf->H * in.buf->W, &ksi), dso = stats_differ(p->ln_out, out.buf->H * out.buf->W, &kso);
             if (dsi > 0.0 || dso > 0.0) fprintf(stderr, "[MF_DEBUG=copies] LayerNorm statistics: read differ by %.3e (item %d), left differ by %.3e (item %d)\n", dsi, ksi, dso, kso);
+            // MF_DEBUG_DUMP=<prefix>: the first layer whose copies disagree although its inputs agree leaves both items' outputs, its LayerNorm statistics, column sums and
+            // bias as raw files (<prefix>_meta.txt, _y0.f32, _yk.f32, _stats.f64, _cs.f32, _bias.f32) for offline analysis (tools/pkfma_dump_analyze.py)
+            static bool dumped = false;
+            const char* dump = getenv("MF_DEBUG_DUMP");
+            if (dump && !dumped && di == 0.0 && dout > 0.0) {
+                dumped = true;
+                const ActBuf& b = *out.buf;
+                const size_t n = (size_t)b.per_batch();
+                auto plane = [&](int item, std::vector<float>& f) {
+                    std::vector<bf16_t> h(n), l(b.lo ? n : 0);
+                    (void)hipMemcpy(h.data(), b.hi + (size_t)item * n, n * sizeof(bf16_t), hipMemcpyDeviceToHost);
+                    if (b.lo) (void)hipMemcpy(l.data(), b.lo + (size_t)item * n, n * sizeof(bf16_t), hipMemcpyDeviceToHost);
+                    f.resize(n);
+                    for (size_t i = 0; i < n; ++i) f[i] = mf_bf2f(h[i]) + (b.lo ? mf_bf2f(l[i]) : 0.f);
+                };
+                auto put = [&](const char* suffix, const void* data, size_t bytes) {
+                    const std::string path = std::string(dump) + suffix;
+                    if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(data, 1, bytes, f); fclose(f); }
+                };
+                std::vector<float> y0, yk;
+                plane(0, y0); plane(ko, yk);
+                put("_y0.f32", y0.data(), n * 4); put("_yk.f32", yk.data(), n * 4);
+                const int tok = in.buf->H * in.buf->W;
+                if (p->ln_in) {
+                    std::vector<double> st((size_t)tok * 2);
+                    (void)hipMemcpy(st.data(), p->ln_in, st.size() * 8, hipMemcpyDeviceToHost);
+                    put("_stats.f64", st.data(), st.size() * 8);
+                    std::vector<float> cs(p->Npad);
+                    (void)hipMemcpy(cs.data(), p->ln_cs, cs.size() * 4, hipMemcpyDeviceToHost);
+                    put("_cs.f32", cs.data(), cs.size() * 4);
+                }
+                std::vector<float> bias(p->Npad);
+                (void)hipMemcpy(bias.data(), p->bias, bias.size() * 4, hipMemcpyDeviceToHost);
+                put("_bias.f32", bias.data(), bias.size() * 4);
+                char kn2[96], meta[512];
+                mf_conv_kernel_name(p, batch, kn2, sizeof(kn2));
+                snprintf(meta, sizeof(meta), "C %d\nWp %d\nH %d\nW %d\nhalo %d\ncoff %d\nvC %d\ncin %d\ncout %d\nNpad %d\nitem %d\ntokens %d\nln_eps %g\nact %d\nkernel %s\n", b.C, b.Wp(), b.H, b.W,
+                         b.halo, out.coff, out.C, p->d.cin, p->d.cout, p->Npad, ko, tok, (double)p->ln_eps, p->d.act, kn2);
+                put("_meta.txt", meta, strlen(meta));
+            }
             if (di > 0.0 || dout > 0.0) {
                 char kn[96];
                 mf_conv_kernel_name(p, batch, kn, sizeof(kn));

@@ -737,8 +737,8 @@ __global__ __launch_bounds__((WGM * WGN + (SP ? 4 : 0)) * 64, HS == 1 ? 2 : 1) v
                 if constexpr (W16) {
                     if (a.wide_store) {                                   // (wave-uniform; every lane takes part in the exchange, the store is masked)
                         if (row_ok && c < a.N) {
-                            gs[i] += (v[0] + v[1]) + (v[2] + v[3]);
-                            gq[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                            gs[i] += mf_sum4(v[0], v[1], v[2], v[3]);      // sums of neighbours of one register pair: see mf_opaque (mf_common.h)
+                            gq[i] += mf_sum4(v[0] * v[0], v[1] * v[1], v[2] * v[2], v[3] * v[3]);
                         }
                         uint32_t h[4], l[4];
 #pragma unroll
@@ -750,8 +750,8 @@ __global__ __launch_bounds__((WGM * WGN + (SP ? 4 : 0)) * 64, HS == 1 ? 2 : 1) v
                 }
                 if (!row_ok || c >= a.N) continue;
                 if constexpr (Q) {
-                    gs[i] += (v[0] + v[1]) + (v[2] + v[3]);
-                    gq[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    gs[i] += mf_sum4(v[0], v[1], v[2], v[3]);      // sums of neighbours of one register pair: see mf_opaque (mf_common.h)
+                    gq[i] += mf_sum4(v[0] * v[0], v[1] * v[1], v[2] * v[2], v[3] * v[3]);
                 }
                 uint32_t h[4];
 #pragma unroll

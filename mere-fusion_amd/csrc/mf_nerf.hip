@@ -306,7 +306,7 @@ __device__ __forceinline__ bool composite_ray(uint32_t n, uint32_t n_step, float
         if (dl[0] == 0) break;
         const float alpha = 1.0f - __expf(-sg[0] * dl[0]);
         const float T = 1 - weight_sum;
-        const float weight = alpha * T;
+        const float weight = alpha * mf_opaque(T);          // (alpha, T) share a register pair: see mf_opaque
         weight_sum += weight;
         t = dl[1];
         d += weight * t;
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(CT) void k_loop_composite(int* ctl, int N, int max_
                 else {
                     const float alpha = 1.0f - __expf(-sg[k] * d0[k]);
                     const float T = 1 - weight_sum;
-                    const float weight = alpha * T;
+                    const float weight = alpha * mf_opaque(T);          // (alpha, T) share a register pair: see mf_opaque
                     weight_sum += weight;
                     t = d1[k];
                     d += weight * t;

@@ -690,4 +690,14 @@ extern "C" int mf_nerf_head_finish(mf_nerf_head* h, int n_rays, const float* bg_
     return mf_nerf_finish(image, depth, weights_sum ? weights_sum : h->wsum, h->nears, h->fars, bg_color, bg_per_ray, bg_const, n_rays, frame_u8, stream);
 }
 
+extern "C" int mf_nerf_head_sums(mf_nerf_head* h, int n_rays, float* ambient_aud, float* ambient_eye, float* uncertainty, void* stream) {
+    MF_REQUIRE(h && n_rays > 0 && n_rays <= h->cap, "nerf_head_sums: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t bytes = (size_t)n_rays * sizeof(float);
+    if (ambient_aud) MF_HIP(hipMemcpyAsync(ambient_aud, h->aasum, bytes, hipMemcpyDeviceToDevice, s));
+    if (ambient_eye) MF_HIP(hipMemcpyAsync(ambient_eye, h->aesum, bytes, hipMemcpyDeviceToDevice, s));
+    if (uncertainty) MF_HIP(hipMemcpyAsync(uncertainty, h->unsum, bytes, hipMemcpyDeviceToDevice, s));
+    return MF_OK;
+}
+
 extern "C" void mf_nerf_head_destroy(mf_nerf_head* h) { delete h; }

@@ -5,4 +5,7 @@ ahead of the reference checkout on sys.path; see INTEGRATION.md.  Modules that a
 from pkgutil import extend_path
 
 __path__ = extend_path(__path__, __name__)
+from mere_fusion_amd import placement as _placement  # noqa: E402
+
+_placement.ensure_placed(session=False)      # multi-GPU node: the process takes a GPU before anything touches the device (lipreal.py:29 `device = 'cuda'`); the models charge a session each
 from . import audio  # noqa: E402,F401

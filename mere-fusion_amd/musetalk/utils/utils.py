@@ -5,6 +5,7 @@ import os
 import numpy as np
 import torch
 
+from ... import placement
 from ..models.unet import UNet
 from ..models.vae import VAE
 from ..whisper.audio2feature import Audio2Feature
@@ -23,9 +24,14 @@ def load_diffusion_model():
 
 
 def load_all_model():
-    """musetalk/utils/utils.py:19-25 -> (audio_processor, vae, unet, pe)."""
+    """musetalk/utils/utils.py:19-25 -> (audio_processor, vae, unet, pe).  musereal.py:55 calls it in the session's own process (`inference`): on a multi-GPU
+    node this is where that process takes its GPU (placement.py), before anything touches the device."""
+    placed = placement.ensure_placed(session=True)
     audio_processor = load_audio_model()
     vae, unet, pe = load_diffusion_model()
+    if placed is not None:
+        import weakref
+        weakref.finalize(unet, placement.uncharge, 1.0)               # the session's share of its GPU goes back when its models die
     return audio_processor, vae, unet, pe
 
 

@@ -13,7 +13,7 @@ import os
 import torch
 from torch import nn
 
-from ... import _lib, ops
+from ... import _lib, ops, placement
 
 
 class _Block(nn.Module):
@@ -65,6 +65,9 @@ class Wav2Lip(nn.Module):
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {self.precision!r}")
         self._handle = None
         self._handle_device = None
+        # lipreal.py:43-53 builds the model in the session's own process and then says `.to('cuda')`: on a multi-GPU node this is where the process takes its
+        # GPU (placement.py: least-loaded, before the HIP runtime is up; a no-op with one GPU, under torch.distributed.run, or with MF_PLACEMENT=0)
+        placement.charge_session(self)
 
     # ---- handle lifetime: any change to the parameters invalidates the packed weights ----------
     def _drop_handle(self):

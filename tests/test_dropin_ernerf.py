@@ -1,0 +1,156 @@
+"""The ER-NeRF drop-in seam (VERDICT r05 missing #1): `from ernerf.nerf_triplane.network import NeRFNetwork` (app.py:17) with only PYTHONPATH changed must give
+the reference's own class with the MI355X render path in front, and a frame rendered through `model.render(...)` must come from the device loop
+(mf_nerf_head_render) and match the reference's golden frame.
+
+CPU part (needs the reference checkout, which the GPU box does not have): the import chain, the class wiring, invalidation on load_state_dict, the
+no-CPU-path error.  GPU part (no reference there): the same mixin in front of a stand-in base that carries the reference's attributes and state-dict names --
+the golden frame of tests/golden/ernerf_golden.npz was rendered by the reference's NeRFNetwork itself (tests/golden/make_ernerf_golden.py)."""
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+REF = "/root/reference"
+
+_PROBE = r'''
+import sys, importlib, argparse
+from unittest import mock
+for _ in range(60):
+    try:
+        net = importlib.import_module("ernerf.nerf_triplane.network")      # app.py:17
+        break
+    except ModuleNotFoundError as e:                                          # third-party modules the inference path never touches (cv2, trimesh, ...)
+        sys.modules[e.name] = mock.MagicMock(name=e.name)
+import torch
+from mere_fusion_amd.ernerf.network import HipRenderMixin
+mro = net.NeRFNetwork.__mro__
+assert mro[1] is HipRenderMixin, mro
+assert mro[2].__module__ == "ernerf.nerf_triplane._reference_network" and mro[2].__name__ == "NeRFNetwork", mro
+assert net._ref.__file__.startswith("REFROOT"), net._ref.__file__
+assert net.AudioNet is net._ref.AudioNet and net.MLP is net._ref.MLP
+import ernerf.nerf_triplane.renderer as R, ernerf.nerf_triplane.provider as P    # fall through to the reference's own files
+assert R.__file__.startswith("REFROOT") and P.__file__.startswith("REFROOT")
+assert issubclass(net.NeRFNetwork, R.NeRFRenderer)
+opt = argparse.Namespace(asr_model="esperanto", emb=False, att=2, bound=1, min_near=0.05, density_thresh=10, density_thresh_torso=0.01, exp_eye=True,
+                         test_train=False, smooth_lips=False, torso=False, cuda_ray=True, ind_num=16, ind_dim=4, train_camera=False, unc_loss=1)
+m = net.NeRFNetwork(opt).eval()                                                  # app.py:379
+keys = set(m.state_dict())
+assert {"encoder_xy.embeddings", "sigma_net.net.0.weight", "audio_net.encoder_conv.0.weight", "density_bitfield", "individual_codes"} <= keys
+m.__dict__["_mf"] = {"stale": True}
+m.load_state_dict(m.state_dict())                                                # Trainer.load_checkpoint
+assert m._mf is None, "load_state_dict must drop the device objects"
+m.__dict__["_mf"] = {"stale": True}
+m.float()
+assert m._mf is None, "_apply must drop the device objects"
+N = 16
+try:
+    m.render(torch.zeros(1, N, 3), torch.zeros(1, N, 3), torch.zeros(8, 44, 16), torch.zeros(1, N, 2), torch.eye(4)[None], eye=torch.zeros(1, 1), index=[0],
+             staged=True, bg_color=None, perturb=False, dt_gamma=1 / 256, max_steps=16)
+    raise SystemExit("rendering CPU tensors must raise")
+except RuntimeError as e:
+    assert "no CPU path" in str(e), e
+print("DROPIN-OK")
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "ernerf")), reason="no reference checkout here (the GPU box)")
+def test_reference_import_resolves_to_the_mixed_in_class(lib_built):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "mere-fusion_amd", "dropin"), REF]), MF_PLACEMENT="0")
+    out = subprocess.run([sys.executable, "-c", _PROBE.replace("REFROOT", REF)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DROPIN-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+class _ReferenceShapedBase(torch.nn.Module):
+    """What `HipRenderMixin` touches of the reference's NeRFNetwork / NeRFRenderer (renderer.py:62-133, network.py:93-165): attributes, buffers and parameters
+    under the reference's names.  Its own `run_cuda` fails: if the mixin fell back to the base, the test would know."""
+
+    def __init__(self, opt, sd):
+        super().__init__()
+        self.opt, self.bound, self.grid_size, self.density_scale, self.min_near = opt, opt.bound, 128, 1, opt.min_near
+        self.exp_eye, self.test_train, self.smooth_lips, self.torso, self.train_camera = opt.exp_eye, False, opt.smooth_lips, False, False
+        self.individual_dim, self.emb, self.att = opt.ind_dim, False, opt.att
+        self.density_thresh_torso, self.mean_density_torso = 0.01, 0.0
+        self.individual_codes = torch.nn.Parameter(torch.zeros(opt.ind_num, opt.ind_dim))
+        self.register_buffer("density_bitfield", torch.zeros(128 ** 3 // 8, dtype=torch.uint8))
+        self._names = {}
+        for k, v in sd.items():
+            name = "p_" + k.replace(".", "__")
+            self.register_parameter(name, torch.nn.Parameter(v.clone(), requires_grad=False))
+            self._names[name] = k
+        if self.smooth_lips:
+            self.enc_a = None
+
+    def state_dict(self, *a, **k):
+        sd = super().state_dict(*a, **k)
+        return {self._names.get(key, key): v for key, v in sd.items()}
+
+    def load_state_dict(self, sd, *a, **k):
+        back = {v: n for n, v in self._names.items()}
+        return super().load_state_dict({back.get(key, key): v for key, v in sd.items()}, *a, **k)
+
+    def run_cuda(self, *a, **k):
+        raise AssertionError("the reference's run_cuda was reached: the device loop did not run")
+
+    def render(self, rays_o, rays_d, auds, bg_coords, poses, staged=False, max_ray_batch=4096, **kwargs):          # renderer.py:657-677
+        return self.run_cuda(rays_o, rays_d, auds, bg_coords, poses, **kwargs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("smooth", [False, True])
+def test_hip_render_through_the_mixin_matches_the_reference_golden(lib_built, smooth):
+    from mere_fusion_amd import weights as W
+    from mere_fusion_amd.ernerf.network import HipRenderMixin
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ernerf_golden.npz"))
+    sd = W.make_ernerf_field_state_dict(int(g["offsets"][-1]), 0)
+    sd = {k: (v * 0.35 if k.startswith("sigma_net.net.2") else v) for k, v in sd.items()}
+    sd.update({k[len("audio_sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("audio_sd/")})
+    opt = argparse.Namespace(asr_model="esperanto", emb=False, att=2, bound=1, min_near=0.05, exp_eye=True, smooth_lips=smooth, ind_num=16, ind_dim=4)
+
+    class Net(HipRenderMixin, _ReferenceShapedBase):
+        pass
+
+    m = Net(opt, sd)
+    with torch.no_grad():
+        m.individual_codes[0].copy_(torch.from_numpy(g["render_ind_code"]))
+        m.density_bitfield.copy_(torch.from_numpy(W.make_ernerf_sphere_bitfield()))
+    m = m.cuda().eval()
+    m.density_scale = 40.0                                                      # set after construction, as the GUI does: read per frame
+    Wd = int(g["render_W"])
+    ro, rd = W.make_ernerf_camera_rays(Wd)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    bg = torch.tensor([0.1, 0.2, 0.3]).expand(Wd * Wd, 3).contiguous().cuda()
+    kw = dict(eye=cu(g["field_e"]), index=[0], staged=True, bg_color=bg, perturb=False, dt_gamma=1 / 256, max_steps=16, T_thresh=1e-4)
+    res = m.render(cu(ro)[None], cu(rd)[None], cu(g["auds"]), torch.zeros(1, Wd * Wd, 2, device="cuda"), torch.eye(4, device="cuda")[None], **kw)
+    assert m.mf_frames == 1 and tuple(res["image"].shape) == (1, Wd * Wd, 3) and tuple(res["depth"].shape) == (1, Wd * Wd)
+    err = np.abs(res["image"].reshape(-1, 3).cpu().numpy() - g["render_image"]).max()
+    derr = np.abs(res["depth"].reshape(-1).cpu().numpy() - g["render_depth"]).max()
+    aerr = np.abs(res["ambient_aud"].reshape(-1).cpu().numpy() - g["render_amb_aud"])
+    eerr = np.abs(res["ambient_eye"].reshape(-1).cpu().numpy() - g["render_amb_eye"])
+    print(f"model.render through the drop-in mixin (smooth_lips={smooth}) vs the reference's golden frame: image {err:.3e}, depth {derr:.3e}, "
+          f"ambient sums {aerr.max():.3e} / {eerr.max():.3e}")
+    assert err <= 1e-3 and derr <= 1e-3
+    assert (aerr / (1 + np.abs(g["render_amb_aud"]))).max() <= 2e-3 and eerr.max() <= 2e-3
+    # a second frame: the first frame's lazy sums are gone, the EMA state lives on the module as the reference keeps it (renderer.py:190-194)
+    res2 = m.render(cu(ro)[None], cu(rd)[None], cu(g["auds"]) * 1.1, torch.zeros(1, Wd * Wd, 2, device="cuda"), torch.eye(4, device="cuda")[None], **kw)
+    assert m.mf_frames == 2
+    m.render(cu(ro)[None], cu(rd)[None], cu(g["auds"]), torch.zeros(1, Wd * Wd, 2, device="cuda"), torch.eye(4, device="cuda")[None], **kw)
+    with pytest.raises(KeyError, match="gone"):
+        res2["ambient_aud"]                                                    # res2's frame is no longer the head's last one
+    if smooth:
+        assert m.enc_a is not None and tuple(m.enc_a.shape) == (1, 32)
+        assert float((res2["image"] - res["image"]).abs().max()) > 0            # another audio window, another frame
+    # weights change -> the device objects are rebuilt from the new state dict
+    first = m._mf["renderer"]
+    m.load_state_dict(m.state_dict())
+    assert m._mf is None
+    m.render(cu(ro)[None], cu(rd)[None], cu(g["auds"]), torch.zeros(1, Wd * Wd, 2, device="cuda"), torch.eye(4, device="cuda")[None], **kw)
+    assert m._mf["renderer"] is not first
+    # training mode leaves the fast path (and here reaches the stand-in's failing run_cuda)
+    m.train()
+    with pytest.raises(AssertionError, match="reference's run_cuda"):
+        m.render(cu(ro)[None], cu(rd)[None], cu(g["auds"]), torch.zeros(1, Wd * Wd, 2, device="cuda"), torch.eye(4, device="cuda")[None], **kw)

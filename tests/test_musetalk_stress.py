@@ -68,3 +68,40 @@ def test_vae_f16_fp6_under_channel_scale_stress(lib_built, seed, one_sided):
           f"on values up to {scale:.2f} (gate {TOL_IMAGE}); uint8 max diff {d.max()}, differing pixels {100 * (d > 0).mean():.3f} %")
     assert np.isfinite(ierr) and ierr <= TOL_IMAGE, (ierr, scale)
     assert d.max() <= 1 and (d > 0).mean() < TOL_U8_FRACTION, (d.max(), (d > 0).mean())
+
+
+def test_vae_on_a_map_that_is_not_a_multiple_of_64_pixels(lib_built):
+    """maps whose pixel count is not a multiple of 64 take the per-thread-parameter conversion kernel (k_affine_silu_to_q, the fallback of
+    mf_affine_silu_to_act_q) and ragged 16 x 16 tiles of the f16 + FP6 conv; nothing at the BASELINE sizes does.  A 9 x 9 latent grid (18^2, 36^2, 72^2 maps:
+    36^2 = 1296 = 20.25 x 64 pixels, 512 channels, two and a quarter tiles per side) against the fp32 oracle, same gates as the full-size decoder."""
+    from mere_fusion_amd.musetalk.models.vae import VAE
+    from mere_fusion_amd import _lib
+    from oracle import musetalk_ref as R
+    import ctypes as C
+    B = 4
+    vsd = W.make_musetalk_vae_state_dict(MUSETALK_V1, 0)
+    cfg = vae_config_json(MUSETALK_V1["vae"])
+    cfg["latent_size"] = 9
+    vae = VAE(config=cfg, state_dict=vsd, max_batch=B)
+    # the op list of the handle must show the conversion pass on the 36 x 36 level (otherwise this test no longer covers the fallback kernel)
+    l = _lib.lib()
+    n = l.mf_vae_num_ops(vae._h)
+    kernels = []
+    for i in range(n):
+        nm, kn, fl = C.create_string_buffer(160), C.create_string_buffer(160), C.c_double()
+        l.mf_vae_op_info(vae._h, i, nm, 160, kn, 160, C.byref(fl))
+        kernels.append(kn.value.decode())
+    assert any("k_affine_silu_to_q" in k for k in kernels), kernels
+    lat = (torch.randn(2, 4, 9, 9, generator=torch.Generator().manual_seed(77)) * 0.18215).repeat(B // 2, 1, 1, 1)
+    want_img = R.vae_decode(vsd, MUSETALK_V1["vae"], lat[:2] / MUSETALK_V1["vae"]["scaling_factor"])
+    want_u8 = R.decode_latents(vsd, MUSETALK_V1["vae"], lat[:2])
+    frames, image = vae.decode_latents_device(lat.cuda(), want_image=True)
+    assert tuple(frames.shape) == (B, 72, 72, 3)
+    ierr = (image.cpu()[:2] - want_img).abs().max().item()
+    d = np.abs(frames.cpu().numpy()[:2].astype(int) - want_u8.astype(int))
+    same = (frames[:2] == frames[2:]).all().item()
+    print(f"sd-vae-ft-mse decoder on a 9 x 9 latent grid ({n} ops): image L-inf {ierr:.3e} (gate {TOL_IMAGE}); uint8 max diff {d.max()}, differing pixels {100 * (d > 0).mean():.3f} %; "
+          f"copies bit-identical: {same}")
+    assert np.isfinite(ierr) and ierr <= TOL_IMAGE
+    assert d.max() <= 1 and (d > 0).mean() < TOL_U8_FRACTION
+    assert same

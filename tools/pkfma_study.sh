@@ -1,14 +1,17 @@
-# GPU box: the packed-FMA root-cause study.  bash tools/pkfma_study.sh [calls]   (after tools/pkfma_variants.sh + the reproducer were built here)
+# GPU box: the packed-FMA root-cause study.  bash tools/pkfma_study.sh <calls> <variant> ...   ("shipped" = the product library;
+# other names = build_ab/lib<name>.so from tools/pkfma_variants.sh / tools/pkfma_variants2.py, built in the container)
 cd $GRAFT_REPO_ROOT
-N=${1:-40}
+N=${1:-40}; shift
 O=gpurun_out/pkfma_study.txt
-: > $O
-echo "== standalone reproducer (tools/pkfma_repro.hip)" | tee -a $O
-timeout 300 tools/bin/pkfma_repro 200 2>&1 | tee -a $O
-for v in "" packed packed_nop packed_f32 dbg_fast dbg_fast_nops dbg_fast_scalar; do
-  [ -n "$v" ] && [ ! -f build_ab/lib$v.so ] && continue
-  echo "== library: ${v:-shipped}" | tee -a $O
-  env ${v:+MF_LIB_PATH=build_ab/lib$v.so} timeout 600 python tools/unet_copies_probe.py 8 $N 2>&1 | grep -v Warning | tail -12 | tee -a $O
+export MF_TUNE_CACHE=$GRAFT_REPO_ROOT/mere-fusion_amd/tune/gfx950.txt        # every build launches the shipped configurations
+for v in "$@"; do
+  if [ "$v" = repro ]; then
+    echo "== standalone reproducer (tools/pkfma_repro.hip)" | tee -a $O
+    timeout 300 tools/bin/pkfma_repro 200 2>&1 | tee -a $O
+    continue
+  fi
+  [ "$v" != shipped ] && [ ! -f build_ab/lib$v.so ] && continue
+  echo "== library: $v" | tee -a $O
+  if [ "$v" = shipped ]; then timeout 600 python tools/unet_copies_probe.py 8 $N 2>&1 | grep "^\[\|^call [01]:" | tee -a $O
+  else MF_LIB_PATH=build_ab/lib$v.so timeout 600 python tools/unet_copies_probe.py 8 $N 2>&1 | grep "^\[build\|^call [01]:" | tee -a $O; fi
 done
-echo "== MF_DEBUG=copies, packed build, eager" | tee -a $O
-MF_LIB_PATH=build_ab/libpacked.so MF_DEBUG=copies MF_NO_GRAPH=1 timeout 900 python tools/unet_copies_probe.py 8 6 2>&1 | grep "copies\|call" | head -60 | tee -a $O
