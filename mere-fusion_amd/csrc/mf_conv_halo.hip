@@ -24,11 +24,6 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-// Ablation builds (tools/halo_ablate.sh; wrong results, timing only): bit 0 = no epilogue stores / residual reads, bit 1 = weights loaded
-// once instead of streamed, bit 2 = no per-slice halo DMA, bit 3 = pixel fragments read from LDS once per slice.
-#ifndef MF_HALO_ABLATE
-#define MF_HALO_ABLATE 0
-#endif
 #ifndef MF_HALO_RING9
 #define MF_HALO_RING9 0
 #endif
@@ -147,7 +142,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4 && (PH / WGM) * (BN
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
             const bf16_t* src = wsrc[i] + (int64_t)step * w_tap;
-            if ((MF_HALO_ABLATE & 2) && step >= RING) continue;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 wr[ring][i][kk][0] = *reinterpret_cast<const bf16x8*>(src + kk * 32);
@@ -216,7 +210,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4 && (PH / WGM) * (BN
                 const int step2 = slice * 9 + tap + DIST;
                 load_step((tap + DIST) % RING, step2 < n_steps ? step2 : n_steps - 1);
             }
-            if (idx + 1 < NF && !((MF_HALO_ABLATE & 8) && idx > 0)) rd(idx + 1, n_hi, n_lo);
+            if (idx + 1 < NF) rd(idx + 1, n_hi, n_lo);
             // pin the prefetch ABOVE this fragment's MFMAs (hipcc otherwise sinks it to its first use
             // and every MFMA group eats a full LDS round trip)
             __builtin_amdgcn_sched_barrier(0);
@@ -244,7 +238,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4 && (PH / WGM) * (BN
         const bool more = slice + 1 < a.n_slices;
         if (NST == 2) {
             const int st = slice & 1;
-            if (more && !(MF_HALO_ABLATE & 4)) load_halo(slice + 1, st ^ 1);   // flies under this slice's MFMAs
+            if (more) load_halo(slice + 1, st ^ 1);   // flies under this slice's MFMAs
             compute(st, slice);
             if (more) __syncthreads();         // next halo landed; everyone is done with this one
         } else {
@@ -260,15 +254,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4 && (PH / WGM) * (BN
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
-    if (MF_HALO_ABLATE & 1) {
-        float keep = 0.f;
-#pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (keep == 1234.5f) a.y_hi[0] = 1;
-        return;
-    }
     // Loads ahead of the stores they do not depend on (see mf_conv_halo2.hip's epilogue): bias quads once, the residuals of a row group
     // in one burst, then that group's stores -- a load issued behind a store waits for the store's acknowledgement too (one in-order vmcnt).
     float4 bq[FN];
@@ -278,7 +263,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4 && (PH / WGM) * (BN
         c = c < a.Npad - 3 ? c : a.Npad - 4;
         bq[i] = *reinterpret_cast<const float4*>(a.bias + c);
     }
-    const bool has_res = a.r_hi != nullptr && !(MF_HALO_ABLATE & 0);
+    const bool has_res = a.r_hi != nullptr;
     const int ox = x0 + fr;
     constexpr int JG = (FM * FN * NP <= 32) ? FM : (32 / (FN * NP) >= 1 ? 32 / (FN * NP) : 1);   // rows per residual burst
 #pragma unroll

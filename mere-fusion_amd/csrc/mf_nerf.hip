@@ -106,21 +106,21 @@ __global__ __launch_bounds__(NT) void k_march_rays(uint32_t n_alive, uint32_t n_
     const float dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / (float)H;
     const float dt_min = fminf(dt_max, 2 * SQRT3 / (float)max_steps);
     uint32_t step = 0;
-    t += clampf_(t * dt_gamma, dt_min, dt_max) * noise;
+    t = fmaf(clampf_(t * dt_gamma, dt_min, dt_max), noise, t);                    /* the reference build contracts this (and the lines marked fmaf below) */
     while (t < far && step < n_step) {
-        const float x = clampf_(ox + t * dx, -bound, bound);
-        const float y = clampf_(oy + t * dy, -bound, bound);
-        const float z = clampf_(oz + t * dz, -bound, bound);
+        const float x = clampf_(fmaf(t, dx, ox), -bound, bound);
+        const float y = clampf_(fmaf(t, dy, oy), -bound, bound);
+        const float z = clampf_(fmaf(t, dz, oz), -bound, bound);
         const float dt = clampf_(t * dt_gamma, dt_min, dt_max);
         const int la = mip_from_pos(x, y, z, (float)C), lb = mip_from_dt(dt, (float)H, (float)C);
         const int level = la > lb ? la : lb;
         const float mip_bound = fminf(scalbnf(1.f, level), bound);
         const float mip_rbound = 1 / mip_bound;
         // the reference forms this product in double (`0.5 * ...`), narrows to float in clamp() and truncates
-        const int nx = (int)clampf_((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-        const int ny = (int)clampf_((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-        const int nz = (int)clampf_((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-        const uint32_t gi = (uint32_t)((float)level * H3 + (float)morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        const int nx = (int)clampf_((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+        const int ny = (int)clampf_((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+        const int nz = (int)clampf_((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+        const uint32_t gi = (uint32_t)fmaf((float)level, H3, (float)morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
         const bool occ = grid[gi / 8] & (1 << (gi % 8));
         if (occ) {
             px[0] = x; px[1] = y; px[2] = z;
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(NT) void k_march_rays(uint32_t n_alive, uint32_t n_
             px += 3; pd += 3; pt += 2;
             step++;
         } else {
-            const float tx = ((((float)nx + 0.5f + 0.5f * signf_(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
-            const float ty = ((((float)ny + 0.5f + 0.5f * signf_(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
-            const float tz = ((((float)nz + 0.5f + 0.5f * signf_(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+            const float tx = fmaf(mip_bound, fmaf(((float)nx + 0.5f + 0.5f * signf_(dx)) * rH, 2.0f, -1.0f), -x) * rdx;
+            const float ty = fmaf(mip_bound, fmaf(((float)ny + 0.5f + 0.5f * signf_(dy)) * rH, 2.0f, -1.0f), -y) * rdy;
+            const float tz = fmaf(mip_bound, fmaf(((float)nz + 0.5f + 0.5f * signf_(dz)) * rH, 2.0f, -1.0f), -z) * rdz;
             const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
             do {
                 t += clampf_(t * dt_gamma, dt_min, dt_max);
@@ -187,24 +187,24 @@ __global__ __launch_bounds__(NT) void k_loop_march(const int* __restrict__ ctl, 
         const float mip_bound0 = fminf(1.f, bound), mip_rbound0 = 1 / mip_bound0, halfH = 0.5f * (float)H;
         // voxel of the position at parameter tj: clamped position, cell, occupancy bit index, mip bound -- the reference's operations in its order
         auto cell = [&](float tj, float dtj, float& x, float& y, float& z, int& nx, int& ny, int& nz, uint32_t& gi, float& mip_bound) __attribute__((always_inline)) {
-            x = clampf_(ox + tj * dx, -bound, bound);
-            y = clampf_(oy + tj * dy, -bound, bound);
-            z = clampf_(oz + tj * dz, -bound, bound);
+            x = clampf_(fmaf(tj, dx, ox), -bound, bound);
+            y = clampf_(fmaf(tj, dy, oy), -bound, bound);
+            z = clampf_(fmaf(tj, dz, oz), -bound, bound);
             if constexpr (FAST) {
                 mip_bound = mip_bound0;
-                nx = (int)clampf_((x * mip_rbound0 + 1) * halfH, 0.0f, (float)(H - 1));
-                ny = (int)clampf_((y * mip_rbound0 + 1) * halfH, 0.0f, (float)(H - 1));
-                nz = (int)clampf_((z * mip_rbound0 + 1) * halfH, 0.0f, (float)(H - 1));
+                nx = (int)clampf_(fmaf(x, mip_rbound0, 1.0f) * halfH, 0.0f, (float)(H - 1));
+                ny = (int)clampf_(fmaf(y, mip_rbound0, 1.0f) * halfH, 0.0f, (float)(H - 1));
+                nz = (int)clampf_(fmaf(z, mip_rbound0, 1.0f) * halfH, 0.0f, (float)(H - 1));
                 gi = s_spread[nx] | (s_spread[ny] << 1) | (s_spread[nz] << 2);       // = morton3d(nx, ny, nz)
             } else {
                 const int la = mip_from_pos(x, y, z, (float)C), lb = mip_from_dt(dtj, (float)H, (float)C);
                 const int level = la > lb ? la : lb;
                 mip_bound = fminf(scalbnf(1.f, level), bound);
                 const float mip_rbound = 1 / mip_bound;
-                nx = (int)clampf_((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-                ny = (int)clampf_((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-                nz = (int)clampf_((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-                gi = (uint32_t)((float)level * H3 + (float)morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+                nx = (int)clampf_((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+                ny = (int)clampf_((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+                nz = (int)clampf_((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+                gi = (uint32_t)fmaf((float)level, H3, (float)morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
             }
         };
         // The reference's loop (raymarching.cu:862-925) reads one occupancy bit per iteration and the next position depends on it: a ray
@@ -238,9 +238,9 @@ __global__ __launch_bounds__(NT) void k_loop_march(const int* __restrict__ ctl, 
                     step++;
                     tt = -FLT_MAX;
                 } else {
-                    const float tx = ((((float)nxs[j] + 0.5f + 0.5f * signf_(dx)) * rH * 2 - 1) * mbs[j] - xs[j]) * rdx;
-                    const float ty = ((((float)nys[j] + 0.5f + 0.5f * signf_(dy)) * rH * 2 - 1) * mbs[j] - ys[j]) * rdy;
-                    const float tz = ((((float)nzs[j] + 0.5f + 0.5f * signf_(dz)) * rH * 2 - 1) * mbs[j] - zs[j]) * rdz;
+                    const float tx = fmaf(mbs[j], fmaf(((float)nxs[j] + 0.5f + 0.5f * signf_(dx)) * rH, 2.0f, -1.0f), -xs[j]) * rdx;
+                    const float ty = fmaf(mbs[j], fmaf(((float)nys[j] + 0.5f + 0.5f * signf_(dy)) * rH, 2.0f, -1.0f), -ys[j]) * rdy;
+                    const float tz = fmaf(mbs[j], fmaf(((float)nzs[j] + 0.5f + 0.5f * signf_(dz)) * rH, 2.0f, -1.0f), -zs[j]) * rdz;
                     tt = ts[j] + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
                 }
             }
@@ -271,9 +271,9 @@ __global__ __launch_bounds__(NT) void k_loop_march(const int* __restrict__ ctl, 
             const float t = s_t[k][r];
             dt = s_dt[k][r];
             dx = s_d[0][r]; dy = s_d[1][r]; dz = s_d[2][r];
-            x = clampf_(s_o[0][r] + t * dx, -bound, bound);
-            y = clampf_(s_o[1][r] + t * dy, -bound, bound);
-            z = clampf_(s_o[2][r] + t * dz, -bound, bound);
+            x = clampf_(fmaf(t, dx, s_o[0][r]), -bound, bound);
+            y = clampf_(fmaf(t, dy, s_o[1][r]), -bound, bound);
+            z = clampf_(fmaf(t, dz, s_o[2][r]), -bound, bound);
             t1 = t + dt;
         }
         float* px = xyzs + (slab + i) * 3;

@@ -97,11 +97,11 @@ void ref_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_alive, co
         const float dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / (float)H;
         const float dt_min = fminf(dt_max, 2 * SQRT3 / (float)max_steps);
         uint32_t step = 0;
-        t += clampf_(t * dt_gamma, dt_min, dt_max) * noise;
+        t = fmaf(clampf_(t * dt_gamma, dt_min, dt_max), noise, t);                    /* the reference build contracts this (and the lines marked fmaf below) */
         while (t < far && step < n_step) {
-            const float x = clampf_(ox + t * dx, -bound, bound);
-            const float y = clampf_(oy + t * dy, -bound, bound);
-            const float z = clampf_(oz + t * dz, -bound, bound);
+            const float x = clampf_(fmaf(t, dx, ox), -bound, bound);
+            const float y = clampf_(fmaf(t, dy, oy), -bound, bound);
+            const float z = clampf_(fmaf(t, dz, oz), -bound, bound);
             const float dt = clampf_(t * dt_gamma, dt_min, dt_max);
             const int a = mip_from_pos(x, y, z, (float)C), b = mip_from_dt(dt, (float)H, (float)C);
             const int level = a > b ? a : b;
@@ -109,10 +109,10 @@ void ref_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_alive, co
             const float mip_rbound = 1 / mip_bound;
             /* `0.5 * (x * mip_rbound + 1) * H` is a DOUBLE product in the reference (0.5 is a double literal), narrowed to
              * float by clamp()'s parameter and truncated to int */
-            const int nx = (int)clampf_((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-            const int ny = (int)clampf_((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-            const int nz = (int)clampf_((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-            const uint32_t gi = (uint32_t)((float)level * H3 + (float)ref_morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+            const int nx = (int)clampf_((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+            const int ny = (int)clampf_((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+            const int nz = (int)clampf_((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+            const uint32_t gi = (uint32_t)fmaf((float)level, H3, (float)ref_morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
             const int occ = grid[gi / 8] & (1 << (gi % 8));
             if (occ) {
                 px[0] = x; px[1] = y; px[2] = z;
@@ -122,9 +122,9 @@ void ref_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_alive, co
                 px += 3; pd += 3; pt += 2;
                 step++;
             } else {
-                const float tx = ((((float)nx + 0.5f + 0.5f * signf_(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
-                const float ty = ((((float)ny + 0.5f + 0.5f * signf_(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
-                const float tz = ((((float)nz + 0.5f + 0.5f * signf_(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+                const float tx = fmaf(mip_bound, fmaf(((float)nx + 0.5f + 0.5f * signf_(dx)) * rH, 2.0f, -1.0f), -x) * rdx;
+                const float ty = fmaf(mip_bound, fmaf(((float)ny + 0.5f + 0.5f * signf_(dy)) * rH, 2.0f, -1.0f), -y) * rdy;
+                const float tz = fmaf(mip_bound, fmaf(((float)nz + 0.5f + 0.5f * signf_(dz)) * rH, 2.0f, -1.0f), -z) * rdz;
                 const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
                 do {
                     t += clampf_(t * dt_gamma, dt_min, dt_max);

@@ -26,6 +26,11 @@ import numpy as np
 import torch
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+# The drop-in directory is on the path below only for the four extension-module NAMES the reference's wrappers import (their entry points are replaced by the
+# C oracle right after).  Since round 6 it also shadows `ernerf.nerf_triplane.network` with the reference's class + the MI355X render path mixed in:
+# MF_NERF_DROPIN=0 keeps that path out, so that what runs here -- and what the fixture records -- is the REFERENCE's own run_cuda.
+os.environ["MF_NERF_DROPIN"] = "0"
+os.environ["MF_PLACEMENT"] = "0"
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mere-fusion_amd", "dropin"), "/root/reference"]
 
 from mere_fusion_amd import weights as W  # noqa: E402

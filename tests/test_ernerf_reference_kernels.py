@@ -8,9 +8,11 @@ calls both modules with the same seeded arguments and compares what they wrote. 
 this repo's C restatement (oracle/ernerf_ref.c).  gridencoder.cu does not build on ROCm 7.2 (see build_ref_ernerf.py) and stays with the
 restatement + KATs.
 
-Bar: indices / flags / sample positions bit-exact; float accumulators within a few ulp -- the reference is compiled with hipcc's default
-FMA contraction (as nvcc contracts it on the reference's own hardware), the product kernels with contraction off (they are also held
-bit-exact against the plain-C oracle), so one rounding per fused multiply-add may differ; tolerances are written at each comparison."""
+Bar: indices / flags / sample positions / step sizes bit-exact (march_rays, near/far, the composite's termination flags and per-ray t); float accumulators
+(the composite's blended sums, the encoders) within a few ulp.  The reference is compiled with hipcc's default FMA contraction (as nvcc contracts it on its
+own hardware); the product's march kernels are compiled with contraction OFF and carry explicit fmaf() at exactly the places the reference build fuses
+(read off its ISA: profiles/r06_march_rays_reference_isa.txt), and so does the plain-C oracle the CPU tests pin them to -- the restatement follows the
+reference, not the other way round."""
 import importlib.util
 import os
 import sys
@@ -96,22 +98,19 @@ def test_near_far_and_march_rays_vs_reference_kernels(lib_built, n_rays, cascade
         res[tag] = [t.cpu().numpy() for t in (xyzs, dirs, deltas)]
     x_r, d_r, dl_r = res["ref"]; x_h, d_h, dl_h = res["hip"]
     assert (dl_r[:, 0] > 0).mean() > 0.05                                           # the scene does produce samples
-    # a17: which steps are samples (dt > 0) is the occupancy / DDA control flow.  It agrees on every ray except where a sample position sits
-    # within an ulp of a voxel face: there the reference's contracted o + t * d and the product's separately rounded one fall into
-    # different cells and the march continues from another voxel.  Such rays are COUNTED (bounded at 2e-4 of the rays; measured <= 4 of 49 k)
-    # and left out of the value comparison; nothing else is masked.
+    # a17: index work -- which steps are samples (the occupancy / DDA control flow), the sample positions o + t d, the step sizes and the running t -- is held
+    # BIT-EXACT against the reference's own kernel.  The reference build (hipcc here, nvcc on its own hardware) contracts a * b + c into fused multiply-adds at
+    # six places of kernel_march_rays (raymarching.cu:870-927: the noise offset, o + t d, x * mip_rbound + 1, level * H3 + morton, the two nested products of
+    # the voxel-exit distances); the product kernels AND the plain-C oracle (oracle/ernerf_ref.c) carry explicit fmaf() at exactly those places and nowhere else
+    # (round 6, VERDICT r05 item 5: until then the product followed its own restatement, and up to 4 of 49 152 rays stepped into a neighbouring voxel).
     flags_h, flags_r = (dl_h[:, 0] > 0).reshape(na, n_step), (dl_r[:, 0] > 0).reshape(na, n_step)
-    tie_rays = (flags_h != flags_r).any(1) | (np.abs(x_h - x_r).reshape(na, n_step * 3).max(1) > 1e-3)
-    print(f"[march_rays vs reference kernel] {na} rays x {n_step}: {int(tie_rays.sum())} voxel-face tie rays")
-    assert tie_rays.sum() <= max(1, int(2e-4 * na)), f"{int(tie_rays.sum())} rays march differently"
-    keep = np.repeat(~tie_rays, n_step)
-    np.testing.assert_array_equal(d_h[keep], d_r[keep])                             # dirs are copies
-    # positions o + t d and the running t: one FMA contraction per component on the reference side -> a few ulp of the largest term
-    exact = float((x_h[keep] == x_r[keep]).mean())
-    print(f"[march_rays vs reference kernel] xyzs bit-equal on {100 * exact:.3f} % of components, max |diff| {np.abs(x_h[keep] - x_r[keep]).max():.2e} "
-          f"(xyzs), {np.abs(dl_h[keep] - dl_r[keep]).max():.2e} (deltas)")
-    np.testing.assert_allclose(x_h[keep], x_r[keep], rtol=0, atol=4e-7)              # |coordinates| <= 1 (bound 1) or 2: 2-4 ulp absolute
-    np.testing.assert_allclose(dl_h[keep], dl_r[keep], rtol=0, atol=1e-6)
+    tie_rays = (flags_h != flags_r).any(1)
+    exact = float((x_h == x_r).mean())
+    print(f"[march_rays vs reference kernel] {na} rays x {n_step}: {int(tie_rays.sum())} rays with different sample flags; xyzs bit-equal on {100 * exact:.4f} % of components")
+    assert tie_rays.sum() == 0, f"{int(tie_rays.sum())} rays march differently"
+    np.testing.assert_array_equal(d_h, d_r)                                          # dirs are copies
+    np.testing.assert_array_equal(x_h, x_r)
+    np.testing.assert_array_equal(dl_h, dl_r)
 
 
 @pytest.mark.gpu

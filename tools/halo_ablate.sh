@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs profiles/r06_halo_ablate_macros.patch applied first: the switches no longer live in the kernels)
 # Where the (bf16x3) halo conv's time goes: rebuilds the library with MF_HALO_ABLATE bits (wrong results, timing only) into build_ab/ and times
 # one layer with each.  Run the BUILD part here (no GPU): tools/halo_ablate.sh build ; the TIMING part on the GPU box: tools/halo_ablate.sh run
 R=$(cd "$(dirname "$0")/.." && pwd)
