@@ -96,8 +96,9 @@ def main():
              ("every level f16+xl", {k: "f16+xl" for k in LEVELS}, "f16+f6"),
              ("every level f16x1", {k: "f16x1" for k in LEVELS}, "f16+f6")]
     passes = {"f16x1": 1.0, "f16+wl": 1.25, "f16+xl": 1.25, "f16+f6": 1.5}
-    # share of the roofline kernel's MFMA work per level (18 launches at batch 8: mid + up0 4 + 2 at 32^2 ... see DESIGN section 4); used for the "passes saved" column
-    work = {"mid": 4, "up0": 3, "up1": 3 + 1, "up2": 3 + 1, "up3": 3}      # resnet convs weigh 2 x 154.6 GFLOP per resnet, the big upsamplers 309.2: in units of 309.2 GFLOP
+    # algorithmic GFLOP per frame-batch of 8 of the f16 + FP6 launches per level (profiles/r05_layers.json: mid 4 x 38.6, up0 6 x 38.6, up1 928 + its upsampler 618,
+    # up2 1082 + 618, up3 1082): the "pass-equivalents" column weighs the levels by it
+    work = {"mid": 154.6, "up0": 232.0, "up1": 1546.0, "up2": 1700.0, "up3": 1082.0}
     total = sum(work.values())
     print(f"VAE decoder, {'reduced' if a.small else 'sd-vae-ft-mse'} config, {a.frames} frame(s); gates: image L-inf <= 5e-4, uint8 max diff 1 on <= 0.7 %\n")
     print("| plan | MFMA pass-equivalents of the 3x3 convs (ships = 1.5) | seeded weights: image L-inf | uint8 max / % differing | stressed weights (marginal, other levels bf16x3): image L-inf | uint8 max / % | verdict |")
