@@ -307,3 +307,38 @@ def test_graphs_survive_workspace_growth(lib_built, sd0):
                 os.environ["MF_NO_GRAPH"] = old
     assert torch.equal(first, again)
     assert torch.equal(eager, again)
+
+
+@pytest.mark.gpu
+def test_reference_process_model_through_the_dropin(lib_built):
+    """lipreal.py's flow, unedited: import the drop-in (`from wav2lip.models import Wav2Lip`, lipreal.py:25), ask `torch.cuda.is_available()` at import time (:29), then
+    start the session's worker with the DEFAULT `mp.Process` (:170) and let it build the model, say `.to('cuda')` and run it.  With plain PyTorch-ROCm the forked
+    worker dies with "Cannot re-initialize CUDA in forked subprocess" (tools/fork_probe.py); the drop-in import settles the start method first (procmodel.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    script = r'''
+import multiprocessing as mp, sys
+from wav2lip.models import Wav2Lip                      # lipreal.py:25
+import torch
+device = 'cuda' if torch.cuda.is_available() else 'cpu'  # lipreal.py:29
+
+def inference(q):                                         # lipreal.py:75: the worker loads the model itself
+    from mere_fusion_amd import weights as W
+    m = Wav2Lip(); m.load_state_dict(W.make_wav2lip_state_dict(0)); m = m.to(device).eval()
+    mel, face, _ = W.make_lip_inputs(2, 0)
+    with torch.no_grad():
+        q.put(float(m(mel.to(device), face.to(device)).float().mean()))
+
+if __name__ == "__main__":
+    q = mp.Queue()                                        # lipreal.py:160: default context
+    p = mp.Process(target=inference, args=(q,)); p.start()
+    print("WORKER", mp.get_start_method(), q.get(timeout=240)); p.join(30)
+'''
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mf_procmodel_probe.py")
+    with open(path, "w") as f:
+        f.write(script)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "mere-fusion_amd", "dropin")]))
+    out = subprocess.run([sys.executable, path], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "WORKER spawn 0." in out.stdout, out.stdout[-1000:] + out.stderr[-3000:]
