@@ -154,3 +154,62 @@ def test_hip_render_through_the_mixin_matches_the_reference_golden(lib_built, sm
     m.train()
     with pytest.raises(AssertionError, match="reference's run_cuda"):
         m.render(cu(ro)[None], cu(rd)[None], cu(g["auds"]), torch.zeros(1, Wd * Wd, 2, device="cuda"), torch.eye(4, device="cuda")[None], **kw)
+
+
+@pytest.mark.gpu
+def test_hip_render_through_the_mixin_with_the_torso_branch(lib_built):
+    """`opt.torso` models (the deployed ER-NeRF checkpoints): `run_cuda` mixes the head over `run_torso`'s background (renderer.py:272-277).  The mixin must build the
+    torso from the module's own tensors (`torso_*`, `anchor_points`, `individual_codes_torso`, `density_grid_torso`, `mean_density_torso` as set AFTER the load) and give
+    the same frame as the hand-assembled HipHeadRenderer + HipTorso + HipAudioEncoder that tests/test_ernerf.py holds to the reference's goldens piece by piece."""
+    from mere_fusion_amd import weights as W
+    from mere_fusion_amd.ernerf.audio import HipAudioEncoder
+    from mere_fusion_amd.ernerf.field import HipNeRFField, grid_geometry
+    from mere_fusion_amd.ernerf.network import HipRenderMixin
+    from mere_fusion_amd.ernerf.renderer import HipHeadRenderer
+    from mere_fusion_amd.ernerf.torso import HipTorso
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ernerf_golden.npz"))
+    sd = W.make_ernerf_field_state_dict(int(g["offsets"][-1]), 0)
+    sd = {k: (v * 0.35 if k.startswith("sigma_net.net.2") else v) for k, v in sd.items()}
+    sd.update({k[len("audio_sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("audio_sd/")})
+    t_offsets, _ = grid_geometry(num_levels=16, base_resolution=16, log2_hashmap_size=16, desired_resolution=2048)
+    tsd = W.make_ernerf_torso_state_dict(int(t_offsets[-1]), 0)
+    opt = argparse.Namespace(asr_model="esperanto", emb=False, att=2, bound=1, min_near=0.05, exp_eye=True, smooth_lips=True, ind_num=16, ind_dim=4, torso_shrink=0.8)
+
+    class Base(_ReferenceShapedBase):
+        def __init__(self, opt, sd, tsd):
+            super().__init__(opt, {**sd, **{k: v for k, v in tsd.items() if k not in ("density_grid_torso",)}})
+            self.torso, self.individual_dim_torso = True, 8
+            self.register_buffer("density_grid_torso", tsd["density_grid_torso"].clone())
+
+    class Net(HipRenderMixin, Base):
+        pass
+
+    m = Net(opt, sd, tsd)
+    with torch.no_grad():
+        m.individual_codes[0].copy_(torch.from_numpy(g["render_ind_code"]))
+        m.density_bitfield.copy_(torch.from_numpy(W.make_ernerf_sphere_bitfield()))
+    m = m.cuda().eval()
+    m.density_scale, m.mean_density_torso = 40.0, 0.3                       # `load_checkpoint` assigns mean_density_torso after the state dict (utils.py)
+    Wd = 48
+    ro, rd = W.make_ernerf_camera_rays(Wd)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u = (torch.arange(Wd, dtype=torch.float32) + 0.5) / Wd * 2 - 1
+    yy, xx = torch.meshgrid(u, u, indexing="ij")
+    bg_coords = torch.stack([xx, yy], -1).reshape(1, -1, 2).contiguous().cuda()
+    pose = torch.from_numpy(g["torso_pose"])[None].cuda()
+    bg = torch.tensor([0.3, 0.5, 0.7]).expand(Wd * Wd, 3).contiguous().cuda()
+    auds = [cu(g["auds"]), cu(g["auds"]) * 1.2]
+    kw = dict(eye=cu(g["field_e"]), index=[0], staged=True, bg_color=bg, perturb=False, dt_gamma=1 / 256, max_steps=16, T_thresh=1e-4)
+    got = [m.render(cu(ro)[None], cu(rd)[None], a, bg_coords, pose, **kw) for a in auds]
+    assert m.mf_frames == 2
+    # the same two frames from hand-assembled objects
+    full = {k: v.detach() for k, v in m.state_dict().items()}
+    r = HipHeadRenderer(HipNeRFField(full, max_samples=Wd * Wd), m.density_bitfield, density_scale=40.0,
+                        torso=HipTorso(full, torso_shrink=0.8, individual_dim=8, density_thresh_torso=0.01, mean_density_torso=0.3, max_pixels=Wd * Wd),
+                        audio=HipAudioEncoder(full, att=2), ind_code=m.individual_codes[0].detach(), smooth_lips=True)
+    for i, a in enumerate(auds):
+        want = r.render(cu(ro), cu(rd), a, bg_coords, pose, cu(g["field_e"]), bg_color=bg, loop="device", dt_gamma=1 / 256, max_steps=16, T_thresh=1e-4)
+        assert torch.equal(got[i]["image"].reshape(-1, 3), want["image"]) and torch.equal(got[i]["depth"].reshape(-1), want["depth"]), i
+    assert float((got[0]["image"] - got[1]["image"]).abs().max()) > 0          # another audio window (and the EMA carried on the module): another frame
+    img = got[0]["image"].reshape(Wd, Wd, 3)
+    assert float(img.std()) > 0.02 and float((img - bg.reshape(Wd, Wd, 3)).abs().amax(-1).gt(1e-3).float().mean()) > 0.05   # head and torso both drew something
