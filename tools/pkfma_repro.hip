@@ -45,7 +45,7 @@ __device__ __forceinline__ void noise_wave(const float* __restrict__ t_in, float
 // One case = one packed instruction with its modifiers, and the two scalar instructions that say what its halves must be.  Sources: A = v[100:101], B = v[102:103],
 // C = v[104:105], filled from (a.x, a.y), (b.x, b.y), (c.x, c.y).
 enum { C_FMA_PLAIN, C_FMA_HI_FROM_LO_1, C_FMA_LO_FROM_HI_1, C_FMA_LO_FROM_HI_0, C_FMA_LO_FROM_HI_2, C_FMA_BOTH_FROM_HI_1, C_MUL_LO_FROM_HI_1, C_ADD_LO_FROM_HI_1,
-       C_FMA16_LO_FROM_HI_1, C_FMA_LO_FROM_HI_1_NOP, N_CASES };
+       C_FMA16_LO_FROM_HI_1, C_FMA_LO_FROM_HI_1_NOP, C_ADD_LO_FROM_HI_0, C_MOV_SEL10, C_MOV_SEL01, N_CASES };
 static const char* case_names[] = {
     "v_pk_fma_f32                                   (no select)",
     "v_pk_fma_f32 op_sel_hi:[1,0,1]                 (high result <- src1 LOW)",
@@ -57,6 +57,9 @@ static const char* case_names[] = {
     "v_pk_add_f32 op_sel:[0,1]                      (both results <- src1 HIGH)",
     "v_pk_fma_f16 op_sel:[0,1,0]                    (16-bit halves of ONE register: low result <- src1 high half)",
     "v_pk_fma_f32 op_sel:[0,1,0] after s_nop 7      (the kernel's form, 8 wait states behind its producers)",
+    "v_pk_add_f32 op_sel:[1,0]                      (low result <- src0 HIGH)",
+    "v_pk_mov_b32 op_sel:[1,0]                      (D = (src0 HIGH, src1 low))",
+    "v_pk_mov_b32 op_sel:[0,1]                      (D = (src0 low, src1 HIGH))",
 };
 
 template <int CASE, int NOISE>
@@ -80,6 +83,9 @@ __global__ __launch_bounds__(512) void k_repro(const float* __restrict__ t_in, i
         if (CASE == C_FMA_BOTH_FROM_HI_1) { asm volatile(FILL "v_pk_fma_f32 %0, v[100:101], v[102:103], v[104:105] op_sel:[0,1,0]" OPS); w0 = __builtin_fmaf(a.x, b.y, c.x); w1 = __builtin_fmaf(a.y, b.y, c.y); }
         if (CASE == C_FMA_LO_FROM_HI_1_NOP) { asm volatile(FILL "s_nop 7\n\tv_pk_fma_f32 %0, v[100:101], v[102:103], v[104:105] op_sel:[0,1,0]" OPS); w0 = __builtin_fmaf(a.x, b.y, c.x); w1 = __builtin_fmaf(a.y, b.y, c.y); }
         if (CASE == C_MUL_LO_FROM_HI_1)   { asm volatile(FILL "v_pk_mul_f32 %0, v[100:101], v[102:103] op_sel:[0,1]" OPS); w0 = a.x * b.y; w1 = a.y * b.y; }
+        if (CASE == C_ADD_LO_FROM_HI_0)   { asm volatile(FILL "v_pk_add_f32 %0, v[100:101], v[102:103] op_sel:[1,0]" OPS); w0 = a.y + b.x; w1 = a.y + b.y; }
+        if (CASE == C_MOV_SEL10)          { asm volatile(FILL "v_pk_mov_b32 %0, v[100:101], v[102:103] op_sel:[1,0]" OPS); w0 = a.y; w1 = b.x; }
+        if (CASE == C_MOV_SEL01)          { asm volatile(FILL "v_pk_mov_b32 %0, v[100:101], v[102:103] op_sel:[0,1]" OPS); w0 = a.x; w1 = b.y; }
         if (CASE == C_ADD_LO_FROM_HI_1)   { asm volatile(FILL "v_pk_add_f32 %0, v[100:101], v[102:103] op_sel:[0,1]" OPS); w0 = a.x + b.y; w1 = a.y + b.y; }
         if (CASE == C_FMA16_LO_FROM_HI_1) {     // the 16-bit packed form (the selects pick halves of ONE 32-bit register), against the same instruction on a pre-swizzled src1
             typedef __fp16 h2v __attribute__((ext_vector_type(2)));
@@ -138,7 +144,7 @@ int main(int argc, char** argv) {
     run<C_FMA_PLAIN, N_NONE>(); run<C_FMA_HI_FROM_LO_1, N_NONE>(); run<C_FMA_BOTH_FROM_HI_1, N_NONE>(); run<C_FMA_LO_FROM_HI_1, N_NONE>();
     run<C_FMA_PLAIN, N_MFMA>(); run<C_FMA_HI_FROM_LO_1, N_MFMA>();
     run<C_FMA_BOTH_FROM_HI_1, N_MFMA>(); run<C_FMA_LO_FROM_HI_1, N_MFMA>(); run<C_FMA_LO_FROM_HI_0, N_MFMA>(); run<C_FMA_LO_FROM_HI_2, N_MFMA>();
-    run<C_MUL_LO_FROM_HI_1, N_MFMA>(); run<C_ADD_LO_FROM_HI_1, N_MFMA>(); run<C_FMA16_LO_FROM_HI_1, N_MFMA>(); run<C_FMA_LO_FROM_HI_1_NOP, N_MFMA>();
+    run<C_MUL_LO_FROM_HI_1, N_MFMA>(); run<C_ADD_LO_FROM_HI_1, N_MFMA>(); run<C_ADD_LO_FROM_HI_0, N_MFMA>(); run<C_MOV_SEL10, N_MFMA>(); run<C_MOV_SEL01, N_MFMA>(); run<C_FMA16_LO_FROM_HI_1, N_MFMA>(); run<C_FMA_LO_FROM_HI_1_NOP, N_MFMA>();
     run<C_FMA_BOTH_FROM_HI_1, N_LDSDMA>(); run<C_FMA_BOTH_FROM_HI_1, N_LDS>(); run<C_FMA_BOTH_FROM_HI_1, N_GLOBAL>(); run<C_FMA_BOTH_FROM_HI_1, N_FP64>();
     return 0;
 }
