@@ -1139,7 +1139,8 @@ class ErNeRFRunner:
         from mere_fusion_amd.ernerf.audio import HipAudioEncoder
         from mere_fusion_amd.ernerf.torso import HipTorso
         t_offs, _ = grid_geometry(num_levels=16, base_resolution=16, log2_hashmap_size=16, desired_resolution=2048)
-        self.torso = HipTorso(W.make_ernerf_torso_state_dict(int(t_offs[-1]), seed), precision=precision, max_pixels=width * width, device=device)
+        self.torso_sd = W.make_ernerf_torso_state_dict(int(t_offs[-1]), seed)
+        self.torso = HipTorso(self.torso_sd, precision=precision, max_pixels=width * width, device=device)
         tmpl = {"audio_net.encoder_conv.0.weight": torch.empty(32, 44, 3), "audio_net.encoder_conv.0.bias": torch.empty(32),
                 "audio_net.encoder_conv.2.weight": torch.empty(32, 32, 3), "audio_net.encoder_conv.2.bias": torch.empty(32),
                 "audio_net.encoder_conv.4.weight": torch.empty(64, 32, 3), "audio_net.encoder_conv.4.bias": torch.empty(64),
@@ -1150,7 +1151,8 @@ class ErNeRFRunner:
         for i, (ci, co) in enumerate(((32, 16), (16, 8), (8, 4), (4, 2), (2, 1))):
             tmpl[f"audio_att_net.attentionConvNet.{2 * i}.weight"] = torch.empty(co, ci, 3)
             tmpl[f"audio_att_net.attentionConvNet.{2 * i}.bias"] = torch.empty(co)
-        self.audio = HipAudioEncoder(W.make_ernerf_audio_state_dict(tmpl, seed), att=2, device=device)
+        self.audio_sd = W.make_ernerf_audio_state_dict(tmpl, seed)
+        self.audio = HipAudioEncoder(self.audio_sd, att=2, device=device)
         self.auds = torch.randn(8, 44, 16, generator=g).to(device)
         u = (torch.arange(width, dtype=torch.float32) + 0.5) / width * 2 - 1
         yy, xx = torch.meshgrid(u, u, indexing="ij")
@@ -1214,6 +1216,62 @@ class ErNeRFRunner:
             out["hbm_kernels"][name] = {"launches_per_frame": k["launches_per_frame"], "ms_per_frame": k["ms_per_frame"],
                                         "alg_bytes_per_frame": int(k["units"]), "achieved_gbytes_per_s": round(gbs, 1), "frac_of_8tbs": round(gbs / 8000.0, 4)}
         return out
+
+    def through_dropin(self, frames=30):
+        """The same frame through the DROP-IN seam: a module with the reference NeRFNetwork's attributes and state-dict names and
+        `HipRenderMixin` in front -- what `from ernerf.nerf_triplane.network import NeRFNetwork` resolves to -- rendered by `model.render(...)` with the arguments
+        `Trainer.test_step` passes (utils.py:949-950): device tensors for the eye feature, `index`, `**vars(opt)`.  One host sync per frame, as the reference has it
+        (`test_gui_with_data` copies the frame to the host right away).  (The reference's own class needs its checkout, which the GPU box lacks;
+        tests/test_dropin_ernerf.py checks the import chain against it in the build container.)"""
+        import argparse
+        from mere_fusion_amd.ernerf.network import HipRenderMixin
+        dev = self.ro.device
+        full = {**self.sd, **self.torso_sd, **self.audio_sd}
+        runner = self
+
+        class _RefShaped(torch.nn.Module):                    # renderer.py:62-133 / network.py:93-165: the attributes the render path reads
+            def __init__(s, opt):
+                super().__init__()
+                s.opt, s.bound, s.grid_size, s.density_scale, s.min_near = opt, 1, 128, 40.0, 0.05
+                s.exp_eye, s.test_train, s.smooth_lips, s.torso, s.train_camera, s.emb, s.att = True, False, True, True, False, False, 2
+                s.individual_dim, s.individual_dim_torso, s.density_thresh_torso, s.mean_density_torso = 4, 8, 0.01, 0.0
+                s.enc_a, s._n = None, {}
+                s.individual_codes = torch.nn.Parameter(runner.ind.expand(16, 4).contiguous().clone(), requires_grad=False)
+                s.register_buffer("density_bitfield", torch.from_numpy(runner.bitfield).clone())
+                for k, v in full.items():
+                    n = "p_" + k.replace(".", "__")
+                    s.register_parameter(n, torch.nn.Parameter(v.clone().float(), requires_grad=False))
+                    s._n[n] = k
+
+            def state_dict(s, *a, **k):
+                return {s._n.get(key, key): v for key, v in super().state_dict(*a, **k).items()}
+
+            def run_cuda(s, *a, **k):
+                raise RuntimeError("the reference's run_cuda was reached")
+
+            def render(s, rays_o, rays_d, auds, bg_coords, poses, staged=False, max_ray_batch=4096, **kw):      # renderer.py:657-677
+                return s.run_cuda(rays_o, rays_d, auds, bg_coords, poses, **kw)
+
+        class _Net(HipRenderMixin, _RefShaped):
+            pass
+        m = _Net(argparse.Namespace(torso_shrink=0.8)).to(dev).eval()
+        kw = dict(eye=self.d_eye, index=[0], staged=True, bg_color=None, perturb=False, dt_gamma=1 / 256, max_steps=16, T_thresh=1e-4, torso_shrink=0.8)
+        args = (self.ro[None], self.rd[None], self.auds, self.bg_coords[None], self.pose.to(dev))
+        import gc
+        for _ in range(3):
+            m.render(*args, **kw)
+        torch.cuda.synchronize()
+        gc.collect()                                          # (handles of earlier legs die here, not inside the timed frames: their hipFree synchronises the device)
+        per = []
+        for _ in range(frames):
+            t0 = time.perf_counter()
+            out = m.render(*args, **kw)
+            torch.cuda.synchronize()                          # the reference syncs here: outputs['image'] goes to the host (utils.py:1211)
+            per.append(time.perf_counter() - t0)
+        dt = float(np.median(per))
+        return {"frames_per_s": round(1.0 / dt, 1), "ms_per_frame": round(dt * 1e3, 3), "ms_per_frame_mean": round(float(np.mean(per)) * 1e3, 3),
+                "device_loop_frames": int(m.mf_frames), "image_shape": list(out["image"].shape),
+                "note": "model.render(...) through HipRenderMixin with the arguments Trainer.test_step passes; one host sync per frame (as Trainer.test_gui_with_data has)"}
 
     def samples_per_frame(self):
         if self.trace is None:        # the device loop keeps no host-side trace: count the same frame once through the host loop
@@ -1293,6 +1351,7 @@ def ernerf_report(args, device, world, rank, value=None, ms_per_step=None, run=N
     rep["parity"] = run.parity()
     if getattr(args, "extras", 1):
         rep["asr_frontend"] = wav2vec2_report(args, device)
+        rep["through_dropin"] = run.through_dropin()
     if args.profile_iters > 0:
         rep["roofline"] = run.roofline(args.profile_iters)
     if args.cpu_seconds > 0:
@@ -1452,6 +1511,7 @@ def compact_line(full):
         e_ = _pick(e, ("value", "unit", "ms_per_step", "dtype", "samples_per_frame"))
         e_["roofline"] = _pick(e.get("roofline", {}), ("kernel", "avg_launch_us", "achieved", "peak", "frac"))
         e_["image_linf_vs_oracle"] = _dig(e, "parity", "image_linf_max_vs_oracle")
+        e_["through_dropin_frames_per_s"] = _dig(e, "through_dropin", "frames_per_s")
         e_["cpu_baseline"] = _pick(e.get("cpu_baseline", {}), ("value", "unit", "cores", "kind"))
         out["ernerf"] = e_
     wh = full.get("whisper")
@@ -1558,7 +1618,7 @@ def main():
                     "dtype": args.precision, "data": "synthetic",
                     "config": {"workload": rep["workload"] + "; seeded random-init field", "sessions_at_25fps": round(value / 25.0, 1),
                                "parallelism": f"{world} independent replicas, sessions sharded by GPU, no collective"}}
-            for k in ("samples_per_frame", "march_iterations", "field_tflops_algorithmic", "roofline", "parity", "cpu_baseline"):
+            for k in ("samples_per_frame", "march_iterations", "field_tflops_algorithmic", "roofline", "parity", "cpu_baseline", "through_dropin"):
                 if k in rep:
                     line[k] = rep[k]
             emit(line)

@@ -50,6 +50,12 @@ class HipHeadRenderer:
         # (the torso on a second stream beside the head paid while it was a ~0.3 ms launch chain; as one 71 us kernel the cross-stream dependency cost more
         # than the overlap returned, 0.737 vs 0.711 ms per frame: the path left in round 5)
         enc_a = audio_part()
+        if device_loop and self.torso is not None and not kw.get("graph"):
+            # the head loop is enqueued FIRST and left unfinished; the torso's per-frame host work (the wrapped anchors: a 4 x 4 inverse and 42 sines, ~90 us, and the
+            # device -> host copy of the pose when it lives on the device as the reference's does) then runs while the GPU marches, and the background mix closes the
+            # frame.  Same kernels, same bits; a caller that syncs every frame (the reference's loop, through the drop-in) no longer pays that host time on top
+            out = self.run_cuda_device(rays_o, rays_d, enc_a, self.ind_code, eye, bg_color=None, finish=False, **kw)
+            return self.finish_device(out, self.torso.run_torso(bg_coords, poses, bg_color)["bg_color"])
         if self.torso is not None:
             bg_color = self.torso.run_torso(bg_coords, poses, bg_color)["bg_color"]
         if device_loop:

@@ -16,25 +16,24 @@ from .field import grid_geometry
 
 
 def freq_encode_host(x, degree):
-    """FreqEncoder.forward (freq.py:66-78 -> kernel_freq, freqencoder.cu:30-58) for a handful of values, in float32 like the kernel."""
+    """FreqEncoder.forward (freq.py:66-78 -> kernel_freq, freqencoder.cu:30-58) for a handful of values, in float32 like the kernel: output c >= D is
+    sin(x[c % D] * 2^(col // 2) + (col % 2) * pi / 2) with col = c // D - 1.  (Vectorised: this runs on the host once per frame.)"""
     x = np.asarray(x, np.float32).reshape(-1)
     D = x.shape[0]
-    out = np.empty(D + 2 * D * degree, np.float32)
-    out[:D] = x
-    for c in range(D, out.shape[0]):
-        col, d = c // D - 1, c % D
-        out[c] = np.sin(np.float32(np.ldexp(x[d], col // 2)) + np.float32((col % 2) * (np.float32(np.pi) / 2)), dtype=np.float32)
-    return out
+    c = np.arange(D, D + 2 * D * degree)
+    col, d = c // D - 1, c % D
+    arg = np.ldexp(x[d], col // 2).astype(np.float32) + ((col % 2).astype(np.float32) * np.float32(np.float32(np.pi) / 2)).astype(np.float32)
+    return np.concatenate([x, np.sin(arg.astype(np.float32), dtype=np.float32)])
 
 
 def wrapped_anchor_code(anchor_points, poses, ind_code):
     """network.py:175-178: anchors through the inverse pose, perspective-divided, FreqEncoder(6, 3), then the individual code."""
-    a = torch.as_tensor(anchor_points, dtype=torch.float32).cpu()
-    p = torch.as_tensor(poses, dtype=torch.float32).cpu().reshape(1, 4, 4)
-    w = a[None, ...] @ p.permute(0, 2, 1).inverse()
+    a = anchor_points.numpy() if torch.is_tensor(anchor_points) else np.asarray(anchor_points, np.float32)
+    p = (poses.detach().float().cpu().numpy() if torch.is_tensor(poses) else np.asarray(poses, np.float32)).reshape(4, 4)
+    w = torch.from_numpy(a)[None, ...] @ torch.from_numpy(p)[None].permute(0, 2, 1).inverse()          # (torch's own 4 x 4 inverse: the reference's arithmetic)
     w = (w[:, :, :2] / w[:, :, 3, None] / w[:, :, 2, None]).reshape(-1)
     enc = freq_encode_host(w.numpy(), 3)
-    code = np.zeros(0, np.float32) if ind_code is None else torch.as_tensor(ind_code).detach().float().cpu().numpy().reshape(-1)
+    code = np.zeros(0, np.float32) if ind_code is None else (ind_code.numpy() if torch.is_tensor(ind_code) and not ind_code.is_cuda else torch.as_tensor(ind_code).detach().float().cpu().numpy()).reshape(-1)
     return np.concatenate([enc, code]).astype(np.float32)
 
 
