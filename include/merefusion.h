@@ -354,6 +354,10 @@ int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const float* rays_
  * NULL when none was passed to the render call. */
 int mf_nerf_head_finish(mf_nerf_head* h, int n_rays, const float* bg_color, int bg_per_ray, float bg_const, float* image, float* depth,
                         const float* weights_sum, uint8_t* frame_u8, void* stream);
+/* The eye feature `e` of `NeRFNetwork.forward` (network.py:249, `data['eye']`: a [1, 1] device tensor in the reference's loader) read from DEVICE memory by every
+ * later mf_nerf_head_render on `h` instead of its by-value `eye` argument: no host copy of a value that lives on the device, and a captured graph follows a changing
+ * value.  NULL: back to the by-value argument.  The float must stay valid until the renders that use it have finished. */
+int mf_nerf_head_set_eye(mf_nerf_head* h, const float* eye_dev);
 /* The per-ray sums `run_cuda` also returns at inference (`results['ambient_aud' | 'ambient_eye' | 'uncertainty']`, renderer.py:286-288) of the LAST frame
  * rendered through `h`: device-to-device copies enqueued on `stream` behind that frame (any of the three may be NULL). */
 int mf_nerf_head_sums(mf_nerf_head* h, int n_rays, float* ambient_aud, float* ambient_eye, float* uncertainty, void* stream);

@@ -162,6 +162,7 @@ SIGNATURES = {
     "mf_nerf_head_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 5),
     "mf_nerf_head_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 5),
+    "mf_nerf_head_set_eye": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mf_nerf_head_sums": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4),
     "mf_nerf_head_destroy": (None, [C.c_void_p]),
     "mf_nerf_torso_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

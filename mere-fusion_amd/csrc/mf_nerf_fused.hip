@@ -50,6 +50,7 @@ struct FusedArgs {
     float bound, eye;
     int n_ind, has_eye, M, ntiles;
     const int* M_dev;                // device-side sample count (sync-free render loop), or null
+    const float* eye_dev;            // the eye feature read from device memory (mf_nerf_head_set_eye: no host copy of a value that lives on the device), or null
     float sigma_scale;               // NeRFRenderer.density_scale (renderer.py:261)
     float *sigmas, *rgbs, *amb_aud, *amb_eye, *unc;
 };
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(NWAVE * 64) void k_nerf_field_fused(const FusedArgs
         reinterpret_cast<u32x4*>(smem)[i] = reinterpret_cast<const u32x4*>(a.w)[i];
     if (tid < NLEV) { lt.scale[tid] = a.scale[tid]; lt.resolution[tid] = a.resolution[tid]; lt.offset[tid] = a.offset[tid]; lt.hashmap_size[tid] = a.hashmap_size[tid]; lt.mask[tid] = (a.hashmap_size[tid] & (a.hashmap_size[tid] - 1)) == 0 ? a.hashmap_size[tid] - 1 : 0u; }
     __syncthreads();
+    const float eye_v = a.eye_dev ? *a.eye_dev : a.eye;
     const float* const emb0 = a.emb[0];
     const float* const emb1 = a.emb[1];
     const float* const emb2 = a.emb[2];
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(NWAVE * 64) void k_nerf_field_fused(const FusedArgs
                 // row 0 of the block lives in lanes g == 0 (element 0); the other lanes hold zero-weight rows
                 const float s = 1.f / (1.f + __expf(-e2[sf][0]));
                 eye_att[sf] = s;
-                eyeh[sf] = g == 0 ? pack4(a.eye * s, 0.f, 0.f, 0.f) : Z;
+                eyeh[sf] = g == 0 ? pack4(eye_v * s, 0.f, 0.f, 0.f) : Z;
             }
         }
 
@@ -496,9 +498,9 @@ int mf_nerf_fused_pack(const float* const w[9], int n_ind, bool has_eye, bool x3
 
 int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound,
                          const float* xyzs, const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M,
-                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev, float sigma_scale) {
+                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev, float sigma_scale, const float* eye_dev) {
     FusedArgs a{};
-    a.M_dev = M_dev; a.sigma_scale = sigma_scale;
+    a.M_dev = M_dev; a.sigma_scale = sigma_scale; a.eye_dev = eye_dev;
     a.xyzs = xyzs; a.dirs = dirs; a.enc_a = enc_a; a.ind = ind; a.w = packed;
     for (int p = 0; p < 3; ++p) a.emb[p] = emb[p];
     for (int l = 0; l < NLEV; ++l) {

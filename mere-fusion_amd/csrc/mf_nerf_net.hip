@@ -30,7 +30,7 @@ int mf_nerf_fused_pack(const float* const w[9], int n_ind, bool has_eye, bool x3
 int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound,
                          const float* xyzs, const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M,
                          float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev = nullptr,
-                         float sigma_scale = 1.f);
+                         float sigma_scale = 1.f, const float* eye_dev = nullptr);
 
 // mf_nerf_torso.hip: the whole torso branch as one fp32 kernel (default); the GEMM chain below stays for A/B (MF_TORSO=gemm)
 int mf_nerf_torso_fused_weight_count();
@@ -622,6 +622,7 @@ struct mf_nerf_head {
     std::vector<void*> dev;
     float *aabb, *nears, *fars, *rays_t, *xyzs, *dirs, *deltas, *sig, *rgb, *aa, *ae, *un, *wsum, *aasum, *aesum, *unsum;
     int *alive[2], *ctl;
+    const float* eye_dev = nullptr;      // mf_nerf_head_set_eye: the eye feature stays on the device
     ~mf_nerf_head() { for (void* d : dev) (void)hipFree(d); }
 };
 
@@ -673,7 +674,7 @@ extern "C" int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const f
                                      h->aasum, h->aesum, h->unsum, s)))
             return rc;
         if ((rc = mf_nerf_fused_launch(f->fused_w, x3, f->emb, c.offsets, c.log2_per_level_scale, c.base_resolution, c.bound, h->xyzs, h->dirs, enc_a, ind_code,
-                                       c.individual_dim, eye, c.exp_eye, N, h->sig, h->rgb, h->aa, h->ae, h->un, s, h->ctl + 3, density_scale)))
+                                       c.individual_dim, eye, c.exp_eye, N, h->sig, h->rgb, h->aa, h->ae, h->un, s, h->ctl + 3, density_scale, h->eye_dev)))
             return rc;
         if ((rc = mf_nerf_loop_round(h->ctl, N, max_steps, a_in, a_out, h->rays_t, rays_o, rays_d, c.bound, dt_gamma, cascades, grid_size, density_bitfield,
                                      h->fars, h->xyzs, h->dirs, h->deltas, 1, T_thresh, h->sig, h->rgb, h->aa, h->ae, h->un, ws, depth, image,
@@ -688,6 +689,12 @@ extern "C" int mf_nerf_head_finish(mf_nerf_head* h, int n_rays, const float* bg_
                                    const float* weights_sum, uint8_t* frame_u8, void* stream) {
     MF_REQUIRE(h && image && depth && n_rays > 0 && n_rays <= h->cap && bg_per_ray >= 0, "nerf_head_finish: bad argument");
     return mf_nerf_finish(image, depth, weights_sum ? weights_sum : h->wsum, h->nears, h->fars, bg_color, bg_per_ray, bg_const, n_rays, frame_u8, stream);
+}
+
+extern "C" int mf_nerf_head_set_eye(mf_nerf_head* h, const float* eye_dev) {
+    MF_REQUIRE(h, "nerf_head_set_eye: null handle");
+    h->eye_dev = eye_dev;
+    return MF_OK;
 }
 
 extern "C" int mf_nerf_head_sums(mf_nerf_head* h, int n_rays, float* ambient_aud, float* ambient_eye, float* uncertainty, void* stream) {

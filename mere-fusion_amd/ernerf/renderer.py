@@ -112,7 +112,12 @@ class HipHeadRenderer:
         bgc = float(1.0 if bg_color is None else (0.0 if bg is not None else bg_color))
         ea = enc_a.float().reshape(-1).contiguous()
         ic = ind_code.float().reshape(-1).contiguous() if ind_code is not None else None
-        ev = float(eye.reshape(-1)[0]) if eye is not None else 0.0
+        # the eye feature: a device tensor (the reference's loader hands one over, provider.py) is read by the kernels where it lives -- no device -> host copy, no
+        # sync in front of the frame; a host tensor / None goes by value as before
+        eye_dev = eye.float().reshape(-1)[:1].contiguous() if (torch.is_tensor(eye) and eye.is_cuda) else None
+        ev = 0.0 if (eye is None or eye_dev is not None) else float(eye.reshape(-1)[0])
+        self._eye_keep = eye_dev
+        _lib.check(self._lib.mf_nerf_head_set_eye(self._head, p(eye_dev)), "mf_nerf_head_set_eye")
 
         def enqueue(out):
             _lib.check(self._lib.mf_nerf_head_render(self._head, p(rays_o), p(rays_d), N, p(self.bitfield), self.cascade, self.grid_size, self.min_near,
@@ -128,12 +133,13 @@ class HipHeadRenderer:
             enqueue(out)
             return out
         # graph mode: static input / output buffers per (ray count, scalar arguments); inputs are copied in unless they already live there
-        key = (N, ev, bool(want_u8), bgc, bool(finish), None if bg is None else bg.numel(), float(dt_gamma), int(max_steps), float(T_thresh))
+        key = (N, ev, eye_dev is not None, bool(want_u8), bgc, bool(finish), None if bg is None else bg.numel(), float(dt_gamma), int(max_steps), float(T_thresh))
         hit = self._graphs.get(key)
-        live = (rays_o, rays_d, ea, ic, bg)
+        live = (rays_o, rays_d, ea, ic, bg, eye_dev)
         if hit is None:
             static = tuple(None if t is None else t.clone() for t in live)
-            rays_o, rays_d, ea, ic, bg = static
+            rays_o, rays_d, ea, ic, bg, eye_dev = static
+            _lib.check(self._lib.mf_nerf_head_set_eye(self._head, p(eye_dev)), "mf_nerf_head_set_eye")
             out = fresh()
             enqueue(out)                                   # warm-up outside the capture
             torch.cuda.synchronize()
