@@ -5,8 +5,6 @@ package for everything else (`musetalk.mere_musetalk`, `musetalk.utils.preproces
 from pkgutil import extend_path
 
 __path__ = extend_path(__path__, __name__)
-from mere_fusion_amd import placement as _placement, procmodel as _procmodel  # noqa: E402
-
-_procmodel.ensure_start_method()             # ROCm: the reference's per-session `mp.Process(target=inference)` must be spawned, not forked (procmodel.py)
+from mere_fusion_amd import placement as _placement  # noqa: E402
 
 _placement.ensure_placed(session=False)      # multi-GPU node: the process takes a GPU before anything touches the device (musereal.py:58); the models charge a session each

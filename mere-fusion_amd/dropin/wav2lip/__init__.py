@@ -5,9 +5,7 @@ ahead of the reference checkout on sys.path; see INTEGRATION.md.  Modules that a
 from pkgutil import extend_path
 
 __path__ = extend_path(__path__, __name__)
-from mere_fusion_amd import placement as _placement, procmodel as _procmodel  # noqa: E402
-
-_procmodel.ensure_start_method()             # ROCm: the reference's per-session `mp.Process(target=inference)` must be spawned, not forked (procmodel.py)
+from mere_fusion_amd import placement as _placement  # noqa: E402
 
 _placement.ensure_placed(session=False)      # multi-GPU node: the process takes a GPU before anything touches the device (lipreal.py:29 `device = 'cuda'`); the models charge a session each
 from . import audio  # noqa: E402,F401

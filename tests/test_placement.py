@@ -91,18 +91,3 @@ def test_placement_stays_out_of_the_way(tmp_path, monkeypatch):
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,6")                             # the deployment's own visibility is the set to choose from
     monkeypatch.delenv("MF_GPUS")
     assert placement.physical_gpus() == ["4", "6"]
-
-
-def test_dropin_import_chooses_spawn_unless_the_application_did(tmp_path):
-    """procmodel.py: the reference starts its per-session workers with the default start method (fork) AFTER `torch.cuda.is_available()` -- which PyTorch-ROCm refuses to
-    serve in the child (tools/fork_probe.py).  Importing the drop-in, which the reference does first, settles on spawn; an explicit choice of the application stands."""
-    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "mere-fusion_amd", "dropin")]), MF_PLACEMENT="0")
-    env.pop("MF_MP_START", None)
-    probe = "import multiprocessing as mp; {pre}; import wav2lip; print('METHOD', mp.get_start_method(allow_none=True))"
-    run = lambda pre, **e: subprocess.run([sys.executable, "-W", "always", "-c", probe.format(pre=pre)], env=dict(env, **e), capture_output=True, text=True, timeout=300)
-    out = run("pass")
-    assert "METHOD spawn" in out.stdout, out.stdout + out.stderr
-    out = run("mp.set_start_method('fork')")
-    assert "METHOD fork" in out.stdout and "forked session process cannot use the GPU" in out.stderr, out.stdout + out.stderr
-    out = run("pass", MF_MP_START="keep")
-    assert "METHOD None" in out.stdout, out.stdout + out.stderr

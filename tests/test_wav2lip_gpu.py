@@ -311,29 +311,35 @@ def test_graphs_survive_workspace_growth(lib_built, sd0):
 
 @pytest.mark.gpu
 def test_reference_process_model_through_the_dropin(lib_built):
-    """lipreal.py's flow, unedited: import the drop-in (`from wav2lip.models import Wav2Lip`, lipreal.py:25), ask `torch.cuda.is_available()` at import time (:29), then
-    start the session's worker with the DEFAULT `mp.Process` (:170) and let it build the model, say `.to('cuda')` and run it.  With plain PyTorch-ROCm the forked
-    worker dies with "Cannot re-initialize CUDA in forked subprocess" (tools/fork_probe.py); the drop-in import settles the start method first (procmodel.py)."""
+    """The reference's process model, unedited: `app.py:549` sets the start method to spawn, a session's `LipReal` is built later (`from lipreal import LipReal`, app.py:339),
+    `lipreal.py` imports the drop-in (:25), asks `torch.cuda.is_available()` at import time (:29) and starts the session's worker with `mp.Process(target=inference)` (:170),
+    which builds the model, says `.to('cuda')` and runs it.  The spawned worker re-imports everything through the same PYTHONPATH: the drop-in, its placement hook and the
+    library must come up in it on their own.  (fork instead of spawn cannot work on ROCm once the parent has asked `is_available()`: tools/fork_probe.py -- which is why
+    app.py's own choice matters and the drop-in does not touch it.)"""
     import os
     import subprocess
     import sys
     root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     script = r'''
 import multiprocessing as mp, sys
-from wav2lip.models import Wav2Lip                      # lipreal.py:25
-import torch
-device = 'cuda' if torch.cuda.is_available() else 'cpu'  # lipreal.py:29
 
 def inference(q):                                         # lipreal.py:75: the worker loads the model itself
+    import torch
+    from wav2lip.models import Wav2Lip
     from mere_fusion_amd import weights as W
+    device = 'cuda' if torch.cuda.is_available() else 'cpu'
     m = Wav2Lip(); m.load_state_dict(W.make_wav2lip_state_dict(0)); m = m.to(device).eval()
     mel, face, _ = W.make_lip_inputs(2, 0)
     with torch.no_grad():
         q.put(float(m(mel.to(device), face.to(device)).float().mean()))
 
 if __name__ == "__main__":
-    q = mp.Queue()                                        # lipreal.py:160: default context
-    p = mp.Process(target=inference, args=(q,)); p.start()
+    mp.set_start_method('spawn')                          # app.py:549
+    from wav2lip.models import Wav2Lip                    # lipreal.py:25 (imported when the first session is built, app.py:339)
+    import torch
+    device = 'cuda' if torch.cuda.is_available() else 'cpu'   # lipreal.py:29
+    q = mp.Queue()                                        # lipreal.py:160
+    p = mp.Process(target=inference, args=(q,)); p.start()     # lipreal.py:170
     print("WORKER", mp.get_start_method(), q.get(timeout=240)); p.join(30)
 '''
     path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mf_procmodel_probe.py")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Does the reference's process model work on ROCm as it is?  lipreal.py / musereal.py import torch, ask `torch.cuda.is_available()` at import time (lipreal.py:29) and then
+"""Fork or spawn on ROCm?  lipreal.py / musereal.py import torch, ask `torch.cuda.is_available()` at import time (lipreal.py:29) and then
 start one `mp.Process(target=inference)` per session with the DEFAULT start method (fork on Linux; lipreal.py:170, musereal.py:162); the child loads the model and runs
 it on the GPU.  This probe does the same with the drop-in Wav2Lip, for fork and for spawn, with and without the parent having touched the device.
     python tools/fork_probe.py        (GPU box)"""
