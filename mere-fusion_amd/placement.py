@@ -24,6 +24,9 @@ import os
 
 _state = {"pid": None, "gpu": None, "charged": 0.0, "n": 0}
 UNBOUNDED = 1 << 30
+# what a process that holds a GPU without a session weighs (the reference's parent process; app.py before its first ER-NeRF session): enough to break ties, so that eight
+# app.py processes started together take eight GPUs instead of all taking GPU 0, and far too little to use up a GPU's capacity (the capacity test allows for it)
+HOLDER_WEIGHT = 1.0 / 64
 
 
 def _dir():
@@ -91,7 +94,7 @@ def choose(held, capacity, weight):
     for g, w, _ in held.values():
         if 0 <= g < len(load):
             load[g] += w
-    free = [g for g in range(len(capacity)) if load[g] + weight <= capacity[g]]
+    free = [g for g in range(len(capacity)) if load[g] + weight <= capacity[g] + 0.5]
     if not free:
         return None
     return min(free, key=lambda g: (load[g] / capacity[g], load[g], g))
@@ -115,7 +118,7 @@ def place(n_gpus, weight=1.0, pid=None, want=None):
             g = mine[0]
             if weight:
                 others = sum(w for p, (gg, w, _) in held.items() if gg == g)
-                if others + weight > cap[g]:
+                if others + weight > cap[g] + 0.5:
                     raise RuntimeError("Maximum number of sessions reached")
                 mine[1] += weight
             return g
@@ -189,7 +192,8 @@ def enabled():
 def ensure_placed(session=True):
     """The first call in a process chooses its GPU (a forked / spawned child chooses again, among all the node's GPUs); every call with session=True charges one
     more session to that GPU -- the model constructors of the drop-in (`uncharge()` gives it back when the model dies) -- while session=False only makes sure the
-    process HAS a GPU: the reference's parent process, which runs the front-ends (mel, Whisper features) but no model, does not count as a session.
+    process HAS a GPU: the reference's parent process, which runs the front-ends (mel, Whisper features) but no model, does not count as a session (it holds its
+    GPU with HOLDER_WEIGHT: a tie-breaker, not a session).
     -> the chosen entry of physical_gpus(), or None when placement is off or there is at most one GPU.
 
     Before the HIP runtime is up the choice is made by narrowing HIP_VISIBLE_DEVICES to the one GPU: every thread of the process -- the reference builds its
@@ -211,9 +215,9 @@ def ensure_placed(session=True):
     if up:
         import torch
         cur = torch.cuda.current_device()
-        g = place(len(phys), weight=w, want=cur if cur < len(phys) else None)
+        g = place(len(phys), weight=w or HOLDER_WEIGHT, want=cur if cur < len(phys) else None)
     else:
-        g = place(len(phys), weight=w)
+        g = place(len(phys), weight=w or HOLDER_WEIGHT)
         os.environ.setdefault("MF_ORIG_VISIBLE_DEVICES", ",".join(phys))
         os.environ["HIP_VISIBLE_DEVICES"] = phys[g]
     atexit.register(release)

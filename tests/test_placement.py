@@ -51,12 +51,27 @@ def test_five_session_processes_spread_three_two_and_release(tmp_path):
         kids[0][0].wait()
         kid7 = _spawn(env)
         assert kid7[1] == "0"                                                    # 2 / 3 after the kill -> GPU 0
-        for p, *_ in kids[1:] + [kid6, kid7, (parent,)]:
+        # processes that hold a GPU without a session still spread (eight app.py started together must not all take GPU 0): 3 + 1/64 + 1 | 2 + 1 at this point
+        fronts = [_spawn(env, kind="frontend") for _ in range(3)]
+        assert sorted(f[1] for f in fronts) == ["0", "1", "1"] or sorted(f[1] for f in fronts) == ["0", "0", "1"], [f[1] for f in fronts]
+        for p, *_ in kids[1:] + [kid6, kid7, (parent,)] + fronts:
             p.stdin.write("\n"); p.stdin.flush()
             p.wait(timeout=30)
         assert placement.table() == {}                                           # everyone released at exit
     finally:
         os.environ.pop("MF_PLACEMENT_DIR", None)
+
+
+def test_holders_without_sessions_spread_over_the_gpus(tmp_path):
+    from mere_fusion_amd import placement
+    env = {k: v for k, v in os.environ.items() if k not in ("HIP_VISIBLE_DEVICES", "MF_ORIG_VISIBLE_DEVICES", "MF_PLACED_GPU", "LOCAL_RANK", "MF_PLACEMENT")}
+    env.update(MF_PLACEMENT_DIR=str(tmp_path), MF_GPUS="4")
+    procs = [_spawn(env, kind="frontend") for _ in range(4)]
+    try:
+        assert [p[1] for p in procs] == ["0", "1", "2", "3"]                     # four app.py processes started together: one GPU each
+    finally:
+        for p, *_ in procs:
+            p.stdin.write("\n"); p.stdin.flush(); p.wait(timeout=30)
 
 
 def test_capacity_is_the_admission_cap(tmp_path):
