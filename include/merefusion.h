@@ -338,9 +338,12 @@ typedef struct mf_nerf_head mf_nerf_head;
 /* Scratch for up to max_rays rays over `field` (which must outlive the head and use the fused field kernel). */
 int mf_nerf_head_create(mf_nerf_field* field, int max_rays, mf_nerf_head** out);
 /* The inference branch of `NeRFRenderer.run_cuda` (renderer.py:231-291) for one frame, enqueued in one go: near/far,
- * max_steps rounds of (round control -> march_rays -> field -> composite_rays_triplane -> compaction) whose counters
+ * up to max_steps rounds of (round control -> march_rays -> field -> composite_rays_triplane -> compaction) whose counters
  * (n_alive, n_step = max(min(N // n_alive, 8), 1), step) live on the device, then the background mix / depth
  * normalisation of :275-280.  No host synchronisation: the call only enqueues (capturable in a hipGraph).
+ * Only the rounds the frames before needed (+ 1; every round until a first frame has reported) go out as launches; ONE
+ * further launch stands for the rest of the max_steps rounds and runs them itself if the loop has not ended by then
+ * (mf_nerf_head_plan_rounds / _set_rounds below; MF_NERF_TAIL_AFTER=<k>|off overrides).
  * rays_o, rays_d [N,3]; density_bitfield [cascades * grid_size^3 / 8]; enc_a [32]; ind_code [individual_dim] or NULL;
  * bg as in mf_nerf_finish.  Outputs: image [N,3], depth [N], weights_sum [N] (optional), frame_u8 [N,3] (optional).
  * Survivors of a round keep no particular order (rays are independent), unlike the reference's boolean mask.
@@ -358,6 +361,15 @@ int mf_nerf_head_finish(mf_nerf_head* h, int n_rays, const float* bg_color, int 
  * later mf_nerf_head_render on `h` instead of its by-value `eye` argument: no host copy of a value that lives on the device, and a captured graph follows a changing
  * value.  NULL: back to the by-value argument.  The float must stay valid until the renders that use it have finished. */
 int mf_nerf_head_set_eye(mf_nerf_head* h, const float* eye_dev);
+/* Rounds of a frame enqueued as (march, field, composite) launches before the tail launch.  _plan_rounds returns what the next mf_nerf_head_render would
+ * choose from the round counts earlier frames posted (device -> pinned host word, read without a sync); _set_rounds(r >= 0) pins the count -- a caller that
+ * captures the enqueue in a hipGraph pins what it keyed the graph on -- and _set_rounds(-1) returns to following the feedback.  _last_rounds: the round count
+ * the most recently FINISHED frame posted (0 before the first), and the tail's error flag. */
+int mf_nerf_head_plan_rounds(mf_nerf_head* h, int max_steps, int* rounds);
+int mf_nerf_head_set_rounds(mf_nerf_head* h, int rounds);
+int mf_nerf_head_last_rounds(mf_nerf_head* h, int* rounds, int* error_flag);
+/* Diagnostics: the first n_ints words of the loop's control block (synchronous copy; layout in csrc/mf_nerf_march.h). */
+int mf_nerf_head_ctl_snapshot(mf_nerf_head* h, int* out, int n_ints);
 /* The per-ray sums `run_cuda` also returns at inference (`results['ambient_aud' | 'ambient_eye' | 'uncertainty']`, renderer.py:286-288) of the LAST frame
  * rendered through `h`: device-to-device copies enqueued on `stream` behind that frame (any of the three may be NULL). */
 int mf_nerf_head_sums(mf_nerf_head* h, int n_rays, float* ambient_aud, float* ambient_eye, float* uncertainty, void* stream);

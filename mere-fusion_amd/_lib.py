@@ -164,6 +164,10 @@ SIGNATURES = {
     "mf_nerf_head_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 5),
     "mf_nerf_head_set_eye": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mf_nerf_head_sums": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4),
+    "mf_nerf_head_plan_rounds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "mf_nerf_head_set_rounds": (C.c_int, [C.c_void_p, C.c_int]),
+    "mf_nerf_head_last_rounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mf_nerf_head_ctl_snapshot": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "mf_nerf_head_destroy": (None, [C.c_void_p]),
     "mf_nerf_torso_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mf_nerf_torso_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 4),

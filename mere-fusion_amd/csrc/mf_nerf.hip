@@ -12,6 +12,7 @@
 // correctly rounded default of hipcc.
 #include "mf_common.h"
 #include "mf_nerf_grid.h"
+#include "mf_nerf_march.h"
 #include <cstdlib>
 #include <cstring>
 #include <cfloat>
@@ -22,35 +23,6 @@
 namespace {
 
 constexpr int NT = 256;
-
-__device__ __forceinline__ float signf_(float x) { return copysignf(1.0f, x); }
-__device__ __forceinline__ float clampf_(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
-
-// raymarching.cu:42-54
-__device__ __forceinline__ int mip_from_pos(float x, float y, float z, float max_cascade) {
-    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-    int exponent;
-    frexpf(mx, &exponent);
-    return (int)fminf(max_cascade - 1, fmaxf(0.f, (float)exponent));
-}
-__device__ __forceinline__ int mip_from_dt(float dt, float H, float max_cascade) {
-    const float mx = dt * H * 0.5f;
-    int exponent;
-    frexpf(mx, &exponent);
-    return (int)fminf(max_cascade - 1, fmaxf(0.f, (float)exponent));
-}
-
-// raymarching.cu:56-71
-__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
-}
-__device__ __forceinline__ uint32_t morton3d(uint32_t x, uint32_t y, uint32_t z) {
-    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
-}
 
 // kernel_near_far_from_aabb, raymarching.cu:92-145
 __global__ __launch_bounds__(NT) void k_near_far_from_aabb(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -88,57 +60,7 @@ __global__ __launch_bounds__(NT) void k_march_rays(uint32_t n_alive, uint32_t n_
                                                    const float* __restrict__ noises) {
     const uint32_t n = threadIdx.x + blockIdx.x * NT;
     if (n >= n_alive || n_step == 0) return;
-    const float SQRT3 = 1.7320508075688772f;
-    const int index = rays_alive[n];
-    const float noise = noises ? noises[n] : 0.f;
-    const float* ro = rays_o + (size_t)index * 3;
-    const float* rd = rays_d + (size_t)index * 3;
-    float* px = xyzs + (size_t)n * n_step * 3;
-    float* pd = dirs + (size_t)n * n_step * 3;
-    float* pt = deltas + (size_t)n * n_step * 2;
-    const float ox = ro[0], oy = ro[1], oz = ro[2];
-    const float dx = rd[0], dy = rd[1], dz = rd[2];
-    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
-    const float rH = 1 / (float)H;
-    const float H3 = (float)(H * H * H);
-    float t = rays_t[index];
-    const float far = fars[index];
-    const float dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / (float)H;
-    const float dt_min = fminf(dt_max, 2 * SQRT3 / (float)max_steps);
-    uint32_t step = 0;
-    t = fmaf(clampf_(t * dt_gamma, dt_min, dt_max), noise, t);                    /* the reference build contracts this (and the lines marked fmaf below) */
-    while (t < far && step < n_step) {
-        const float x = clampf_(fmaf(t, dx, ox), -bound, bound);
-        const float y = clampf_(fmaf(t, dy, oy), -bound, bound);
-        const float z = clampf_(fmaf(t, dz, oz), -bound, bound);
-        const float dt = clampf_(t * dt_gamma, dt_min, dt_max);
-        const int la = mip_from_pos(x, y, z, (float)C), lb = mip_from_dt(dt, (float)H, (float)C);
-        const int level = la > lb ? la : lb;
-        const float mip_bound = fminf(scalbnf(1.f, level), bound);
-        const float mip_rbound = 1 / mip_bound;
-        // the reference forms this product in double (`0.5 * ...`), narrows to float in clamp() and truncates
-        const int nx = (int)clampf_((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
-        const int ny = (int)clampf_((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
-        const int nz = (int)clampf_((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
-        const uint32_t gi = (uint32_t)fmaf((float)level, H3, (float)morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-        const bool occ = grid[gi / 8] & (1 << (gi % 8));
-        if (occ) {
-            px[0] = x; px[1] = y; px[2] = z;
-            pd[0] = dx; pd[1] = dy; pd[2] = dz;
-            t += dt;
-            pt[0] = dt; pt[1] = t;
-            px += 3; pd += 3; pt += 2;
-            step++;
-        } else {
-            const float tx = fmaf(mip_bound, fmaf(((float)nx + 0.5f + 0.5f * signf_(dx)) * rH, 2.0f, -1.0f), -x) * rdx;
-            const float ty = fmaf(mip_bound, fmaf(((float)ny + 0.5f + 0.5f * signf_(dy)) * rH, 2.0f, -1.0f), -y) * rdy;
-            const float tz = fmaf(mip_bound, fmaf(((float)nz + 0.5f + 0.5f * signf_(dz)) * rH, 2.0f, -1.0f), -z) * rdz;
-            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-            do {
-                t += clampf_(t * dt_gamma, dt_min, dt_max);
-            } while (t < tt);
-        }
-    }
+    march_ray_ref(n, n_step, rays_alive[n], noises ? noises[n] : 0.f, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, false);
 }
 
 // k_march_rays for the device-controlled loop: the same per-ray DDA (same float operations in the same order), but a lane only
@@ -285,50 +207,7 @@ __global__ __launch_bounds__(NT) void k_loop_march(const int* __restrict__ ctl, 
     }
 }
 
-// kernel_composite_rays_triplane, raymarching.cu:2142-2249
-// one ray of the composite; returns true when the ray ended inside this round (rays_alive[n] = -1 in the reference)
-__device__ __forceinline__ bool composite_ray(uint32_t n, uint32_t n_step, float T_thresh, int index, float* rays_t, const float* __restrict__ sigmas,
-                                              const float* __restrict__ rgbs, const float* __restrict__ deltas, const float* __restrict__ ambs_aud,
-                                              const float* __restrict__ ambs_eye, const float* __restrict__ uncertainties, float* weights_sum, float* depth,
-                                              float* image, float* amb_aud_sum, float* amb_eye_sum, float* uncertainty_sum) {
-    const float* sg = sigmas + (size_t)n * n_step;
-    const float* rg = rgbs + (size_t)n * n_step * 3;
-    const float* dl = deltas + (size_t)n * n_step * 2;
-    const float* aa = ambs_aud + (size_t)n * n_step;
-    const float* ae = ambs_eye + (size_t)n * n_step;
-    const float* un = uncertainties + (size_t)n * n_step;
-    float t = rays_t[index];
-    float weight_sum = weights_sum[index], d = depth[index];
-    float r = image[3 * index], g = image[3 * index + 1], b = image[3 * index + 2];
-    float a_aud = amb_aud_sum[index], a_eye = amb_eye_sum[index], u = uncertainty_sum[index];
-    uint32_t step = 0;
-    while (step < n_step) {
-        if (dl[0] == 0) break;
-        const float alpha = 1.0f - __expf(-sg[0] * dl[0]);
-        const float T = 1 - weight_sum;
-        const float weight = alpha * mf_opaque(T);          // (alpha, T) share a register pair: see mf_opaque
-        weight_sum += weight;
-        t = dl[1];
-        d += weight * t;
-        r += weight * rg[0];
-        g += weight * rg[1];
-        b += weight * rg[2];
-        a_aud += aa[0];
-        a_eye += ae[0];
-        u += weight * un[0];
-        if (T < T_thresh) break;
-        sg++; rg += 3; dl += 2; step++; aa++; ae++; un++;
-    }
-    if (step >= n_step) rays_t[index] = t;
-    weights_sum[index] = weight_sum;
-    depth[index] = d;
-    image[3 * index] = r; image[3 * index + 1] = g; image[3 * index + 2] = b;
-    amb_aud_sum[index] = a_aud;
-    amb_eye_sum[index] = a_eye;
-    uncertainty_sum[index] = u;
-    return step < n_step;
-}
-
+// kernel_composite_rays_triplane, raymarching.cu:2142-2249 (composite_ray: mf_nerf_march.h)
 __global__ __launch_bounds__(NT) void k_composite_rays_triplane(uint32_t n_alive, uint32_t n_step, float T_thresh, int* rays_alive,
                                                                 float* rays_t, const float* __restrict__ sigmas,
                                                                 const float* __restrict__ rgbs, const float* __restrict__ deltas,
@@ -492,19 +371,13 @@ __global__ __launch_bounds__(NT) void k_nerf_resize(const float* __restrict__ im
 }
 
 // ---- device-controlled render loop (no host sync between rounds) ---------------------------------------------------------
-// ctl: [0] n_alive, [1] n_step, [2] step after this round, [3] M = n_alive * n_step, [6..7] one 64-bit counter: survivors appended so far (low
-// word) and blocks done (high word)
-// head of a round: `while step < max_steps`, `n_alive <= 0 -> break`, n_step = max(min(N // n_alive, 8), 1) (renderer.py:246-256)
-__device__ __forceinline__ void loop_next_round(int* ctl, int n_alive, int step, int N, int max_steps) {
-    int n_step = 0;
-    if (n_alive > 0 && step < max_steps) { n_step = N / n_alive; n_step = n_step < 8 ? n_step : 8; n_step = n_step > 1 ? n_step : 1; }
-    ctl[0] = n_step ? n_alive : 0; ctl[1] = n_step; ctl[2] = step + n_step; ctl[3] = n_step ? n_alive * n_step : 0;
-    ctl[6] = 0; ctl[7] = 0;
-}
+// control block `ctl` and the head of a round (loop_next_round): mf_nerf_march.h
 __global__ void k_loop_init(int* ctl, int N, int max_steps, int* alive, float* rays_t, const float* __restrict__ nears, float* weights_sum, float* depth,
                             float* image, float* amb_aud_sum, float* amb_eye_sum, float* unc_sum) {
     const int n = blockIdx.x * NT + threadIdx.x;
-    if (n == 0) { ctl[4] = 0; ctl[5] = 0; loop_next_round(ctl, N, 0, N, max_steps); }
+    if (n == 0) { ctl[4] = 0; ctl[5] = 0; ctl[LOOP_CTL_ROUNDS] = 0; ctl[LOOP_CTL_ERR] = 0; loop_next_round(ctl, N, 0, N, max_steps); }
+    // the tail kernel's tickets (take | finished | survivors | ready, one entry per round: mf_nerf_fused.hip k_loop_tail)
+    for (int i = n; i < 4 * (max_steps + 1); i += (int)gridDim.x * NT) ctl[LOOP_CTL_TAIL + i] = 0;
     if (n >= N) return;
     alive[n] = n;                                   // renderer.py:242
     rays_t[n] = nears[n];                           // renderer.py:243

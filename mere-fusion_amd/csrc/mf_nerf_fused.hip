@@ -19,7 +19,10 @@
 //   * each lane gathers only the grid features its own B fragments need (channels 4g..4g+3 of each 16-block): 36 bilinear
 //     lookups per sample spread over its 4 lanes, straight from the L2-resident tables.
 #include "mf_nn.h"
+#include "mf_nerf_march.h"
 #include <cmath>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -92,21 +95,13 @@ __device__ __forceinline__ BFrag join(const Half& p0, const Half& p1) {
 // per-level constants in LDS: the level index differs from lane to lane, which kernel-argument arrays cannot serve
 struct LevelTab { float scale[NLEV]; uint32_t resolution[NLEV], offset[NLEV], hashmap_size[NLEV], mask[NLEV]; };   // mask: hashmap_size - 1 if that is a power of two, else 0
 
+// One 16-sample fragment per wave of the radiance field: samples s0 .. s0 + 15 (those below M) of a.xyzs / a.dirs -> a.sigmas, a.rgbs, a.amb_*, a.unc.
+// `smem`: the NFRAG * NP KiB of weight fragments, `lt`: the level constants, both already in LDS.  A sample's result depends on nothing but that sample
+// (a column of every MFMA), so any launch shape that calls this gets the same bits.
 template <bool X3>
-__global__ __launch_bounds__(NWAVE * 64) void k_nerf_field_fused(const FusedArgs a) {
+__device__ __forceinline__ void field_tile(const FusedArgs& a, const char* smem, const LevelTab& lt, const float eye_v, const int s0, const int M) {
     constexpr int NP = X3 ? 2 : 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // NFRAG * NP KiB of weight fragments
-    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    __shared__ LevelTab lt;
-    const int M = a.M_dev ? *a.M_dev : a.M;
-    const int ntiles = (M + TILE - 1) / TILE;
-    if ((int)blockIdx.x >= ntiles) return;          // also the "round already finished" case of the device-controlled loop (M == 0)
-    for (int i = tid; i < NFRAG * NP * 64; i += NWAVE * 64)
-        reinterpret_cast<u32x4*>(smem)[i] = reinterpret_cast<const u32x4*>(a.w)[i];
-    if (tid < NLEV) { lt.scale[tid] = a.scale[tid]; lt.resolution[tid] = a.resolution[tid]; lt.offset[tid] = a.offset[tid]; lt.hashmap_size[tid] = a.hashmap_size[tid]; lt.mask[tid] = (a.hashmap_size[tid] & (a.hashmap_size[tid] - 1)) == 0 ? a.hashmap_size[tid] - 1 : 0u; }
-    __syncthreads();
-    const float eye_v = a.eye_dev ? *a.eye_dev : a.eye;
+    const int lane = threadIdx.x & 63, fr = lane & 15, g = lane >> 4;
     const float* const emb0 = a.emb[0];
     const float* const emb1 = a.emb[1];
     const float* const emb2 = a.emb[2];
@@ -132,8 +127,7 @@ __global__ __launch_bounds__(NWAVE * 64) void k_nerf_field_fused(const FusedArgs
 #define LAYER_FENCE() __builtin_amdgcn_sched_barrier(0)
 
     const float inv2b = 1.f / (2.f * a.bound);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int s0 = tile * TILE + wave * 16 * NSF;
+    {
         // ---- inputs of this lane's two samples ------------------------------------------------------------------
         float px[NSF], py[NSF], pz[NSF], dx[NSF], dy[NSF], dz[NSF];
         bool live[NSF];
@@ -413,6 +407,161 @@ __global__ __launch_bounds__(NWAVE * 64) void k_nerf_field_fused(const FusedArgs
     }
 }
 
+// weight fragments and level constants into LDS (every thread of the workgroup; ends with a barrier)
+template <bool X3>
+__device__ __forceinline__ void field_stage_weights(const FusedArgs& a, char* smem, LevelTab& lt, int nthreads) {
+    constexpr int NP = X3 ? 2 : 1;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NFRAG * NP * 64; i += nthreads)
+        reinterpret_cast<u32x4*>(smem)[i] = reinterpret_cast<const u32x4*>(a.w)[i];
+    if (tid < NLEV) { lt.scale[tid] = a.scale[tid]; lt.resolution[tid] = a.resolution[tid]; lt.offset[tid] = a.offset[tid]; lt.hashmap_size[tid] = a.hashmap_size[tid]; lt.mask[tid] = (a.hashmap_size[tid] & (a.hashmap_size[tid] - 1)) == 0 ? a.hashmap_size[tid] - 1 : 0u; }
+    __syncthreads();
+}
+
+template <bool X3>
+__global__ __launch_bounds__(NWAVE * 64) void k_nerf_field_fused(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // NFRAG * NP KiB of weight fragments
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ LevelTab lt;
+    const int M = a.M_dev ? *a.M_dev : a.M;
+    const int ntiles = (M + TILE - 1) / TILE;
+    if ((int)blockIdx.x >= ntiles) return;          // also the "round already finished" case of the device-controlled loop (M == 0)
+    field_stage_weights<X3>(a, smem, lt, NWAVE * 64);
+    const float eye_v = a.eye_dev ? *a.eye_dev : a.eye;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+        field_tile<X3>(a, smem, lt, eye_v, tile * TILE + wave * 16 * NSF, M);
+}
+
+// ---- the render loop's TAIL: every round the launch chain did not enqueue, in one launch ------------------------------------------------------
+// mf_nerf_head_render enqueues R rounds as (march, field, composite) launches -- R follows the round counts of the frames before (a frame needs ~5 of the
+// max_steps = 16 the reference allows: renderer.py:246-270) -- and then this kernel ONCE.  It finds the loop ended (ctl[1] == 0: the usual case, one empty launch
+// instead of 3 x (16 - R)) or runs the remaining rounds itself:
+//   * a round is cut into chunks of 1024 alive rays; a workgroup takes a chunk by ticket and carries it through the WHOLE round -- march (one ray per lane, the
+//     reference's loop: march_ray_ref), field (field_tile over the chunk's own samples), composite (composite_ray) and the append of its survivors.  Rays do not
+//     interact inside a round, so the only grid-wide step is the head of the next round (survivor count -> n_step): the workgroup that finishes the round's last
+//     chunk computes it and publishes `ready[j + 1]`; the others wait for that flag -- and only for that flag, which a RUNNING workgroup will set.  No workgroup
+//     ever waits for one that has not started, so the kernel needs no co-residency (two sessions' tails on one GPU cannot block each other).
+//   * same per-ray and per-sample arithmetic as the launches (the survivors' order differs; results do not depend on it), so a frame is the same bits wherever the
+//     chain hands over (tests/test_ernerf.py: hand-over after 0, 1, 2, 3 rounds against the launch-only loop).
+// Visibility between workgroups (other XCDs have their own L2): agent-scope release (fence + atomic) by the writer, acquire (atomic + fence) by the readers.
+struct TailArgs {
+    int* ctl;
+    int N, max_steps, first_parity;      // first_parity: which of alive[0 / 1] the first tail round reads
+    float T_thresh, dt_gamma;
+    uint32_t C, H;
+    int* alive[2];
+    float* rays_t;
+    const float *rays_o, *rays_d, *fars;
+    const uint8_t* grid;
+    float *xyzs, *dirs, *deltas;
+    float *wsum, *depth, *image, *aasum, *aesum, *unsum;
+};
+constexpr int TAIL_RC = NWAVE * 64;      // rays per chunk: one per lane
+#ifndef MF_TAIL_SPINS
+#define MF_TAIL_SPINS (1 << 20)
+#endif
+constexpr int TAIL_SPINS = MF_TAIL_SPINS;   // polls of ~2 us before a waiting workgroup gives up (seconds)
+
+template <bool X3>
+__global__ __launch_bounds__(NWAVE * 64) void k_loop_tail(const FusedArgs a, const TailArgs t) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ LevelTab lt;
+    __shared__ int s_i[4], s_wave[NWAVE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the round about to run, as the last composite launch (or k_loop_init) left it; nothing writes ctl[0..2] while this kernel runs
+    int n_alive = t.ctl[0], n_step = t.ctl[1], step_after = t.ctl[2];
+    if (n_step <= 0) return;                                                       // the loop has ended: the usual case
+    field_stage_weights<X3>(a, smem, lt, NWAVE * 64);
+    const float eye_v = a.eye_dev ? *a.eye_dev : a.eye;
+    const int TS = t.max_steps + 1;
+    int* const take = t.ctl + LOOP_CTL_TAIL;
+    int* const fin = take + TS;
+    int* const surv = fin + TS;
+    int* const ready = surv + TS;
+    int* const p_alive = ready + TS;
+    int* const p_step = p_alive + TS;
+    int* const p_after = p_step + TS;
+    // every loop condition below is a wave-uniform SCALAR (readfirstlane of a value all lanes read from LDS): the workgroup's 16 waves take every branch together
+    // and meet at every barrier.  (Written with plain ints the compiler cannot prove the ticket loop's exit uniform, builds per-lane exit masks around the
+    // barriers, and the waves of a workgroup left the loop at different times -- a hang, found with the stage markers of profiles/r06_tail_trace.patch.)
+    auto uni = [](int x) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(x); };
+    auto next_ticket = [&](int j) __attribute__((always_inline)) {
+        if (tid == 0) s_i[0] = atomicAdd(&take[j], 1);
+        __syncthreads();
+        const int c = uni(s_i[0]);
+        __syncthreads();
+        return c;
+    };
+    n_alive = uni(n_alive); n_step = uni(n_step); step_after = uni(step_after);
+    for (int j = 0; j < t.max_steps; ++j) {
+        const int* a_in = t.alive[(t.first_parity + j) & 1];
+        int* a_out = t.alive[(t.first_parity + j + 1) & 1];
+        const int nchunks = (n_alive + TAIL_RC - 1) / TAIL_RC;
+        for (int c = next_ticket(j); c < nchunks; c = next_ticket(j)) {
+            const int base = c * TAIL_RC;
+            const int rays_here = min(TAIL_RC, n_alive - base);
+            const uint32_t n = (uint32_t)(base + tid);
+            int v = -1;
+            if (tid < rays_here) {
+                v = a_in[n];
+                march_ray_ref(n, (uint32_t)n_step, v, 0.f, t.rays_t, t.rays_o, t.rays_d, a.bound, t.dt_gamma, (uint32_t)t.max_steps, t.C, t.H, t.grid, t.fars,
+                              t.xyzs, t.dirs, t.deltas, true);
+            }
+            __threadfence();
+            __syncthreads();
+            const int m0 = base * n_step, mend = m0 + rays_here * n_step;
+            for (int s0 = m0; s0 < mend; s0 += TILE) field_tile<X3>(a, smem, lt, eye_v, s0 + wave * 16 * NSF, mend);
+            __threadfence();
+            __syncthreads();
+            bool keep = false;
+            if (tid < rays_here)
+                keep = !composite_ray(n, (uint32_t)n_step, t.T_thresh, v, t.rays_t, a.sigmas, a.rgbs, t.deltas, a.amb_aud, a.amb_eye, a.unc, t.wsum, t.depth, t.image,
+                                      t.aasum, t.aesum, t.unsum);
+            // `rays_alive = rays_alive[rays_alive >= 0]` (renderer.py:266): wave-aggregated append, one atomic per chunk
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) s_wave[wave] = __popcll(m);
+            __syncthreads();
+            int before = 0, mine = 0;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) { before += w < wave ? s_wave[w] : 0; mine += s_wave[w]; }
+            if (tid == 0) s_i[1] = atomicAdd(&surv[j], mine);
+            __syncthreads();
+            if (keep) a_out[s_i[1] + before + __popcll(m & ((1ull << lane) - 1))] = v;
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) {
+                const int done = atomicAdd(&fin[j], 1);
+                if (done == nchunks - 1) {                                          // the round's last chunk: head of the next round
+                    const int na = __hip_atomic_load(&surv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int ns = j + 1 < t.max_steps ? loop_n_step(na, step_after, t.N, t.max_steps) : 0;
+                    p_alive[j + 1] = ns ? na : 0; p_step[j + 1] = ns; p_after[j + 1] = step_after + ns;
+                    if (ns) t.ctl[LOOP_CTL_ROUNDS] += 1;
+                    else loop_post_feedback(t.ctl);
+                    __hip_atomic_store(&ready[j + 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (tid == 0) {
+            // every chunk of round j is taken, each by a workgroup that is running it: the flag WILL be set.  The bound only turns a protocol bug into an error the
+            // host sees (ctl[9] -> the feedback word) instead of a hung GPU.
+            int spins = 0;
+            while (__hip_atomic_load(&ready[j + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0 && spins < TAIL_SPINS) { __builtin_amdgcn_s_sleep(32); ++spins; }
+            if (spins >= TAIL_SPINS) {
+                __hip_atomic_store(&t.ctl[LOOP_CTL_ERR], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                loop_post_feedback(t.ctl);
+                s_i[1] = 0; s_i[2] = 0; s_i[3] = 0;
+            } else {
+                s_i[1] = p_alive[j + 1]; s_i[2] = p_step[j + 1]; s_i[3] = p_after[j + 1];
+            }
+        }
+        __syncthreads();
+        n_alive = uni(s_i[1]); n_step = uni(s_i[2]); step_after = uni(s_i[3]);
+        __syncthreads();
+        if (n_step <= 0) return;
+        __threadfence();                                                            // every lane sees what the other workgroups wrote in round j
+    }
+}
 }  // namespace
 
 // ---- host: weight fragments in the kernel's K order ----------------------------------------------------------------------
@@ -496,10 +645,9 @@ int mf_nerf_fused_pack(const float* const w[9], int n_ind, bool has_eye, bool x3
     return MF_OK;
 }
 
-int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound,
-                         const float* xyzs, const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M,
-                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev, float sigma_scale, const float* eye_dev) {
-    FusedArgs a{};
+static void fused_args(FusedArgs& a, const bf16_t* packed, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound, const float* xyzs,
+                       const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M, float* sigmas, float* rgbs, float* amb_aud,
+                       float* amb_eye, float* unc, const int* M_dev, float sigma_scale, const float* eye_dev) {
     a.M_dev = M_dev; a.sigma_scale = sigma_scale; a.eye_dev = eye_dev;
     a.xyzs = xyzs; a.dirs = dirs; a.enc_a = enc_a; a.ind = ind; a.w = packed;
     for (int p = 0; p < 3; ++p) a.emb[p] = emb[p];
@@ -513,16 +661,57 @@ int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3
     a.bound = bound; a.eye = eye; a.n_ind = n_ind; a.has_eye = has_eye; a.M = M;
     a.ntiles = (M + TILE - 1) / TILE;
     a.sigmas = sigmas; a.rgbs = rgbs; a.amb_aud = amb_aud; a.amb_eye = amb_eye; a.unc = unc;
+}
+
+template <typename K>
+static int fused_lds_attr(K kernel, bool& done, size_t lds) {
+    if (!done) {
+        MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done = true;
+    }
+    return MF_OK;
+}
+
+int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound,
+                         const float* xyzs, const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M,
+                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev, float sigma_scale, const float* eye_dev) {
+    FusedArgs a{};
+    fused_args(a, packed, emb, offsets, log2_pls, base_res, bound, xyzs, dirs, enc_a, ind, n_ind, eye, has_eye, M, sigmas, rgbs, amb_aud, amb_eye, unc, M_dev, sigma_scale, eye_dev);
     const size_t lds = (size_t)NFRAG * (x3 ? 2 : 1) * 1024;
     static bool attr_done[2] = {false, false};
-    if (!attr_done[x3]) {
-        if (x3) MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nerf_field_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nerf_field_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done[x3] = true;
-    }
+    int rc;
+    if ((rc = x3 ? fused_lds_attr(k_nerf_field_fused<true>, attr_done[1], lds) : fused_lds_attr(k_nerf_field_fused<false>, attr_done[0], lds))) return rc;
     const int grid = std::min(a.ntiles, 256);
     if (x3) hipLaunchKernelGGL(k_nerf_field_fused<true>, dim3(grid), dim3(NWAVE * 64), lds, s, a);
     else hipLaunchKernelGGL(k_nerf_field_fused<false>, dim3(grid), dim3(NWAVE * 64), lds, s, a);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+
+// the render loop's tail (k_loop_tail): the rounds after the `rounds_launched` that mf_nerf_head_render enqueued as launches, in one launch
+int mf_nerf_tail_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound, const float* enc_a,
+                        const float* ind, int n_ind, float eye, int has_eye, float sigma_scale, const float* eye_dev, float* sigmas, float* rgbs, float* amb_aud,
+                        float* amb_eye, float* unc, int* ctl, int N, int max_steps, int rounds_launched, float T_thresh, float dt_gamma, uint32_t cascades,
+                        uint32_t grid_size, int* alive0, int* alive1, float* rays_t, const float* rays_o, const float* rays_d, const float* fars,
+                        const uint8_t* bitfield, float* xyzs, float* dirs, float* deltas, float* wsum, float* depth, float* image, float* aasum, float* aesum,
+                        float* unsum, hipStream_t s) {
+    FusedArgs a{};
+    fused_args(a, packed, emb, offsets, log2_pls, base_res, bound, xyzs, dirs, enc_a, ind, n_ind, eye, has_eye, N, sigmas, rgbs, amb_aud, amb_eye, unc, nullptr, sigma_scale, eye_dev);
+    TailArgs t{};
+    t.ctl = ctl; t.N = N; t.max_steps = max_steps; t.first_parity = rounds_launched & 1; t.T_thresh = T_thresh; t.dt_gamma = dt_gamma; t.C = cascades; t.H = grid_size;
+    t.alive[0] = alive0; t.alive[1] = alive1; t.rays_t = rays_t; t.rays_o = rays_o; t.rays_d = rays_d; t.fars = fars; t.grid = bitfield;
+    t.xyzs = xyzs; t.dirs = dirs; t.deltas = deltas; t.wsum = wsum; t.depth = depth; t.image = image; t.aasum = aasum; t.aesum = aesum; t.unsum = unsum;
+    const size_t lds = (size_t)NFRAG * (x3 ? 2 : 1) * 1024;
+    static bool attr_done[2] = {false, false};
+    int rc;
+    if ((rc = x3 ? fused_lds_attr(k_loop_tail<true>, attr_done[1], lds) : fused_lds_attr(k_loop_tail<false>, attr_done[0], lds))) return rc;
+    // workgroups: enough to run a round that still has every ray (hand-over after 0 rounds: 256 chunks at 512 x 512) at the chip's width; when the loop has ended -- the
+    // usual case -- each of them reads three words and leaves
+    const char* e = getenv("MF_NERF_TAIL_WGS");
+    int grid = std::min(256, std::max(1, (N + TAIL_RC - 1) / TAIL_RC));
+    if (e && atoi(e) > 0) grid = std::min(grid, atoi(e));
+    if (x3) hipLaunchKernelGGL(k_loop_tail<true>, dim3(grid), dim3(NWAVE * 64), lds, s, a, t);
+    else hipLaunchKernelGGL(k_loop_tail<false>, dim3(grid), dim3(NWAVE * 64), lds, s, a, t);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

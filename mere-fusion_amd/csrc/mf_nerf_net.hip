@@ -13,6 +13,7 @@
 // sigma_net's last layer writes its 65 outputs straight into CI[0..64]; colour_net's weight columns are permuted to that layout
 // (and zero on h0), so geo_feat is never copied.
 #include "mf_nn.h"
+#include "mf_nerf_march.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -31,6 +32,12 @@ int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3
                          const float* xyzs, const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M,
                          float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev = nullptr,
                          float sigma_scale = 1.f, const float* eye_dev = nullptr);
+int mf_nerf_tail_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound, const float* enc_a,
+                        const float* ind, int n_ind, float eye, int has_eye, float sigma_scale, const float* eye_dev, float* sigmas, float* rgbs, float* amb_aud,
+                        float* amb_eye, float* unc, int* ctl, int N, int max_steps, int rounds_launched, float T_thresh, float dt_gamma, uint32_t cascades,
+                        uint32_t grid_size, int* alive0, int* alive1, float* rays_t, const float* rays_o, const float* rays_d, const float* fars,
+                        const uint8_t* bitfield, float* xyzs, float* dirs, float* deltas, float* wsum, float* depth, float* image, float* aasum, float* aesum,
+                        float* unsum, hipStream_t s);
 
 // mf_nerf_torso.hip: the whole torso branch as one fp32 kernel (default); the GEMM chain below stays for A/B (MF_TORSO=gemm)
 int mf_nerf_torso_fused_weight_count();
@@ -602,7 +609,9 @@ extern "C" void mf_nerf_torso_destroy(mf_nerf_torso* h) { delete h; }
 // Head render loop without host round trips: `run_cuda`'s inference branch (renderer.py:231-291) with the round control
 // (n_alive, n_step, step) kept in HBM.  The reference compacts `rays_alive` with a boolean mask and reads its length back on the
 // host every round; here k_loop_ctl / k_loop_compact (mf_nerf.hip) do both on the device, every launch has a fixed grid and
-// exits when its round has nothing to do, and max_steps rounds are enqueued back to back -- capturable as one hipGraph.
+// exits when its round has nothing to do.  A frame needs ~5 of the max_steps = 16 rounds the reference allows, so only as many rounds as the frames before
+// needed (+ 1) are enqueued as launches and ONE tail launch (k_loop_tail, mf_nerf_fused.hip) stands for the rest: it finds the loop ended, or runs the
+// remaining rounds itself -- no round is ever dropped, and nothing waits for the host.  The whole frame is capturable as one hipGraph.
 // =========================================================================================================================
 extern "C" int mf_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t n_rays, float min_near, float* nears,
                                      float* fars, void* stream);
@@ -623,8 +632,37 @@ struct mf_nerf_head {
     float *aabb, *nears, *fars, *rays_t, *xyzs, *dirs, *deltas, *sig, *rgb, *aa, *ae, *un, *wsum, *aasum, *aesum, *unsum;
     int *alive[2], *ctl;
     const float* eye_dev = nullptr;      // mf_nerf_head_set_eye: the eye feature stays on the device
-    ~mf_nerf_head() { for (void* d : dev) (void)hipFree(d); }
+    // round-count feedback: two words of pinned host memory the device posts to when a frame's loop ends ([0] rounds the frame ran, [1] the tail's error flag);
+    // read without a sync, so it tells about a frame that finished some calls ago
+    volatile int* fb = nullptr;
+    int ctl_rounds = 0;                  // the control block holds tail tickets for this many rounds
+    int hist[4] = {0, 0, 0, 0}, hist_n = 0;
+    int fixed_rounds = -1;               // mf_nerf_head_set_rounds: >= 0 pins the launched-round count (a captured graph is keyed on it), -1 = follow the feedback
+    ~mf_nerf_head() {
+        for (void* d : dev) (void)hipFree(d);
+        if (fb) (void)hipHostFree((void*)fb);
+    }
 };
+
+constexpr int HEAD_MAX_ROUNDS = 1024;     // max_steps accepted by mf_nerf_head_render (one round per step at least: renderer.py:270)
+
+// How many rounds of the next frame are enqueued as (march, field, composite) launches; the tail launch covers the rest.  The most rounds any of the last four
+// observed frames ran, plus one; every round (no tail) until a first frame has reported.  MF_NERF_TAIL_AFTER=<k> fixes it (tests, A/B: 0 = the tail runs the whole
+// loop, "off" = launches only, as before round 6).
+static int head_plan(mf_nerf_head* h, int max_steps) {
+    const char* e = getenv("MF_NERF_TAIL_AFTER");
+    if (e && *e) {
+        if (!strcmp(e, "off")) return max_steps;
+        const int k = atoi(e);
+        return k < 0 ? max_steps : (k < max_steps ? k : max_steps);
+    }
+    const int seen = h->fb ? h->fb[0] : 0;
+    if (seen > 0) { h->hist[h->hist_n & 3] = seen; h->hist_n++; }
+    if (h->hist_n == 0) return max_steps;
+    int m = 0;
+    for (int i = 0; i < 4; ++i) m = h->hist[i] > m ? h->hist[i] : m;
+    return m + 1 < max_steps ? m + 1 : max_steps;
+}
 
 extern "C" int mf_nerf_head_create(mf_nerf_field* field, int max_rays, mf_nerf_head** out) {
     MF_REQUIRE(field && out && max_rays > 0, "nerf_head_create: bad argument");
@@ -640,8 +678,20 @@ extern "C" int mf_nerf_head_create(mf_nerf_field* field, int max_rays, mf_nerf_h
     if ((rc = fm(&h->aabb, 6)) || (rc = fm(&h->nears, N)) || (rc = fm(&h->fars, N)) || (rc = fm(&h->rays_t, N)) || (rc = fm(&h->xyzs, 3 * N)) ||
         (rc = fm(&h->dirs, 3 * N)) || (rc = fm(&h->deltas, 2 * N)) || (rc = fm(&h->sig, N)) || (rc = fm(&h->rgb, 3 * N)) || (rc = fm(&h->aa, N)) ||
         (rc = fm(&h->ae, N)) || (rc = fm(&h->un, N)) || (rc = fm(&h->wsum, N)) || (rc = fm(&h->aasum, N)) || (rc = fm(&h->aesum, N)) ||
-        (rc = fm(&h->unsum, N)) || (rc = im(&h->alive[0], N)) || (rc = im(&h->alive[1], N)) || (rc = im(&h->ctl, 8)))
+        (rc = fm(&h->unsum, N)) || (rc = im(&h->alive[0], N)) || (rc = im(&h->alive[1], N)) ||
+        (rc = im(&h->ctl, (size_t)LOOP_CTL_TAIL + (size_t)LOOP_TAIL_ARRAYS * (HEAD_MAX_ROUNDS + 1))))
         return rc;
+    h->ctl_rounds = HEAD_MAX_ROUNDS;
+    MF_HIP(hipMemset(h->ctl, 0, ((size_t)LOOP_CTL_TAIL + (size_t)LOOP_TAIL_ARRAYS * (HEAD_MAX_ROUNDS + 1)) * sizeof(int)));
+    {
+        int* fb = nullptr;
+        MF_HIP(hipHostMalloc((void**)&fb, 4 * sizeof(int), hipHostMallocMapped));
+        fb[0] = fb[1] = fb[2] = fb[3] = 0;
+        h->fb = fb;
+        void* fb_dev = nullptr;
+        MF_HIP(hipHostGetDevicePointer(&fb_dev, fb, 0));
+        MF_HIP(hipMemcpy(h->ctl + LOOP_CTL_FB, &fb_dev, sizeof(fb_dev), hipMemcpyHostToDevice));
+    }
     const float b = field->cfg.bound;
     const float aabb[6] = {-b, -b / 2, -b, b, b / 2, b};                                    // aabb_infer, renderer.py:86-89
     MF_HIP(hipMemcpy(h->aabb, aabb, sizeof(aabb), hipMemcpyHostToDevice));
@@ -654,7 +704,7 @@ extern "C" int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const f
                                    const float* ind_code, float eye, const float* bg_color, int bg_per_ray, float bg_const, float* image, float* depth,
                                    float* weights_sum, uint8_t* frame_u8, void* stream) {
     MF_REQUIRE(h && rays_o && rays_d && density_bitfield && enc_a && image && depth, "nerf_head_render: null argument");
-    MF_REQUIRE(n_rays > 0 && n_rays <= h->cap && max_steps > 0 && max_steps <= 1024, "nerf_head_render: n_rays=%d (capacity %d) max_steps=%d", n_rays, h->cap, max_steps);
+    MF_REQUIRE(n_rays > 0 && n_rays <= h->cap && max_steps > 0 && max_steps <= HEAD_MAX_ROUNDS, "nerf_head_render: n_rays=%d (capacity %d) max_steps=%d", n_rays, h->cap, max_steps);
     hipStream_t s = (hipStream_t)stream;
     mf_nerf_field* f = h->field;
     const mf_nerf_field_config& c = f->cfg;
@@ -666,7 +716,9 @@ extern "C" int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const f
     if ((rc = mf_nerf_loop_init(h->ctl, N, max_steps, h->alive[0], h->rays_t, h->nears, ws, depth, image, h->aasum, h->aesum, h->unsum, s))) return rc;
     const bool x3 = f->precision == MF_PREC_BF16X3;
     // at least one sample per alive ray and round, so max_steps rounds always suffice (step += n_step >= 1, renderer.py:270)
-    for (int it = 0; it < max_steps; ++it) {
+    MF_REQUIRE(!h->fb || h->fb[1] == 0, "nerf_head_render: the tail kernel of an earlier frame gave up waiting for a round (control block error flag)");
+    const int rounds = h->fixed_rounds >= 0 ? (h->fixed_rounds < max_steps ? h->fixed_rounds : max_steps) : head_plan(h, max_steps);
+    for (int it = 0; it < rounds; ++it) {
         int* a_in = h->alive[it & 1];
         int* a_out = h->alive[(it + 1) & 1];
         if ((rc = mf_nerf_loop_round(h->ctl, N, max_steps, a_in, a_out, h->rays_t, rays_o, rays_d, c.bound, dt_gamma, cascades, grid_size, density_bitfield,
@@ -681,6 +733,13 @@ extern "C" int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const f
                                      h->aasum, h->aesum, h->unsum, s)))
             return rc;
     }
+    // at least one sample per alive ray and round, so max_steps rounds always suffice (step += n_step >= 1, renderer.py:270): with every round enqueued there is no tail
+    if (rounds < max_steps &&
+        (rc = mf_nerf_tail_launch(f->fused_w, x3, f->emb, c.offsets, c.log2_per_level_scale, c.base_resolution, c.bound, enc_a, ind_code, c.individual_dim, eye, c.exp_eye,
+                                  density_scale, h->eye_dev, h->sig, h->rgb, h->aa, h->ae, h->un, h->ctl, N, max_steps, rounds, T_thresh, dt_gamma, cascades, grid_size,
+                                  h->alive[0], h->alive[1], h->rays_t, rays_o, rays_d, h->fars, density_bitfield, h->xyzs, h->dirs, h->deltas, ws, depth, image,
+                                  h->aasum, h->aesum, h->unsum, s)))
+        return rc;
     if (bg_per_ray < 0) return MF_OK;                                                       // finished later by mf_nerf_head_finish
     return mf_nerf_finish(image, depth, ws, h->nears, h->fars, bg_color, bg_per_ray, bg_const, N, frame_u8, stream);
 }
@@ -694,6 +753,31 @@ extern "C" int mf_nerf_head_finish(mf_nerf_head* h, int n_rays, const float* bg_
 extern "C" int mf_nerf_head_set_eye(mf_nerf_head* h, const float* eye_dev) {
     MF_REQUIRE(h, "nerf_head_set_eye: null handle");
     h->eye_dev = eye_dev;
+    return MF_OK;
+}
+
+extern "C" int mf_nerf_head_plan_rounds(mf_nerf_head* h, int max_steps, int* rounds) {
+    MF_REQUIRE(h && rounds && max_steps > 0 && max_steps <= HEAD_MAX_ROUNDS, "nerf_head_plan_rounds: bad argument");
+    *rounds = head_plan(h, max_steps);
+    return MF_OK;
+}
+
+extern "C" int mf_nerf_head_set_rounds(mf_nerf_head* h, int rounds) {
+    MF_REQUIRE(h && rounds >= -1 && rounds <= HEAD_MAX_ROUNDS, "nerf_head_set_rounds: bad argument");
+    h->fixed_rounds = rounds;
+    return MF_OK;
+}
+
+extern "C" int mf_nerf_head_last_rounds(mf_nerf_head* h, int* rounds, int* error_flag) {
+    MF_REQUIRE(h && h->fb, "nerf_head_last_rounds: null handle");
+    if (rounds) *rounds = h->fb[0];
+    if (error_flag) *error_flag = h->fb[1];
+    return MF_OK;
+}
+
+extern "C" int mf_nerf_head_ctl_snapshot(mf_nerf_head* h, int* out, int n_ints) {
+    MF_REQUIRE(h && out && n_ints > 0 && (size_t)n_ints <= (size_t)LOOP_CTL_TAIL + (size_t)LOOP_TAIL_ARRAYS * (HEAD_MAX_ROUNDS + 1), "nerf_head_ctl_snapshot: bad argument");
+    MF_HIP(hipMemcpy(out, h->ctl, (size_t)n_ints * sizeof(int), hipMemcpyDeviceToHost));
     return MF_OK;
 }
 

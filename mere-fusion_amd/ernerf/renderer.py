@@ -96,7 +96,7 @@ class HipHeadRenderer:
     def run_cuda_device(self, rays_o, rays_d, enc_a, ind_code, eye, bg_color=None, dt_gamma=1 / 256, max_steps=16, T_thresh=1e-4, want_u8=False,
                         graph=False, finish=True):
         """The same frame as run_cuda with the round control on the device (mf_nerf_head_render): one enqueue, no host sync between
-        rounds.  graph=True captures the enqueue once per (ray count, tensors) into a CUDA graph and replays it."""
+        rounds.  graph=True captures the enqueue once per (ray count, tensors, launched rounds) into a CUDA graph and replays it."""
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
         N, dev = rays_o.shape[0], rays_o.device
@@ -132,8 +132,12 @@ class HipHeadRenderer:
             out = fresh()
             enqueue(out)
             return out
-        # graph mode: static input / output buffers per (ray count, scalar arguments); inputs are copied in unless they already live there
-        key = (N, ev, eye_dev is not None, bool(want_u8), bgc, bool(finish), None if bg is None else bg.numel(), float(dt_gamma), int(max_steps), float(T_thresh))
+        # graph mode: static input / output buffers per (ray count, scalar arguments); inputs are copied in unless they already live there.  The number of rounds
+        # enqueued as launches (the tail launch stands for the rest) follows the frames before: a graph is captured per count -- two or three in a session
+        planned = C.c_int(0)
+        _lib.check(self._lib.mf_nerf_head_plan_rounds(self._head, int(max_steps), C.byref(planned)), "mf_nerf_head_plan_rounds")
+        key = (N, ev, eye_dev is not None, bool(want_u8), bgc, bool(finish), None if bg is None else bg.numel(), float(dt_gamma), int(max_steps), float(T_thresh),
+               planned.value)
         hit = self._graphs.get(key)
         live = (rays_o, rays_d, ea, ic, bg, eye_dev)
         if hit is None:
@@ -141,11 +145,15 @@ class HipHeadRenderer:
             rays_o, rays_d, ea, ic, bg, eye_dev = static
             _lib.check(self._lib.mf_nerf_head_set_eye(self._head, p(eye_dev)), "mf_nerf_head_set_eye")
             out = fresh()
-            enqueue(out)                                   # warm-up outside the capture
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                enqueue(out)
+            _lib.check(self._lib.mf_nerf_head_set_rounds(self._head, planned.value), "mf_nerf_head_set_rounds")
+            try:
+                enqueue(out)                               # warm-up outside the capture
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    enqueue(out)
+            finally:
+                _lib.check(self._lib.mf_nerf_head_set_rounds(self._head, -1), "mf_nerf_head_set_rounds")
             hit = (g, out, static)
             self._graphs[key] = hit
         else:

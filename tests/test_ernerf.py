@@ -842,6 +842,74 @@ def test_hip_full_frame_device_loop(lib_built):
         assert want["frame_u8"].float().std().item() > 5
 
 
+def _head_frame(r, graph=False):
+    """one head frame of a bench.ErNeRFRunner through mf_nerf_head_render, with the three per-ray sums and the round count the frame posted"""
+    from mere_fusion_amd import _lib
+    out = r.r.run_cuda_device(r.ro, r.rd, r.d_enc_a, r.d_ind, r.eye, bg_color=1.0, want_u8=True, graph=graph)
+    N = r.ro.shape[0]
+    sums = [torch.empty(N, device=r.ro.device) for _ in range(3)]
+    _lib.check(_lib.lib().mf_nerf_head_sums(r.r._head, N, *[C.c_void_p(t.data_ptr()) for t in sums], C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    rounds, err = C.c_int(), C.c_int()
+    _lib.check(_lib.lib().mf_nerf_head_last_rounds(r.r._head, C.byref(rounds), C.byref(err)))
+    assert err.value == 0
+    return [out["image"].clone(), out["depth"].clone(), out["weights_sum"].clone(), out["frame_u8"].clone()] + sums, rounds.value
+
+
+@pytest.mark.gpu
+def test_loop_tail_same_bits_wherever_the_launch_chain_hands_over(lib_built, monkeypatch):
+    """mf_nerf_head_render enqueues some rounds as (march, field, composite) launches and ONE tail launch for the rest (k_loop_tail).  Wherever the chain hands
+    over -- the tail runs the whole loop, the last rounds, or nothing -- the frame is the same bits as the launch-only loop, with 256, 3 or 1 tail workgroups
+    (a lone workgroup runs every chunk of every round itself; three take chunks by ticket and wait for each other's rounds)."""
+    import bench
+    r = bench.ErNeRFRunner("bf16x3", 128, torch.device("cuda:0"), seed=3)
+    host = r.r.run_cuda(r.ro, r.rd, r.d_enc_a, r.d_ind, r.eye, bg_color=1.0, want_u8=True)
+    monkeypatch.setenv("MF_NERF_TAIL_AFTER", "off")
+    want, rounds = _head_frame(r)
+    assert rounds == len(host["trace"]) >= 4, (rounds, host["trace"])
+    assert want[0].std().item() > 0.05
+    for after, wgs in (("0", None), ("1", None), ("2", None), ("3", None), (str(rounds), None), ("0", "1"), ("1", "3"), ("2", "1")):
+        monkeypatch.setenv("MF_NERF_TAIL_AFTER", after)
+        if wgs is None:
+            monkeypatch.delenv("MF_NERF_TAIL_WGS", raising=False)
+        else:
+            monkeypatch.setenv("MF_NERF_TAIL_WGS", wgs)
+        got, n = _head_frame(r)
+        assert n == rounds, (after, wgs, n, rounds)
+        for a, b, name in zip(got, want, ("image", "depth", "weights_sum", "frame_u8", "ambient_aud", "ambient_eye", "uncertainty")):
+            assert torch.equal(a, b), (after, wgs, name, (a.float() - b.float()).abs().max().item())
+
+
+@pytest.mark.gpu
+def test_launched_rounds_follow_the_frames_before(lib_built, monkeypatch):
+    """Without MF_NERF_TAIL_AFTER: every round goes out as launches until a first frame has posted its round count; after that the chain is that count + 1 rounds
+    and the tail launch; a captured graph is keyed on the count.  Same bits all along."""
+    import bench
+    from mere_fusion_amd import _lib
+    monkeypatch.delenv("MF_NERF_TAIL_AFTER", raising=False)
+    monkeypatch.delenv("MF_NERF_TAIL_WGS", raising=False)
+    r = bench.ErNeRFRunner("bf16x3", 96, torch.device("cuda:0"), seed=5)
+
+    def plan():
+        k = C.c_int()
+        _lib.check(_lib.lib().mf_nerf_head_plan_rounds(r.r._head, 16, C.byref(k)))
+        return k.value
+    first, rounds = _head_frame(r)
+    assert 0 < rounds < 15
+    assert plan() == rounds + 1
+    second, n2 = _head_frame(r)
+    assert n2 == rounds and all(torch.equal(a, b) for a, b in zip(first, second))
+    g1, _ = _head_frame(r, graph=True)
+    g2, _ = _head_frame(r, graph=True)
+    assert all(torch.equal(a, b) for a, b in zip(first, g1)) and all(torch.equal(a, b) for a, b in zip(first, g2))
+    assert [k[-1] for k in r.r._graphs] == [rounds + 1]
+    # a pinned count wins over the feedback, -1 returns to it
+    _lib.check(_lib.lib().mf_nerf_head_set_rounds(r.r._head, 0))
+    third, n3 = _head_frame(r)
+    _lib.check(_lib.lib().mf_nerf_head_set_rounds(r.r._head, -1))
+    assert n3 == rounds and all(torch.equal(a, b) for a, b in zip(first, third))
+
+
 _RESIZE_CASES = [(24, 24, 24, 24), (24, 32, 45, 70), (64, 48, 17, 31), (1, 5, 4, 9), (50, 50, 450, 450)]
 
 
