@@ -1170,6 +1170,15 @@ class ErNeRFRunner:
         else:
             self.last = self.r.render(self.ro, self.rd, self.auds, self.bg_coords, self.pose, self.eye, bg_color=1.0, want_u8=True, loop="device")
 
+    def launched_rounds(self):
+        """rounds of the next frame that go out as (march, field, composite) launches; one tail launch stands for the other max_steps - that many
+        (mf_nerf_head_render follows the round counts the frames before posted)"""
+        if getattr(self.r, "_head", None) is None:
+            return None
+        k = C.c_int(0)
+        _lib.check(_lib.lib().mf_nerf_head_plan_rounds(self.r._head, 16, C.byref(k)), "mf_nerf_head_plan_rounds")
+        return {"as_launches": k.value, "tail_launch_covers": 16 - k.value}
+
     def roofline(self, iters=5):
         """Per-kernel rates of one frame's head loop, measured live: the reference-shaped host loop (renderer.run_cuda) enqueues every kernel
         from Python on torch's current stream, so torch.cuda.Event pairs on that stream bracket each one.  MFMA kernel: the fused field,
@@ -1346,7 +1355,7 @@ def ernerf_report(args, device, world, rank, value=None, ms_per_step=None, run=N
                        "(march -> tri-plane field -> composite) x <= 16 steps, uint8 frame; synthetic occupancy, rays resident in HBM "
                        "(BASELINE.json configs[4])",
            "value": round(value, 1), "unit": "frames/s", "ms_per_step": round(ms_per_step, 3), "dtype": args.precision,
-           "samples_per_frame": int(smp), "march_iterations": len(run.trace), "loop": run.loop,
+           "samples_per_frame": int(smp), "march_iterations": len(run.trace), "loop": run.loop, "launched_rounds": run.launched_rounds(),
            "field_tflops_algorithmic": round(smp * 46368 * value / max(world, 1) / 1e12, 2)}
     rep["parity"] = run.parity()
     if getattr(args, "extras", 1):
