@@ -46,6 +46,7 @@ constexpr int NFRAG = frag_base(NLAYER);      // 63
 
 struct FusedArgs {
     const float *xyzs, *dirs, *enc_a, *ind;
+    const float* deltas;             // the march's (dt, t) per sample slot, or null: a slot with dt == 0 holds no sample (the ray ended, or missed) and is not evaluated
     const float* emb[3];
     const bf16_t* w;                 // packed fragments [NFRAG][planes][64 lanes][8]
     float scale[NLEV];
@@ -126,6 +127,14 @@ __device__ __forceinline__ void field_tile(const FusedArgs& a, const char* smem,
     // between layers: stops the scheduler from hoisting the next layers' 1-KiB weight fragments into registers early
 #define LAYER_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+    // The reference runs the network over every slot of the round's [n_alive x n_step] tensors, the zero-filled ones of rays that produced fewer samples included
+    // (renderer.py:258-261); composite_rays stops at a slot with dt == 0 before it reads that slot's outputs (raymarching.cu:2180).  A fragment whose 16 slots are
+    // all empty -- rays that miss the head in round 1 lie side by side, ended rays leave whole runs -- is skipped: same frame, fewer gathers and MFMAs.
+    if (a.deltas) {
+        const int mq = s0 + fr;
+        const bool has = mq < M && a.deltas[2 * (size_t)mq] != 0.f;
+        if (!__any(has)) return;
+    }
     const float inv2b = 1.f / (2.f * a.bound);
     {
         // ---- inputs of this lane's two samples ------------------------------------------------------------------
@@ -647,8 +656,8 @@ int mf_nerf_fused_pack(const float* const w[9], int n_ind, bool has_eye, bool x3
 
 static void fused_args(FusedArgs& a, const bf16_t* packed, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound, const float* xyzs,
                        const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M, float* sigmas, float* rgbs, float* amb_aud,
-                       float* amb_eye, float* unc, const int* M_dev, float sigma_scale, const float* eye_dev) {
-    a.M_dev = M_dev; a.sigma_scale = sigma_scale; a.eye_dev = eye_dev;
+                       float* amb_eye, float* unc, const int* M_dev, float sigma_scale, const float* eye_dev, const float* deltas) {
+    a.M_dev = M_dev; a.sigma_scale = sigma_scale; a.eye_dev = eye_dev; a.deltas = deltas;
     a.xyzs = xyzs; a.dirs = dirs; a.enc_a = enc_a; a.ind = ind; a.w = packed;
     for (int p = 0; p < 3; ++p) a.emb[p] = emb[p];
     for (int l = 0; l < NLEV; ++l) {
@@ -674,9 +683,11 @@ static int fused_lds_attr(K kernel, bool& done, size_t lds) {
 
 int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound,
                          const float* xyzs, const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M,
-                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev, float sigma_scale, const float* eye_dev) {
+                         float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev, float sigma_scale, const float* eye_dev,
+                         const float* deltas) {
     FusedArgs a{};
-    fused_args(a, packed, emb, offsets, log2_pls, base_res, bound, xyzs, dirs, enc_a, ind, n_ind, eye, has_eye, M, sigmas, rgbs, amb_aud, amb_eye, unc, M_dev, sigma_scale, eye_dev);
+    fused_args(a, packed, emb, offsets, log2_pls, base_res, bound, xyzs, dirs, enc_a, ind, n_ind, eye, has_eye, M, sigmas, rgbs, amb_aud, amb_eye, unc, M_dev, sigma_scale, eye_dev,
+               deltas);
     const size_t lds = (size_t)NFRAG * (x3 ? 2 : 1) * 1024;
     static bool attr_done[2] = {false, false};
     int rc;
@@ -696,7 +707,9 @@ int mf_nerf_tail_launch(const bf16_t* packed, bool x3, const float* const emb[3]
                         const uint8_t* bitfield, float* xyzs, float* dirs, float* deltas, float* wsum, float* depth, float* image, float* aasum, float* aesum,
                         float* unsum, hipStream_t s) {
     FusedArgs a{};
-    fused_args(a, packed, emb, offsets, log2_pls, base_res, bound, xyzs, dirs, enc_a, ind, n_ind, eye, has_eye, N, sigmas, rgbs, amb_aud, amb_eye, unc, nullptr, sigma_scale, eye_dev);
+    const char* skip = getenv("MF_NERF_SKIP_EMPTY");
+    fused_args(a, packed, emb, offsets, log2_pls, base_res, bound, xyzs, dirs, enc_a, ind, n_ind, eye, has_eye, N, sigmas, rgbs, amb_aud, amb_eye, unc, nullptr, sigma_scale, eye_dev,
+               skip && skip[0] == '0' ? nullptr : deltas);
     TailArgs t{};
     t.ctl = ctl; t.N = N; t.max_steps = max_steps; t.first_parity = rounds_launched & 1; t.T_thresh = T_thresh; t.dt_gamma = dt_gamma; t.C = cascades; t.H = grid_size;
     t.alive[0] = alive0; t.alive[1] = alive1; t.rays_t = rays_t; t.rays_o = rays_o; t.rays_d = rays_d; t.fars = fars; t.grid = bitfield;

@@ -31,7 +31,7 @@ int mf_nerf_fused_pack(const float* const w[9], int n_ind, bool has_eye, bool x3
 int mf_nerf_fused_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound,
                          const float* xyzs, const float* dirs, const float* enc_a, const float* ind, int n_ind, float eye, int has_eye, int M,
                          float* sigmas, float* rgbs, float* amb_aud, float* amb_eye, float* unc, hipStream_t s, const int* M_dev = nullptr,
-                         float sigma_scale = 1.f, const float* eye_dev = nullptr);
+                         float sigma_scale = 1.f, const float* eye_dev = nullptr, const float* deltas = nullptr);
 int mf_nerf_tail_launch(const bf16_t* packed, bool x3, const float* const emb[3], const int* offsets, float log2_pls, int base_res, float bound, const float* enc_a,
                         const float* ind, int n_ind, float eye, int has_eye, float sigma_scale, const float* eye_dev, float* sigmas, float* rgbs, float* amb_aud,
                         float* amb_eye, float* unc, int* ctl, int N, int max_steps, int rounds_launched, float T_thresh, float dt_gamma, uint32_t cascades,
@@ -718,6 +718,8 @@ extern "C" int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const f
     // at least one sample per alive ray and round, so max_steps rounds always suffice (step += n_step >= 1, renderer.py:270)
     MF_REQUIRE(!h->fb || h->fb[1] == 0, "nerf_head_render: the tail kernel of an earlier frame gave up waiting for a round (control block error flag)");
     const int rounds = h->fixed_rounds >= 0 ? (h->fixed_rounds < max_steps ? h->fixed_rounds : max_steps) : head_plan(h, max_steps);
+    const char* skip_env = getenv("MF_NERF_SKIP_EMPTY");                       // "0": evaluate every slot as the reference does (A/B)
+    const bool skip_empty = !(skip_env && skip_env[0] == '0');
     for (int it = 0; it < rounds; ++it) {
         int* a_in = h->alive[it & 1];
         int* a_out = h->alive[(it + 1) & 1];
@@ -726,7 +728,8 @@ extern "C" int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const f
                                      h->aasum, h->aesum, h->unsum, s)))
             return rc;
         if ((rc = mf_nerf_fused_launch(f->fused_w, x3, f->emb, c.offsets, c.log2_per_level_scale, c.base_resolution, c.bound, h->xyzs, h->dirs, enc_a, ind_code,
-                                       c.individual_dim, eye, c.exp_eye, N, h->sig, h->rgb, h->aa, h->ae, h->un, s, h->ctl + 3, density_scale, h->eye_dev)))
+                                       c.individual_dim, eye, c.exp_eye, N, h->sig, h->rgb, h->aa, h->ae, h->un, s, h->ctl + 3, density_scale, h->eye_dev,
+                                       skip_empty ? h->deltas : nullptr)))
             return rc;
         if ((rc = mf_nerf_loop_round(h->ctl, N, max_steps, a_in, a_out, h->rays_t, rays_o, rays_d, c.bound, dt_gamma, cascades, grid_size, density_bitfield,
                                      h->fars, h->xyzs, h->dirs, h->deltas, 1, T_thresh, h->sig, h->rgb, h->aa, h->ae, h->un, ws, depth, image,

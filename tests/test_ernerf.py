@@ -881,6 +881,31 @@ def test_loop_tail_same_bits_wherever_the_launch_chain_hands_over(lib_built, mon
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision,width,max_steps", [("bf16", 20, 64), ("bf16x3", 33, 5), ("bf16x3", 40, 1)])
+def test_loop_tail_other_shapes(lib_built, monkeypatch, precision, width, max_steps):
+    """The tail with a ray count that is no multiple of its 1 024-ray chunks (400, 1 089, 1 600 rays), the one-pass bf16 field, a long loop (max_steps 64: one
+    ticket set per possible round) and the shortest ones (5 steps, 1 step: the loop ends by `step >= max_steps` with rays still alive)."""
+    import bench
+    from mere_fusion_amd import _lib
+    r = bench.ErNeRFRunner(precision, width, torch.device("cuda:0"), seed=7)
+
+    def frame(after):
+        monkeypatch.setenv("MF_NERF_TAIL_AFTER", after)
+        out = r.r.run_cuda_device(r.ro, r.rd, r.d_enc_a, r.d_ind, r.eye, bg_color=1.0, want_u8=True, max_steps=max_steps)
+        torch.cuda.synchronize()
+        rounds, err = C.c_int(), C.c_int()
+        _lib.check(_lib.lib().mf_nerf_head_last_rounds(r.r._head, C.byref(rounds), C.byref(err)))
+        assert err.value == 0
+        return [out[k].clone() for k in ("image", "depth", "weights_sum", "frame_u8")], rounds.value
+    want, rounds = frame("off")
+    assert 1 <= rounds <= max_steps
+    for after in ("0", "1", "2"):
+        got, n = frame(after)
+        assert n == rounds
+        assert all(torch.equal(a, b) for a, b in zip(got, want)), (after, rounds)
+
+
+@pytest.mark.gpu
 def test_launched_rounds_follow_the_frames_before(lib_built, monkeypatch):
     """Without MF_NERF_TAIL_AFTER: every round goes out as launches until a first frame has posted its round count; after that the chain is that count + 1 rounds
     and the tail launch; a captured graph is keyed on the count.  Same bits all along."""
