@@ -449,12 +449,15 @@ __global__ __launch_bounds__(CT) void k_loop_composite(int* ctl, int N, int max_
         }
         keep = live;
         if (keep) rays_t[v] = t;
-        weights_sum[v] = weight_sum;
-        depth[v] = d;
-        image[3 * v] = r; image[3 * v + 1] = g; image[3 * v + 2] = b;
-        amb_aud_sum[v] = a_aud;
-        amb_eye_sum[v] = a_eye;
-        uncertainty_sum[v] = u;
+        // a ray whose first slot is empty (it missed, or ran out of the volume: seven of ten rays in round 1) blended nothing: its sums are what they were
+        if (d0[0] != 0) {
+            weights_sum[v] = weight_sum;
+            depth[v] = d;
+            image[3 * v] = r; image[3 * v + 1] = g; image[3 * v + 2] = b;
+            amb_aud_sum[v] = a_aud;
+            amb_eye_sum[v] = a_eye;
+            uncertainty_sum[v] = u;
+        }
     }
     // one atomic per block: ctl[5] counts survivors, ctl[6] blocks; packed in one 64-bit add so the last block also learns the total
     __shared__ int s_wave[CT / 64];

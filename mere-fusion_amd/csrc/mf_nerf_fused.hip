@@ -718,11 +718,11 @@ int mf_nerf_tail_launch(const bf16_t* packed, bool x3, const float* const emb[3]
     static bool attr_done[2] = {false, false};
     int rc;
     if ((rc = x3 ? fused_lds_attr(k_loop_tail<true>, attr_done[1], lds) : fused_lds_attr(k_loop_tail<false>, attr_done[0], lds))) return rc;
-    // workgroups: enough to run a round that still has every ray (hand-over after 0 rounds: 256 chunks at 512 x 512) at the chip's width; when the loop has ended -- the
-    // usual case -- each of them reads three words and leaves
+    // workgroups: 64 (one per 1 024 rays if the frame has fewer).  When the loop has ended -- the usual case -- each of them reads three words and leaves, and the
+    // launch costs what its waves cost to start: 4.9 us with 256 workgroups of 16 waves, a quarter of that with 64; when it has not, the late rounds the tail is
+    // there for have a few ten thousand rays at most (a 512 x 512 frame's fifth round: 30 k)
     const char* e = getenv("MF_NERF_TAIL_WGS");
-    int grid = std::min(256, std::max(1, (N + TAIL_RC - 1) / TAIL_RC));
-    if (e && atoi(e) > 0) grid = std::min(grid, atoi(e));
+    const int grid = std::min(std::max(1, (N + TAIL_RC - 1) / TAIL_RC), e && atoi(e) > 0 ? std::min(atoi(e), 256) : 64);
     if (x3) hipLaunchKernelGGL(k_loop_tail<true>, dim3(grid), dim3(NWAVE * 64), lds, s, a, t);
     else hipLaunchKernelGGL(k_loop_tail<false>, dim3(grid), dim3(NWAVE * 64), lds, s, a, t);
     MF_HIP(hipGetLastError());

@@ -859,7 +859,7 @@ def _head_frame(r, graph=False):
 @pytest.mark.gpu
 def test_loop_tail_same_bits_wherever_the_launch_chain_hands_over(lib_built, monkeypatch):
     """mf_nerf_head_render enqueues some rounds as (march, field, composite) launches and ONE tail launch for the rest (k_loop_tail).  Wherever the chain hands
-    over -- the tail runs the whole loop, the last rounds, or nothing -- the frame is the same bits as the launch-only loop, with 256, 3 or 1 tail workgroups
+    over -- the tail runs the whole loop, the last rounds, or nothing -- the frame is the same bits as the launch-only loop, with 16 (one per chunk), 3 or 1 tail workgroups
     (a lone workgroup runs every chunk of every round itself; three take chunks by ticket and wait for each other's rounds)."""
     import bench
     r = bench.ErNeRFRunner("bf16x3", 128, torch.device("cuda:0"), seed=3)
