@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmerefusion_hip.so")
 OBJ = os.path.normpath(os.path.join(HERE, "..", "build", "obj"))
-SOURCES = ["mf_api.cpp", "mf_conv.hip", "mf_conv_halo.hip", "mf_conv_halo2.hip", "mf_conv_tail.hip", "mf_aux.hip", "mf_wav2lip.hip", "mf_conv_api.hip", "mf_mel.hip",
+SOURCES = ["mf_api.cpp", "mf_conv.hip", "mf_conv_halo.hip", "mf_conv_halo2.hip", "mf_conv_thin.hip", "mf_conv_tail.hip", "mf_aux.hip", "mf_wav2lip.hip", "mf_conv_api.hip", "mf_mel.hip",
            "mf_nn.hip", "mf_attn.hip", "mf_whisper.hip", "mf_musetalk.hip", "mf_nerf.hip", "mf_nerf_net.hip", "mf_nerf_fused.hip", "mf_nerf_torso.hip", "mf_nerf_audio.hip",
            "mf_blend.hip", "mf_session.hip", "mf_wav2vec2.hip", "mf_net.hip", "mf_probe.hip"]
 # -pragma-unroll-threshold: the 256 x 256 implicit-GEMM tile's `#pragma unroll` loops (128 accumulator registers, 8 x 4 fragments) exceed LLVM's default

@@ -105,6 +105,22 @@ struct HaloArgs {
     int wide_store;                             // f16 + FP6 tiles: the output view starts on an 8-channel group, C % 8 == 0, N % 32 == 0: 16-byte epilogue stores
 };
 struct HaloTile { int ph, bn, wgm, wgn; };
+
+// thin-input convolution (mf_conv_thin.hip): cin <= 16, cout <= 32, k7 s1 / k3 s1 / k3 s2 -- the input patch in LDS once, every tap read out of it
+struct ThinArgs {
+    const bf16_t* x_hi; const bf16_t* x_lo;     // input view base (channel offset applied)
+    const bf16_t* w;                            // lane-ordered A fragments [fragment][step][plane][64][8] (mf_thin_pack)
+    const float* bias;
+    bf16_t* y_hi; bf16_t* y_lo;                 // interior origin of the output view
+    int batch, H, W, N;                         // OUTPUT map, output channels
+    int pad, in_halo, in_hp, in_wp, x_ld;       // input buffer geometry
+    int64_t xb, yb; int yi, yj;
+    int act;
+};
+bool mf_thin_supported(int k, int stride, int cin, int cout);
+int mf_thin_nks(int k, int cin);
+void mf_thin_pack(const float* w, const float* scale, int cout, int cin, int k, bool x3, std::vector<bf16_t>& dst);
+int mf_thin_launch(const ThinArgs& a, int k, int stride, int cin, int cout, bool x3, hipStream_t s);
 HaloTile mf_halo_pick_tile(int H, int W, int N, int batch, int cin = 0);
 int mf_halo_launch(const HaloArgs& a, const HaloTile& t, bool x3, hipStream_t s);
 // second generation (mf_conv_halo2.hip): weights shared through an LDS ring; pick_tile returns ph == 0 to decline
@@ -138,6 +154,7 @@ struct ConvPlan {
                                  // (the UNet's 640-channel 16 x 16 layers at >= 40 frames per step; the caller keeps a bf16x3 plan for smaller steps)
     bool q = false;       // MF_PREC_F16Q: w_hi = f16 [slice][tap][Npad][32], w_lo = [slice][tap][Npad][q6(wh) 32 B | q6(wl) 32 B] (24 B codes + E8M0 byte + pad)
     bool halo = false;    // 3x3 s1 p1 on a >= 16x16 map: LDS halo-tile kernel, weights packed [slice][tap][Npad][CK]
+    bool thin = false;    // (with halo: the kernel addresses the input itself) cin <= 16 on a large map: k_conv_thin, weights packed by mf_thin_pack into w_hi
     bf16_t* up_hi = nullptr;  // nearest-2x-upsample + 3x3 layers that qualify for the fat halo tiles: [phase][slice][4 taps][Npad][CK], pre-summed taps
     bf16_t* up_lo = nullptr;
     ConvPlan* alt = nullptr;  // wide halo layers (> 256 channels) only run on the LDS-weights kernel's fat tiles, which need a few hundred

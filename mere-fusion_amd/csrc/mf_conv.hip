@@ -1488,6 +1488,26 @@ int mf_conv_plan_create(ConvPlan* p, const mf_conv2d_desc& d, const float* weigh
               (narrow || wide_ok) && d.cout % 4 == 0;
     // the f16 + FP6 format's halo tile is 128 channels wide (the UNet's 320-channel 32 x 32 layers run it with a half-empty third tile: odd_wide); other shapes take the implicit GEMM
     if (precision == MF_PREC_F16Q && !(d.cin % 32 == 0 && (d.cout % 128 == 0 || odd_wide))) p->halo = false;
+    // thin input (cin <= 16, cout <= 32) on a large map: Wav2Lip's first face-encoder layers (mf_conv_thin.hip).  MF_CONV_THIN=0: the implicit GEMM as before (A/B, tests).
+    {
+        const char* e = getenv("MF_CONV_THIN");
+        p->thin = !d.transposed && !d.upsample && d.kh == d.kw && d.stride_h == d.stride_w && d.pad_h == d.pad_w && d.pad_h == d.kh / 2 && d.pad_hi == 0 &&
+                  mf_thin_supported(d.kh, d.stride_h, d.cin, d.cout) && d.residual == 0 && d.act <= 2 && precision != MF_PREC_F16Q &&
+                  (int64_t)p->out_h * p->out_w >= 16 * 16 && !(e && e[0] == '0');
+    }
+    if (p->thin) {
+        p->halo = true;                         // (bind, tuning and naming treat it as a kernel that addresses its input itself)
+        p->n_slices = 1;
+        p->goff_total = 0;
+        std::vector<bf16_t> packed;
+        mf_thin_pack(weight, scale.data(), d.cout, d.cin, d.kh, precision != MF_PREC_BF16, packed);
+        MF_HIP(hipMalloc(&p->w_hi, packed.size() * sizeof(bf16_t)));
+        MF_HIP(hipMemcpy(p->w_hi, packed.data(), packed.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+        MF_HIP(hipMalloc(&p->bias, p->Npad * sizeof(float)));
+        MF_HIP(hipMemcpy(p->bias, fbias.data(), p->Npad * sizeof(float), hipMemcpyHostToDevice));
+        p->bound_in_ld = p->bound_in_wp = -1;
+        return MF_OK;
+    }
     const bool want_alt = p->halo && !narrow;
     if (p->halo) {
         // ---- pack for the halo-tile kernel: [slice][tap][Npad][CK], channels past cin are zero --------
@@ -1831,6 +1851,19 @@ static int conv_launch_impl(ConvPlan* p, const ActView& in, const ActView& out, 
     MF_REQUIRE(!x3 || (ib.lo && ob.lo), "conv: BF16X3 needs lo planes");
     MF_REQUIRE(p->precision != MF_PREC_F16Q || p->q, "conv (f16q): the plan was not packed in this format");
 
+    if (p->thin) {
+        MF_REQUIRE(!res.buf && ib.halo >= p->d.pad_h, "thin conv: no residual, and the input buffer's zero ring must cover the padding");
+        ThinArgs ta{};
+        ta.x_hi = ib.hi + in.coff; ta.x_lo = x3 ? ib.lo + in.coff : nullptr;
+        ta.w = p->w_hi; ta.bias = p->bias;
+        ta.batch = batch; ta.H = p->out_h; ta.W = p->out_w; ta.N = p->d.cout;
+        ta.pad = p->d.pad_h; ta.in_halo = ib.halo; ta.in_hp = ib.Hp(); ta.in_wp = ib.Wp(); ta.x_ld = ib.C; ta.xb = ib.per_batch();
+        const int64_t yb0 = ((int64_t)ob.halo * ob.Wp() + ob.halo) * ob.C + out.coff;
+        ta.y_hi = ob.hi + yb0; ta.y_lo = x3 ? ob.lo + yb0 : nullptr;
+        ta.yb = ob.per_batch(); ta.yi = ob.Wp() * ob.C; ta.yj = ob.C;
+        ta.act = p->d.act;
+        return mf_thin_launch(ta, p->d.kh, p->d.stride_h, p->d.cin, p->d.cout, x3, stream);
+    }
     if (p->halo) {
         HaloArgs ha{};
         ha.q = p->q ? 1 : 0;
@@ -2439,6 +2472,10 @@ void mf_conv_kernel_name(const ConvPlan* p, int batch, char* buf, int cap) {
         const long grid = (long)batch * cdiv(p->out_h, 16) * cdiv(p->out_w, 16) * cdiv(p->d.cout, 128) * ns * 512;
         if (ns > 1) snprintf(buf, cap, "k_conv3x3_halo_w<16,128,%s,true,1> f16+fp6 split %d grid %ld", qt, ns, grid);
         else snprintf(buf, cap, "k_conv3x3_halo_w<16,128,%s,true,1> f16+fp6 grid %ld", qt, grid);
+        return;
+    }
+    if (p->thin) {
+        snprintf(buf, cap, "k_conv_thin<%d,%d,%d,%d,%s>", p->d.kh, p->d.stride_h, p->d.cin <= 8 ? 8 : 16, (p->d.cout + 15) / 16, x3);
         return;
     }
     if (p->halo) {

@@ -235,3 +235,39 @@ def test_channel_multiples_of_80_vs_fp64(lib_built, cin, cout, k, H, W, B, res):
             assert err <= 1e-4, (nb, err)                # bf16x3: observed ~5e-6
     finally:
         l.mf_conv2d_destroy(h)
+
+
+THIN_CASES = [(6, 16, 7, 1, 50, 37, 3), (16, 32, 3, 2, 96, 96, 4), (12, 32, 3, 2, 33, 47, 2), (1, 32, 3, 1, 80, 16, 5), (3, 20, 3, 1, 40, 40, 2), (8, 16, 3, 2, 32, 32, 1)]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,B", THIN_CASES)
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_thin_input_conv_matches_fp64(lib_built, monkeypatch, cin, cout, k, stride, H, W, B, precision):
+    """Convolutions with <= 16 input channels (Wav2Lip's first face-encoder layers, wav2lip.py:19-21; the audio encoder's first layer) on k_conv_thin -- the input
+    patch in LDS once, every tap read out of it -- and on the implicit GEMM they used to take (MF_CONV_THIN=0), both against a float64 convolution: k7 s1, k3 s1,
+    k3 s2, odd map sizes, channel counts that are no multiple of 8 / 16, one and two output fragments."""
+    from mere_fusion_amd import _lib
+    l = _lib.lib()
+    _lib.init_device(0)
+    g = torch.Generator().manual_seed(cin * 11 + H)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(B, cin, H, W, generator=g).cuda()
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.cuda().double(), b.cuda().double(), stride=stride, padding=k // 2)).float()
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MF_CONV_THIN", mode)
+        d = _lib.MfConv2dDesc(cin=cin, cout=cout, kh=k, kw=k, stride_h=stride, stride_w=stride, pad_h=k // 2, pad_w=k // 2, transposed=0, output_padding=0, residual=0,
+                              act=1, in_h=H, in_w=W)
+        h = C.c_void_p()
+        _lib.check(l.mf_conv2d_create(C.byref(d), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), None, None, None, None, _lib.PRECISIONS[precision], C.byref(h)))
+        try:
+            oh, ow = C.c_int(), C.c_int()
+            l.mf_conv2d_out_shape(h, C.byref(oh), C.byref(ow))
+            assert (oh.value, ow.value) == tuple(ref.shape[2:])
+            y = torch.full(tuple(ref.shape), float("nan"), device="cuda")
+            _lib.check(l.mf_conv2d_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), B, None))
+            torch.cuda.synchronize()
+            err = float((y - ref).abs().max() / ref.abs().max())
+            assert err <= (1e-3 if precision == "bf16x3" else 3e-2), (mode, err)
+        finally:
+            l.mf_conv2d_destroy(h)
