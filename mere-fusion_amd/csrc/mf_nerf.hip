@@ -30,22 +30,8 @@ __global__ __launch_bounds__(NT) void k_near_far_from_aabb(const float* __restri
                                                            float* nears, float* fars) {
     const uint32_t n = threadIdx.x + blockIdx.x * NT;
     if (n >= N) return;
-    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
-    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
-    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
-    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, t;
-    if (near > far) { t = near; near = far; far = t; }
-    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
-    if (near_y > far_y) { t = near_y; near_y = far_y; far_y = t; }
-    if (near > far_y || near_y > far) { nears[n] = fars[n] = FLT_MAX; return; }
-    if (near_y > near) near = near_y;
-    if (far_y < far) far = far_y;
-    float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
-    if (near_z > far_z) { t = near_z; near_z = far_z; far_z = t; }
-    if (near > far_z || near_z > far) { nears[n] = fars[n] = FLT_MAX; return; }
-    if (near_z > near) near = near_z;
-    if (far_z < far) far = far_z;
-    if (near < min_near) near = min_near;
+    float near, far;
+    near_far_ray(rays_o, rays_d, aabb, n, min_near, near, far);
     nears[n] = near;
     fars[n] = far;
 }
@@ -372,15 +358,24 @@ __global__ __launch_bounds__(NT) void k_nerf_resize(const float* __restrict__ im
 
 // ---- device-controlled render loop (no host sync between rounds) ---------------------------------------------------------
 // control block `ctl` and the head of a round (loop_next_round): mf_nerf_march.h
-__global__ void k_loop_init(int* ctl, int N, int max_steps, int* alive, float* rays_t, const float* __restrict__ nears, float* weights_sum, float* depth,
-                            float* image, float* amb_aud_sum, float* amb_eye_sum, float* unc_sum) {
+// rays_o != null: near / far of every ray (k_near_far_from_aabb's arithmetic) are computed and stored here too -- one launch less at the head of a frame
+__global__ void k_loop_init(int* ctl, int N, int max_steps, int* alive, float* rays_t, float* nears, float* weights_sum, float* depth,
+                            float* image, float* amb_aud_sum, float* amb_eye_sum, float* unc_sum, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                            const float* __restrict__ aabb, float min_near, float* fars) {
     const int n = blockIdx.x * NT + threadIdx.x;
     if (n == 0) { ctl[4] = 0; ctl[5] = 0; ctl[LOOP_CTL_ROUNDS] = 0; ctl[LOOP_CTL_ERR] = 0; loop_next_round(ctl, N, 0, N, max_steps); }
     // the tail kernel's tickets (take | finished | survivors | ready, one entry per round: mf_nerf_fused.hip k_loop_tail)
     for (int i = n; i < 4 * (max_steps + 1); i += (int)gridDim.x * NT) ctl[LOOP_CTL_TAIL + i] = 0;
     if (n >= N) return;
     alive[n] = n;                                   // renderer.py:242
-    rays_t[n] = nears[n];                           // renderer.py:243
+    float near = 0.f;
+    if (rays_o) {
+        float far;
+        near_far_ray(rays_o, rays_d, aabb, (uint32_t)n, min_near, near, far);
+        nears[n] = near;
+        fars[n] = far;
+    } else near = nears[n];
+    rays_t[n] = near;                               // renderer.py:243
     weights_sum[n] = depth[n] = amb_aud_sum[n] = amb_eye_sum[n] = unc_sum[n] = 0.f;
     image[3 * n] = image[3 * n + 1] = image[3 * n + 2] = 0.f;
 }
@@ -596,10 +591,11 @@ extern "C" int mf_nerf_resize_frame(const float* image, const float* depth, int 
 }
 
 // ---- launchers of the device-controlled loop pieces (used by mf_nerf_head_render, mf_nerf_net.hip) -----------------------------
-int mf_nerf_loop_init(int* ctl, int N, int max_steps, int* alive, float* rays_t, const float* nears, float* weights_sum, float* depth, float* image,
-                      float* amb_aud_sum, float* amb_eye_sum, float* unc_sum, hipStream_t s) {
+int mf_nerf_loop_init(int* ctl, int N, int max_steps, int* alive, float* rays_t, float* nears, float* weights_sum, float* depth, float* image,
+                      float* amb_aud_sum, float* amb_eye_sum, float* unc_sum, hipStream_t s, const float* rays_o, const float* rays_d, const float* aabb, float min_near,
+                      float* fars) {
     hipLaunchKernelGGL(k_loop_init, dim3(blocks(N)), dim3(NT), 0, s, ctl, N, max_steps, alive, rays_t, nears, weights_sum, depth, image, amb_aud_sum, amb_eye_sum,
-                       unc_sum);
+                       unc_sum, rays_o, rays_d, aabb, min_near, fars);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

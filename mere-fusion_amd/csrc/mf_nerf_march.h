@@ -43,6 +43,30 @@ __device__ __forceinline__ uint32_t morton3d(uint32_t x, uint32_t y, uint32_t z)
     return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
 }
 
+// kernel_near_far_from_aabb for one ray (raymarching.cu:92-145)
+__device__ __forceinline__ void near_far_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ aabb, uint32_t n,
+                                             float min_near, float& near_out, float& far_out) {
+#pragma clang fp contract(off)
+    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, t;
+    if (near > far) { t = near; near = far; far = t; }
+    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
+    if (near_y > far_y) { t = near_y; near_y = far_y; far_y = t; }
+    if (near > far_y || near_y > far) { near_out = far_out = FLT_MAX; return; }
+    if (near_y > near) near = near_y;
+    if (far_y < far) far = far_y;
+    float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
+    if (near_z > far_z) { t = near_z; near_z = far_z; far_z = t; }
+    if (near > far_z || near_z > far) { near_out = far_out = FLT_MAX; return; }
+    if (near_z > near) near = near_z;
+    if (far_z < far) far = far_z;
+    if (near < min_near) near = min_near;
+    near_out = near;
+    far_out = far;
+}
+
 // kernel_march_rays for alive slot n (raymarching.cu:828-929): up to n_step samples into xyzs / dirs / deltas at slot n.  `zero_rest`: the
 // slots the ray does not reach are zeroed here (the reference's caller hands over zero-filled tensors, raymarching.py:383-385).
 __device__ __forceinline__ void march_ray_ref(uint32_t n, uint32_t n_step, int index, float noise, const float* __restrict__ rays_t,

@@ -617,8 +617,9 @@ extern "C" int mf_near_far_from_aabb(const float* rays_o, const float* rays_d, c
                                      float* fars, void* stream);
 extern "C" int mf_nerf_finish(float* image, float* depth, const float* weights_sum, const float* nears, const float* fars, const float* bg_color,
                               int bg_per_ray, float bg_const, uint32_t n_rays, uint8_t* frame_u8, void* stream);
-int mf_nerf_loop_init(int* ctl, int N, int max_steps, int* alive, float* rays_t, const float* nears, float* weights_sum, float* depth, float* image,
-                      float* amb_aud_sum, float* amb_eye_sum, float* unc_sum, hipStream_t s);
+int mf_nerf_loop_init(int* ctl, int N, int max_steps, int* alive, float* rays_t, float* nears, float* weights_sum, float* depth, float* image,
+                      float* amb_aud_sum, float* amb_eye_sum, float* unc_sum, hipStream_t s, const float* rays_o, const float* rays_d, const float* aabb, float min_near,
+                      float* fars);
 int mf_nerf_loop_round(int* ctl, int N, int max_steps, const int* alive_in, int* alive_out, float* rays_t, const float* rays_o, const float* rays_d,
                        float bound, float dt_gamma, uint32_t cascades, uint32_t grid_size, const uint8_t* bitfield, const float* fars,
                        float* xyzs, float* dirs, float* deltas, int phase, float T_thresh, const float* sigmas, const float* rgbs, const float* amb_aud,
@@ -712,8 +713,10 @@ extern "C" int mf_nerf_head_render(mf_nerf_head* h, const float* rays_o, const f
     const int N = n_rays;
     float* ws = weights_sum ? weights_sum : h->wsum;
     int rc;
-    if ((rc = mf_near_far_from_aabb(rays_o, rays_d, h->aabb, N, min_near, h->nears, h->fars, stream))) return rc;
-    if ((rc = mf_nerf_loop_init(h->ctl, N, max_steps, h->alive[0], h->rays_t, h->nears, ws, depth, image, h->aasum, h->aesum, h->unsum, s))) return rc;
+    // near / far (raymarching.cu:92-145) inside the loop's init launch
+    if ((rc = mf_nerf_loop_init(h->ctl, N, max_steps, h->alive[0], h->rays_t, h->nears, ws, depth, image, h->aasum, h->aesum, h->unsum, s, rays_o, rays_d, h->aabb, min_near,
+                                h->fars)))
+        return rc;
     const bool x3 = f->precision == MF_PREC_BF16X3;
     // at least one sample per alive ray and round, so max_steps rounds always suffice (step += n_step >= 1, renderer.py:270)
     MF_REQUIRE(!h->fb || h->fb[1] == 0, "nerf_head_render: the tail kernel of an earlier frame gave up waiting for a round (control block error flag)");
