@@ -1278,9 +1278,78 @@ class ErNeRFRunner:
             torch.cuda.synchronize()                          # the reference syncs here: outputs['image'] goes to the host (utils.py:1211)
             per.append(time.perf_counter() - t0)
         dt = float(np.median(per))
-        return {"frames_per_s": round(1.0 / dt, 1), "ms_per_frame": round(dt * 1e3, 3), "ms_per_frame_mean": round(float(np.mean(per)) * 1e3, 3),
-                "device_loop_frames": int(m.mf_frames), "image_shape": list(out["image"].shape),
-                "note": "model.render(...) through HipRenderMixin with the arguments Trainer.test_step passes; one host sync per frame (as Trainer.test_gui_with_data has)"}
+        rep = {"frames_per_s": round(1.0 / dt, 1), "ms_per_frame": round(dt * 1e3, 3), "ms_per_frame_mean": round(float(np.mean(per)) * 1e3, 3),
+               "device_loop_frames": int(m.mf_frames), "image_shape": list(out["image"].shape),
+               "note": "model.render(...) through HipRenderMixin with the arguments Trainer.test_step passes; one host sync per frame (as Trainer.test_gui_with_data has)"}
+        # The WHOLE per-frame sequence of nerfreal.py:70-111 around that render: the loader's get_rays (provider.py:302 -> utils.py:255-341), model.render,
+        # test_gui_with_data's resize + device -> host copies (utils.py:1208-1212), the uint8 conversion of nerfreal.py:111 -- once with the reference's operations
+        # (restated: the GPU box has no reference checkout) and once with the drop-in's `utils` module (mere_fusion_amd/ernerf/frontend.py: same results)
+        import torch.nn.functional as F
+        from mere_fusion_amd.ernerf import frontend as fe
+        Wd = self.width
+        intr = np.array([Wd / 0.7, Wd / 0.7, Wd / 2, Wd / 2])          # the camera of weights.make_ernerf_camera_rays as (fx, fy, cx, cy) + the pose below
+
+        def ref_get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, rect=None):
+            device, B = poses.device, poses.shape[0]
+            fx, fy, cx, cy = intrinsics
+            i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=device), torch.linspace(0, H - 1, H, device=device), indexing="ij")
+            i = i.t().reshape([1, H * W]).expand([B, H * W]) + 0.5
+            j = j.t().reshape([1, H * W]).expand([B, H * W]) + 0.5
+            inds = torch.arange(H * W, device=device).expand([B, H * W])
+            zs = torch.ones_like(i)
+            directions = torch.stack(((i - cx) / fx * zs, (j - cy) / fy * zs, zs), dim=-1)
+            directions = directions / torch.norm(directions, dim=-1, keepdim=True)
+            rays_d = directions @ poses[:, :3, :3].transpose(-1, -2)
+            return {"i": i, "j": j, "inds": inds, "rays_o": poses[..., :3, 3][..., None, :].expand_as(rays_d), "rays_d": rays_d}
+
+        class _Model:
+            def eval(s):
+                pass
+
+        class _Tr(fe.TrainerMixin):
+            def __init__(s):
+                s.model, s.ema, s.fp16, s.opt = _Model(), None, True, argparse.Namespace(color_space="srgb")
+
+            def test_step(s, data, perturb=False):
+                o = m.render(data["rays_o"], data["rays_d"], args[2], args[3], data["poses"], **kw)
+                return o["image"].reshape(-1, Wd, Wd, 3), o["depth"].reshape(-1, Wd, Wd)
+        tr = _Tr()
+        pose_h = torch.eye(4)[None].clone()
+        pose_h[0, :3, 3] = torch.tensor([0.02, -0.01, -2.2])
+
+        def frame_reference_style():
+            poses = pose_h.to(dev)
+            r = ref_get_rays(poses, intr, Wd, Wd)
+            with torch.no_grad():
+                with torch.cuda.amp.autocast(enabled=True):
+                    preds, depth = tr.test_step({"rays_o": r["rays_o"], "rays_d": r["rays_d"], "poses": poses})
+            preds = F.interpolate(preds.permute(0, 3, 1, 2), size=(Wd, Wd), mode="bilinear").permute(0, 2, 3, 1).contiguous()
+            depth = F.interpolate(depth.unsqueeze(1), size=(Wd, Wd), mode="nearest").squeeze(1)
+            img, _ = preds[0].detach().cpu().numpy(), depth[0].detach().cpu().numpy()
+            return (img * 255).astype(np.uint8)
+
+        def frame_dropin():
+            poses = pose_h.to(dev)
+            r = fe.get_rays(ref_get_rays, poses, intr, Wd, Wd)
+            o = tr.test_gui_with_data({"rays_o": r["rays_o"], "rays_d": r["rays_d"], "poses": poses}, Wd, Wd)
+            return (o["image"] * 255).astype(np.uint8)
+        loop = {}
+        for name, fn in (("reference_operations", frame_reference_style), ("dropin_utils", frame_dropin)):
+            for _ in range(3):
+                last = fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(frames):
+                t0 = time.perf_counter()
+                last = fn()
+                ts.append(time.perf_counter() - t0)
+            loop[name] = {"ms_per_frame": round(float(np.median(ts)) * 1e3, 3), "frames_per_s": round(1.0 / float(np.median(ts)), 1)}
+            loop[name + "_u8_mean"] = round(float(last.mean()), 3)
+        loop["same_frame"] = bool(loop.pop("reference_operations_u8_mean") == loop.pop("dropin_utils_u8_mean"))
+        loop["note"] = ("pose -> get_rays -> model.render -> resize + device -> host -> uint8, as nerfreal.py:70-111 runs it per frame: with the reference's operations "
+                        "around the render, and with the drop-in's ernerf.nerf_triplane.utils (rays cached per (H, W, intrinsics), pinned copies, one sync)")
+        rep["whole_frame_loop"] = loop
+        return rep
 
     def samples_per_frame(self):
         if self.trace is None:        # the device loop keeps no host-side trace: count the same frame once through the host loop
@@ -1521,6 +1590,9 @@ def compact_line(full):
         e_["roofline"] = _pick(e.get("roofline", {}), ("kernel", "avg_launch_us", "achieved", "peak", "frac"))
         e_["image_linf_vs_oracle"] = _dig(e, "parity", "image_linf_max_vs_oracle")
         e_["through_dropin_frames_per_s"] = _dig(e, "through_dropin", "frames_per_s")
+        wl = _dig(e, "through_dropin", "whole_frame_loop")
+        if wl:            # nerfreal.py's whole per-frame sequence (rays -> render -> resize -> host -> uint8): the reference's operations around the render / the drop-in's utils
+            e_["whole_frame_loop_ms"] = {"reference_operations": _dig(wl, "reference_operations", "ms_per_frame"), "dropin_utils": _dig(wl, "dropin_utils", "ms_per_frame")}
         e_["cpu_baseline"] = _pick(e.get("cpu_baseline", {}), ("value", "unit", "cores", "kind"))
         out["ernerf"] = e_
     wh = full.get("whisper")

@@ -54,6 +54,38 @@ try:
     raise SystemExit("rendering CPU tensors must raise")
 except RuntimeError as e:
     assert "no CPU path" in str(e), e
+# ---- utils: app.py:16 `from ernerf.nerf_triplane.utils import *`, provider.py `from .utils import get_rays` ------------------------------------------------
+import numpy as np
+from mere_fusion_amd.ernerf.frontend import TrainerMixin
+U = importlib.import_module("ernerf.nerf_triplane.utils")
+assert not U.__file__.startswith("REFROOT") and U._ref.__file__.startswith("REFROOT"), (U.__file__, U._ref.__file__)
+assert U.Trainer.__mro__[1] is TrainerMixin and U.Trainer.__mro__[2] is U._ref.Trainer, U.Trainer.__mro__
+assert P.get_rays is U.get_rays and R.custom_meshgrid is U._ref.custom_meshgrid                       # the reference's own modules bind the drop-in's names
+missing = [n for n in vars(U._ref) if not n.startswith("_") and n not in vars(U)]
+assert not missing, missing                                                                              # `import *` exports what the reference's module exports
+g = torch.Generator().manual_seed(5)
+def pose(n):
+    q, _ = torch.linalg.qr(torch.randn(n, 3, 3, generator=g))
+    m = torch.eye(4).repeat(n, 1, 1); m[:, :3, :3] = q; m[:, :3, 3] = torch.randn(n, 3, generator=g)
+    return m
+intr = np.array([1200.0, 1190.0, 8.3, 5.9])
+for n in (1, 1, 2):                                                                                      # first call fills the cache, the second one hits it
+    ps = pose(n)
+    want = U._ref.get_rays(ps, intr, 12, 17, -1)
+    got = U.get_rays(ps, intr, 12, 17, -1)
+    for k in ("rays_o", "rays_d", "i", "j", "inds"):
+        assert got[k].shape == want[k].shape and torch.equal(got[k], want[k]), (n, k)
+assert U.get_rays(pose(1), intr, 12, 17, 7)["rays_d"].shape == (1, 7, 3)                                 # sampled rays: the reference's function
+# Trainer.test_gui_with_data on CPU tensors falls back to the reference's operations: same arrays
+class _Model:
+    def eval(self): pass
+tr = U.Trainer.__new__(U.Trainer)
+tr.model, tr.ema, tr.fp16, tr.opt = _Model(), None, False, argparse.Namespace(color_space="linear")
+img, dep = torch.rand(1, 9, 11, 3, generator=g), torch.rand(1, 9, 11, generator=g)
+tr.test_step = lambda data, perturb=False: (img.clone(), dep.clone())
+want = U._ref.Trainer.test_gui_with_data(tr, {}, 14, 10)
+got = tr.test_gui_with_data({}, 14, 10)
+assert got["image"].shape == (10, 14, 3) and np.array_equal(got["image"], want["image"]) and np.array_equal(got["depth"], want["depth"])
 print("DROPIN-OK")
 '''
 
@@ -213,3 +245,73 @@ def test_hip_render_through_the_mixin_with_the_torso_branch(lib_built):
     assert float((got[0]["image"] - got[1]["image"]).abs().max()) > 0          # another audio window (and the EMA carried on the module): another frame
     img = got[0]["image"].reshape(Wd, Wd, 3)
     assert float(img.std()) > 0.02 and float((img - bg.reshape(Wd, Wd, 3)).abs().amax(-1).gt(1e-3).float().mean()) > 0.05   # head and torso both drew something
+
+
+@pytest.mark.gpu
+def test_frontend_rays_and_gui_tail_on_the_gpu(lib_built):
+    """The two per-frame pieces either side of `model.render` (mere_fusion_amd/ernerf/frontend.py) on the device: `get_rays` against the operations of
+    utils.py:274-336 (whole-frame branch, restated here: the GPU box has no reference checkout) -- same bits, first call and cache hit, one and two poses; the
+    `test_gui_with_data` mixin against F.interpolate + .cpu() (utils.py:1208-1212) at equal and at different sizes, and the pinned result ring (an array stays
+    what it was for the next three frames)."""
+    import torch.nn.functional as F
+    from mere_fusion_amd.ernerf import frontend as fe
+
+    def ref_get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, rect=None):
+        device = poses.device
+        B = poses.shape[0]
+        fx, fy, cx, cy = intrinsics
+        i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=device), torch.linspace(0, H - 1, H, device=device), indexing="ij")
+        i = i.t().reshape([1, H * W]).expand([B, H * W]) + 0.5
+        j = j.t().reshape([1, H * W]).expand([B, H * W]) + 0.5
+        inds = torch.arange(H * W, device=device).expand([B, H * W])
+        zs = torch.ones_like(i)
+        xs = (i - cx) / fx * zs
+        ys = (j - cy) / fy * zs
+        directions = torch.stack((xs, ys, zs), dim=-1)
+        directions = directions / torch.norm(directions, dim=-1, keepdim=True)
+        rays_d = directions @ poses[:, :3, :3].transpose(-1, -2)
+        rays_o = poses[..., :3, 3][..., None, :].expand_as(rays_d)
+        return {"i": i, "j": j, "inds": inds, "rays_o": rays_o, "rays_d": rays_d}
+    g = torch.Generator().manual_seed(9)
+
+    def pose(n):
+        q, _ = torch.linalg.qr(torch.randn(n, 3, 3, generator=g))
+        m = torch.eye(4).repeat(n, 1, 1)
+        m[:, :3, :3] = q
+        m[:, :3, 3] = torch.randn(n, 3, generator=g)
+        return m.cuda()
+    intr = np.array([1200.0, 1190.0, 225.3, 221.9])
+    for n in (1, 1, 2):
+        ps = pose(n)
+        want, got = ref_get_rays(ps, intr, 450, 450), fe.get_rays(ref_get_rays, ps, intr, 450, 450)
+        for k in ("rays_o", "rays_d", "i", "j", "inds"):
+            assert got[k].shape == want[k].shape and torch.equal(got[k], want[k]), (n, k)
+
+    class _Model:
+        def eval(self):
+            pass
+
+    class _T(fe.TrainerMixin):
+        _mf_linear_to_srgb = staticmethod(lambda x: torch.where(x < 0.0031308, 12.92 * x, 1.055 * x ** 0.41666 - 0.055))
+
+        def __init__(self, color_space):
+            self.model, self.ema, self.fp16, self.opt = _Model(), None, True, argparse.Namespace(color_space=color_space)
+            self.frames = []
+
+        def test_step(self, data, perturb=False):
+            return self.frames[-1]
+    for (h, w, H, W), cs in (((24, 24, 24, 24), "srgb"), ((24, 32, 45, 70), "linear"), ((50, 50, 450, 450), "srgb")):
+        t = _T(cs)
+        outs = []
+        for k in range(5):
+            img, dep = torch.rand(1, h, w, 3, generator=g).cuda(), torch.rand(1, h, w, generator=g).cuda()
+            t.frames.append((img, dep))
+            out = t.test_gui_with_data({}, W, H)
+            pi = t._mf_linear_to_srgb(img) if cs == "linear" else img
+            want = F.interpolate(pi.permute(0, 3, 1, 2), size=(H, W), mode="bilinear").permute(0, 2, 3, 1).contiguous()[0].cpu().numpy()
+            want_d = F.interpolate(dep.unsqueeze(1), size=(H, W), mode="nearest").squeeze(1)[0].cpu().numpy()
+            assert out["image"].dtype == np.float32 and out["image"].shape == (H, W, 3) and out["depth"].shape == (H, W)
+            assert np.abs(out["image"] - want).max() <= 2.4e-7 and np.array_equal(out["depth"], want_d), (h, w, H, W, k)
+            outs.append((out["image"], want))
+            for a, b in outs[-4:]:                                   # the ring: the last four results are still what they were
+                assert np.abs(a - b).max() <= 2.4e-7
