@@ -1316,9 +1316,10 @@ class ErNeRFRunner:
         tr = _Tr()
         pose_h = torch.eye(4)[None].clone()
         pose_h[0, :3, 3] = torch.tensor([0.02, -0.01, -2.2])
+        pose_d = pose_h.to(dev)                                         # the loader keeps its poses on the device (provider.py:253) and indexes them per frame
 
         def frame_reference_style():
-            poses = pose_h.to(dev)
+            poses = pose_d[[0]]
             r = ref_get_rays(poses, intr, Wd, Wd)
             with torch.no_grad():
                 with torch.cuda.amp.autocast(enabled=True):
@@ -1329,7 +1330,7 @@ class ErNeRFRunner:
             return (img * 255).astype(np.uint8)
 
         def frame_dropin():
-            poses = pose_h.to(dev)
+            poses = pose_d[[0]]
             r = fe.get_rays(ref_get_rays, poses, intr, Wd, Wd)
             o = tr.test_gui_with_data({"rays_o": r["rays_o"], "rays_d": r["rays_d"], "poses": poses}, Wd, Wd)
             return (o["image"] * 255).astype(np.uint8)
