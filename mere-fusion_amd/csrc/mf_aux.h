@@ -31,4 +31,7 @@ int mf_nchw_to_act_q(const float* src, int C, const ActBuf& dst, int batch, hipS
 // The producer side of MF_PREC_F16Q inside a network: v = x * scale[b][c] + shift[b][c] (a finalised GroupNorm, mf_groupnorm_affine), optional SiLU, written
 // straight into the f16 + FP6-block planes of `dst` (same geometry as x) -- the GroupNorm-apply pass of a resnet whose convolution reads the new format.
 // post: per-channel multiplier applied BEHIND the activation (device, x.C floats, powers of two), or null -- the channel equalisation of the MX blocks (mf_musetalk.hip gn_conv)
-int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* shift, int silu, const ActBuf& dst, int batch, hipStream_t s, const float* post = nullptr);
+// gn_stats != null (maps of a multiple of 64 pixels): scale / shift are not read -- the kernel forms the affine itself from the GroupNorm's (sum, sum of squares) per
+// (sample, group), gamma and beta (the values mf_groupnorm_affine would have written, bit for bit): no k_gn_affine launch in front
+int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* shift, int silu, const ActBuf& dst, int batch, hipStream_t s, const float* post = nullptr,
+                            const double* gn_stats = nullptr, const float* gn_gamma = nullptr, const float* gn_beta = nullptr, int gn_groups = 0, float gn_eps = 0.f);

@@ -383,10 +383,13 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q(const bf16_t* __restri
 // (needs H * W % 64 == 0), so the 96 per-channel parameters are scalar loads into SGPRs instead of 24 vector loads and 96 VGPRs per thread, and the
 // four waves of a workgroup cover four neighbouring blocks of the same pixels (their 64-byte pieces are halves of the same lines).  Thread <-> data
 // ownership, the LDS transposition and the arithmetic are k_affine_silu_to_q's, bit for bit.
-template <bool SILU, bool POST>
+// GN: `scale` / `shift` are not read; the wave forms the affine of its 32 channels itself from the GroupNorm statistics (one channel per lane, mf_gn_affine_pair -- the
+// expression k_gn_affine evaluates, same bits) and hands the 64 values to the scalar registers with v_readlane: the k_gn_affine launch in front of every conversion goes
+struct GnAffineSrc { const double* stats; const float* gamma; const float* beta; double inv_n; float eps; int groups, cpg; };
+template <bool SILU, bool POST, bool GN = false>
 __global__ __launch_bounds__(256) void k_affine_silu_to_q_u(const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, int xC, int xcoff, int xhalo, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const float* __restrict__ post, int C, int H, int W, bf16_t* yh, bf16_t* yl,
-                                                            int yC, int yhalo, int nchunk, int cpb, int nblk, int xcd_order) {
+                                                            int yC, int yhalo, int nchunk, int cpb, int nblk, int xcd_order, const GnAffineSrc gn) {
     __shared__ uint4 s_img[2][4][256];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Workgroup b runs on XCD b % 8.  Each XCD walks its OWN sequence of waves (chunk' = jw / nblk, g = jw % nblk, chunk = 8 * chunk' + xcd): all blocks of a
@@ -406,8 +409,23 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q_u(const bf16_t* __rest
     const int y = pix / W, x = pix - y * W;
     const int xo = ((b * (H + 2 * xhalo) + y + xhalo) * (W + 2 * xhalo) + x + xhalo) * xC + xcoff + g * 32;
     const int yo = ((b * (H + 2 * yhalo) + y + yhalo) * (W + 2 * yhalo) + x + yhalo) * yC + g * 32;
-    const float* __restrict__ sc = scale + b * C + g * 32;          // wave-uniform: scalar loads
-    const float* __restrict__ sh = shift + b * C + g * 32;
+    float sc[32], sh[32];                                           // wave-uniform: scalar loads (or, GN, v_readlane of the values formed here)
+    if constexpr (GN) {
+        const int k = lane & 31, c = g * 32 + k;
+        const double2 sq = *reinterpret_cast<const double2*>(gn.stats + 2 * (b * gn.groups + c / gn.cpg));
+        float my_sc, my_sh;
+        mf_gn_affine_pair(sq.x, sq.y, gn.inv_n, gn.eps, gn.gamma[c], gn.beta[c], my_sc, my_sh);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            sc[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_sc), j));
+            sh[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_sh), j));
+        }
+    } else {
+        const float* __restrict__ scp = scale + b * C + g * 32;
+        const float* __restrict__ shp = shift + b * C + g * 32;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { sc[j] = scp[j]; sh[j] = shp[j]; }
+    }
     const float* __restrict__ po = post + g * 32;
     typedef float v16f __attribute__((ext_vector_type(16)));
     typedef _Float16 v32h __attribute__((ext_vector_type(32)));
@@ -480,8 +498,15 @@ __global__ __launch_bounds__(256) void k_affine_silu_to_q_u(const bf16_t* __rest
 }
 }  // namespace
 
-int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* shift, int silu, const ActBuf& dst, int batch, hipStream_t s, const float* post) {
+int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* shift, int silu, const ActBuf& dst, int batch, hipStream_t s, const float* post,
+                            const double* gn_stats, const float* gn_gamma, const float* gn_beta, int gn_groups, float gn_eps) {
     const ActBuf& xb = *x.buf;
+    GnAffineSrc gn{};
+    if (gn_stats) {
+        MF_REQUIRE(gn_gamma && gn_beta && gn_groups > 0 && x.C % gn_groups == 0, "affine_silu_to_act_q: GroupNorm statistics need gamma, beta and a group count that divides C");
+        gn.stats = gn_stats; gn.gamma = gn_gamma; gn.beta = gn_beta; gn.groups = gn_groups; gn.cpg = x.C / gn_groups; gn.eps = gn_eps;
+        gn.inv_n = 1.0 / ((double)xb.H * xb.W * gn.cpg);
+    }
     MF_REQUIRE(x.C % 32 == 0 && x.coff % 8 == 0 && dst.C == x.C && dst.H == xb.H && dst.W == xb.W && dst.lo && xb.lo && scale && shift,
                "affine_silu_to_act_q: needs 32-channel blocks, matching geometry and a second plane on both sides");
     MF_REQUIRE((int64_t)batch * xb.per_batch() < ((int64_t)1 << 31) && (int64_t)batch * dst.per_batch() < ((int64_t)1 << 31),
@@ -495,15 +520,19 @@ int mf_affine_silu_to_act_q(const ActView& x, const float* scale, const float* s
         const int xcd_order = nblk > 4 && waves >= 16384;
         const int64_t waves_per_xcd = (int64_t)((nchunk + 7) / 8) * nblk;
         const dim3 grid(xcd_order ? (unsigned)(8 * ((waves_per_xcd + 3) / 4)) : (unsigned)((waves + 3) / 4));
-#define MF_AFFQ_U(S, P)                                                                                                                                                     \
-    hipLaunchKernelGGL((k_affine_silu_to_q_u<S, P>), grid, dim3(256), 0, s, xb.hi, xb.lo, xb.C, x.coff, xb.halo, scale, shift, post, x.C, xb.H, xb.W, dst.hi, dst.lo, dst.C, \
-                       dst.halo, nchunk, cpb, nblk, xcd_order)
-        if (silu) { if (post) MF_AFFQ_U(true, true); else MF_AFFQ_U(true, false); }
-        else      { if (post) MF_AFFQ_U(false, true); else MF_AFFQ_U(false, false); }
+#define MF_AFFQ_U(S, P, G)                                                                                                                                                  \
+    hipLaunchKernelGGL((k_affine_silu_to_q_u<S, P, G>), grid, dim3(256), 0, s, xb.hi, xb.lo, xb.C, x.coff, xb.halo, scale, shift, post, x.C, xb.H, xb.W, dst.hi, dst.lo, dst.C, \
+                       dst.halo, nchunk, cpb, nblk, xcd_order, gn)
+        if (gn_stats) {        // (the GroupNorm case is always followed by SiLU in the networks that use this format)
+            MF_REQUIRE(silu, "affine_silu_to_act_q: the statistics form is built with SiLU");
+            if (post) MF_AFFQ_U(true, true, true); else MF_AFFQ_U(true, false, true);
+        } else if (silu) { if (post) MF_AFFQ_U(true, true, false); else MF_AFFQ_U(true, false, false); }
+        else      { if (post) MF_AFFQ_U(false, true, false); else MF_AFFQ_U(false, false, false); }
 #undef MF_AFFQ_U
         MF_HIP(hipGetLastError());
         return MF_OK;
     }
+    MF_REQUIRE(!gn_stats, "affine_silu_to_act_q: maps that are not a multiple of 64 pixels take scale / shift arrays (mf_groupnorm_affine first)");
     hipLaunchKernelGGL(k_affine_silu_to_q, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xb.hi, xb.lo, xb.C, x.coff, xb.halo, scale, shift, post, x.C, silu, xb.H, xb.W, dst.hi,
                        dst.lo, dst.C, dst.halo, total);
     MF_HIP(hipGetLastError());

@@ -66,6 +66,16 @@ __device__ __forceinline__ float mf_opaque(float x) {
     return x;
 }
 // (a + b) + (c + d) with every partial sum a scalar of its own (a pair of partial sums added to each other is the same hazard one level up)
+// GroupNorm as a per-(sample, channel) affine: from the (sum, sum of squares) of a group, y = x * sc + sh with sc = rstd * gamma, sh = beta - mean * sc.
+// One definition for k_gn_affine (mf_nn.hip) and the conversion kernel that forms the pair itself (mf_aux.hip): every product and the fused steps are spelled out,
+// so both give the same bits whatever the contraction setting of the including file.
+__device__ __forceinline__ void mf_gn_affine_pair(double sum, double sumsq, double inv_n, float eps, float gamma, float beta, float& sc, float& sh) {
+    const double mean = sum * inv_n;
+    const double var = fmax(__builtin_fma(-mean, mean, sumsq * inv_n), 0.0);
+    const float rstd = rsqrtf((float)var + eps);
+    sc = rstd * gamma;
+    sh = __builtin_fmaf(-(float)mean, sc, beta);
+}
 __device__ __forceinline__ float mf_sum4(float a, float b, float c, float d) {
     const float ab = a + mf_opaque(b), cd = c + mf_opaque(d);
     return mf_opaque(ab) + mf_opaque(cd);

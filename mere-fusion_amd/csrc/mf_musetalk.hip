@@ -28,6 +28,20 @@ namespace {
 
 typedef std::function<int(int, hipStream_t)> Op;
 
+// GroupNorm -> SiLU -> the f16 + FP6 format in front of a conv of that format.  `fuse` (maps of a multiple of 64 pixels): the conversion kernel forms the per-channel
+// affine itself from the statistics -- the k_gn_affine launch in front of each of the VAE decoder's 28 conversions goes (same bits: mf_gn_affine_pair).
+// MF_GN_AFFINE_FUSE=0 keeps the two launches (A/B, tests).
+static int gn_silu_to_q(const ActView& x, const float* dg, const float* db, int groups, float eps, double* st, float* scale, float* shift, const ActBuf& tq, int B,
+                        hipStream_t s, bool have_stats, const float* post, bool fuse) {
+    const ActBuf& xb = *x.buf;
+    if (fuse && (xb.H * xb.W) % 64 == 0) {
+        if (!have_stats) { const int rc = mf_groupnorm_stats(x, groups, st, B, s); if (rc) return rc; }
+        return mf_affine_silu_to_act_q(x, scale, shift, 1, tq, B, s, post, st, dg, db, groups, eps);
+    }
+    const int r1 = mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s, have_stats);
+    return r1 ? r1 : mf_affine_silu_to_act_q(x, scale, shift, 1, tq, B, s, post);
+}
+
 struct Net {
     int precision = MF_PREC_BF16X3;
     int cap = 1;
@@ -235,6 +249,7 @@ struct Net {
         // f16 + FP6 operand format for the wide 3x3 convs on large maps (MF_CONV_Q=0: bf16x3 everywhere): GroupNorm-apply writes the conv's input in the new
         // format, the conv runs one f16 + half a block-scaled FP6 MFMA per tap where bf16x3 runs three; outputs and residuals stay bf16 (hi, lo).
         static const bool q_on = [] { const char* e = getenv("MF_CONV_Q"); return !e || atoi(e) != 0; }();
+        const bool gn_fuse = [] { const char* e = getenv("MF_GN_AFFINE_FUSE"); return !e || atoi(e) != 0; }();      // (read per handle: tests build both)
         // (maps below 64 x 64 -- the 512-channel 32 x 32 levels -- run it with the channel slices split over two workgroups per tile, mf_q_split_count)
         const int q_minpx = 32 * 32;
         // The UNet's 320-channel convs on its 32 x 32 maps (cout = 2.5 tiles of 128): from 16 frames per step (q_dual_min) the f16 + FP6 tile runs them at 640-730 TF where the
@@ -333,8 +348,7 @@ struct Net {
                 push(gname, epi ? "k_gn_apply | k_affine_silu_to_q from q_dual_min frames (statistics from the producer's epilogue)" : "k_gn_stats+k_gn_apply | +k_affine_silu_to_q from q_dual_min frames", 0.0,
                      [=](int B, hipStream_t s) {
                          if (B < q_dual_min()) return mf_groupnorm(x, tv, dg, db, groups, eps, true, st, B, s, epi);
-                         const int r1 = mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s, epi);
-                         return r1 ? r1 : mf_affine_silu_to_act_q(x, scale, shift, 1, *tq, B, s, d_post);
+                         return gn_silu_to_q(x, dg, db, groups, eps, st, scale, shift, *tq, B, s, epi, d_post, gn_fuse);
                      });
                 char kn[96];
                 mf_conv_kernel_name(cap >= q_dual_min() ? p : p3, cap, kn, sizeof(kn));
@@ -353,8 +367,7 @@ struct Net {
             if ((rc = mf_conv_bind(p, *t))) return rc;
             const ActBuf* tq = t;
             push(gname, epi ? "k_affine_silu_to_q (statistics from the producer's epilogue)" : "k_gn_stats+k_affine_silu_to_q", 0.0, [=](int B, hipStream_t s) {
-                const int r1 = mf_groupnorm_affine(x, dg, db, groups, eps, st, scale, shift, B, s, epi);
-                return r1 ? r1 : mf_affine_silu_to_act_q(x, scale, shift, 1, *tq, B, s, d_post);
+                return gn_silu_to_q(x, dg, db, groups, eps, st, scale, shift, *tq, B, s, epi, d_post, gn_fuse);
             });
             char kn[96];
             mf_conv_kernel_name(p, cap, kn, sizeof(kn));

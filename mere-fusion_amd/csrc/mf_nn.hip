@@ -486,12 +486,10 @@ __global__ void k_gn_affine(const double* __restrict__ stats, const float* __res
     if (i >= total) return;
     const int b = i / C, c = i - b * C, g = c / cpg;
     const double2 sq = *reinterpret_cast<const double2*>(stats + 2 * (b * groups + g));
-    const double mean = sq.x * inv_n;
-    const double var = fmax(sq.y * inv_n - mean * mean, 0.0);
-    const float rstd = rsqrtf((float)var + eps);
-    const float sc = rstd * gamma[c];
+    float sc, sh;
+    mf_gn_affine_pair(sq.x, sq.y, inv_n, eps, gamma[c], beta[c], sc, sh);
     scale[i] = sc;
-    shift[i] = beta[c] - (float)mean * sc;
+    shift[i] = sh;
 }
 }  // namespace
 

@@ -105,3 +105,35 @@ def test_vae_on_a_map_that_is_not_a_multiple_of_64_pixels(lib_built):
     assert np.isfinite(ierr) and ierr <= TOL_IMAGE
     assert d.max() <= 1 and (d > 0).mean() < TOL_U8_FRACTION
     assert same
+
+
+def test_groupnorm_affine_inside_the_conversion_kernel_is_bit_identical(lib_built, monkeypatch):
+    """The VAE decoder's GroupNorm -> SiLU -> f16 + FP6 conversions form the per-channel affine inside the conversion kernel (mf_gn_affine_pair, one channel per
+    lane, handed to the scalar registers by v_readlane) instead of a k_gn_affine launch in front of each: the same frames and the same fp32 image, bit for bit,
+    as the two-launch form (MF_GN_AFFINE_FUSE=0) -- on a reduced 16 x 16 latent grid (maps 32^2 ... 128^2: every level a multiple of 64 pixels) and with the
+    four-decade stress weights."""
+    from mere_fusion_amd.musetalk.models.vae import VAE
+    from mere_fusion_amd import _lib
+    import ctypes as C
+    B = 2
+    vsd, _ = stressed_vae_state_dict(W.make_musetalk_vae_state_dict(MUSETALK_V1, 0), 3)
+    cfg = vae_config_json(MUSETALK_V1["vae"])
+    cfg["latent_size"] = 16
+    lat = (torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(5)) * 0.18215).cuda()
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MF_GN_AFFINE_FUSE", mode)
+        vae = VAE(config=cfg, state_dict=vsd, max_batch=B)
+        l = _lib.lib()
+        names = []
+        for i in range(l.mf_vae_num_ops(vae._h)):
+            nm, kn, fl = C.create_string_buffer(160), C.create_string_buffer(160), C.c_double()
+            l.mf_vae_op_info(vae._h, i, nm, 160, kn, 160, C.byref(fl))
+            names.append(kn.value.decode())
+        assert any("k_affine_silu_to_q" in k for k in names), names
+        frames, image = vae.decode_latents_device(lat, want_image=True)
+        torch.cuda.synchronize()
+        outs[mode] = (frames.clone(), image.clone())
+        del vae
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    assert outs["1"][1].float().std().item() > 0.01
