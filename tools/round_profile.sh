@@ -5,7 +5,7 @@
 # MuseTalk steps at both batch sizes (each counter set in its own pass, --kernel-trace the only trace domain beside --pmc).
 # Launch configurations: the tuning table shipped beside the library -- what a deployment runs.  Outputs under gpurun_out/ (copied into profiles/ afterwards).
 #   usage: tools/round_profile.sh [tag] [parts: tests,bench,stats,b64,pmc]
-TAG=${1:-r05}; PARTS=${2:-tests,bench,stats,b64,pmc}
+TAG=${1:-r06}; PARTS=${2:-tests,bench,stats,b64,pmc}
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
 cd $R
 has() { case ",$PARTS," in *",$1,"*) return 0;; esac; return 1; }
