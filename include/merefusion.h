@@ -341,7 +341,7 @@ int mf_nerf_head_create(mf_nerf_field* field, int max_rays, mf_nerf_head** out);
  * up to max_steps rounds of (round control -> march_rays -> field -> composite_rays_triplane -> compaction) whose counters
  * (n_alive, n_step = max(min(N // n_alive, 8), 1), step) live on the device, then the background mix / depth
  * normalisation of :275-280.  No host synchronisation: the call only enqueues (capturable in a hipGraph).
- * Only the rounds the frames before needed (+ 1; every round until a first frame has reported) go out as launches; ONE
+ * Only the rounds the frames before needed (every round until a first frame has reported) go out as launches; ONE
  * further launch stands for the rest of the max_steps rounds and runs them itself if the loop has not ended by then
  * (mf_nerf_head_plan_rounds / _set_rounds below; MF_NERF_TAIL_AFTER=<k>|off overrides).
  * rays_o, rays_d [N,3]; density_bitfield [cascades * grid_size^3 / 8]; enc_a [32]; ind_code [individual_dim] or NULL;
