@@ -465,7 +465,8 @@ __global__ __launch_bounds__(CT) void k_loop_composite(int* ctl, int N, int max_
 #pragma unroll
     for (int w = 0; w < CT / 64; ++w) { before += w < wave ? s_wave[w] : 0; mine += s_wave[w]; }
     if (threadIdx.x == 0) {
-        __threadfence();
+        // (no fence in front of it: the block that arrives last reads nothing the others wrote but this counter -- an atomic at the device's coherence point -- and the
+        // survivors and sums are for the NEXT launch.  An agent-scope fence here writes back the XCD's dirty L2 lines from every block: 0.483 -> 0.473 ms per frame without)
         s_old = atomicAdd(reinterpret_cast<unsigned long long*>(ctl + 6), ((unsigned long long)1 << 32) | (unsigned long long)mine);
     }
     __syncthreads();
