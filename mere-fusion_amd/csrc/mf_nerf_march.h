@@ -195,7 +195,8 @@ __device__ __forceinline__ void loop_post_feedback(int* ctl) {
     if (fb) {
         fb[1] = ctl[LOOP_CTL_ERR];
         fb[0] = ctl[LOOP_CTL_ROUNDS];
-        __threadfence_system();
+        // (no fence: the two words are pinned host memory -- the stores go out over the bus as they are -- and the host only ever wants a recent value; a
+        // system-scope fence here would write back the L2's dirty lines once per frame, on the loop's critical path)
     }
 }
 __device__ __forceinline__ void loop_next_round(int* ctl, int n_alive, int step, int N, int max_steps) {
