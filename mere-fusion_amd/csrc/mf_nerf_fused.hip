@@ -445,7 +445,7 @@ __global__ __launch_bounds__(NWAVE * 64) void k_nerf_field_fused(const FusedArgs
 // mf_nerf_head_render enqueues R rounds as (march, field, composite) launches -- R follows the round counts of the frames before (a frame needs ~5 of the
 // max_steps = 16 the reference allows: renderer.py:246-270) -- and then this kernel ONCE.  It finds the loop ended (ctl[1] == 0: the usual case, one empty launch
 // instead of 3 x (16 - R)) or runs the remaining rounds itself:
-//   * a round is cut into chunks of 1024 alive rays; a workgroup takes a chunk by ticket and carries it through the WHOLE round -- march (one ray per lane, the
+//   * a round is cut into chunks of 512 alive rays; a workgroup takes a chunk by ticket and carries it through the WHOLE round -- march (one ray per lane, the
 //     reference's loop: march_ray_ref), field (field_tile over the chunk's own samples), composite (composite_ray) and the append of its survivors.  Rays do not
 //     interact inside a round, so the only grid-wide step is the head of the next round (survivor count -> n_step): the workgroup that finishes the round's last
 //     chunk computes it and publishes `ready[j + 1]`; the others wait for that flag -- and only for that flag, which a RUNNING workgroup will set.  No workgroup
@@ -458,30 +458,34 @@ struct TailArgs {
     int N, max_steps, first_parity;      // first_parity: which of alive[0 / 1] the first tail round reads
     float T_thresh, dt_gamma;
     uint32_t C, H;
-    int* alive[2];
+    int *alive0, *alive1;                // (two fields, selected -- a dynamically indexed array in the kernel arguments goes through scratch, and a kernel with scratch
+                                         // costs more to dispatch: the EMPTY tail launch is what every frame pays)
     float* rays_t;
     const float *rays_o, *rays_d, *fars;
     const uint8_t* grid;
     float *xyzs, *dirs, *deltas;
     float *wsum, *depth, *image, *aasum, *aesum, *unsum;
 };
-constexpr int TAIL_RC = NWAVE * 64;      // rays per chunk: one per lane
+constexpr int TAIL_NW = 8;               // waves per tail workgroup: two per SIMD, so the compiler has 256 registers per lane -- with the field's 16 waves (128) the loop
+                                         // state around field_tile spilled, and a kernel with SCRATCH costs more to dispatch: 4.8 us for the empty tail launch every frame pays
+constexpr int TAIL_RC = TAIL_NW * 64;    // rays per chunk: one per lane
+constexpr int TAIL_TILE = TAIL_NW * 16 * NSF;
 #ifndef MF_TAIL_SPINS
 #define MF_TAIL_SPINS (1 << 20)
 #endif
 constexpr int TAIL_SPINS = MF_TAIL_SPINS;   // polls of ~2 us before a waiting workgroup gives up (seconds)
 
 template <bool X3>
-__global__ __launch_bounds__(NWAVE * 64) void k_loop_tail(const FusedArgs a, const TailArgs t) {
+__global__ __launch_bounds__(TAIL_NW * 64) void k_loop_tail(const FusedArgs a, const TailArgs t) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ LevelTab lt;
-    __shared__ int s_i[4], s_wave[NWAVE];
+    __shared__ int s_i[4], s_wave[TAIL_NW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the round about to run, as the last composite launch (or k_loop_init) left it; nothing writes ctl[0..2] while this kernel runs
     int n_alive = t.ctl[0], n_step = t.ctl[1], step_after = t.ctl[2];
     if (n_step <= 0) return;                                                       // the loop has ended: the usual case
-    field_stage_weights<X3>(a, smem, lt, NWAVE * 64);
+    field_stage_weights<X3>(a, smem, lt, TAIL_NW * 64);
     const float eye_v = a.eye_dev ? *a.eye_dev : a.eye;
     const int TS = t.max_steps + 1;
     int* const take = t.ctl + LOOP_CTL_TAIL;
@@ -504,8 +508,9 @@ __global__ __launch_bounds__(NWAVE * 64) void k_loop_tail(const FusedArgs a, con
     };
     n_alive = uni(n_alive); n_step = uni(n_step); step_after = uni(step_after);
     for (int j = 0; j < t.max_steps; ++j) {
-        const int* a_in = t.alive[(t.first_parity + j) & 1];
-        int* a_out = t.alive[(t.first_parity + j + 1) & 1];
+        const bool odd = ((t.first_parity + j) & 1) != 0;
+        const int* a_in = odd ? t.alive1 : t.alive0;
+        int* a_out = odd ? t.alive0 : t.alive1;
         const int nchunks = (n_alive + TAIL_RC - 1) / TAIL_RC;
         for (int c = next_ticket(j); c < nchunks; c = next_ticket(j)) {
             const int base = c * TAIL_RC;
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(NWAVE * 64) void k_loop_tail(const FusedArgs a, con
             __threadfence();
             __syncthreads();
             const int m0 = base * n_step, mend = m0 + rays_here * n_step;
-            for (int s0 = m0; s0 < mend; s0 += TILE) field_tile<X3>(a, smem, lt, eye_v, s0 + wave * 16 * NSF, mend);
+            for (int s0 = m0; s0 < mend; s0 += TAIL_TILE) field_tile<X3>(a, smem, lt, eye_v, s0 + wave * 16 * NSF, mend);
             __threadfence();
             __syncthreads();
             bool keep = false;
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(NWAVE * 64) void k_loop_tail(const FusedArgs a, con
             __syncthreads();
             int before = 0, mine = 0;
 #pragma unroll
-            for (int w = 0; w < NWAVE; ++w) { before += w < wave ? s_wave[w] : 0; mine += s_wave[w]; }
+            for (int w = 0; w < TAIL_NW; ++w) { before += w < wave ? s_wave[w] : 0; mine += s_wave[w]; }
             if (tid == 0) s_i[1] = atomicAdd(&surv[j], mine);
             __syncthreads();
             if (keep) a_out[s_i[1] + before + __popcll(m & ((1ull << lane) - 1))] = v;
@@ -712,19 +717,19 @@ int mf_nerf_tail_launch(const bf16_t* packed, bool x3, const float* const emb[3]
                skip && skip[0] == '0' ? nullptr : deltas);
     TailArgs t{};
     t.ctl = ctl; t.N = N; t.max_steps = max_steps; t.first_parity = rounds_launched & 1; t.T_thresh = T_thresh; t.dt_gamma = dt_gamma; t.C = cascades; t.H = grid_size;
-    t.alive[0] = alive0; t.alive[1] = alive1; t.rays_t = rays_t; t.rays_o = rays_o; t.rays_d = rays_d; t.fars = fars; t.grid = bitfield;
+    t.alive0 = alive0; t.alive1 = alive1; t.rays_t = rays_t; t.rays_o = rays_o; t.rays_d = rays_d; t.fars = fars; t.grid = bitfield;
     t.xyzs = xyzs; t.dirs = dirs; t.deltas = deltas; t.wsum = wsum; t.depth = depth; t.image = image; t.aasum = aasum; t.aesum = aesum; t.unsum = unsum;
     const size_t lds = (size_t)NFRAG * (x3 ? 2 : 1) * 1024;
     static bool attr_done[2] = {false, false};
     int rc;
     if ((rc = x3 ? fused_lds_attr(k_loop_tail<true>, attr_done[1], lds) : fused_lds_attr(k_loop_tail<false>, attr_done[0], lds))) return rc;
-    // workgroups: 64 (one per 1 024 rays if the frame has fewer).  When the loop has ended -- the usual case -- each of them reads three words and leaves, and the
+    // workgroups: 64 (one per 512 rays if the frame has fewer).  When the loop has ended -- the usual case -- each of them reads three words and leaves, and the
     // launch costs what its waves cost to start: 4.9 us with 256 workgroups of 16 waves, a quarter of that with 64; when it has not, the late rounds the tail is
     // there for have a few ten thousand rays at most (a 512 x 512 frame's fifth round: 30 k)
     const char* e = getenv("MF_NERF_TAIL_WGS");
     const int grid = std::min(std::max(1, (N + TAIL_RC - 1) / TAIL_RC), e && atoi(e) > 0 ? std::min(atoi(e), 256) : 64);
-    if (x3) hipLaunchKernelGGL(k_loop_tail<true>, dim3(grid), dim3(NWAVE * 64), lds, s, a, t);
-    else hipLaunchKernelGGL(k_loop_tail<false>, dim3(grid), dim3(NWAVE * 64), lds, s, a, t);
+    if (x3) hipLaunchKernelGGL(k_loop_tail<true>, dim3(grid), dim3(TAIL_NW * 64), lds, s, a, t);
+    else hipLaunchKernelGGL(k_loop_tail<false>, dim3(grid), dim3(TAIL_NW * 64), lds, s, a, t);
     MF_HIP(hipGetLastError());
     return MF_OK;
 }

@@ -883,7 +883,7 @@ def test_loop_tail_same_bits_wherever_the_launch_chain_hands_over(lib_built, mon
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision,width,max_steps", [("bf16", 20, 64), ("bf16x3", 33, 5), ("bf16x3", 40, 1)])
 def test_loop_tail_other_shapes(lib_built, monkeypatch, precision, width, max_steps):
-    """The tail with a ray count that is no multiple of its 1 024-ray chunks (400, 1 089, 1 600 rays), the one-pass bf16 field, a long loop (max_steps 64: one
+    """The tail with a ray count that is no multiple of its 512-ray chunks (400, 1 089, 1 600 rays), the one-pass bf16 field, a long loop (max_steps 64: one
     ticket set per possible round) and the shortest ones (5 steps, 1 step: the loop ends by `step >= max_steps` with rays still alive)."""
     import bench
     from mere_fusion_amd import _lib
