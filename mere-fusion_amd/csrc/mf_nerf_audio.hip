@@ -48,7 +48,9 @@ __device__ __forceinline__ float group_sum(float acc, int P) {
 }
 
 // out[n][co][t] = act(b[co] + sum_{ci,k} w[co][ci][k] * in[n][ci][t*stride + k - 1]), zero padding 1; weights already in wbuf / bbuf
-__device__ void conv1d(const float* in, float* out, const Layer& L, int n, int tin, int stride, bool act, const float* wbuf, const float* bbuf) {
+// (inlined, the layer by value: a reference to a member of the kernel's argument struct put the struct into scratch -- 160 B per lane -- and a kernel with scratch
+// costs more to dispatch and reads its loop bounds from memory)
+__device__ __forceinline__ void conv1d(const float* in, float* out, const Layer L, int n, int tin, int stride, bool act, const float* wbuf, const float* bbuf) {
     const int tout = (tin + 2 - 3) / stride + 1;
     const int nout = n * L.cout * tout;
     const int P = lanes_per_output(nout, L.cin), sub = threadIdx.x & (P - 1), groups = blockDim.x / P;
@@ -71,7 +73,7 @@ __device__ void conv1d(const float* in, float* out, const Layer& L, int n, int t
 }
 
 // out[n][o] = act(b[o] + sum_i w[o][i] * in[n][i])
-__device__ void linear(const float* in, float* out, const Layer& L, int n, bool act, const float* wbuf, const float* bbuf) {
+__device__ __forceinline__ void linear(const float* in, float* out, const Layer L, int n, bool act, const float* wbuf, const float* bbuf) {
     const int nout = n * L.cout;
     const int P = lanes_per_output(nout, L.cin), sub = threadIdx.x & (P - 1), groups = blockDim.x / P;
     for (int idx = threadIdx.x / P; idx < nout; idx += groups) {
@@ -104,16 +106,18 @@ __global__ __launch_bounds__(1024) void k_audio_encode(const AudioArgs a, const 
     const bool att = a.use_att && n_win_all == SEQ;
     {
         // the arena in one burst: <= 9 independent 16-byte loads per thread, then the LDS stores
-        constexpr int R = 9;                  // ceil(37 k floats / 4 / 1024)
-        float4 r[R];
+        // (spelled out nine times: as `float4 r[9]` filled and drained by two unrolled loops the array stayed in scratch -- 160 B per lane, dynamic offsets -- and a kernel
+        // with scratch costs more to dispatch)
         const float4* src = reinterpret_cast<const float4*>(a.arena);
         const int n4 = a.arena_n >> 2;
-#pragma unroll
-        for (int k = 0; k < R; ++k) { const int i = threadIdx.x + k * 1024; if (i < n4) r[k] = src[i]; }
+#define MF_AUD_LD(k) const int i##k = threadIdx.x + k * 1024; const float4 r##k = src[i##k < n4 ? i##k : n4 - 1];
+        MF_AUD_LD(0) MF_AUD_LD(1) MF_AUD_LD(2) MF_AUD_LD(3) MF_AUD_LD(4) MF_AUD_LD(5) MF_AUD_LD(6) MF_AUD_LD(7) MF_AUD_LD(8)
+#undef MF_AUD_LD
         // network.py:61-62: the centre 16 steps of the window (win_size 16 -> all of them)
         for (int i = threadIdx.x; i < n_win * a.in_dim * WIN; i += blockDim.x) bufA[i] = auds[i];
-#pragma unroll
-        for (int k = 0; k < R; ++k) { const int i = threadIdx.x + k * 1024; if (i < n4) reinterpret_cast<float4*>(wts)[i] = r[k]; }
+#define MF_AUD_ST(k) if (i##k < n4) reinterpret_cast<float4*>(wts)[i##k] = r##k;
+        MF_AUD_ST(0) MF_AUD_ST(1) MF_AUD_ST(2) MF_AUD_ST(3) MF_AUD_ST(4) MF_AUD_ST(5) MF_AUD_ST(6) MF_AUD_ST(7) MF_AUD_ST(8)
+#undef MF_AUD_ST
         __syncthreads();
     }
     auto W = [&](const Layer& L) { return wts + L.woff; };
