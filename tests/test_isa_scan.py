@@ -37,3 +37,14 @@ __global__ void k_good(f2v* p) { f2v a = p[0], b = p[1], c = p[2], r;
     offenders, census, kernels = isa_scan.scan(str(obj))
     assert list(offenders) == ["_Z5k_badPDv2_f"] and len(offenders["_Z5k_badPDv2_f"]) == 2, offenders
     assert census[("v_pk_fma_f32", "1,0,1")] == 1 and census[("v_pk_add_f32", "")] >= 1
+
+
+def test_only_the_f16_fp6_halo_tile_uses_scratch(lib_built):
+    """A kernel with scratch costs more to dispatch and keeps private arrays / spills in memory (round 6: the ER-NeRF audio encoder's staging array, 160 B per lane, and
+    the loop's tail kernel, 24 B, each cost microseconds per frame).  The only kernels allowed to ask for it are the LDS-weights halo tiles, which spill a few registers
+    at their 256-register cap by design (round 4)."""
+    import isa_scan
+    sc = isa_scan.scratch_users(os.path.join(ROOT, "mere-fusion_amd", "libmerefusion_hip.so"))
+    others = {k: v for k, v in sc.items() if "k_conv3x3_halo_w" not in k}
+    assert not others, others
+    assert all(v[0] <= 128 for v in sc.values()), sc            # ... and only a few registers' worth

@@ -67,12 +67,33 @@ def scan(lib):
     return offenders, census, kernels
 
 
+def scratch_users(lib):
+    """-> {kernel symbol: (scratch bytes per lane, vgpr count)} of the kernels whose code object asks for private (scratch) memory.  Such a kernel costs more to
+    dispatch and keeps its spills / private arrays in memory ("Scratch in small kernels"): tests/test_isa_scan.py holds the list to the one
+    kernel family that spills by design."""
+    out = {}
+    for co in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", f.name], check=True, capture_output=True, text=True).stdout
+        for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            size = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+            vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+            if name and size and int(size.group(1)) > 0:
+                out[name.group(1)] = (int(size.group(1)), int(vg.group(1)) if vg else -1)
+    return out
+
+
 def main():
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mere-fusion_amd", "libmerefusion_hip.so")
     offenders, census, kernels = scan(lib)
     total = sum(census.values())
     print(f"{os.path.normpath(lib)}: {kernels} functions, {total} packed-fp32 FMA / MUL / ADD instructions; by op_sel: "
           + ", ".join(f"{k[0]} op_sel:[{k[1]}] x {v}" for k, v in sorted(census.items()) if k[1]) + ("" if any(k[1] for k in census) else "none with op_sel"))
+    sc = scratch_users(lib)
+    print(f"  kernels with scratch: {len(sc)}" + ("" if not sc else " -- " + ", ".join(f"{k[:48]} {v[0]} B" for k, v in sorted(sc.items())[:8])))
     for fn, ins in sorted(offenders.items()):
         try:
             fn = subprocess.run(["c++filt", fn], capture_output=True, text=True).stdout.strip().split("(")[0]
